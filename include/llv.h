@@ -1,0 +1,225 @@
+/*
+ * llv.h -- C ABI of libllv.so: the MI355X (gfx950) kernels behind the low-light
+ * video detection hot path (enhance-CNN -> ResNet/FPN -> RetinaHead -> decode -> NMS).
+ *
+ * Conventions
+ *   - extern "C", plain pointers and sizes; no torch / C++ types cross this boundary.
+ *   - Every pointer is a DEVICE pointer unless the name ends in _host. Buffers are
+ *     caller-owned; no entry point allocates, frees or synchronises (graph-capture safe).
+ *   - `stream` is a hipStream_t passed as void*. Work is stream-ordered.
+ *   - Return value: 0 = LLV_OK, negative = LLV_E_* (bad argument, launch failure).
+ *     Nothing throws. llv_strerror() maps a code to text.
+ *   - Activations are NHWC fp16 ("channels-last half"), channel counts padded to a
+ *     multiple of 8 unless stated; accumulation and epilogues are fp32.
+ *
+ * What each entry point replaces in the reference (paths relative to /root/reference):
+ *   llv_conv2d_nhwc_fwd      torch.nn.Conv2d (+ folded BatchNorm2d, ReLU, residual add, nearest
+ *                            upsample-add, PixelShuffle) as used by
+ *                            mmdetection/mmdet/models/backbones/resnet.py:260-299,622-640,
+ *                            mmdetection/mmdet/models/necks/fpn.py:170-221,
+ *                            mmdetection/mmdet/models/dense_heads/retina_head.py:93-114,
+ *                            mmtracking/mmtrack/models/cleaners/FastDVDnet.py:7-116,
+ *                            mmtracking/mmtrack/models/aggregators/embed_aggregator.py:64-72
+ *   llv_maxpool3x3s2_nhwc    nn.MaxPool2d(3,2,1), resnet.py:570,632
+ *   llv_pack_nchw_f32_to_nhwc_f16 / llv_unpack_nhwc_f16_to_nchw_f32
+ *                            layout change at the model boundary (img tensor N,3,H,W fp32:
+ *                            mmdetection/mmdet/models/detectors/base.py:169-183)
+ *   llv_retina_decode_topk   AnchorHead._get_bboxes per-level sigmoid/max/topk/gather/delta2bbox,
+ *                            mmdetection/mmdet/models/dense_heads/anchor_head.py:636-711 and
+ *                            mmdetection/mmdet/core/bbox/coder/delta_xywh_bbox_coder.py:134-237,
+ *                            anchors from mmdetection/mmdet/core/anchor/anchor_generator.py:207-270
+ *   llv_multiclass_nms       multiclass_nms -> mmcv.ops.batched_nms -> mmcv.ops.nms,
+ *                            mmdetection/mmdet/core/post_processing/bbox_nms.py:7-93
+ *   llv_nms                  mmcv.ops.nms(boxes, scores, iou_threshold, offset=0) (mmcv-full 1.3.0,
+ *                            un-vendored; call site bbox_nms.py:2,84)
+ *   llv_embed_aggregate      EmbedAggregator.forward tail (L2-norm, cosine, softmax over frames,
+ *                            weighted sum), embed_aggregator.py:70-81
+ *   llv_flow_warp            flow_warp_feats, mmtracking/mmtrack/core/motion/flow.py:4-41
+ *   llv_sigmoid_focal_loss_* mmcv.ops.sigmoid_focal_loss fwd/bwd, call site
+ *                            mmdetection/mmdet/models/losses/focal_loss.py:59-98
+ *   llv_iou_assign           MaxIoUAssigner.assign + bbox_overlaps,
+ *                            mmdetection/mmdet/core/bbox/assigners/max_iou_assigner.py:60-212,
+ *                            mmdetection/mmdet/core/bbox/iou_calculators/iou2d_calculator.py:43-159
+ */
+#ifndef LLV_H_
+#define LLV_H_
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define LLV_OK 0
+#define LLV_E_BADARG (-1)
+#define LLV_E_LAUNCH (-2)
+#define LLV_E_UNSUPPORTED (-3)
+#define LLV_E_WORKSPACE (-4)
+
+#define LLV_ABI_VERSION 1
+
+#define LLV_MAX_SEG 5 /* pyramid levels batched into one conv launch */
+#define LLV_MAX_SRC 3 /* input tensors concatenated along C by one conv launch */
+
+/* llv_conv_desc.flags */
+#define LLV_CONV_RELU 1        /* y = max(y, 0) last */
+#define LLV_CONV_RES_ADD 2     /* y = conv + bias + res */
+#define LLV_CONV_RES_RSUB 4    /* y = res - (conv + bias)   (FastDVDnet.py:115 `in1 - x`) */
+#define LLV_CONV_PIXSHUF 8     /* store through nn.PixelShuffle(2): out (2Ho,2Wo,cout/4) */
+#define LLV_CONV_RES_UPS 16    /* res is (res_h,res_w), nearest-upsampled to (Ho,Wo) (fpn.py:185-191) */
+#define LLV_CONV_OUT_F32 32    /* y is fp32 instead of fp16 */
+#define LLV_CONV_RELU_IN_RES 64 /* reserved */
+
+/*
+ * One convolution launch, implicit GEMM on MFMA (fp16 in, fp32 accumulate).
+ *
+ *   y[p, co] = epilogue( bias[co] + sum_{r,q,c} w[co][r][q][c] * x[pix(p,r,q), c] )
+ *
+ * x      : n_src tensors, NHWC fp16, x_ld channels per pixel each; the launch sees them
+ *          concatenated along C (src_cvec 8-channel vectors per source). n_src == 1 normally.
+ * w      : per group [w_rows][k_pad] fp16, k = (r*kw + q)*cin + c, zero padded to k_pad (mult of 32)
+ *          and to w_rows (mult of 16) rows; groups are consecutive.
+ * bias   : fp32 [groups*cout] (folded BN shift or conv bias), never NULL.
+ * res    : optional NHWC fp16 residual (res_ld channels per pixel), see flags.
+ * y      : NHWC fp16 (or fp32 with LLV_CONV_OUT_F32), y_ld channels per pixel.
+ * cin    : per-group input channels, multiple of 8 (zero padded by the producer).
+ * cout   : per-group output channels stored, multiple of 4.
+ * Segments: n_seg >= 1 images-sets of different spatial size that share the weights (the five
+ *          FPN levels through one RetinaHead tower conv). Segment s has `batch` images of
+ *          seg_h[s] x seg_w[s] pixels starting at pixel offset seg_xoff[s] of x, and writes
+ *          batch x seg_ho[s] x seg_wo[s] pixels starting at pixel offset seg_yoff[s] of y.
+ * groups : blockIdx.y; group g reads channels [g*cin, (g+1)*cin) of x and writes
+ *          channels [g*cout, (g+1)*cout) of y.
+ */
+typedef struct llv_conv_desc {
+    const void* x[LLV_MAX_SRC];
+    const void* w;
+    const float* bias;
+    const void* res;
+    void* y;
+    int32_t n_src, src_cvec;
+    int32_t x_ld, y_ld, res_ld;
+    int32_t cin, cout, w_rows, k_pad;
+    int32_t kh, kw, stride, pad;
+    int32_t groups, batch;
+    int32_t n_seg;
+    int32_t seg_h[LLV_MAX_SEG], seg_w[LLV_MAX_SEG], seg_ho[LLV_MAX_SEG], seg_wo[LLV_MAX_SEG];
+    int64_t seg_xoff[LLV_MAX_SEG], seg_yoff[LLV_MAX_SEG];
+    int32_t flags;
+    int32_t res_h, res_w;
+    int32_t tile; /* 0 = auto; else LLV_TILE_* to force a tile shape (tests, tuning) */
+} llv_conv_desc;
+
+#define LLV_TILE_AUTO 0
+#define LLV_TILE_128x128 1 /* cout tile x pixel tile */
+#define LLV_TILE_64x256 2
+#define LLV_TILE_32x256 3
+#define LLV_TILE_16x256 4
+#define LLV_TILE_64x64 5
+#define LLV_TILE_256x128 6
+#define LLV_TILE_128x256 7
+
+int llv_abi_version(void);
+const char* llv_strerror(int code);
+
+int llv_conv2d_nhwc_fwd(const llv_conv_desc* desc, void* stream);
+/* algorithmic FLOPs (2*MACs, true channels) the launch described by desc performs */
+double llv_conv2d_flops(const llv_conv_desc* desc);
+
+/* 3x3 stride-2 pad-1 max pooling, NHWC fp16, c multiple of 8. */
+int llv_maxpool3x3s2_nhwc(const void* x, void* y, int batch, int h, int w, int c, void* stream);
+
+/* NCHW fp32 -> NHWC fp16 with c_pad >= c channels per pixel (extra channels zeroed).
+ * Optional per-channel affine (x*scale[c] + shift[c]) applied first when scale != NULL. */
+int llv_pack_nchw_f32_to_nhwc_f16(const float* x, void* y, int batch, int c, int h, int w, int c_pad,
+                                  const float* scale, const float* shift, void* stream);
+/* NHWC fp16 (ld channels per pixel) -> NCHW fp32, first c channels. */
+int llv_unpack_nhwc_f16_to_nchw_f32(const void* x, float* y, int batch, int c, int h, int w, int ld,
+                                    void* stream);
+/* NHWC fp32 (ld channels per pixel) -> NCHW fp32, first c channels. */
+int llv_unpack_nhwc_f32_to_nchw_f32(const float* x, float* y, int batch, int c, int h, int w, int ld,
+                                    void* stream);
+
+/*
+ * RetinaNet box decode for one image: per level sigmoid -> max over classes -> top-k
+ * (score desc, anchor index asc) -> gather -> delta2bbox -> clip -> /scale_factor.
+ */
+typedef struct llv_decode_desc {
+    int32_t n_levels;
+    int32_t num_classes;   /* C */
+    int32_t num_anchors;   /* A (base anchors per cell) */
+    int32_t nms_pre;       /* <=0: keep all */
+    int32_t level_h[LLV_MAX_SEG], level_w[LLV_MAX_SEG];
+    int32_t stride_w[LLV_MAX_SEG], stride_h[LLV_MAX_SEG];
+    int64_t cls_off[LLV_MAX_SEG]; /* pixel offset of the level inside cls / reg buffers */
+    int64_t reg_off[LLV_MAX_SEG];
+    int32_t cls_ld, reg_ld;       /* channels per pixel (>= A*C, >= A*4) */
+    int32_t logits_f32;           /* 1: cls/reg are fp32, 0: fp16 */
+    const void* cls;              /* NHWC logits, channel = a*C + c */
+    const void* reg;              /* NHWC deltas, channel = a*4 + k */
+    const float* base_anchors;    /* [n_levels][A][4] fp32 (anchor_generator.py:142-185) */
+    float means[4], stds[4];
+    float max_ratio;              /* |log(wh_ratio_clip)| */
+    int32_t clip;                 /* clip_border && max_shape given */
+    float img_h, img_w;           /* max_shape */
+    float scale_factor[4];        /* divide when rescale */
+    int32_t rescale;
+    /* outputs */
+    float* boxes;                 /* [n_cand][4] */
+    float* scores;                /* [n_cand][C] */
+    int32_t* cand_anchor;         /* [n_cand] global anchor index (level offset + cell*A + a) */
+    int32_t n_cand;               /* sum over levels of min(nms_pre, h*w*A), filled by llv_retina_decode_ncand */
+    void* workspace; size_t workspace_bytes;
+} llv_decode_desc;
+
+int llv_retina_decode_ncand(const llv_decode_desc* desc);
+size_t llv_retina_decode_workspace_bytes(const llv_decode_desc* desc);
+int llv_retina_decode_topk(const llv_decode_desc* desc, void* stream);
+
+/*
+ * multiclass_nms for one image. boxes [n][4] fp32, scores [n][c_ld] fp32 (first C columns used).
+ * Output: dets [max_num][5], labels [max_num] int64, count[1] int32, keep_flat [max_num] int32
+ * (flat index i*C + c of each kept detection, score-descending).
+ */
+size_t llv_multiclass_nms_workspace_bytes(int n, int num_classes, int max_num);
+int llv_multiclass_nms(const float* boxes, const float* scores, int n, int num_classes, int c_ld,
+                       float score_thr, float iou_thr, int max_num, float* dets, int64_t* labels,
+                       int32_t* count, int32_t* keep_flat, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* Plain single-class NMS: keep [n] int64 (score-descending kept indices), count[1] int32. n <= 8192. */
+size_t llv_nms_workspace_bytes(int n);
+int llv_nms(const float* boxes, const float* scores, int n, float iou_thr, int64_t* keep, int32_t* count,
+            void* workspace, size_t workspace_bytes, void* stream);
+
+/*
+ * EmbedAggregator tail. x_embed [hw][c], ref_embed [n][hw][c] (fp16 NHWC, ld channels per pixel),
+ * ref [n][hw][c] fp16 -> out [hw][c] fp16.
+ */
+int llv_embed_aggregate(const void* x_embed, const void* ref_embed, const void* ref, void* out, int n_ref,
+                        int64_t hw, int c, int embed_ld, int ref_ld, int out_ld, void* stream);
+
+/* flow_warp_feats: x NHWC fp16 (n,h,w,c), flow NCHW fp32 (n,2,hf,wf) -> y NHWC fp16. */
+int llv_flow_warp(const void* x, const float* flow, void* y, int n, int h, int w, int c, int ld, int hf,
+                  int wf, void* stream);
+
+/* sigmoid focal loss (mmcv semantics): logits [n][c] fp32, labels [n] int64 (c == background).
+ * fwd writes loss [n][c]; bwd writes grad_input [n][c] = dloss/dlogit (unweighted). */
+int llv_sigmoid_focal_loss_fwd(const float* logits, const int64_t* labels, float* loss, int64_t n, int c,
+                               float gamma, float alpha, void* stream);
+int llv_sigmoid_focal_loss_bwd(const float* logits, const int64_t* labels, float* grad, int64_t n, int c,
+                               float gamma, float alpha, void* stream);
+
+/* MaxIoUAssigner on device. gt [k][4], anchors [n][4], valid [n] uint8 (may be NULL) ->
+ * assigned_gt_inds [n] int64 (-1 ignore / 0 negative / 1-based gt), max_overlaps [n] fp32. */
+size_t llv_iou_assign_workspace_bytes(int k, int64_t n);
+int llv_iou_assign(const float* gt, int k, const float* anchors, const uint8_t* valid, int64_t n,
+                   float pos_iou_thr, float neg_iou_thr, float min_pos_iou, int match_low_quality,
+                   int gt_max_assign_all, int64_t* assigned_gt_inds, float* max_overlaps, void* workspace,
+                   size_t workspace_bytes, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LLV_H_ */

@@ -1,0 +1,125 @@
+"""ctypes binding of libllv.so (the C ABI declared in include/llv.h).
+
+This is the only place the shared library is opened. There is no fallback: if the library is
+missing or an entry point fails, the caller gets an exception.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, 'libllv.so')
+
+LLV_MAX_SEG = 5
+LLV_MAX_SRC = 3
+
+# llv_conv_desc.flags
+CONV_RELU = 1
+CONV_RES_ADD = 2
+CONV_RES_RSUB = 4
+CONV_PIXSHUF = 8
+CONV_RES_UPS = 16
+CONV_OUT_F32 = 32
+
+TILE_AUTO, TILE_128x128, TILE_64x256, TILE_32x256, TILE_16x256, TILE_64x64 = 0, 1, 2, 3, 4, 5
+TILE_256x128, TILE_128x256 = 6, 7
+
+
+class LlvError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    _fields_ = [
+        ('x', C.c_void_p * LLV_MAX_SRC),
+        ('w', C.c_void_p),
+        ('bias', C.c_void_p),
+        ('res', C.c_void_p),
+        ('y', C.c_void_p),
+        ('n_src', C.c_int32), ('src_cvec', C.c_int32),
+        ('x_ld', C.c_int32), ('y_ld', C.c_int32), ('res_ld', C.c_int32),
+        ('cin', C.c_int32), ('cout', C.c_int32), ('w_rows', C.c_int32), ('k_pad', C.c_int32),
+        ('kh', C.c_int32), ('kw', C.c_int32), ('stride', C.c_int32), ('pad', C.c_int32),
+        ('groups', C.c_int32), ('batch', C.c_int32),
+        ('n_seg', C.c_int32),
+        ('seg_h', C.c_int32 * LLV_MAX_SEG), ('seg_w', C.c_int32 * LLV_MAX_SEG),
+        ('seg_ho', C.c_int32 * LLV_MAX_SEG), ('seg_wo', C.c_int32 * LLV_MAX_SEG),
+        ('seg_xoff', C.c_int64 * LLV_MAX_SEG), ('seg_yoff', C.c_int64 * LLV_MAX_SEG),
+        ('flags', C.c_int32),
+        ('res_h', C.c_int32), ('res_w', C.c_int32),
+        ('tile', C.c_int32),
+    ]
+
+
+class DecodeDesc(C.Structure):
+    _fields_ = [
+        ('n_levels', C.c_int32), ('num_classes', C.c_int32), ('num_anchors', C.c_int32), ('nms_pre', C.c_int32),
+        ('level_h', C.c_int32 * LLV_MAX_SEG), ('level_w', C.c_int32 * LLV_MAX_SEG),
+        ('stride_w', C.c_int32 * LLV_MAX_SEG), ('stride_h', C.c_int32 * LLV_MAX_SEG),
+        ('cls_off', C.c_int64 * LLV_MAX_SEG), ('reg_off', C.c_int64 * LLV_MAX_SEG),
+        ('cls_ld', C.c_int32), ('reg_ld', C.c_int32),
+        ('logits_f32', C.c_int32),
+        ('cls', C.c_void_p), ('reg', C.c_void_p), ('base_anchors', C.c_void_p),
+        ('means', C.c_float * 4), ('stds', C.c_float * 4),
+        ('max_ratio', C.c_float),
+        ('clip', C.c_int32),
+        ('img_h', C.c_float), ('img_w', C.c_float),
+        ('scale_factor', C.c_float * 4),
+        ('rescale', C.c_int32),
+        ('boxes', C.c_void_p), ('scores', C.c_void_p), ('cand_anchor', C.c_void_p),
+        ('n_cand', C.c_int32),
+        ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t),
+    ]
+
+
+# name -> (restype, argtypes); every symbol include/llv.h declares
+_P, _I, _L, _F, _Z = C.c_void_p, C.c_int, C.c_int64, C.c_float, C.c_size_t
+SIGNATURES = {
+    'llv_abi_version': (_I, []),
+    'llv_strerror': (C.c_char_p, [_I]),
+    'llv_conv2d_nhwc_fwd': (_I, [C.POINTER(ConvDesc), _P]),
+    'llv_conv2d_flops': (C.c_double, [C.POINTER(ConvDesc)]),
+    'llv_maxpool3x3s2_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'llv_pack_nchw_f32_to_nhwc_f16': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
+    'llv_unpack_nhwc_f16_to_nchw_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    'llv_unpack_nhwc_f32_to_nchw_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),
+    'llv_retina_decode_ncand': (_I, [C.POINTER(DecodeDesc)]),
+    'llv_retina_decode_workspace_bytes': (_Z, [C.POINTER(DecodeDesc)]),
+    'llv_retina_decode_topk': (_I, [C.POINTER(DecodeDesc), _P]),
+    'llv_multiclass_nms_workspace_bytes': (_Z, [_I, _I, _I]),
+    'llv_multiclass_nms': (_I, [_P, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    'llv_nms_workspace_bytes': (_Z, [_I]),
+    'llv_nms': (_I, [_P, _P, _I, _F, _P, _P, _P, _Z, _P]),
+    'llv_embed_aggregate': (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
+    'llv_flow_warp': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'llv_sigmoid_focal_loss_fwd': (_I, [_P, _P, _P, _L, _I, _F, _F, _P]),
+    'llv_sigmoid_focal_loss_bwd': (_I, [_P, _P, _P, _L, _I, _F, _F, _P]),
+    'llv_iou_assign_workspace_bytes': (_Z, [_I, _L]),
+    'llv_iou_assign': (_I, [_P, _I, _P, _P, _L, _F, _F, _F, _I, _I, _P, _P, _P, _Z, _P]),
+}
+
+_lib = None
+
+
+def lib():
+    """Open libllv.so once. Raises LlvError if it has not been built."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise LlvError(
+                f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
+                f'or `make -C {os.path.join(_HERE, "csrc")}`. There is no CPU fallback.')
+        handle = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the ABI lost a symbol
+            fn.restype = res
+            fn.argtypes = args
+        if handle.llv_abi_version() != 1:
+            raise LlvError('libllv.so ABI version mismatch')
+        _lib = handle
+    return _lib
+
+
+def check(code, what=''):
+    if code != 0:
+        msg = lib().llv_strerror(code).decode()
+        raise LlvError(f'{what or "llv call"} failed: {msg} ({code})')

@@ -1,0 +1,287 @@
+// elementwise.hip -- HBM-bound helpers around the conv path: max pooling, layout packing at the
+// model boundary, EmbedAggregator tail, flow warp. All NHWC, 16-byte (8 x fp16) per lane accesses.
+
+#include <hip/hip_runtime.h>
+#include <hip/hip_fp16.h>
+#include "llv.h"
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+
+namespace {
+
+constexpr int kBlock = 256;
+inline int grid_for(long work) {
+    long g = (work + kBlock - 1) / kBlock;
+    if (g < 1) g = 1;
+    if (g > 256L * 16) g = 256L * 16;  // grid-stride beyond 16 blocks per CU
+    return (int)g;
+}
+
+// nn.MaxPool2d(kernel_size=3, stride=2, padding=1) (resnet.py:570); padding never wins the max.
+__global__ void maxpool3x3s2_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y, int batch,
+                                    int h, int w, int c8, int ho, int wo) {
+    const long total = (long)batch * ho * wo * c8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % c8);
+        long p = i / c8;
+        const int ox = (int)(p % wo); p /= wo;
+        const int oy = (int)(p % ho);
+        const int n = (int)(p / ho);
+        f16x8 m;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) m[e] = (_Float16)(-65504.f);
+        bool any = false;
+#pragma unroll
+        for (int dy = 0; dy < 3; ++dy) {
+            const int iy = oy * 2 - 1 + dy;
+            if ((unsigned)iy >= (unsigned)h) continue;
+#pragma unroll
+            for (int dx = 0; dx < 3; ++dx) {
+                const int ix = ox * 2 - 1 + dx;
+                if ((unsigned)ix >= (unsigned)w) continue;
+                const f16x8 v = *reinterpret_cast<const f16x8*>(x + (((long)n * h + iy) * w + ix) * (c8 * 8) + cv * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) m[e] = v[e] > m[e] ? v[e] : m[e];
+                any = true;
+            }
+        }
+        (void)any;
+        *reinterpret_cast<f16x8*>(y + i * 8) = m;
+    }
+}
+
+// NCHW fp32 -> NHWC fp16 (c_pad channels, zeros beyond c); one lane per pixel.
+__global__ void pack_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int batch, int c, long hw,
+                            int c_pad, const float* __restrict__ scale, const float* __restrict__ shift) {
+    const long total = (long)batch * hw;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long n = i / hw, p = i - n * hw;
+        for (int cb = 0; cb < c_pad; cb += 8) {
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const int ch = cb + e;
+                float v = 0.f;
+                if (ch < c) {
+                    v = x[(n * c + ch) * hw + p];
+                    if (scale) v = v * scale[ch] + shift[ch];
+                }
+                o[e] = (_Float16)v;
+            }
+            *reinterpret_cast<f16x8*>(y + i * c_pad + cb) = o;
+        }
+    }
+}
+
+template <typename T>
+__global__ void unpack_kernel(const T* __restrict__ x, float* __restrict__ y, int batch, int c, long hw, int ld) {
+    const long total = (long)batch * c * hw;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long p = i % hw;
+        const long t = i / hw;
+        const int ch = (int)(t % c);
+        const long n = t / c;
+        y[i] = (float)x[(n * hw + p) * ld + ch];
+    }
+}
+
+// EmbedAggregator tail (embed_aggregator.py:70-81). One wave per pixel: lanes stride the channels.
+//   xe = x_embed / ||x_embed||, re_n = ref_embed_n / ||ref_embed_n||, w_n = softmax_n(sum_c re_n*xe),
+//   out = sum_n w_n * ref_n.
+__global__ void embed_aggregate_kernel(const _Float16* __restrict__ xe, const _Float16* __restrict__ re,
+                                       const _Float16* __restrict__ ref, _Float16* __restrict__ out, int n_ref,
+                                       long hw, int c, int embed_ld, int ref_ld, int out_ld) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    extern __shared__ float sw[];  // [waves per block][n_ref]
+    float* myw = sw + (threadIdx.x >> 6) * n_ref;
+    for (long p = wave; p < hw; p += nwaves) {
+        // |x|^2
+        float xx = 0.f;
+        for (int ch = lane * 8; ch < c; ch += 512) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(xe + p * embed_ld + ch);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) xx += (float)v[e] * (float)v[e];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) xx += __shfl_xor(xx, o);
+        const float xn = sqrtf(xx);
+        float mx = -INFINITY;
+        for (int n = 0; n < n_ref; ++n) {
+            float rr = 0.f, rx = 0.f;
+            for (int ch = lane * 8; ch < c; ch += 512) {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(re + ((long)n * hw + p) * embed_ld + ch);
+                const f16x8 u = *reinterpret_cast<const f16x8*>(xe + p * embed_ld + ch);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) { rr += (float)v[e] * (float)v[e]; rx += (float)v[e] * (float)u[e]; }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { rr += __shfl_xor(rr, o); rx += __shfl_xor(rx, o); }
+            const float cs = rx / (sqrtf(rr) * xn);
+            if (lane == 0) myw[n] = cs;
+            mx = fmaxf(mx, cs);
+        }
+        __builtin_amdgcn_wave_barrier();
+        float den = 0.f;
+        for (int n = 0; n < n_ref; ++n) den += expf(myw[n] - mx);
+        for (int ch = lane * 8; ch < c; ch += 512) {
+            float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int n = 0; n < n_ref; ++n) {
+                const float wgt = expf(myw[n] - mx) / den;
+                const f16x8 v = *reinterpret_cast<const f16x8*>(ref + ((long)n * hw + p) * ref_ld + ch);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += wgt * (float)v[e];
+            }
+            f16x8 o;
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (_Float16)acc[e];
+            *reinterpret_cast<f16x8*>(out + p * out_ld + ch) = o;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// flow_warp_feats (mmtracking/mmtrack/core/motion/flow.py:4-41), reproduced operation by operation:
+//  1. flow -> bilinear resize (align_corners=False, scale_factor = W_x/W_f) to (h,w), times scale;
+//  2. grid = (x + u)/W*2-1, (y + v)/H*2-1   (divides by W,H -- not W-1 -- as the reference does);
+//  3. grid_sample(bilinear, padding_mode='border', align_corners=True).
+__device__ __forceinline__ float bilerp_flow(const float* f, int hf, int wf, float sy, float sx) {
+    // PyTorch upsample_bilinear2d, align_corners=False: src = max(0, (dst+0.5)*scale - 0.5)
+    sy = sy < 0.f ? 0.f : sy;
+    sx = sx < 0.f ? 0.f : sx;
+    int y0 = (int)sy, x0 = (int)sx;
+    y0 = y0 < hf - 1 ? y0 : hf - 1;
+    x0 = x0 < wf - 1 ? x0 : wf - 1;
+    const int y1 = y0 < hf - 1 ? y0 + 1 : y0, x1 = x0 < wf - 1 ? x0 + 1 : x0;
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    return hy * (hx * f[y0 * wf + x0] + lx * f[y0 * wf + x1]) + ly * (hx * f[y1 * wf + x0] + lx * f[y1 * wf + x1]);
+}
+
+__global__ void flow_warp_kernel(const _Float16* __restrict__ x, const float* __restrict__ flow,
+                                 _Float16* __restrict__ y, int nb, int h, int w, int c8, int ld, int hf, int wf,
+                                 float rscale_h, float rscale_w, float mul) {
+    const long total = (long)nb * h * w * c8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % c8);
+        long p = i / c8;
+        const int ox = (int)(p % w); p /= w;
+        const int oy = (int)(p % h);
+        const int n = (int)(p / h);
+        const float sy = ((float)oy + 0.5f) * rscale_h - 0.5f;
+        const float sx = ((float)ox + 0.5f) * rscale_w - 0.5f;
+        const float* fu = flow + ((long)n * 2 + 0) * hf * wf;
+        const float* fv = flow + ((long)n * 2 + 1) * hf * wf;
+        const float u = bilerp_flow(fu, hf, wf, sy, sx) * mul;
+        const float v = bilerp_flow(fv, hf, wf, sy, sx) * mul;
+        float gx = ((float)ox + u) / (float)w * 2.f - 1.f;
+        float gy = ((float)oy + v) / (float)h * 2.f - 1.f;
+        // grid_sample align_corners=True: pix = (g+1)/2*(size-1); border: clamp to [0,size-1]
+        float fx = (gx + 1.f) * 0.5f * (float)(w - 1);
+        float fy = (gy + 1.f) * 0.5f * (float)(h - 1);
+        fx = fminf(fmaxf(fx, 0.f), (float)(w - 1));
+        fy = fminf(fmaxf(fy, 0.f), (float)(h - 1));
+        const int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
+        const int x1 = x0 + 1, y1 = y0 + 1;
+        const float lx = fx - (float)x0, ly = fy - (float)y0;
+        const float w00 = (1.f - lx) * (1.f - ly), w01 = lx * (1.f - ly), w10 = (1.f - lx) * ly, w11 = lx * ly;
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        const _Float16* xb = x + (long)n * h * w * ld + cv * 8;
+        auto tap = [&](int yy, int xx, float wt) {
+            if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w) {
+                const f16x8 t = *reinterpret_cast<const f16x8*>(xb + ((long)yy * w + xx) * ld);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += wt * (float)t[e];
+            }
+        };
+        tap(y0, x0, w00); tap(y0, x1, w01); tap(y1, x0, w10); tap(y1, x1, w11);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)acc[e];
+        *reinterpret_cast<f16x8*>(y + (((long)n * h + oy) * w + ox) * ld + cv * 8) = o;
+    }
+}
+
+}  // namespace
+
+extern "C" int llv_maxpool3x3s2_nhwc(const void* x, void* y, int batch, int h, int w, int c, void* stream) {
+    if (!x || !y || batch < 1 || h < 1 || w < 1 || c < 8 || (c & 7)) return LLV_E_BADARG;
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long total = (long)batch * ho * wo * (c / 8);
+    hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream,
+                       (const _Float16*)x, (_Float16*)y, batch, h, w, c / 8, ho, wo);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_pack_nchw_f32_to_nhwc_f16(const float* x, void* y, int batch, int c, int h, int w, int c_pad,
+                                             const float* scale, const float* shift, void* stream) {
+    if (!x || !y || batch < 1 || c < 1 || h < 1 || w < 1 || c_pad < c || (c_pad & 7)) return LLV_E_BADARG;
+    if ((scale == nullptr) != (shift == nullptr)) return LLV_E_BADARG;
+    const long total = (long)batch * h * w;
+    hipLaunchKernelGGL(pack_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, x, (_Float16*)y,
+                       batch, c, (long)h * w, c_pad, scale, shift);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_unpack_nhwc_f16_to_nchw_f32(const void* x, float* y, int batch, int c, int h, int w, int ld,
+                                               void* stream) {
+    if (!x || !y || batch < 1 || c < 1 || h < 1 || w < 1 || ld < c) return LLV_E_BADARG;
+    const long total = (long)batch * c * h * w;
+    hipLaunchKernelGGL((unpack_kernel<_Float16>), dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream,
+                       (const _Float16*)x, y, batch, c, (long)h * w, ld);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_unpack_nhwc_f32_to_nchw_f32(const float* x, float* y, int batch, int c, int h, int w, int ld,
+                                               void* stream) {
+    if (!x || !y || batch < 1 || c < 1 || h < 1 || w < 1 || ld < c) return LLV_E_BADARG;
+    const long total = (long)batch * c * h * w;
+    hipLaunchKernelGGL((unpack_kernel<float>), dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, x, y,
+                       batch, c, (long)h * w, ld);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_embed_aggregate(const void* x_embed, const void* ref_embed, const void* ref, void* out,
+                                   int n_ref, int64_t hw, int c, int embed_ld, int ref_ld, int out_ld,
+                                   void* stream) {
+    if (!x_embed || !ref_embed || !ref || !out || n_ref < 1 || n_ref > 256 || hw < 1 || c < 8 || (c & 7))
+        return LLV_E_BADARG;
+    if ((embed_ld & 7) || (ref_ld & 7) || (out_ld & 7) || embed_ld < c || ref_ld < c || out_ld < c) return LLV_E_BADARG;
+    long waves = hw;
+    long blocks = (waves + 3) / 4;
+    if (blocks > 256L * 8) blocks = 256L * 8;
+    hipLaunchKernelGGL(embed_aggregate_kernel, dim3((int)blocks), dim3(256), 4 * n_ref * sizeof(float),
+                       (hipStream_t)stream, (const _Float16*)x_embed, (const _Float16*)ref_embed,
+                       (const _Float16*)ref, (_Float16*)out, n_ref, (long)hw, c, embed_ld, ref_ld, out_ld);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_flow_warp(const void* x, const float* flow, void* y, int n, int h, int w, int c, int ld,
+                             int hf, int wf, void* stream) {
+    if (!x || !flow || !y || n < 1 || h < 1 || w < 1 || c < 8 || (c & 7) || (ld & 7) || ld < c || hf < 1 || wf < 1)
+        return LLV_E_BADARG;
+    // F.interpolate(scale_factor=s) with s = W_x / W_f: output size floor(in*s); the reference relies on
+    // it matching (h,w). recompute_scale_factor is None -> the given scale_factor is used for the
+    // coordinate map: src = (dst + 0.5)/s - 0.5 for both axes.
+    const float s = (float)w / (float)wf;
+    if ((int)floor((double)hf * (double)s) != h || (int)floor((double)wf * (double)s) != w) return LLV_E_BADARG;
+    const float rs = 1.f / s;
+    const long total = (long)n * h * w * (c / 8);
+    hipLaunchKernelGGL(flow_warp_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream,
+                       (const _Float16*)x, flow, (_Float16*)y, n, h, w, c / 8, ld, hf, wf, rs, rs, s);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_abi_version(void) { return LLV_ABI_VERSION; }
+
+extern "C" const char* llv_strerror(int code) {
+    switch (code) {
+        case LLV_OK: return "ok";
+        case LLV_E_BADARG: return "bad argument";
+        case LLV_E_LAUNCH: return "kernel launch failed";
+        case LLV_E_UNSUPPORTED: return "unsupported configuration";
+        case LLV_E_WORKSPACE: return "workspace too small";
+        default: return "unknown error";
+    }
+}

@@ -1,0 +1,311 @@
+// nms.hip -- per-image multiclass NMS on device, index-exact against the oracle.
+//
+// Reference semantics (mmdetection/mmdet/core/post_processing/bbox_nms.py:7-93 -> mmcv 1.3.0
+// batched_nms -> nms, un-vendored; restated in oracle/postprocess.py):
+//   - candidates = every (box i, class c) with score[i][c] > score_thr, flat index i*C + c
+//   - boxes_for_nms = box + c * (max_coordinate + 1), max over the candidates' boxes (fp32 arithmetic)
+//   - greedy NMS in (score desc) order, suppress when IoU > iou_thr, offset 0 areas
+//   - output sorted by score desc, truncated to max_num
+// Ties in score are ordered by flat index ascending (the oracle's total order).
+//
+// Because the class offset makes classes independent, each class is one workgroup:
+//   compact (ordered) -> LDS bitonic sort of 64-bit (score, index) keys -> wave 0 runs the greedy
+//   scan 64 boxes at a time: every lane first tests its box against the LDS-resident kept boxes,
+//   then the 64 lanes resolve each other with __ballot / ffs / __shfl broadcasts.
+// A class can contribute at most max_num boxes to the final top-max_num, so each class stops at
+// max_num kept and the merge kernel sorts at most C*max_num keys. Exact, no truncation heuristics.
+// Built with -ffp-contract=off so the IoU arithmetic is bit-identical to IEEE fp32 on the host.
+
+#include <hip/hip_runtime.h>
+#include "llv.h"
+#include "sort_util.h"
+
+namespace {
+
+constexpr int kMaxN = 8192;      // boxes per class list (LDS keys: 64 KiB)
+constexpr int kMaxMerge = 8192;  // C * max_num
+
+struct NmsWs {
+    float* maxc;        // [1] max coordinate over candidate boxes (ordered-uint encoded)
+    unsigned* maxc_u;
+    int* any;           // [1] any candidate
+    int* cls_cnt;       // [C]
+    uint64_t* cls_keys; // [C][max_num]  (score, flat index) of kept per class
+};
+
+__device__ __forceinline__ bool iou_gt(const float4 a, const float4 b, float thr) {
+    const float left = fmaxf(a.x, b.x), right = fminf(a.z, b.z);
+    const float top = fmaxf(a.y, b.y), bottom = fminf(a.w, b.w);
+    const float width = fmaxf(right - left, 0.f), height = fmaxf(bottom - top, 0.f);
+    const float inter = width * height;
+    const float sa = (a.z - a.x) * (a.w - a.y);
+    const float sb = (b.z - b.x) * (b.w - b.y);
+    return inter / (sa + sb - inter) > thr;
+}
+
+// max coordinate over boxes that have at least one class above the threshold
+__global__ __launch_bounds__(1024) void nms_prepare_kernel(const float* __restrict__ boxes,
+                                                           const float* __restrict__ scores, int n, int C,
+                                                           int c_ld, float thr, unsigned* maxc_u, int* any,
+                                                           int* cls_cnt) {
+    __shared__ unsigned smax[16];
+    __shared__ int sany[16];
+    unsigned m = 0;
+    int a = 0;
+    for (int i = threadIdx.x; i < n; i += blockDim.x) {
+        bool v = false;
+        for (int c = 0; c < C; ++c) v |= scores[(long)i * c_ld + c] > thr;
+        if (v) {
+            a = 1;
+            const float4 b = reinterpret_cast<const float4*>(boxes)[i];
+            const float mm = fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w));
+            const unsigned u = llv::f32_ordered(mm);
+            m = u > m ? u : m;
+        }
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) {
+        const unsigned t = __shfl_xor(m, o);
+        m = t > m ? t : m;
+        a |= __shfl_xor(a, o);
+    }
+    if ((threadIdx.x & 63) == 0) { smax[threadIdx.x >> 6] = m; sany[threadIdx.x >> 6] = a; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { m = smax[w] > m ? smax[w] : m; a |= sany[w]; }
+        *maxc_u = m;
+        *any = a;
+    }
+    for (int c = threadIdx.x; c < C; c += blockDim.x) cls_cnt[c] = 0;
+}
+
+// Greedy scan over `cnt` sorted keys (LDS) by wave 0. box_of(idx) gives the (offset) box of
+// candidate idx. Kept keys are appended to out_keys (global) and kept boxes to kept (LDS/global).
+template <typename BoxFn>
+__device__ inline int greedy_scan(const uint64_t* keys, int cnt, float thr, int max_keep, float4* kept,
+                                  uint64_t* out_keys, BoxFn box_of) {
+    const int lane = threadIdx.x & 63;
+    int nkept = 0;
+    for (int base = 0; base < cnt && nkept < max_keep; base += 64) {
+        const int i = base + lane;
+        const bool valid = i < cnt;
+        uint64_t key = 0;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+            key = keys[i];
+            b = box_of(llv::key_index(key));
+        }
+        bool alive = valid;
+        for (int j = 0; j < nkept; ++j) {
+            if (alive && iou_gt(kept[j], b, thr)) alive = false;
+        }
+        unsigned long long mask = __ballot(alive);
+        int start = 0;
+        while (nkept < max_keep) {
+            const unsigned long long rem = start >= 64 ? 0ull : (mask >> start) << start;
+            if (!rem) break;
+            const int t = __ffsll((long long)rem) - 1;
+            float4 kb;
+            kb.x = __shfl(b.x, t); kb.y = __shfl(b.y, t); kb.z = __shfl(b.z, t); kb.w = __shfl(b.w, t);
+            const uint64_t kk = __shfl((unsigned long long)key, t);
+            if (lane == 0) { kept[nkept] = kb; out_keys[nkept] = kk; }
+            ++nkept;
+            if (alive && lane > t && iou_gt(kb, b, thr)) alive = false;
+            mask = __ballot(alive);
+            start = t + 1;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+    return nkept;
+}
+
+// one workgroup per class
+__global__ __launch_bounds__(256) void nms_class_kernel(const float* __restrict__ boxes,
+                                                        const float* __restrict__ scores, int n, int C, int c_ld,
+                                                        float score_thr, float iou_thr, int max_num,
+                                                        const unsigned* maxc_u, const int* any, int* cls_cnt,
+                                                        uint64_t* cls_keys) {
+    if (!*any) return;
+    const int c = blockIdx.x;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(sm);                     // [np2]
+    const int np2_max = llv::next_pow2(n);
+    float4* kept = reinterpret_cast<float4*>(sm + (size_t)np2_max * 8);   // [max_num]
+    int* scratch = reinterpret_cast<int*>(sm + (size_t)np2_max * 8 + (size_t)max_num * 16);  // [17]
+
+    // ordered compaction of candidates of this class
+    int cnt = 0;
+    for (int base = 0; base < n; base += blockDim.x) {
+        const int i = base + threadIdx.x;
+        float s = 0.f;
+        bool v = false;
+        if (i < n) {
+            s = scores[(long)i * c_ld + c];
+            v = s > score_thr;
+        }
+        int tot;
+        const int pos = llv::block_exclusive_scan(v ? 1 : 0, scratch, &tot);
+        if (v) keys[cnt + pos] = llv::make_key(s, (unsigned)i * (unsigned)C + (unsigned)c);
+        cnt += tot;
+    }
+    if (cnt == 0) return;
+    const int np2 = llv::next_pow2(cnt);
+    for (int i = cnt + threadIdx.x; i < np2; i += blockDim.x) keys[i] = 0;
+    __syncthreads();
+    llv::bitonic_sort_desc(keys, np2);
+
+    if (threadIdx.x < 64) {
+        // boxes_for_nms = boxes + idxs.to(boxes) * (max_coordinate + 1)   (mmcv batched_nms)
+        const float off = (float)c * (llv::f32_unordered(*maxc_u) + 1.0f);
+        auto box_of = [&](unsigned flat) {
+            float4 b = reinterpret_cast<const float4*>(boxes)[flat / (unsigned)C];
+            b.x += off; b.y += off; b.z += off; b.w += off;
+            return b;
+        };
+        const int nk = greedy_scan(keys, cnt, iou_thr, max_num, kept, cls_keys + (long)c * max_num, box_of);
+        if (threadIdx.x == 0) cls_cnt[c] = nk;
+    }
+}
+
+// one workgroup: merge the per-class kept lists, global (score desc, flat asc) order, top max_num
+__global__ __launch_bounds__(1024) void nms_merge_kernel(const float* __restrict__ boxes, int C, int max_num,
+                                                         const int* any, const int* cls_cnt,
+                                                         const uint64_t* cls_keys, float* dets, int64_t* labels,
+                                                         int* count, int* keep_flat) {
+    if (!*any) {
+        if (threadIdx.x == 0) *count = 0;
+        return;
+    }
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(sm);
+    __shared__ int s_off[1025];
+    if (threadIdx.x == 0) {
+        int s = 0;
+        for (int c = 0; c < C; ++c) { s_off[c] = s; s += cls_cnt[c]; }
+        s_off[C] = s;
+    }
+    __syncthreads();
+    const int total = s_off[C];
+    const int np2 = llv::next_pow2(total > 1 ? total : 1);
+    for (int c = 0; c < C; ++c) {
+        const int cc = cls_cnt[c];
+        for (int j = threadIdx.x; j < cc; j += blockDim.x) keys[s_off[c] + j] = cls_keys[(long)c * max_num + j];
+    }
+    for (int i = total + threadIdx.x; i < np2; i += blockDim.x) keys[i] = 0;
+    __syncthreads();
+    llv::bitonic_sort_desc(keys, np2);
+    const int k = total < max_num ? total : max_num;
+    for (int i = threadIdx.x; i < k; i += blockDim.x) {
+        const uint64_t key = keys[i];
+        const unsigned flat = llv::key_index(key);
+        const unsigned bi = flat / (unsigned)C, c = flat - bi * (unsigned)C;
+        const float4 b = reinterpret_cast<const float4*>(boxes)[bi];
+        dets[i * 5 + 0] = b.x; dets[i * 5 + 1] = b.y; dets[i * 5 + 2] = b.z; dets[i * 5 + 3] = b.w;
+        dets[i * 5 + 4] = llv::key_score(key);
+        labels[i] = (int64_t)c;
+        keep_flat[i] = (int)flat;
+    }
+    if (threadIdx.x == 0) *count = k;
+}
+
+// plain single-class NMS (mmcv.ops.nms), n <= kMaxN; kept boxes live in global workspace
+__global__ __launch_bounds__(256) void nms_plain_kernel(const float* __restrict__ boxes,
+                                                        const float* __restrict__ scores, int n, float iou_thr,
+                                                        int64_t* keep, int* count, float4* kept_ws,
+                                                        uint64_t* keys_ws) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(sm);
+    const int np2 = llv::next_pow2(n);
+    for (int i = threadIdx.x; i < np2; i += blockDim.x)
+        keys[i] = i < n ? llv::make_key(scores[i], (unsigned)i) : 0ull;
+    __syncthreads();
+    llv::bitonic_sort_desc(keys, np2);
+    __shared__ int s_nk;
+    if (threadIdx.x < 64) {
+        auto box_of = [&](unsigned idx) { return reinterpret_cast<const float4*>(boxes)[idx]; };
+        const int nk = greedy_scan(keys, n, iou_thr, n, kept_ws, keys_ws, box_of);
+        if (threadIdx.x == 0) s_nk = nk;
+    }
+    __syncthreads();
+    const int nk = s_nk;
+    for (int i = threadIdx.x; i < nk; i += blockDim.x) keep[i] = (int64_t)llv::key_index(keys_ws[i]);
+    if (threadIdx.x == 0) *count = nk;
+}
+
+inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+
+// gfx950 has 160 KiB of LDS per CU; HIP caps dynamic LDS at 64 KiB unless the kernel opts in.
+template <typename K>
+inline void allow_big_lds(K kernel) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024);
+}
+inline void nms_init_once() {
+    static bool done = false;
+    if (done) return;
+    allow_big_lds(nms_class_kernel);
+    allow_big_lds(nms_merge_kernel);
+    allow_big_lds(nms_plain_kernel);
+    done = true;
+}
+
+}  // namespace
+
+extern "C" size_t llv_multiclass_nms_workspace_bytes(int n, int num_classes, int max_num) {
+    if (n < 0 || num_classes < 1 || max_num < 1) return 0;
+    return al(16) + al((size_t)num_classes * 4) + al((size_t)num_classes * max_num * 8);
+}
+
+extern "C" int llv_multiclass_nms(const float* boxes, const float* scores, int n, int num_classes, int c_ld,
+                                  float score_thr, float iou_thr, int max_num, float* dets, int64_t* labels,
+                                  int32_t* count, int32_t* keep_flat, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    if (!dets || !labels || !count || !keep_flat || !workspace || num_classes < 1 || num_classes > 1024 || max_num < 1 ||
+        n < 0 || c_ld < num_classes)
+        return LLV_E_BADARG;
+    if (n > 0 && (!boxes || !scores)) return LLV_E_BADARG;
+    if (workspace_bytes < llv_multiclass_nms_workspace_bytes(n, num_classes, max_num)) return LLV_E_WORKSPACE;
+    if (n > kMaxN || (long)num_classes * max_num > kMaxMerge || (long)n * num_classes > 0x7fffffffL) return LLV_E_UNSUPPORTED;
+    hipStream_t st = (hipStream_t)stream;
+    nms_init_once();
+    char* ws = (char*)workspace;
+    unsigned* maxc_u = (unsigned*)ws;
+    int* any = (int*)(ws + 8);
+    int* cls_cnt = (int*)(ws + al(16));
+    uint64_t* cls_keys = (uint64_t*)(ws + al(16) + al((size_t)num_classes * 4));
+    hipLaunchKernelGGL(nms_prepare_kernel, dim3(1), dim3(1024), 0, st, boxes, scores, n, num_classes, c_ld,
+                       score_thr, maxc_u, any, cls_cnt);
+    if (n > 0) {
+        int np2 = 1;
+        while (np2 < n) np2 <<= 1;
+        const size_t lds = (size_t)np2 * 8 + (size_t)max_num * 16 + 17 * 4;
+        hipLaunchKernelGGL(nms_class_kernel, dim3(num_classes), dim3(256), lds, st, boxes, scores, n, num_classes,
+                           c_ld, score_thr, iou_thr, max_num, maxc_u, any, cls_cnt, cls_keys);
+    }
+    int mp2 = 1;
+    while (mp2 < num_classes * max_num) mp2 <<= 1;
+    hipLaunchKernelGGL(nms_merge_kernel, dim3(1), dim3(1024), (size_t)mp2 * 8, st, boxes, num_classes, max_num, any,
+                       cls_cnt, cls_keys, dets, labels, count, keep_flat);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" size_t llv_nms_workspace_bytes(int n) {
+    if (n < 0) return 0;
+    return al((size_t)(n > 0 ? n : 1) * 16) + al((size_t)(n > 0 ? n : 1) * 8);
+}
+
+extern "C" int llv_nms(const float* boxes, const float* scores, int n, float iou_thr, int64_t* keep,
+                       int32_t* count, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!keep || !count || !workspace || n < 0) return LLV_E_BADARG;
+    if (n > kMaxN) return LLV_E_UNSUPPORTED;
+    if (workspace_bytes < llv_nms_workspace_bytes(n)) return LLV_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (n == 0) return hipMemsetAsync(count, 0, 4, st) == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+    if (!boxes || !scores) return LLV_E_BADARG;
+    nms_init_once();
+    char* ws = (char*)workspace;
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    hipLaunchKernelGGL(nms_plain_kernel, dim3(1), dim3(256), (size_t)np2 * 8, st, boxes, scores, n, iou_thr, keep,
+                       count, (float4*)ws, (uint64_t*)(ws + al((size_t)n * 16)));
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}

@@ -1,0 +1,203 @@
+// train_ops.hip -- training-side kernels of the dense head: sigmoid focal loss (fwd/bwd) and the
+// MaxIoUAssigner (IoU matrix + both arg-maxes + low-quality matching, no k x n matrix in HBM).
+//
+// Reference:
+//   mmcv.ops.sigmoid_focal_loss (mmcv-full 1.3.0, un-vendored) called from
+//     mmdetection/mmdet/models/losses/focal_loss.py:59-98; CPU restatement py_sigmoid_focal_loss :11-56
+//   MaxIoUAssigner.assign_wrt_overlaps  mmdetection/mmdet/core/bbox/assigners/max_iou_assigner.py:134-212
+//   bbox_overlaps (mode='iou', eps=1e-6) mmdetection/mmdet/core/bbox/iou_calculators/iou2d_calculator.py:96-159
+// Built with -ffp-contract=off (IoU values are compared for equality in the low-quality match).
+
+#include <hip/hip_runtime.h>
+#include <float.h>
+#include "llv.h"
+#include "sort_util.h"
+
+namespace {
+
+__global__ void focal_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ t, float* __restrict__ out,
+                                 long n, int c, float gamma, float alpha) {
+    const long total = n * c;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c;
+        const int cls = (int)(i - r * c);
+        const bool pos = t[r] == (int64_t)cls;
+        const float p = 1.f / (1.f + expf(-x[i]));
+        const float term_p = powf(1.f - p, gamma) * logf(fmaxf(p, FLT_MIN));
+        const float term_n = powf(p, gamma) * logf(fmaxf(1.f - p, FLT_MIN));
+        out[i] = pos ? -alpha * term_p : -(1.f - alpha) * term_n;
+    }
+}
+
+__global__ void focal_bwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ t, float* __restrict__ g,
+                                 long n, int c, float gamma, float alpha) {
+    const long total = n * c;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c;
+        const int cls = (int)(i - r * c);
+        const bool pos = t[r] == (int64_t)cls;
+        const float p = 1.f / (1.f + expf(-x[i]));
+        const float gp = powf(1.f - p, gamma) * (1.f - p - gamma * p * logf(fmaxf(p, FLT_MIN)));
+        const float gn = powf(p, gamma) * (gamma * (1.f - p) * logf(fmaxf(1.f - p, FLT_MIN)) - p);
+        g[i] = pos ? -alpha * gp : -(1.f - alpha) * gn;
+    }
+}
+
+__device__ __forceinline__ float iou_eps(const float4 g, const float4 b) {
+    const float area1 = (g.z - g.x) * (g.w - g.y);
+    const float area2 = (b.z - b.x) * (b.w - b.y);
+    const float ltx = fmaxf(g.x, b.x), lty = fmaxf(g.y, b.y);
+    const float rbx = fminf(g.z, b.z), rby = fminf(g.w, b.w);
+    const float w = fmaxf(rbx - ltx, 0.f), h = fmaxf(rby - lty, 0.f);
+    const float overlap = w * h;
+    const float uni = fmaxf(area1 + area2 - overlap, 1e-6f);
+    return overlap / uni;
+}
+
+// pass A: per anchor max/argmax over gts; per gt max over anchors (ordered-uint atomicMax)
+__global__ void assign_pass_a(const float4* __restrict__ gt, int k, const float4* __restrict__ an,
+                              const uint8_t* __restrict__ valid, long n, float* __restrict__ max_ov,
+                              int* __restrict__ argmax, unsigned* gt_max_u) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    float4* sgt = reinterpret_cast<float4*>(sm);
+    for (int j = threadIdx.x; j < k; j += blockDim.x) sgt[j] = gt[j];
+    __syncthreads();
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    const bool ok = i < n && (!valid || valid[i]);
+    float4 b = make_float4(0, 0, 0, 0);
+    if (ok) b = an[i];
+    float best = -1.f;
+    int bi = 0;
+    for (int j = 0; j < k; ++j) {
+        float v = ok ? iou_eps(sgt[j], b) : -1.f;
+        if (ok && v > best) { best = v; bi = j; }
+        // wave max for gt j
+        unsigned u = ok ? llv::f32_ordered(v) : 0u;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            const unsigned t = __shfl_xor(u, o);
+            u = t > u ? t : u;
+        }
+        if ((threadIdx.x & 63) == 0 && u) atomicMax(&gt_max_u[j], u);
+    }
+    if (i < n) {
+        max_ov[i] = ok ? best : 0.f;
+        argmax[i] = bi;
+    }
+}
+
+// pass B (gt_max_assign_all == False): first anchor index reaching each gt's max
+__global__ void assign_pass_b(const float4* __restrict__ gt, int k, const float4* __restrict__ an,
+                              const uint8_t* __restrict__ valid, long n, const unsigned* gt_max_u, int* gt_argmax) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n || (valid && !valid[i])) return;
+    const float4 b = an[i];
+    for (int j = 0; j < k; ++j) {
+        const float v = iou_eps(gt[j], b);
+        if (llv::f32_ordered(v) == gt_max_u[j]) atomicMin(&gt_argmax[j], (int)i);
+    }
+}
+
+__global__ void assign_pass_c(const float4* __restrict__ gt, int k, const float4* __restrict__ an,
+                              const uint8_t* __restrict__ valid, long n, const float* __restrict__ max_ov,
+                              const int* __restrict__ argmax, const unsigned* gt_max_u, const int* gt_argmax,
+                              float pos_thr, float neg_thr, float min_pos, int low_q, int assign_all,
+                              int64_t* __restrict__ out) {
+    const long i = blockIdx.x * (long)blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    if (valid && !valid[i]) { out[i] = -1; return; }
+    int64_t a = -1;
+    const float mo = max_ov[i];
+    if (mo >= 0.f && mo < neg_thr) a = 0;
+    if (mo >= pos_thr) a = (int64_t)argmax[i] + 1;
+    if (low_q) {
+        const float4 b = an[i];
+        for (int j = 0; j < k; ++j) {
+            const float gm = llv::f32_unordered(gt_max_u[j]);
+            if (!(gm >= min_pos)) continue;
+            if (assign_all) {
+                if (iou_eps(gt[j], b) == gm) a = j + 1;
+            } else if (gt_argmax[j] == (int)i) {
+                a = j + 1;
+            }
+        }
+    }
+    out[i] = a;
+}
+
+__global__ void fill_i64(int64_t* p, long n, int64_t v) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) p[i] = v;
+}
+__global__ void init_gt_ws(unsigned* gt_max_u, int* gt_argmax, int k) {
+    for (int j = threadIdx.x; j < k; j += blockDim.x) { gt_max_u[j] = 0u; gt_argmax[j] = 0x7fffffff; }
+}
+
+inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
+inline int grid1d(long n, int b) {
+    long g = (n + b - 1) / b;
+    return (int)(g < 1 ? 1 : g);
+}
+
+}  // namespace
+
+extern "C" int llv_sigmoid_focal_loss_fwd(const float* logits, const int64_t* labels, float* loss, int64_t n, int c,
+                                          float gamma, float alpha, void* stream) {
+    if (n < 0 || c < 1) return LLV_E_BADARG;
+    if (n == 0) return LLV_OK;
+    if (!logits || !labels || !loss) return LLV_E_BADARG;
+    long g = (n * c + 255) / 256;
+    g = g > 8192 ? 8192 : g;
+    hipLaunchKernelGGL(focal_fwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, logits, labels, loss,
+                       (long)n, c, gamma, alpha);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_sigmoid_focal_loss_bwd(const float* logits, const int64_t* labels, float* grad, int64_t n, int c,
+                                          float gamma, float alpha, void* stream) {
+    if (n < 0 || c < 1) return LLV_E_BADARG;
+    if (n == 0) return LLV_OK;
+    if (!logits || !labels || !grad) return LLV_E_BADARG;
+    long g = (n * c + 255) / 256;
+    g = g > 8192 ? 8192 : g;
+    hipLaunchKernelGGL(focal_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, logits, labels, grad,
+                       (long)n, c, gamma, alpha);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" size_t llv_iou_assign_workspace_bytes(int k, int64_t n) {
+    if (k < 0 || n < 0) return 0;
+    return al((size_t)(k > 0 ? k : 1) * 4) * 2 + al((size_t)(n > 0 ? n : 1) * 4);
+}
+
+extern "C" int llv_iou_assign(const float* gt, int k, const float* anchors, const uint8_t* valid, int64_t n,
+                              float pos_iou_thr, float neg_iou_thr, float min_pos_iou, int match_low_quality,
+                              int gt_max_assign_all, int64_t* assigned_gt_inds, float* max_overlaps, void* workspace,
+                              size_t workspace_bytes, void* stream) {
+    if (k < 0 || n < 0 || k > 4096) return LLV_E_BADARG;
+    if (n == 0) return LLV_OK;
+    if (!anchors || !assigned_gt_inds || !max_overlaps || !workspace) return LLV_E_BADARG;
+    if (workspace_bytes < llv_iou_assign_workspace_bytes(k, n)) return LLV_E_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    if (k == 0) {  // max_iou_assigner.py:150-153: everything is background
+        hipLaunchKernelGGL(fill_i64, dim3(grid1d(n, 256) > 4096 ? 4096 : grid1d(n, 256)), dim3(256), 0, st,
+                           assigned_gt_inds, (long)n, (int64_t)0);
+        if (hipMemsetAsync(max_overlaps, 0, (size_t)n * 4, st) != hipSuccess) return LLV_E_LAUNCH;
+        return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+    }
+    if (!gt) return LLV_E_BADARG;
+    char* ws = (char*)workspace;
+    unsigned* gt_max_u = (unsigned*)ws;
+    int* gt_argmax = (int*)(ws + al((size_t)k * 4));
+    int* argmax = (int*)(ws + 2 * al((size_t)k * 4));
+    hipLaunchKernelGGL(init_gt_ws, dim3(1), dim3(256), 0, st, gt_max_u, gt_argmax, k);
+    const int g = grid1d(n, 256);
+    hipLaunchKernelGGL(assign_pass_a, dim3(g), dim3(256), (size_t)k * 16, st, (const float4*)gt, k,
+                       (const float4*)anchors, valid, (long)n, max_overlaps, argmax, gt_max_u);
+    if (match_low_quality && !gt_max_assign_all)
+        hipLaunchKernelGGL(assign_pass_b, dim3(g), dim3(256), 0, st, (const float4*)gt, k, (const float4*)anchors, valid,
+                           (long)n, gt_max_u, gt_argmax);
+    hipLaunchKernelGGL(assign_pass_c, dim3(g), dim3(256), 0, st, (const float4*)gt, k, (const float4*)anchors, valid,
+                       (long)n, max_overlaps, argmax, gt_max_u, gt_argmax, pos_iou_thr, neg_iou_thr, min_pos_iou,
+                       match_low_quality, gt_max_assign_all, assigned_gt_inds);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}

@@ -1,0 +1,450 @@
+"""Torch-facing wrappers over the C ABI (include/llv.h). Tensors only carry device memory and the
+stream; all arithmetic happens in libllv.so. Every function raises if the library is missing or
+the tensors are not on a GPU -- there is no CPU path here (the CPU restatement lives in oracle/).
+"""
+import ctypes as C
+import math
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib
+from ._lib import (CONV_OUT_F32, CONV_PIXSHUF, CONV_RELU, CONV_RES_ADD, CONV_RES_RSUB, CONV_RES_UPS,
+                   ConvDesc, DecodeDesc, LlvError, check, lib)
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return C.c_void_p(t.data_ptr()) if t is not None else C.c_void_p(0)
+
+
+def _need_gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise LlvError('llv ops need tensors on an MI355X device; the CPU restatement is oracle/, '
+                           'not a fallback of this package')
+
+
+def round_up(v, m):
+    return (v + m - 1) // m * m
+
+
+# ----------------------------------------------------------------------------------------------
+# convolution
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class PackedConv:
+    """Weights of one conv launch in the layout llv_conv2d_nhwc_fwd reads (see include/llv.h)."""
+    w: torch.Tensor          # fp16 [groups, w_rows, k_pad]
+    bias: torch.Tensor       # fp32 [groups * cout]
+    cin: int                 # per-group padded input channels (multiple of 8)
+    cout: int                # per-group stored output channels (multiple of 4)
+    w_rows: int
+    k_pad: int
+    kh: int
+    kw: int
+    stride: int
+    pad: int
+    groups: int = 1
+    n_src: int = 1
+    src_cvec: int = 0
+    true_macs_per_pixel: int = 0   # unpadded Cout*Cin/g*kh*kw, for FLOP accounting
+
+    def to(self, device):
+        self.w = self.w.to(device)
+        self.bias = self.bias.to(device)
+        return self
+
+
+def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], stride=1, pad=0,
+              in_map: Optional[Sequence[int]] = None, cout_store: Optional[int] = None,
+              n_src: int = 1, bn=None, eps: float = 1e-5) -> PackedConv:
+    """Pack a dense conv weight [Cout, Cin, kh, kw] (fp32) for the implicit-GEMM kernel.
+
+    in_map[j] = original input channel feeding padded channel j, or -1 for a zero channel; default is
+    identity padded to a multiple of 8. `bn` = (gamma, beta, running_mean, running_var) folds an
+    eval-mode BatchNorm2d that follows the conv (norm_eval / frozen stats, resnet.py:642-651):
+    w' = w * gamma / sqrt(var + eps), b' = beta + (b - mean) * gamma / sqrt(var + eps).
+    """
+    weight = weight.detach().double().cpu()
+    cout, cin, kh, kw = weight.shape
+    b = torch.zeros(cout, dtype=torch.float64) if bias is None else bias.detach().double().cpu()
+    if bn is not None:
+        gamma, beta, mean, var = [t.detach().double().cpu() for t in bn]
+        s = gamma / torch.sqrt(var + eps)
+        weight = weight * s.view(-1, 1, 1, 1)
+        b = beta + (b - mean) * s
+    if in_map is None:
+        in_map = list(range(cin)) + [-1] * (round_up(cin, 8) - cin)
+    cin_pad = len(in_map)
+    assert cin_pad % 8 == 0
+    if cout_store is None:
+        cout_store = round_up(cout, 4)
+    assert cout_store % 4 == 0 and cout_store >= cout
+    w_rows = round_up(cout_store, 16)
+    k = kh * kw * cin_pad
+    k_pad = round_up(k, 32)
+    wp = torch.zeros(w_rows, kh, kw, cin_pad, dtype=torch.float64)
+    idx = torch.tensor([j for j, s in enumerate(in_map) if s >= 0], dtype=torch.long)
+    src = torch.tensor([s for s in in_map if s >= 0], dtype=torch.long)
+    wp[:cout][:, :, :, idx] = weight.permute(0, 2, 3, 1)[:, :, :, src]
+    wfull = torch.zeros(w_rows, k_pad, dtype=torch.float64)
+    wfull[:, :k] = wp.reshape(w_rows, k)
+    bfull = torch.zeros(cout_store, dtype=torch.float64)
+    bfull[:cout] = b
+    return PackedConv(w=wfull.to(torch.float16).unsqueeze(0).contiguous(), bias=bfull.float().contiguous(),
+                      cin=cin_pad, cout=cout_store, w_rows=w_rows, k_pad=k_pad, kh=kh, kw=kw, stride=stride,
+                      pad=pad, groups=1, n_src=n_src, src_cvec=(cin_pad // 8 // n_src) if n_src > 1 else 0,
+                      true_macs_per_pixel=cout * cin * kh * kw)
+
+
+def stack_groups(pcs: List[PackedConv]) -> PackedConv:
+    """Several equal-shape convs as one grouped launch (RetinaHead cls/reg towers side by side)."""
+    p0 = pcs[0]
+    for p in pcs:
+        assert (p.cin, p.cout, p.w_rows, p.k_pad, p.kh, p.kw, p.stride, p.pad, p.groups, p.n_src) == \
+               (p0.cin, p0.cout, p0.w_rows, p0.k_pad, p0.kh, p0.kw, p0.stride, p0.pad, 1, 1)
+    return PackedConv(w=torch.cat([p.w for p in pcs], 0).contiguous(), bias=torch.cat([p.bias for p in pcs]).contiguous(),
+                      cin=p0.cin, cout=p0.cout, w_rows=p0.w_rows, k_pad=p0.k_pad, kh=p0.kh, kw=p0.kw,
+                      stride=p0.stride, pad=p0.pad, groups=len(pcs),
+                      true_macs_per_pixel=sum(p.true_macs_per_pixel for p in pcs))
+
+
+def concat_cout(pcs: List[PackedConv]) -> PackedConv:
+    """Convs sharing the input, outputs concatenated along C (one launch, N = sum of couts)."""
+    p0 = pcs[0]
+    for p in pcs:
+        assert (p.cin, p.k_pad, p.kh, p.kw, p.stride, p.pad, p.groups, p.n_src) == \
+               (p0.cin, p0.k_pad, p0.kh, p0.kw, p0.stride, p0.pad, 1, 1)
+    cout = sum(p.cout for p in pcs)
+    w_rows = round_up(cout, 16)
+    w = torch.zeros(1, w_rows, p0.k_pad, dtype=torch.float16)
+    r = 0
+    for p in pcs:
+        w[0, r:r + p.cout] = p.w[0, :p.cout].cpu()
+        r += p.cout
+    return PackedConv(w=w.contiguous(), bias=torch.cat([p.bias.cpu() for p in pcs]).contiguous(), cin=p0.cin,
+                      cout=cout, w_rows=w_rows, k_pad=p0.k_pad, kh=p0.kh, kw=p0.kw, stride=p0.stride, pad=p0.pad,
+                      true_macs_per_pixel=sum(p.true_macs_per_pixel for p in pcs))
+
+
+def conv_out_size(h, w, pc: PackedConv):
+    return (h + 2 * pc.pad - pc.kh) // pc.stride + 1, (w + 2 * pc.pad - pc.kw) // pc.stride + 1
+
+
+def make_conv_desc(pc: PackedConv, xs: Sequence[torch.Tensor], y: torch.Tensor, batch: int,
+                   segs: Sequence[tuple], x_ld: int, y_ld: int, res: Optional[torch.Tensor] = None,
+                   res_ld: int = 0, flags: int = 0, res_hw=(0, 0), tile: int = 0) -> ConvDesc:
+    """segs: [(h, w, ho, wo, x_pixel_off, y_pixel_off), ...]"""
+    d = ConvDesc()
+    for i in range(_lib.LLV_MAX_SRC):
+        d.x[i] = xs[i].data_ptr() if i < len(xs) else 0
+    d.w = pc.w.data_ptr()
+    d.bias = pc.bias.data_ptr()
+    d.res = res.data_ptr() if res is not None else 0
+    d.y = y.data_ptr()
+    d.n_src, d.src_cvec = pc.n_src, pc.src_cvec
+    d.x_ld, d.y_ld, d.res_ld = x_ld, y_ld, res_ld
+    d.cin, d.cout, d.w_rows, d.k_pad = pc.cin, pc.cout, pc.w_rows, pc.k_pad
+    d.kh, d.kw, d.stride, d.pad = pc.kh, pc.kw, pc.stride, pc.pad
+    d.groups, d.batch = pc.groups, batch
+    d.n_seg = len(segs)
+    for s, (h, w, ho, wo, xo, yo) in enumerate(segs):
+        d.seg_h[s], d.seg_w[s], d.seg_ho[s], d.seg_wo[s] = h, w, ho, wo
+        d.seg_xoff[s], d.seg_yoff[s] = xo, yo
+    d.flags = flags
+    d.res_h, d.res_w = res_hw
+    d.tile = tile
+    return d
+
+
+def launch_conv(desc: ConvDesc):
+    check(lib().llv_conv2d_nhwc_fwd(C.byref(desc), _stream()), 'llv_conv2d_nhwc_fwd')
+
+
+def conv2d(x, pc: PackedConv, res: Optional[torch.Tensor] = None, flags: int = 0, out: Optional[torch.Tensor] = None,
+           tile: int = 0) -> torch.Tensor:
+    """Single-segment convenience: x is (N,H,W,C) fp16 NHWC, or a list of n_src such tensors."""
+    xs = list(x) if isinstance(x, (list, tuple)) else [x]
+    _need_gpu(*xs, pc.w, pc.bias, res, out)
+    n, h, w, cx = xs[0].shape
+    for t in xs:
+        assert t.dtype == torch.float16 and t.is_contiguous() and t.shape[:3] == (n, h, w)
+    ho, wo = conv_out_size(h, w, pc)
+    ctot = pc.groups * pc.cout
+    if flags & CONV_PIXSHUF:
+        oshape = (n, 2 * ho, 2 * wo, ctot // 4)
+    else:
+        oshape = (n, ho, wo, ctot)
+    if out is None:
+        out = torch.empty(oshape, device=xs[0].device, dtype=torch.float32 if flags & CONV_OUT_F32 else torch.float16)
+    else:
+        assert out.shape[:3] == oshape[:3] and out.is_contiguous()
+    res_hw = (0, 0)
+    if res is not None:
+        assert res.dtype == torch.float16 and res.is_contiguous()
+        if flags & CONV_RES_UPS:
+            res_hw = (res.shape[1], res.shape[2])
+    d = make_conv_desc(pc, xs, out, n, [(h, w, ho, wo, 0, 0)], cx, out.shape[3], res,
+                       res.shape[3] if res is not None else 0, flags, res_hw, tile)
+    launch_conv(d)
+    return out
+
+
+def conv_flops(desc: ConvDesc) -> float:
+    return lib().llv_conv2d_flops(C.byref(desc))
+
+
+# ----------------------------------------------------------------------------------------------
+# layout / pooling
+# ----------------------------------------------------------------------------------------------
+def maxpool3x3s2(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    _need_gpu(x)
+    n, h, w, c = x.shape
+    assert x.dtype == torch.float16 and x.is_contiguous()
+    ho, wo = (h - 1) // 2 + 1, (w - 1) // 2 + 1
+    if out is None:
+        out = torch.empty((n, ho, wo, c), device=x.device, dtype=torch.float16)
+    check(lib().llv_maxpool3x3s2_nhwc(_ptr(x), _ptr(out), n, h, w, c, _stream()), 'llv_maxpool3x3s2_nhwc')
+    return out
+
+
+def pack_input(x: torch.Tensor, c_pad: int = 8, scale: Optional[torch.Tensor] = None,
+               shift: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """NCHW fp32 -> NHWC fp16 with zero channel padding (optionally x*scale+shift per channel)."""
+    _need_gpu(x)
+    assert x.dtype == torch.float32 and x.is_contiguous()
+    n, c, h, w = x.shape
+    if out is None:
+        out = torch.empty((n, h, w, c_pad), device=x.device, dtype=torch.float16)
+    check(lib().llv_pack_nchw_f32_to_nhwc_f16(_ptr(x), _ptr(out), n, c, h, w, c_pad, _ptr(scale), _ptr(shift),
+                                               _stream()), 'llv_pack_nchw_f32_to_nhwc_f16')
+    return out
+
+
+def unpack_output(x: torch.Tensor, c: int) -> torch.Tensor:
+    """NHWC fp16/fp32 (first c channels) -> NCHW fp32."""
+    _need_gpu(x)
+    assert x.is_contiguous()
+    n, h, w, ld = x.shape
+    out = torch.empty((n, c, h, w), device=x.device, dtype=torch.float32)
+    if x.dtype == torch.float16:
+        check(lib().llv_unpack_nhwc_f16_to_nchw_f32(_ptr(x), _ptr(out), n, c, h, w, ld, _stream()), 'unpack f16')
+    elif x.dtype == torch.float32:
+        check(lib().llv_unpack_nhwc_f32_to_nchw_f32(_ptr(x), _ptr(out), n, c, h, w, ld, _stream()), 'unpack f32')
+    else:
+        raise LlvError('unpack_output: fp16 or fp32 only')
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# post-processing
+# ----------------------------------------------------------------------------------------------
+@dataclass
+class DecodePlan:
+    """Everything llv_retina_decode_topk needs for a fixed pyramid geometry (buffers are reused)."""
+    desc: DecodeDesc
+    boxes: torch.Tensor
+    scores: torch.Tensor
+    cand_anchor: torch.Tensor
+    workspace: torch.Tensor
+    base_anchors: torch.Tensor
+    n_cand: int
+    keep: list = field(default_factory=list)
+
+
+def make_decode_plan(cls: torch.Tensor, reg: torch.Tensor, level_hw, strides, cls_off, reg_off, cls_ld, reg_ld,
+                     num_classes, num_anchors, base_anchors, nms_pre, means, stds, wh_ratio_clip, img_shape,
+                     scale_factor, rescale) -> DecodePlan:
+    _need_gpu(cls, reg)
+    d = DecodeDesc()
+    d.n_levels = len(level_hw)
+    d.num_classes, d.num_anchors, d.nms_pre = num_classes, num_anchors, nms_pre
+    for l, ((h, w), s) in enumerate(zip(level_hw, strides)):
+        d.level_h[l], d.level_w[l] = h, w
+        sw, sh = (s, s) if isinstance(s, int) else s
+        d.stride_w[l], d.stride_h[l] = sw, sh
+        d.cls_off[l], d.reg_off[l] = cls_off[l], reg_off[l]
+    d.cls_ld, d.reg_ld = cls_ld, reg_ld
+    assert cls.dtype == reg.dtype and cls.dtype in (torch.float16, torch.float32)
+    d.logits_f32 = 1 if cls.dtype == torch.float32 else 0
+    d.cls, d.reg = cls.data_ptr(), reg.data_ptr()
+    ba = torch.stack([b.float() for b in base_anchors]).contiguous().to(cls.device)  # [L][A][4]
+    d.base_anchors = ba.data_ptr()
+    for e in range(4):
+        d.means[e], d.stds[e] = float(means[e]), float(stds[e])
+    d.max_ratio = float(np.float32(np.abs(np.log(wh_ratio_clip))))
+    if img_shape is not None:
+        d.clip, d.img_h, d.img_w = 1, float(img_shape[0]), float(img_shape[1])
+    else:
+        d.clip, d.img_h, d.img_w = 0, 0.0, 0.0
+    sf = np.asarray(scale_factor, dtype=np.float32).reshape(-1)
+    if sf.size == 1:
+        sf = np.repeat(sf, 4)
+    for e in range(4):
+        d.scale_factor[e] = float(sf[e])
+    d.rescale = 1 if rescale else 0
+    n_cand = lib().llv_retina_decode_ncand(C.byref(d))
+    if n_cand < 0:
+        check(n_cand, 'llv_retina_decode_ncand')
+    d.n_cand = n_cand
+    dev = cls.device
+    boxes = torch.empty((n_cand, 4), device=dev, dtype=torch.float32)
+    scores = torch.empty((n_cand, num_classes), device=dev, dtype=torch.float32)
+    cand = torch.empty((n_cand,), device=dev, dtype=torch.int32)
+    wsb = lib().llv_retina_decode_workspace_bytes(C.byref(d))
+    ws = torch.empty((max(wsb, 256),), device=dev, dtype=torch.uint8)
+    d.boxes, d.scores, d.cand_anchor = boxes.data_ptr(), scores.data_ptr(), cand.data_ptr()
+    d.workspace, d.workspace_bytes = ws.data_ptr(), wsb
+    return DecodePlan(d, boxes, scores, cand, ws, ba, n_cand, keep=[cls, reg])
+
+
+def retina_decode_topk(plan: DecodePlan):
+    check(lib().llv_retina_decode_topk(C.byref(plan.desc), _stream()), 'llv_retina_decode_topk')
+    return plan.boxes, plan.scores
+
+
+class NmsBuffers:
+    def __init__(self, n, num_classes, max_num, device):
+        self.n, self.num_classes, self.max_num = n, num_classes, max_num
+        self.dets = torch.zeros((max_num, 5), device=device, dtype=torch.float32)
+        self.labels = torch.zeros((max_num,), device=device, dtype=torch.int64)
+        self.count = torch.zeros((1,), device=device, dtype=torch.int32)
+        self.keep_flat = torch.zeros((max_num,), device=device, dtype=torch.int32)
+        self.ws_bytes = lib().llv_multiclass_nms_workspace_bytes(n, num_classes, max_num)
+        self.ws = torch.empty((max(self.ws_bytes, 256),), device=device, dtype=torch.uint8)
+
+
+def multiclass_nms_into(boxes, scores, score_thr, iou_thr, bufs: NmsBuffers, num_classes=None):
+    """Stream-ordered, no host sync; results land in bufs (dets, labels, count, keep_flat)."""
+    _need_gpu(boxes, scores)
+    assert boxes.dtype == torch.float32 and scores.dtype == torch.float32
+    assert boxes.is_contiguous() and scores.is_contiguous()
+    n = boxes.shape[0]
+    ncls = num_classes if num_classes is not None else scores.shape[1]
+    assert n <= bufs.n and ncls == bufs.num_classes
+    check(lib().llv_multiclass_nms(_ptr(boxes), _ptr(scores), n, ncls, scores.shape[1], float(score_thr),
+                                   float(iou_thr), bufs.max_num, _ptr(bufs.dets), _ptr(bufs.labels), _ptr(bufs.count),
+                                   _ptr(bufs.keep_flat), _ptr(bufs.ws), bufs.ws_bytes, _stream()),
+          'llv_multiclass_nms')
+
+
+def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, return_inds=False):
+    """Same signature and return values as mmdet.core.multiclass_nms (bbox_nms.py:7-93).
+
+    multi_scores carries the background column last, which is ignored, as in the reference.
+    """
+    _need_gpu(multi_bboxes, multi_scores)
+    if multi_bboxes.shape[1] > 4:
+        raise LlvError('class-specific boxes (n, #class*4) are not on the dense-head path')
+    num_classes = multi_scores.shape[1] - 1
+    n = multi_bboxes.shape[0]
+    iou_thr = nms_cfg.get('iou_threshold', nms_cfg.get('iou_thr'))
+    if nms_cfg.get('type', 'nms') != 'nms':
+        raise LlvError(f"nms type {nms_cfg.get('type')} not supported")
+    cap = max_num if max_num > 0 else n * num_classes
+    bufs = NmsBuffers(max(n, 1), num_classes, max(cap, 1), multi_bboxes.device)
+    multiclass_nms_into(multi_bboxes.float().contiguous(), multi_scores.float().contiguous(), score_thr, iou_thr, bufs,
+                        num_classes)
+    k = int(bufs.count.item())
+    dets, labels = bufs.dets[:k].clone(), bufs.labels[:k].clone()
+    if return_inds:
+        return dets, labels, bufs.keep_flat[:k].long()
+    return dets, labels
+
+
+def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float, offset: int = 0):
+    """mmcv.ops.nms(boxes, scores, iou_threshold, offset=0) -> (dets (k,5), keep (k,) int64)."""
+    _need_gpu(boxes, scores)
+    if offset != 0:
+        raise LlvError('offset=1 (legacy areas) is not used on this path')
+    n = boxes.shape[0]
+    boxes = boxes.float().contiguous()
+    scores = scores.float().contiguous()
+    keep = torch.empty((max(n, 1),), device=boxes.device, dtype=torch.int64)
+    count = torch.zeros((1,), device=boxes.device, dtype=torch.int32)
+    wsb = lib().llv_nms_workspace_bytes(n)
+    ws = torch.empty((max(wsb, 256),), device=boxes.device, dtype=torch.uint8)
+    check(lib().llv_nms(_ptr(boxes), _ptr(scores), n, float(iou_threshold), _ptr(keep), _ptr(count), _ptr(ws), wsb,
+                        _stream()), 'llv_nms')
+    k = int(count.item())
+    keep = keep[:k]
+    dets = torch.cat([boxes[keep], scores[keep, None]], dim=1)
+    return dets, keep
+
+
+# ----------------------------------------------------------------------------------------------
+# temporal
+# ----------------------------------------------------------------------------------------------
+def embed_aggregate(x_embed, ref_embed, ref, out=None):
+    """x_embed (1,H,W,C), ref_embed (N,H,W,C), ref (N,H,W,C) fp16 NHWC -> (1,H,W,C)."""
+    _need_gpu(x_embed, ref_embed, ref)
+    n, h, w, c = ref.shape
+    assert x_embed.shape == (1, h, w, c) and ref_embed.shape == (n, h, w, c)
+    for t in (x_embed, ref_embed, ref):
+        assert t.dtype == torch.float16 and t.is_contiguous()
+    if out is None:
+        out = torch.empty((1, h, w, c), device=ref.device, dtype=torch.float16)
+    check(lib().llv_embed_aggregate(_ptr(x_embed), _ptr(ref_embed), _ptr(ref), _ptr(out), n, h * w, c, c, c, c,
+                                    _stream()), 'llv_embed_aggregate')
+    return out
+
+
+def flow_warp(x, flow, out=None):
+    """x (N,H,W,C) fp16 NHWC, flow (N,2,Hf,Wf) fp32 NCHW -> warped (N,H,W,C) fp16."""
+    _need_gpu(x, flow)
+    n, h, w, c = x.shape
+    assert x.dtype == torch.float16 and x.is_contiguous() and flow.dtype == torch.float32 and flow.is_contiguous()
+    assert flow.shape[0] == n and flow.shape[1] == 2
+    if out is None:
+        out = torch.empty_like(x)
+    check(lib().llv_flow_warp(_ptr(x), _ptr(flow), _ptr(out), n, h, w, c, c, flow.shape[2], flow.shape[3], _stream()),
+          'llv_flow_warp')
+    return out
+
+
+# ----------------------------------------------------------------------------------------------
+# training-side
+# ----------------------------------------------------------------------------------------------
+def sigmoid_focal_loss_fwd(logits, labels, gamma=2.0, alpha=0.25):
+    _need_gpu(logits, labels)
+    logits = logits.float().contiguous()
+    labels = labels.long().contiguous()
+    n, c = logits.shape
+    out = torch.empty_like(logits)
+    check(lib().llv_sigmoid_focal_loss_fwd(_ptr(logits), _ptr(labels), _ptr(out), n, c, gamma, alpha, _stream()),
+          'llv_sigmoid_focal_loss_fwd')
+    return out
+
+
+def sigmoid_focal_loss_bwd(logits, labels, gamma=2.0, alpha=0.25):
+    _need_gpu(logits, labels)
+    logits = logits.float().contiguous()
+    labels = labels.long().contiguous()
+    n, c = logits.shape
+    out = torch.empty_like(logits)
+    check(lib().llv_sigmoid_focal_loss_bwd(_ptr(logits), _ptr(labels), _ptr(out), n, c, gamma, alpha, _stream()),
+          'llv_sigmoid_focal_loss_bwd')
+    return out
+
+
+def iou_assign(gt_bboxes, anchors, valid=None, pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0.0,
+               match_low_quality=True, gt_max_assign_all=True):
+    _need_gpu(gt_bboxes, anchors, valid)
+    gt = gt_bboxes.float().contiguous()
+    an = anchors.float().contiguous()
+    k, n = gt.shape[0], an.shape[0]
+    v = valid.to(torch.uint8).contiguous() if valid is not None else None
+    assigned = torch.empty((n,), device=an.device, dtype=torch.int64)
+    max_ov = torch.empty((n,), device=an.device, dtype=torch.float32)
+    wsb = lib().llv_iou_assign_workspace_bytes(k, n)
+    ws = torch.empty((max(wsb, 256),), device=an.device, dtype=torch.uint8)
+    check(lib().llv_iou_assign(_ptr(gt), k, _ptr(an), _ptr(v), n, pos_iou_thr, neg_iou_thr, min_pos_iou,
+                               int(match_low_quality), int(gt_max_assign_all), _ptr(assigned), _ptr(max_ov), _ptr(ws), wsb,
+                               _stream()), 'llv_iou_assign')
+    return assigned, max_ov
