@@ -1,0 +1,198 @@
+"""ResNet backbone with the reference's constructor, parameter names and init
+(mmdetection/mmdet/models/backbones/resnet.py:12-666, utils/res_layer.py:5-103).
+The modules are parameter containers; forward builds/replays a HIP plan (engine.build_resnet)."""
+import torch
+import torch.nn as nn
+from torch.nn.modules.batchnorm import _BatchNorm
+
+from . import engine, ops
+from .cnn import constant_init, kaiming_init
+from .planned import PlannedModule
+from .registry import BACKBONES
+
+
+def _norm(norm_cfg, ch):
+    if norm_cfg.get('type', 'BN') != 'BN':
+        raise NotImplementedError(f'norm {norm_cfg} is outside the hot path (BN with running stats is folded into the conv)')
+    bn = nn.BatchNorm2d(ch)
+    for p in bn.parameters():
+        p.requires_grad = norm_cfg.get('requires_grad', True)
+    return bn
+
+
+class BasicBlock(nn.Module):
+    expansion = 1
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, style='pytorch', with_cp=False,
+                 conv_cfg=None, norm_cfg=dict(type='BN'), dcn=None, plugins=None):
+        super().__init__()
+        assert dcn is None, 'Not implemented yet.'
+        assert plugins is None, 'Not implemented yet.'
+        if dilation != 1:
+            raise NotImplementedError('dilated blocks are outside the hot path')
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=False)
+        self.bn1 = _norm(norm_cfg, planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
+        self.bn2 = _norm(norm_cfg, planes)
+        self.downsample = downsample
+        self.stride = stride
+
+    norm1 = property(lambda self: self.bn1)
+    norm2 = property(lambda self: self.bn2)
+
+
+class Bottleneck(nn.Module):
+    expansion = 4
+
+    def __init__(self, inplanes, planes, stride=1, dilation=1, downsample=None, style='pytorch', with_cp=False,
+                 conv_cfg=None, norm_cfg=dict(type='BN'), dcn=None, plugins=None):
+        super().__init__()
+        assert style in ['pytorch', 'caffe']
+        if dcn is not None or plugins is not None or dilation != 1:
+            raise NotImplementedError('dcn / plugins / dilation are outside the hot path')
+        self.style = style
+        s1, s2 = (1, stride) if style == 'pytorch' else (stride, 1)
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, stride=s1, bias=False)
+        self.bn1 = _norm(norm_cfg, planes)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=s2, padding=1, bias=False)
+        self.bn2 = _norm(norm_cfg, planes)
+        self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
+        self.bn3 = _norm(norm_cfg, planes * self.expansion)
+        self.downsample = downsample
+        self.stride = stride
+
+    norm1 = property(lambda self: self.bn1)
+    norm2 = property(lambda self: self.bn2)
+    norm3 = property(lambda self: self.bn3)
+
+
+class ResLayer(nn.Sequential):
+    """res_layer.py:5-103 (downsample_first=True, no avg_down)."""
+
+    def __init__(self, block, inplanes, planes, num_blocks, stride=1, avg_down=False, conv_cfg=None,
+                 norm_cfg=dict(type='BN'), downsample_first=True, insert_plugins=False, **kwargs):
+        if avg_down or not downsample_first:
+            raise NotImplementedError('avg_down / Hourglass ordering is outside the hot path')
+        self.block = block
+        downsample = None
+        if stride != 1 or inplanes != planes * block.expansion:
+            downsample = nn.Sequential(nn.Conv2d(inplanes, planes * block.expansion, 1, stride=stride, bias=False),
+                                       _norm(norm_cfg, planes * block.expansion))
+        layers = [block(inplanes=inplanes, planes=planes, stride=stride, downsample=downsample, conv_cfg=conv_cfg,
+                        norm_cfg=norm_cfg, **kwargs)]
+        inplanes = planes * block.expansion
+        for _ in range(1, num_blocks):
+            layers.append(block(inplanes=inplanes, planes=planes, stride=1, conv_cfg=conv_cfg, norm_cfg=norm_cfg, **kwargs))
+        super().__init__(*layers)
+
+
+@BACKBONES.register_module()
+class ResNet(PlannedModule):
+    """Same arguments as mmdet's ResNet (resnet.py:302-447).
+
+    Example (mirrors resnet.py:340-352, on a GPU):
+        >>> self = ResNet(depth=18).cuda().eval()
+        >>> outs = self.forward(torch.rand(1, 3, 32, 32).cuda())
+        >>> [tuple(o.shape) for o in outs]
+        [(1, 64, 8, 8), (1, 128, 4, 4), (1, 256, 2, 2), (1, 512, 1, 1)]
+    """
+    arch_settings = {18: (BasicBlock, (2, 2, 2, 2)), 34: (BasicBlock, (3, 4, 6, 3)), 50: (Bottleneck, (3, 4, 6, 3)),
+                     101: (Bottleneck, (3, 4, 23, 3)), 152: (Bottleneck, (3, 8, 36, 3))}
+
+    def __init__(self, depth, in_channels=3, stem_channels=None, base_channels=64, num_stages=4, strides=(1, 2, 2, 2),
+                 dilations=(1, 1, 1, 1), out_indices=(0, 1, 2, 3), style='pytorch', deep_stem=False, avg_down=False,
+                 frozen_stages=-1, conv_cfg=None, norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, dcn=None,
+                 stage_with_dcn=(False, False, False, False), plugins=None, with_cp=False, zero_init_residual=True):
+        super().__init__()
+        if depth not in self.arch_settings:
+            raise KeyError(f'invalid depth {depth} for resnet')
+        if deep_stem or avg_down or dcn is not None or plugins is not None or any(d != 1 for d in dilations) or in_channels != 3:
+            raise NotImplementedError('deep_stem / avg_down / dcn / plugins / dilation are outside the hot path')
+        self.depth = depth
+        stem_channels = stem_channels or base_channels
+        self.stem_channels, self.base_channels, self.num_stages = stem_channels, base_channels, num_stages
+        assert 1 <= num_stages <= 4
+        self.strides, self.dilations = strides, dilations
+        assert len(strides) == len(dilations) == num_stages
+        self.out_indices = out_indices
+        assert max(out_indices) < num_stages
+        self.style, self.frozen_stages, self.norm_cfg, self.norm_eval = style, frozen_stages, norm_cfg, norm_eval
+        self.zero_init_residual = zero_init_residual
+        self.block, stage_blocks = self.arch_settings[depth]
+        self.stage_blocks = stage_blocks[:num_stages]
+        self.inplanes = stem_channels
+        self.conv1 = nn.Conv2d(in_channels, stem_channels, 7, stride=2, padding=3, bias=False)
+        self.bn1 = _norm(norm_cfg, stem_channels)
+        self.res_layers = []
+        for i, num_blocks in enumerate(self.stage_blocks):
+            planes = base_channels * 2 ** i
+            layer = ResLayer(block=self.block, inplanes=self.inplanes, planes=planes, num_blocks=num_blocks,
+                             stride=strides[i], style=style, norm_cfg=norm_cfg)
+            self.inplanes = planes * self.block.expansion
+            name = f'layer{i + 1}'
+            self.add_module(name, layer)
+            self.res_layers.append(name)
+        self._freeze_stages()
+        self.feat_dim = self.block.expansion * base_channels * 2 ** (len(self.stage_blocks) - 1)
+
+    norm1 = property(lambda self: self.bn1)
+
+    def _freeze_stages(self):           # resnet.py:572-588
+        if self.frozen_stages >= 0:
+            self.bn1.eval()
+            for m in [self.conv1, self.bn1]:
+                for p in m.parameters():
+                    p.requires_grad = False
+        for i in range(1, self.frozen_stages + 1):
+            m = getattr(self, f'layer{i}')
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad = False
+
+    def init_weights(self, pretrained=None):   # resnet.py:590-620
+        if isinstance(pretrained, str):
+            from .checkpoint import load_checkpoint
+            load_checkpoint(self, pretrained, strict=False)
+        elif pretrained is None:
+            for m in self.modules():
+                if isinstance(m, nn.Conv2d):
+                    kaiming_init(m)
+                elif isinstance(m, (_BatchNorm, nn.GroupNorm)):
+                    constant_init(m, 1)
+            if self.zero_init_residual:
+                for m in self.modules():
+                    if isinstance(m, Bottleneck):
+                        constant_init(m.bn3, 0)
+                    elif isinstance(m, BasicBlock):
+                        constant_init(m.bn2, 0)
+        else:
+            raise TypeError('pretrained must be a str or None')
+        self.invalidate_plans()
+
+    def train(self, mode=True):         # resnet.py:642-651
+        super().train(mode)
+        self._freeze_stages()
+        if mode and self.norm_eval:
+            for m in self.modules():
+                if isinstance(m, _BatchNorm):
+                    m.eval()
+        return self
+
+    def plan_kwargs(self):
+        return dict(depth=self.depth, strides=self.strides, style=self.style, out_indices=self.out_indices,
+                    num_stages=self.num_stages)
+
+    def forward(self, x):
+        """NCHW fp32 image on the GPU -> tuple of NCHW fp32 stage outputs (BN uses running statistics)."""
+        self._check_input(x)
+        n, c, h, w = x.shape
+
+        def make():
+            b = engine.Builder(x.device)
+            x_in = b.buf(n, h, w, 8)
+            feats = engine.build_resnet(b, engine._cpu_sd(self.state_dict()), x_in, **self.plan_kwargs())
+            return b.plan, x_in, feats
+        plan, x_in, feats = self._plan((n, h, w, str(x.device)), make)
+        ops.pack_input(x.float().contiguous(), 8, out=x_in)
+        plan.run()
+        return tuple(ops.unpack_output(f, f.shape[-1]) for f in feats)

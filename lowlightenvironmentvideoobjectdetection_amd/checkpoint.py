@@ -1,0 +1,53 @@
+"""Checkpoint loading in the reference's format: torch.save({'meta', 'state_dict', 'optimizer'}) with module-path
+keys (mmcv CheckpointHook; call sites mmdetection/mmdet/apis/train.py:166-169, mmtracking/mmtrack/models/vid/base.py:22-37).
+Remote schemes (torchvision://, open-mmlab://, http://) cannot be fetched here: they resolve only from a local
+directory given by $LLV_CHECKPOINT_DIR; otherwise the caller's random-init scheme stays in effect, with a warning."""
+import os
+import warnings
+from collections import OrderedDict
+
+import torch
+
+
+def _resolve(filename):
+    for scheme in ('torchvision://', 'open-mmlab://', 'mmcls://', 'http://', 'https://'):
+        if filename.startswith(scheme):
+            d = os.environ.get('LLV_CHECKPOINT_DIR')
+            name = filename[len(scheme):].rstrip('/').split('/')[-1]
+            if d:
+                for cand in (name, name + '.pth', name + '.pt'):
+                    path = os.path.join(d, cand)
+                    if os.path.isfile(path):
+                        return path
+            return None
+    return filename
+
+
+def load_state_dict_file(filename, map_location='cpu'):
+    path = _resolve(filename)
+    if path is None:
+        return None
+    if not os.path.isfile(path):
+        raise IOError(f'{path} is not a checkpoint file')
+    ckpt = torch.load(path, map_location=map_location, weights_only=False)
+    if isinstance(ckpt, dict) and 'state_dict' in ckpt:
+        sd = ckpt['state_dict']
+    elif isinstance(ckpt, dict) and 'model' in ckpt:
+        sd = ckpt['model']
+    else:
+        sd = ckpt
+    if list(sd.keys()) and list(sd.keys())[0].startswith('module.'):
+        sd = OrderedDict((k[7:], v) for k, v in sd.items())
+    return sd
+
+
+def load_checkpoint(model, filename, map_location='cpu', strict=False, logger=None):
+    sd = load_state_dict_file(filename, map_location)
+    if sd is None:
+        warnings.warn(f'checkpoint {filename} is a remote reference and no local copy was found under '
+                      f'$LLV_CHECKPOINT_DIR; keeping the current (random-init) weights')
+        return None
+    missing, unexpected = model.load_state_dict(sd, strict=strict)
+    if (missing or unexpected) and not strict:
+        warnings.warn(f'load_checkpoint({filename}): missing keys {list(missing)[:8]}..., unexpected {list(unexpected)[:8]}...')
+    return sd

@@ -1,0 +1,2 @@
+from .anchor import AnchorGenerator, anchor_inside_flags, images_to_levels  # noqa: F401
+from .bbox import DeltaXYWHBBoxCoder, bbox2result  # noqa: F401

@@ -1,0 +1,433 @@
+"""Launch plans: a model with fixed input geometry becomes a flat list of C-ABI launches over
+preallocated NHWC fp16 buffers, replayable eagerly or from a captured HIP graph.
+
+Nothing here computes: packing (BN folding, fp16 conversion, channel padding) happens once at build
+time on the host, everything per-frame is a libllv.so launch on the current HIP stream.
+
+Reference structure followed (relative to /root/reference):
+  ResNet / Bottleneck          mmdetection/mmdet/models/backbones/resnet.py:260-299,622-640
+  FPN                          mmdetection/mmdet/models/necks/fpn.py:170-221
+  RetinaHead                   mmdetection/mmdet/models/dense_heads/retina_head.py:93-114
+  get_bboxes                   mmdetection/mmdet/models/dense_heads/anchor_head.py:495-726
+  DenBlock / FastDVDnet        mmtracking/mmtrack/models/cleaners/FastDVDnet.py:77-149
+"""
+import ctypes as C
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import ops
+from ._lib import (CONV_OUT_F32, CONV_PIXSHUF, CONV_RELU, CONV_RES_ADD, CONV_RES_RSUB, CONV_RES_UPS, LlvError, lib)
+
+BN_EPS = 1e-5
+ARCH = {18: ('basic', (2, 2, 2, 2)), 34: ('basic', (3, 4, 6, 3)), 50: ('bottleneck', (3, 4, 6, 3)),
+        101: ('bottleneck', (3, 4, 23, 3)), 152: ('bottleneck', (3, 8, 36, 3))}
+
+
+def _bn(sd, p):
+    return (sd[p + '.weight'], sd[p + '.bias'], sd[p + '.running_mean'], sd[p + '.running_var'])
+
+
+class Plan:
+    """An ordered list of launches. run() replays it on the current stream; capture() records it into a
+    HIP graph (torch.cuda.CUDAGraph drives hipStreamBeginCapture on ROCm) so a frame is one graph launch."""
+
+    def __init__(self, device):
+        self.device = device
+        self.steps = []          # (name, fn, args, flops, bytes)
+        self.keep = []           # tensors the launches point into
+        self.graph = None
+
+    def add(self, name, fn, args, flops=0.0, nbytes=0.0):
+        self.steps.append((name, fn, args, flops, nbytes))
+
+    def extend(self, other: 'Plan'):
+        self.steps += other.steps
+        self.keep += other.keep
+
+    def run(self):
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for name, fn, args, _, _ in self.steps:
+            rc = fn(*args, stream)
+            if rc != 0:
+                raise LlvError(f'{name}: {lib().llv_strerror(rc).decode()} ({rc})')
+
+    def capture(self):
+        self.run()               # warm-up: one-time attribute calls must not happen inside capture
+        torch.cuda.synchronize()
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            self.run()
+        self.graph = g
+        return g
+
+    def replay(self):
+        if self.graph is None:
+            self.run()
+        else:
+            self.graph.replay()
+
+    @property
+    def flops(self):
+        return sum(s[3] for s in self.steps)
+
+    def conv_steps(self):
+        return [s for s in self.steps if s[3] > 0]
+
+
+class Builder:
+    def __init__(self, device):
+        self.dev = device
+        self.plan = Plan(device)
+        self._fn_conv = lib().llv_conv2d_nhwc_fwd
+
+    def buf(self, *shape, dtype=torch.float16):
+        t = torch.zeros(shape, device=self.dev, dtype=dtype)
+        self.plan.keep.append(t)
+        return t
+
+    def conv_desc(self, name, pc: ops.PackedConv, xs, y, batch, segs, x_ld, y_ld, res=None, res_ld=0, flags=0,
+                  res_hw=(0, 0), tile=0):
+        pc.to(self.dev)
+        d = ops.make_conv_desc(pc, xs, y, batch, segs, x_ld, y_ld, res, res_ld, flags, res_hw, tile)
+        m = sum(batch * s[2] * s[3] for s in segs)
+        flops = 2.0 * m * pc.true_macs_per_pixel
+        nbytes = 2.0 * (sum(batch * s[0] * s[1] for s in segs) * pc.cin * pc.groups + m * pc.cout * pc.groups) + \
+            pc.w.numel() * 2.0
+        self.plan.keep += [pc.w, pc.bias, d] + list(xs) + [y] + ([res] if res is not None else [])
+        self.plan.add(name, self._fn_conv, (C.byref(d),), flops, nbytes)
+        return d
+
+    def conv(self, name, x, pc: ops.PackedConv, flags=0, res=None, out=None, tile=0):
+        """x: (N,H,W,C) tensor or list of n_src tensors -> new (N,Ho,Wo,Cout) buffer."""
+        xs = list(x) if isinstance(x, (list, tuple)) else [x]
+        n, h, w, cx = xs[0].shape
+        ho, wo = ops.conv_out_size(h, w, pc)
+        ctot = pc.groups * pc.cout
+        if out is None:
+            if flags & CONV_PIXSHUF:
+                out = self.buf(n, 2 * ho, 2 * wo, ctot // 4)
+            else:
+                out = self.buf(n, ho, wo, ctot, dtype=torch.float32 if flags & CONV_OUT_F32 else torch.float16)
+        res_hw = (res.shape[1], res.shape[2]) if (res is not None and flags & CONV_RES_UPS) else (0, 0)
+        self.conv_desc(name, pc, xs, out, n, [(h, w, ho, wo, 0, 0)], cx, out.shape[-1], res,
+                       res.shape[-1] if res is not None else 0, flags, res_hw, tile)
+        return out
+
+    def maxpool(self, name, x):
+        n, h, w, c = x.shape
+        out = self.buf(n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c)
+        self.plan.add(name, lib().llv_maxpool3x3s2_nhwc, (C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), n, h, w, c),
+                      0.0, 2.0 * (x.numel() + out.numel()))
+        return out
+
+
+# ------------------------------------------------------------------------------------------------
+# RetinaNet stages (ResNet, FPN, RetinaHead, decode + NMS)
+# ------------------------------------------------------------------------------------------------
+def _cpu_sd(sd):
+    return {k: v.detach().float().cpu() for k, v in sd.items()}
+
+
+def build_resnet(b: Builder, sd, x, depth=50, strides=(1, 2, 2, 2), style='pytorch', out_indices=(0, 1, 2, 3), p='',
+                 num_stages=4):
+    """x: (N,H,W,8) fp16 NHWC normalised image (3 real channels). Returns the out_indices stage outputs.
+    resnet.py:622-640 with every BatchNorm folded (norm_eval, running stats) and ReLU / identity-add fused
+    into the producing conv's epilogue."""
+    kind, blocks = ARCH[depth]
+    blocks = blocks[:num_stages]
+    # stem: 7x7/s2 conv (Cin 3 -> padded 8) + BN + ReLU, then 3x3/s2 max pool (resnet.py:559-570)
+    x = b.conv('stem.conv1', x, ops.pack_conv(sd[p + 'conv1.weight'], None, 2, 3, bn=_bn(sd, p + 'bn1'), eps=BN_EPS), CONV_RELU)
+    x = b.maxpool('stem.maxpool', x)
+    feats = []
+    for i, nb in enumerate(blocks):
+        for j in range(nb):
+            q = f'{p}layer{i + 1}.{j}.'
+            stride = strides[i] if j == 0 else 1
+            identity = x
+            if (q + 'downsample.0.weight') in sd:          # res_layer.py:36-58: conv1x1(stride) + BN
+                identity = b.conv(q + 'downsample', x, ops.pack_conv(sd[q + 'downsample.0.weight'], None, stride, 0,
+                                                                     bn=_bn(sd, q + 'downsample.1'), eps=BN_EPS))
+            if kind == 'bottleneck':
+                s1, s2 = (1, stride) if style == 'pytorch' else (stride, 1)          # resnet.py:151-156
+                o = b.conv(q + 'conv1', x, ops.pack_conv(sd[q + 'conv1.weight'], None, s1, 0, bn=_bn(sd, q + 'bn1'),
+                                                         eps=BN_EPS), CONV_RELU)
+                o = b.conv(q + 'conv2', o, ops.pack_conv(sd[q + 'conv2.weight'], None, s2, 1, bn=_bn(sd, q + 'bn2'),
+                                                         eps=BN_EPS), CONV_RELU)
+                x = b.conv(q + 'conv3', o, ops.pack_conv(sd[q + 'conv3.weight'], None, 1, 0, bn=_bn(sd, q + 'bn3'),
+                                                         eps=BN_EPS), CONV_RELU | CONV_RES_ADD, res=identity)
+            else:
+                o = b.conv(q + 'conv1', x, ops.pack_conv(sd[q + 'conv1.weight'], None, stride, 1,
+                                                         bn=_bn(sd, q + 'bn1'), eps=BN_EPS), CONV_RELU)
+                x = b.conv(q + 'conv2', o, ops.pack_conv(sd[q + 'conv2.weight'], None, 1, 1, bn=_bn(sd, q + 'bn2'),
+                                                         eps=BN_EPS), CONV_RELU | CONV_RES_ADD, res=identity)
+        if i in out_indices:
+            feats.append(x)
+    return feats
+
+
+class Pyramid:
+    """All FPN levels in ONE pixel-major buffer (total_cells, C): level l holds batch x h_l x w_l pixels
+    starting at pixel offset level_off[l], so a shared-weight head conv is a single multi-segment launch."""
+
+    def __init__(self, buf, level_hw, level_off, batch):
+        self.buf, self.level_hw, self.level_off, self.batch = buf, level_hw, level_off, batch
+
+    @property
+    def total(self):
+        return self.buf.shape[0]
+
+    def level(self, i, buf=None):
+        buf = self.buf if buf is None else buf
+        h, w = self.level_hw[i]
+        o = self.level_off[i]
+        return buf[o:o + self.batch * h * w].view(self.batch, h, w, buf.shape[-1])
+
+    def segs(self):
+        return [(h, w, h, w, self.level_off[i], self.level_off[i]) for i, (h, w) in enumerate(self.level_hw)]
+
+
+def build_fpn(b: Builder, sd, feats, start_level=0, end_level=-1, num_outs=None, add_extra_convs=False,
+              relu_before_extra_convs=False, p='') -> Pyramid:
+    """fpn.py:170-221: lateral 1x1 convs run top-down with the nearest-upsample-add fused into the epilogue."""
+    batch = feats[0].shape[0]
+    backbone_end = len(feats) if end_level == -1 else end_level
+    n_lat = backbone_end - start_level
+    num_outs = num_outs if num_outs is not None else n_lat
+    lat = [None] * n_lat
+    for i in range(n_lat - 1, -1, -1):
+        pc = ops.pack_conv(sd[f'{p}lateral_convs.{i}.conv.weight'], sd.get(f'{p}lateral_convs.{i}.conv.bias'))
+        if i == n_lat - 1:
+            lat[i] = b.conv(f'neck.lateral{i}', feats[i + start_level], pc)
+        else:
+            lat[i] = b.conv(f'neck.lateral{i}', feats[i + start_level], pc, CONV_RES_ADD | CONV_RES_UPS, res=lat[i + 1])
+    level_hw = [(t.shape[1], t.shape[2]) for t in lat]
+    extra_pcs = []
+    if num_outs > n_lat:
+        if not add_extra_convs:
+            raise LlvError('FPN max-pool extra levels (add_extra_convs=False) are not on the RetinaNet path')
+        for i in range(n_lat, num_outs):
+            pc = ops.pack_conv(sd[f'{p}fpn_convs.{i}.conv.weight'], sd.get(f'{p}fpn_convs.{i}.conv.bias'), 2, 1)
+            if i == n_lat and add_extra_convs == 'on_input':
+                h, w = feats[backbone_end - 1].shape[1], feats[backbone_end - 1].shape[2]
+            else:
+                h, w = level_hw[-1]
+            level_hw.append(ops.conv_out_size(h, w, pc))
+            extra_pcs.append(pc)
+    c_f = lat[0].shape[-1]
+    lvl_off, tot = [], 0
+    for h, w in level_hw:
+        lvl_off.append(tot)
+        tot += batch * h * w
+    pyr = b.buf(tot, c_f)
+    for i in range(n_lat):
+        pc = ops.pack_conv(sd[f'{p}fpn_convs.{i}.conv.weight'], sd.get(f'{p}fpn_convs.{i}.conv.bias'), 1, 1)
+        h, w = level_hw[i]
+        b.conv_desc(f'neck.fpn{i}', pc, [lat[i]], pyr, batch, [(h, w, h, w, 0, lvl_off[i])], c_f, c_f)
+    for k, i in enumerate(range(n_lat, num_outs)):
+        pc = extra_pcs[k]
+        ho, wo = level_hw[i]
+        if i == n_lat:
+            if add_extra_convs == 'on_input':
+                src = feats[backbone_end - 1]
+                (h, w), xo = (src.shape[1], src.shape[2]), 0
+            elif add_extra_convs == 'on_lateral':
+                src, (h, w), xo = lat[-1], level_hw[n_lat - 1], 0
+            else:
+                src, (h, w), xo = pyr, level_hw[n_lat - 1], lvl_off[n_lat - 1]
+        else:
+            if relu_before_extra_convs:
+                raise LlvError('relu_before_extra_convs=True is not supported')
+            src, (h, w), xo = pyr, level_hw[i - 1], lvl_off[i - 1]
+        b.conv_desc(f'neck.fpn{i}', pc, [src], pyr, batch, [(h, w, ho, wo, xo, lvl_off[i])], src.shape[-1], c_f)
+    return Pyramid(pyr, level_hw, lvl_off, batch)
+
+
+def build_retina_head(b: Builder, sd, pyr: Pyramid, stacked_convs=4, logits_f32=True, p=''):
+    """retina_head.py:93-114. The levels share weights -> one multi-segment launch per layer; the cls and
+    reg towers run side by side (layer 0 as one 2x-wide conv on the shared input, layers 1.. as groups=2)."""
+    batch, segs, tot = pyr.batch, pyr.segs(), pyr.total
+    c_f = pyr.buf.shape[-1]
+    pccls = ops.pack_conv(sd[p + 'retina_cls.weight'], sd[p + 'retina_cls.bias'], 1, 1)
+    pcreg = ops.pack_conv(sd[p + 'retina_reg.weight'], sd[p + 'retina_reg.bias'], 1, 1)
+    odt = torch.float32 if logits_f32 else torch.float16
+    of = CONV_OUT_F32 if logits_f32 else 0
+    cls_buf = b.buf(tot, pccls.cout, dtype=odt)
+    reg_buf = b.buf(tot, pcreg.cout, dtype=odt)
+    if stacked_convs > 0:
+        feat_ch = sd[p + 'cls_convs.0.conv.weight'].shape[0]
+        ta = b.buf(tot, 2 * feat_ch)
+        tb = b.buf(tot, 2 * feat_ch) if stacked_convs > 1 else None
+        cur, nxt = ta, tb
+        for i in range(stacked_convs):
+            pcc = ops.pack_conv(sd[f'{p}cls_convs.{i}.conv.weight'], sd[f'{p}cls_convs.{i}.conv.bias'], 1, 1)
+            pcr = ops.pack_conv(sd[f'{p}reg_convs.{i}.conv.weight'], sd[f'{p}reg_convs.{i}.conv.bias'], 1, 1)
+            if i == 0:
+                b.conv_desc('head.tower0', ops.concat_cout([pcc, pcr]), [pyr.buf], cur, batch, segs, c_f, 2 * feat_ch,
+                            flags=CONV_RELU)
+            else:
+                b.conv_desc(f'head.tower{i}', ops.stack_groups([pcc, pcr]), [cur], nxt, batch, segs, 2 * feat_ch,
+                            2 * feat_ch, flags=CONV_RELU)
+                cur, nxt = nxt, cur
+        b.conv_desc('head.retina_cls', pccls, [cur[:, :feat_ch]], cls_buf, batch, segs, 2 * feat_ch, pccls.cout, flags=of)
+        b.conv_desc('head.retina_reg', pcreg, [cur[:, feat_ch:]], reg_buf, batch, segs, 2 * feat_ch, pcreg.cout, flags=of)
+    else:
+        b.conv_desc('head.retina_cls', pccls, [pyr.buf], cls_buf, batch, segs, c_f, pccls.cout, flags=of)
+        b.conv_desc('head.retina_reg', pcreg, [pyr.buf], reg_buf, batch, segs, c_f, pcreg.cout, flags=of)
+    return cls_buf, reg_buf
+
+
+class PostProcess:
+    """Per image: llv_retina_decode_topk then llv_multiclass_nms (anchor_head.py:636-726), no host sync."""
+
+    def __init__(self, b: Builder, cls_buf, reg_buf, pyr: Pyramid, num_classes, anchor_generator, test_cfg,
+                 target_means=(0., 0., 0., 0.), target_stds=(1., 1., 1., 1.), img_shapes=None, scale_factors=None,
+                 rescale=False, clip_border=True):
+        tc = dict(test_cfg)
+        nms_cfg = tc['nms']
+        if nms_cfg.get('type', 'nms') != 'nms':
+            raise LlvError('only greedy nms is on this path')
+        iou_thr = nms_cfg.get('iou_threshold', nms_cfg.get('iou_thr'))
+        A = anchor_generator.num_base_anchors[0]
+        assert cls_buf.shape[-1] >= A * num_classes and reg_buf.shape[-1] >= A * 4
+        self.decode, self.nms, self.num_classes = [], [], num_classes
+        for n in range(pyr.batch):
+            offs = [pyr.level_off[i] + n * h * w for i, (h, w) in enumerate(pyr.level_hw)]
+            img_shape = img_shapes[n] if (img_shapes is not None and clip_border) else None
+            sf = scale_factors[n] if scale_factors is not None else (1., 1., 1., 1.)
+            dp = ops.make_decode_plan(cls_buf, reg_buf, pyr.level_hw, anchor_generator.strides, offs, offs,
+                                      cls_buf.shape[-1], reg_buf.shape[-1], num_classes, A, anchor_generator.base_anchors,
+                                      tc.get('nms_pre', -1), target_means, target_stds, 16 / 1000, img_shape, sf, rescale)
+            nb = ops.NmsBuffers(dp.n_cand, num_classes, tc['max_per_img'], b.dev)
+            self.decode.append(dp)
+            self.nms.append(nb)
+            b.plan.keep += [dp, nb]
+            b.plan.add(f'decode{n}', lib().llv_retina_decode_topk, (C.byref(dp.desc),), 0.0,
+                       float(cls_buf.element_size() * cls_buf.numel()) / pyr.batch)
+            b.plan.add(f'nms{n}', lib().llv_multiclass_nms,
+                       (C.c_void_p(dp.boxes.data_ptr()), C.c_void_p(dp.scores.data_ptr()), dp.n_cand, num_classes, num_classes,
+                        C.c_float(tc['score_thr']), C.c_float(iou_thr), tc['max_per_img'], C.c_void_p(nb.dets.data_ptr()),
+                        C.c_void_p(nb.labels.data_ptr()), C.c_void_p(nb.count.data_ptr()), C.c_void_p(nb.keep_flat.data_ptr()),
+                        C.c_void_p(nb.ws.data_ptr()), C.c_size_t(nb.ws_bytes)), 0.0, 0.0)
+
+    def results(self):
+        """D2H of the detections: [(dets (k,5), labels (k,)), ...] per image."""
+        counts = torch.cat([nb.count for nb in self.nms]).cpu().tolist()
+        return [(nb.dets[:k].cpu(), nb.labels[:k].cpu()) for nb, k in zip(self.nms, counts)]
+
+
+DEFAULT_TEST_CFG = dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05, nms=dict(type='nms', iou_threshold=0.5), max_per_img=100)
+
+
+class RetinaNetPlan:
+    """Whole-detector inference plan for a fixed (batch, H, W). Input: self.x_in (N,H,W,8) fp16 NHWC
+    (3 real channels, normalised image). After run()/replay(): self.post.results()."""
+
+    def __init__(self, sd: Dict[str, torch.Tensor], num_classes: int, batch: int, height: int, width: int, device,
+                 depth=50, strides=(1, 2, 2, 2), style='pytorch', out_indices=(0, 1, 2, 3), start_level=1, num_outs=5,
+                 add_extra_convs='on_input', relu_before_extra_convs=False, stacked_convs=4, anchor_generator=None,
+                 test_cfg=None, target_means=(0., 0., 0., 0.), target_stds=(1., 1., 1., 1.), img_shapes=None,
+                 scale_factors=None, rescale=False, logits_f32=True, x_in=None, prefix=''):
+        from .core.anchor import AnchorGenerator
+        b = Builder(device)
+        self.builder, self.plan = b, b.plan
+        self.num_classes, self.batch = num_classes, batch
+        sd = _cpu_sd(sd)
+        self.x_in = x_in if x_in is not None else b.buf(batch, height, width, 8)
+        self.backbone_feats = build_resnet(b, sd, self.x_in, depth, strides, style, out_indices, p=prefix + 'backbone.')
+        self.pyramid = build_fpn(b, sd, self.backbone_feats, start_level, -1, num_outs, add_extra_convs,
+                                 relu_before_extra_convs, p=prefix + 'neck.')
+        self.cls_buf, self.reg_buf = build_retina_head(b, sd, self.pyramid, stacked_convs, logits_f32, p=prefix + 'bbox_head.')
+        if isinstance(anchor_generator, AnchorGenerator):
+            ag = anchor_generator
+        else:
+            cfg = dict(anchor_generator or dict(octave_base_scale=4, scales_per_octave=3, ratios=[0.5, 1.0, 2.0],
+                                                strides=[8, 16, 32, 64, 128]))
+            cfg.pop('type', None)
+            ag = AnchorGenerator(**cfg)
+        self.anchor_generator = ag
+        if img_shapes is None:
+            img_shapes = [(height, width, 3)] * batch
+        self.post = PostProcess(b, self.cls_buf, self.reg_buf, self.pyramid, num_classes, ag, test_cfg or DEFAULT_TEST_CFG,
+                                target_means, target_stds, img_shapes, scale_factors, rescale)
+
+    def results(self):
+        return self.post.results()
+
+
+# ------------------------------------------------------------------------------------------------
+# FastDVDnet
+# ------------------------------------------------------------------------------------------------
+def _denblock(b: Builder, sd, p, srcs, batch, tag):
+    """One DenBlock over `batch` images whose three input frames are srcs[0..2] (each a view (batch,H,W,8):
+    image n of source s is frame n+s of a clip, so consecutive windows share memory). FastDVDnet.py:102-116."""
+    f = CONV_RELU
+    # inc: Conv2d(9, 90, 3, groups=3) as a block-diagonal dense conv reading the three NHWC8 frames directly
+    wg = sd[p + 'inc.convblock.0.weight']                    # (90, 3, 3, 3)
+    ng = 3
+    og = wg.shape[0] // ng
+    dense = torch.zeros(wg.shape[0], 3 * ng, 3, 3)
+    in_map = []
+    for g in range(ng):
+        dense[og * g:og * (g + 1), 3 * g:3 * g + 3] = wg[og * g:og * (g + 1)]
+        in_map += [3 * g, 3 * g + 1, 3 * g + 2, -1, -1, -1, -1, -1]
+    c_mid = ops.round_up(wg.shape[0], 8)
+    pc = ops.pack_conv(dense, None, 1, 1, in_map=in_map, cout_store=c_mid, n_src=3, bn=_bn(sd, p + 'inc.convblock.1'), eps=BN_EPS)
+    pc.true_macs_per_pixel = wg.shape[0] * wg.shape[1] * 9          # grouped conv: count the true MACs
+    x = b.conv(f'{tag}.inc0', list(srcs), pc, f)
+    w2 = sd[p + 'inc.convblock.3.weight']
+    pc = ops.pack_conv(w2, None, 1, 1, in_map=list(range(w2.shape[1])) + [-1] * (c_mid - w2.shape[1]),
+                       bn=_bn(sd, p + 'inc.convblock.4'), eps=BN_EPS)
+    x0 = b.conv(f'{tag}.inc1', x, pc, f)
+
+    def cbr(name, x, conv, bn, stride=1, flags=f, res=None):
+        return b.conv(name, x, ops.pack_conv(sd[conv + '.weight'], None, stride, 1, bn=_bn(sd, bn), eps=BN_EPS), flags, res=res)
+
+    def down(x, q, t):                                       # DownBlock, FastDVDnet.py:39-49
+        x = cbr(f'{tag}.{t}.0', x, q + 'convblock.0', q + 'convblock.1', 2)
+        x = cbr(f'{tag}.{t}.1', x, q + 'convblock.3.convblock.0', q + 'convblock.3.convblock.1')
+        return cbr(f'{tag}.{t}.2', x, q + 'convblock.3.convblock.3', q + 'convblock.3.convblock.4')
+
+    def up(x, q, t, skip):                                   # UpBlock, FastDVDnet.py:52-61; the skip add of
+        x = cbr(f'{tag}.{t}.0', x, q + 'convblock.0.convblock.0', q + 'convblock.0.convblock.1')   # :111-113 is fused
+        x = cbr(f'{tag}.{t}.1', x, q + 'convblock.0.convblock.3', q + 'convblock.0.convblock.4')
+        pc = ops.pack_conv(sd[q + 'convblock.1.weight'], None, 1, 1)
+        return b.conv(f'{tag}.{t}.2', x, pc, CONV_PIXSHUF | CONV_RES_ADD, res=skip)
+
+    x1 = down(x0, p + 'downc0.', 'down0')
+    x2 = down(x1, p + 'downc1.', 'down1')
+    x1s = up(x2, p + 'upc2.', 'up2', x1)                     # = x1 + upc2(x2)
+    x0s = up(x1s, p + 'upc1.', 'up1', x0)                    # = x0 + upc1(x1 + x2)
+    x = cbr(f'{tag}.out0', x0s, p + 'outc.convblock.0', p + 'outc.convblock.1')
+    pc = ops.pack_conv(sd[p + 'outc.convblock.3.weight'], None, 1, 1, cout_store=8)
+    return pc, x
+
+
+class FastDVDnetPlan:
+    """Denoise `batch` consecutive frames of a clip in one pass.
+
+    self.frames is (batch + 4, H, W, 8): frames t0-2 .. t0+batch+1 (caller replicates clip ends).
+    temp1 runs on the batch+2 distinct triples, temp2 on `batch` triples of temp1 outputs -- every
+    temp1 result is computed once per pass (for batch == 1 this is exactly the reference's 3 + 1
+    DenBlocks per frame). Output: self.out (batch, H, W, 8), channels 0..2 = denoised frame.
+    """
+
+    def __init__(self, sd, batch, height, width, device, frames=None, out=None, prefix=''):
+        if height % 4 or width % 4:
+            raise LlvError('FastDVDnet needs H, W multiples of 4 (two stride-2 stages)')
+        b = Builder(device)
+        self.builder, self.plan, self.batch = b, b.plan, batch
+        sd = {k: v.detach().float().cpu() for k, v in sd.items()}
+        nf = batch + 4
+        self.frames = frames if frames is not None else b.buf(nf, height, width, 8)
+        n1 = batch + 2
+        self.mid = b.buf(n1, height, width, 8)
+        self.out = out if out is not None else b.buf(batch, height, width, 8)
+        p1, p2 = prefix + 'temp1.', prefix + 'temp2.'
+        srcs = [self.frames[s:s + n1] for s in range(3)]
+        pc, x = _denblock(b, sd, p1, srcs, n1, 'temp1')
+        b.conv(f'temp1.out1', x, pc, CONV_RES_RSUB, res=srcs[1], out=self.mid)      # in1 - x   (:115)
+        srcs2 = [self.mid[s:s + batch] for s in range(3)]
+        pc, x = _denblock(b, sd, p2, srcs2, batch, 'temp2')
+        b.conv(f'temp2.out1', x, pc, CONV_RES_RSUB, res=srcs2[1], out=self.out)

@@ -1,0 +1,95 @@
+"""Shared test helpers: reference-style configs, seeded weight randomisation, synthetic dark frames."""
+import math
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+
+def retinanet_cfg(num_classes=80, depth=50, in_channels=(256, 512, 1024, 2048), stacked_convs=4, feat=256, score_thr=0.05):
+    """mmdetection/configs/_base_/models/retinanet_r50_fpn.py:2-60 (pretrained=None: no network here)."""
+    return dict(
+        type='RetinaNet', pretrained=None,
+        backbone=dict(type='ResNet', depth=depth, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                      norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, style='pytorch'),
+        neck=dict(type='FPN', in_channels=list(in_channels), out_channels=feat, start_level=1, add_extra_convs='on_input',
+                  num_outs=5),
+        bbox_head=dict(type='RetinaHead', num_classes=num_classes, in_channels=feat, stacked_convs=stacked_convs,
+                       feat_channels=feat,
+                       anchor_generator=dict(type='AnchorGenerator', octave_base_scale=4, scales_per_octave=3,
+                                             ratios=[0.5, 1.0, 2.0], strides=[8, 16, 32, 64, 128]),
+                       bbox_coder=dict(type='DeltaXYWHBBoxCoder', target_means=[.0, .0, .0, .0],
+                                       target_stds=[1.0, 1.0, 1.0, 1.0]),
+                       loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                       loss_bbox=dict(type='L1Loss', loss_weight=1.0)),
+        train_cfg=None,
+        test_cfg=dict(nms_pre=1000, min_bbox_size=0, score_thr=score_thr, nms=dict(type='nms', iou_threshold=0.5),
+                      max_per_img=100))
+
+
+def randomize(model, seed=0, cls_bias=-2.0):
+    """Seeded weights that exercise every layer: He-normal convs, non-trivial BN statistics (the reference's
+    zero_init_residual would silence the residual branches), a classification bias that lets candidates
+    pass score_thr so NMS does real work (SURVEY.md 8d 'busy' variant)."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, m in model.named_modules():
+            if isinstance(m, nn.Conv2d):
+                fan_in = m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3]
+                std = math.sqrt(2.0 / fan_in)
+                if name.endswith('retina_cls') or name.endswith('retina_reg'):
+                    std *= 0.5
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g) * std)
+                if m.bias is not None:
+                    m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.05)
+                    if name.endswith('retina_cls'):
+                        m.bias.add_(cls_bias)
+            elif isinstance(m, nn.BatchNorm2d):
+                m.weight.copy_(torch.rand(m.weight.shape, generator=g) * 0.5 + 0.5)
+                m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
+                m.running_mean.copy_(torch.randn(m.running_mean.shape, generator=g) * 0.1)
+                m.running_var.copy_(torch.rand(m.running_var.shape, generator=g) * 0.5 + 0.75)
+    if hasattr(model, 'invalidate_plans'):
+        model.invalidate_plans()
+    return model
+
+
+def smooth_image(n, h, w, seed=0):
+    """Low-pass noise + rectangles, normalised-image statistics (zero mean, unit-ish variance), NCHW fp32."""
+    g = torch.Generator().manual_seed(seed)
+    base = torch.randn(n, 3, h // 8 + 1, w // 8 + 1, generator=g)
+    img = torch.nn.functional.interpolate(base, size=(h, w), mode='bilinear', align_corners=False)
+    for k in range(6):
+        y0, x0 = int(torch.randint(0, h - 8, (1,), generator=g)), int(torch.randint(0, w - 8, (1,), generator=g))
+        hh, ww = int(torch.randint(6, max(h // 3, 8), (1,), generator=g)), int(torch.randint(6, max(w // 3, 8), (1,), generator=g))
+        img[:, :, y0:y0 + hh, x0:x0 + ww] += torch.randn(1, 3, 1, 1, generator=g)
+    img += 0.15 * torch.randn(n, 3, h, w, generator=g)
+    return img.contiguous()
+
+
+def img_meta(h, w, pad_h=None, pad_w=None, scale=1.0):
+    pad_h, pad_w = pad_h or h, pad_w or w
+    return dict(filename='synthetic.png', ori_filename='synthetic.png', ori_shape=(h, w, 3), img_shape=(h, w, 3),
+                pad_shape=(pad_h, pad_w, 3), scale_factor=np.array([scale] * 4, dtype=np.float32), flip=False,
+                flip_direction=None, img_norm_cfg=dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True))
+
+
+def match_detections(res, ref, iou_thr=0.9, score_tol=0.03):
+    """Fraction of the oracle's detections (per class arrays of (k,5)) that the device result reproduces."""
+    tot, hit = 0, 0
+    for a, b in zip(res, ref):
+        tot += len(b)
+        if len(a) == 0 or len(b) == 0:
+            continue
+        a_t, b_t = torch.from_numpy(np.ascontiguousarray(a)), torch.from_numpy(np.ascontiguousarray(b))
+        lt = torch.max(a_t[:, None, :2], b_t[None, :, :2])
+        rb = torch.min(a_t[:, None, 2:4], b_t[None, :, 2:4])
+        wh = (rb - lt).clamp(min=0)
+        inter = wh[..., 0] * wh[..., 1]
+        aa = (a_t[:, 2] - a_t[:, 0]) * (a_t[:, 3] - a_t[:, 1])
+        ab = (b_t[:, 2] - b_t[:, 0]) * (b_t[:, 3] - b_t[:, 1])
+        iou = inter / (aa[:, None] + ab[None, :] - inter).clamp(min=1e-6)
+        ds = (a_t[:, None, 4] - b_t[None, :, 4]).abs()
+        ok = (iou > iou_thr) & (ds < score_tol)
+        hit += int(ok.any(0).sum())
+    return hit / max(tot, 1), tot

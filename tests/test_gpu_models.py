@@ -1,0 +1,151 @@
+"""GPU parity of the model plans (backbone, neck, head, whole detector, FastDVDnet) against the fp32 CPU
+oracle on the same seeded weights and inputs, through the registry/config surface of the reference.
+
+Arithmetic type on the device: fp16 storage, fp32 accumulate (the reference's own fp16 mode,
+mmdetection/configs/fp16/retinanet_r50_fpn_fp16_1x_coco.py). Tolerances are relative to each tensor's max
+magnitude and are stated next to each assert."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import img_meta, match_detections, randomize, retinanet_cfg, smooth_image
+
+pytestmark = pytest.mark.gpu
+
+
+def _rel(a, b):
+    return (a - b).abs().max().item() / (b.abs().max().item() + 1e-12)
+
+
+def _registry():
+    import lowlightenvironmentvideoobjectdetection_amd.models  # noqa: F401  (registers everything)
+    from lowlightenvironmentvideoobjectdetection_amd import registry
+    return registry
+
+
+@pytest.mark.parametrize('depth,h,w', [(18, 64, 96), (50, 96, 160)])
+def test_resnet_stage_outputs(dev, depth, h, w):
+    reg = _registry()
+    from oracle.detector import resnet_forward
+    m = randomize(reg.build_backbone(dict(type='ResNet', depth=depth)), seed=depth)
+    x = smooth_image(2, h, w, seed=1)
+    ref = resnet_forward(m.state_dict(), x, depth, prefix='')
+    outs = m.to(dev).eval()(x.to(dev))
+    assert len(outs) == 4
+    for o, r in zip(outs, ref):
+        assert o.shape == r.shape
+        assert _rel(o.cpu(), r) < 1e-2          # fp16 activations through up to 50 layers
+
+
+def test_resnet18_doc_example_shapes(dev):
+    """resnet.py:340-352"""
+    reg = _registry()
+    m = reg.build_backbone(dict(type='ResNet', depth=18)).to(dev).eval()
+    outs = m(torch.rand(1, 3, 32, 32, device=dev))
+    assert [tuple(o.shape) for o in outs] == [(1, 64, 8, 8), (1, 128, 4, 4), (1, 256, 2, 2), (1, 512, 1, 1)]
+
+
+def test_fpn_doc_example_and_values(dev):
+    """fpn.py:50-63 shapes + values vs the oracle (non power-of-two sizes exercise the nearest upsample)."""
+    reg = _registry()
+    from oracle.detector import fpn_forward
+    in_channels = [8, 16, 32, 64]
+    sizes = [(47, 42), (24, 21), (12, 11), (6, 6)]
+    g = torch.Generator().manual_seed(2)
+    inputs = [torch.randn(1, c, s[0], s[1], generator=g) for c, s in zip(in_channels, sizes)]
+    m = randomize(reg.build_neck(dict(type='FPN', in_channels=in_channels, out_channels=16, num_outs=5, start_level=1,
+                                      add_extra_convs='on_input')), seed=3)
+    sd = {'neck.' + k: v for k, v in m.state_dict().items()}
+    ref = fpn_forward(sd, inputs, start_level=1, num_outs=5, add_extra_convs='on_input')
+    outs = m.to(dev)(tuple(t.to(dev) for t in inputs))
+    assert len(outs) == 5
+    for o, r in zip(outs, ref):
+        assert o.shape == r.shape
+        assert _rel(o.cpu(), r) < 4e-3          # three fp16 roundings deep
+
+
+def test_retina_head_doc_example_and_values(dev):
+    """retina_head.py:16-25 + values vs the oracle over 3 levels (multi-segment, grouped towers)."""
+    reg = _registry()
+    from oracle.detector import retina_head_forward
+    head = randomize(reg.build_head(dict(type='RetinaHead', num_classes=11, in_channels=8, feat_channels=16,
+                                         loss_cls=dict(type='FocalLoss', use_sigmoid=True), loss_bbox=dict(type='L1Loss'))), seed=4)
+    g = torch.Generator().manual_seed(5)
+    feats = [torch.randn(2, 8, s, s + 3, generator=g) for s in (16, 8, 4)]
+    sd = {'bbox_head.' + k: v for k, v in head.state_dict().items()}
+    rc, rr = retina_head_forward(sd, feats, 4)
+    head = head.to(dev)
+    cls, regp = head(tuple(f.to(dev) for f in feats))
+    for a, b in zip(cls + regp, rc + rr):
+        assert a.shape == b.shape
+        assert _rel(a.cpu(), b) < 5e-3
+    c1, b1 = head.forward_single(feats[0].to(dev))
+    assert c1.shape[1] / head.num_anchors == head.num_classes and b1.shape[1] / head.num_anchors == 4
+
+
+@pytest.mark.parametrize('h,w,ncls', [(128, 160, 4), (192, 256, 80)])
+def test_retinanet_simple_test_vs_oracle(dev, h, w, ncls):
+    reg = _registry()
+    from oracle.detector import retinanet_simple_test, retinanet_extract_feat
+    det = randomize(reg.build_detector(retinanet_cfg(num_classes=ncls)), seed=7, cls_bias=-1.5)
+    img = smooth_image(1, h, w, seed=8)
+    meta = img_meta(h - 8, w, h, w, scale=1.25)
+    sd = {k: v.clone() for k, v in det.state_dict().items()}
+    ref = retinanet_simple_test(sd, img, meta, num_classes=ncls, rescale=True)
+    det = det.to(dev).eval()
+    res = det(img=[img.to(dev)], img_metas=[[meta]], return_loss=False, rescale=True)
+    assert len(res) == 1 and len(res[0]) == ncls
+    for a in res[0]:
+        assert a.dtype == np.float32 and a.ndim == 2 and a.shape[1] == 5
+    nref = sum(len(r) for r in ref)
+    assert nref > 20, 'the seeded weights must produce detections for this test to mean anything'
+    # pyramid features: fp16 chain vs fp32
+    feats = det.extract_feat(img.to(dev))
+    rfeats = retinanet_extract_feat(sd, img)
+    for a, b in zip(feats, rfeats):
+        assert _rel(a.cpu(), b) < 1.5e-2
+    # detections: >= 85 % of the oracle's boxes reproduced with IoU > 0.9 and |dscore| < 0.03 (fp16 logits move
+    # near-threshold candidates across score_thr / NMS ties; index-exactness on identical inputs is test_gpu_post)
+    frac, tot = match_detections(res[0], ref)
+    assert frac >= 0.85, f'only {frac:.3f} of {tot} oracle detections matched'
+
+
+@pytest.mark.parametrize('n,h,w', [(1, 64, 96), (2, 48, 80)])
+def test_fastdvdnet_vs_oracle(dev, n, h, w):
+    reg = _registry()
+    from oracle.cleaner import fastdvdnet_forward
+    m = randomize(reg.build_cleaner(dict(type='FastDVDnet')), seed=11)
+    g = torch.Generator().manual_seed(12)
+    clean = smooth_image(n, h, w, seed=13)
+    x = torch.cat([clean + 0.3 * torch.randn(n, 3, h, w, generator=g) for _ in range(5)], 1)
+    ref = fastdvdnet_forward(m.state_dict(), x)
+    out = m.to(dev).eval()(x.to(dev))
+    assert out.shape == ref.shape
+    assert _rel(out.cpu(), ref) < 1e-2
+
+
+def test_fastdvdnet_clip_plan_matches_per_frame(dev):
+    """The clip plan (batch of consecutive frames, shared temp1 results) equals per-frame evaluation."""
+    reg = _registry()
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    from oracle.cleaner import fastdvdnet_forward
+    m = randomize(reg.build_cleaner(dict(type='FastDVDnet')), seed=21)
+    h, w, B = 32, 48, 3
+    g = torch.Generator().manual_seed(22)
+    frames = torch.randn(B + 4, 3, h, w, generator=g)
+    refs = [fastdvdnet_forward(m.state_dict(), frames[t:t + 5].reshape(1, 15, h, w)) for t in range(B)]
+    m = m.to(dev).eval()
+    plan = m.make_plan(B, h, w, dev)
+    ops.pack_input(frames.to(dev), 8, out=plan.frames)
+    plan.plan.run()
+    out = ops.unpack_output(plan.out, 3).cpu()
+    for t in range(B):
+        assert _rel(out[t:t + 1], refs[t]) < 1e-2
+
+
+def test_cpu_input_raises(dev):
+    reg = _registry()
+    from lowlightenvironmentvideoobjectdetection_amd._lib import LlvError
+    m = reg.build_backbone(dict(type='ResNet', depth=18))
+    with pytest.raises(LlvError):
+        m(torch.rand(1, 3, 32, 32))
