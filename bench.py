@@ -1,0 +1,202 @@
+#!/usr/bin/env python3
+"""bench.py -- frames/sec of enhance (FastDVDnet) + detect (RetinaNet R-50+FPN, decode, NMS, D2H) on synthetic
+1280x720 dark clips, one process per GPU, no data-path collective (clips shard across ranks: weak scaling).
+
+  python bench.py --gpus 1 --steps 20 --warmup 3
+  python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
+         bench.py --gpus N --steps K --warmup W
+
+A step = one pass of the hot path over `--frames-per-step` consecutive frames of a clip that is already
+resident in HBM (preprocessed: Brighten -> Normalize -> Pad, as the reference's test pipeline does before
+the model; the reference's benchmark.py excludes data loading too). Timed: window copy, 4 DenBlocks per frame
+(3 temp1 + 1 temp2, no reuse across steps), ResNet-50, FPN, RetinaHead, decode/top-k, NMS and the D2H copy
+of the detections. Rank 0 prints ONE JSON line.
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+METRIC = 'frames/sec (enhance+detect) on 1280x720 dark video'
+NUM_CLASSES = 80
+
+
+def retinanet_cfg():
+    """mmdetection/configs/_base_/models/retinanet_r50_fpn.py:2-60 (pretrained=None: no network)."""
+    return dict(
+        type='RetinaNet', pretrained=None,
+        backbone=dict(type='ResNet', depth=50, num_stages=4, out_indices=(0, 1, 2, 3), frozen_stages=1,
+                      norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, style='pytorch'),
+        neck=dict(type='FPN', in_channels=[256, 512, 1024, 2048], out_channels=256, start_level=1,
+                  add_extra_convs='on_input', num_outs=5),
+        bbox_head=dict(type='RetinaHead', num_classes=NUM_CLASSES, in_channels=256, stacked_convs=4, feat_channels=256,
+                       anchor_generator=dict(type='AnchorGenerator', octave_base_scale=4, scales_per_octave=3,
+                                             ratios=[0.5, 1.0, 2.0], strides=[8, 16, 32, 64, 128]),
+                       bbox_coder=dict(type='DeltaXYWHBBoxCoder', target_means=[.0, .0, .0, .0],
+                                       target_stds=[1.0, 1.0, 1.0, 1.0]),
+                       loss_cls=dict(type='FocalLoss', use_sigmoid=True, gamma=2.0, alpha=0.25, loss_weight=1.0),
+                       loss_bbox=dict(type='L1Loss', loss_weight=1.0)),
+        train_cfg=None,
+        test_cfg=dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05, nms=dict(type='nms', iou_threshold=0.5),
+                      max_per_img=100))
+
+
+def build_models(seed):
+    import lowlightenvironmentvideoobjectdetection_amd.models  # noqa: F401
+    from lowlightenvironmentvideoobjectdetection_amd import registry
+    from lowlightenvironmentvideoobjectdetection_amd.synthetic import seeded_weights
+    det = seeded_weights(registry.build_detector(retinanet_cfg()), seed=seed)
+    cleaner = seeded_weights(registry.build_cleaner(dict(type='FastDVDnet')), seed=seed + 1)
+    return det, cleaner
+
+
+def cpu_baseline(det, cleaner, clip_cpu, img_shape):
+    """The oracle (CPU restatement of the reference path) timed on this host: ONE frame of the same workload
+    (5-frame window -> FastDVDnet -> RetinaNet -> decode -> NMS), all cores."""
+    from oracle.cleaner import fastdvdnet_forward
+    from oracle.detector import retinanet_simple_test
+    cores = os.cpu_count() or 1
+    torch.set_num_threads(cores)
+    sd_c = {k: v.detach().float().cpu() for k, v in cleaner.state_dict().items()}
+    sd_d = {k: v.detach().float().cpu() for k, v in det.state_dict().items()}
+    win = clip_cpu[0:5, :, :, :3].float().permute(0, 3, 1, 2).reshape(1, 15, clip_cpu.shape[1], clip_cpu.shape[2]).contiguous()
+    meta = dict(img_shape=img_shape, scale_factor=[1.0, 1.0, 1.0, 1.0])
+    with torch.no_grad():
+        t0 = time.perf_counter()
+        den = fastdvdnet_forward(sd_c, win)
+        t1 = time.perf_counter()
+        retinanet_simple_test(sd_d, den, meta, num_classes=NUM_CLASSES)
+        t2 = time.perf_counter()
+    return dict(value=1.0 / (t2 - t0), unit='frames/s', cores=cores, kind='port',
+                sample=f'1 frame 1280x720 (padded {clip_cpu.shape[1]}x{clip_cpu.shape[2]}): FastDVDnet {t1 - t0:.2f} s + '
+                       f'RetinaNet R-50+FPN/decode/NMS {t2 - t1:.2f} s, torch fp32, {cores} threads')
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument('--gpus', type=int, default=1)
+    ap.add_argument('--steps', type=int, default=30)
+    ap.add_argument('--warmup', type=int, default=5)
+    ap.add_argument('--frames-per-step', type=int, default=1)
+    ap.add_argument('--clip-frames', type=int, default=32)
+    ap.add_argument('--height', type=int, default=720)
+    ap.add_argument('--width', type=int, default=1280)
+    ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--no-cpu-baseline', action='store_true')
+    ap.add_argument('--no-kernel-timing', action='store_true')
+    args = ap.parse_args()
+
+    world = int(os.environ.get('WORLD_SIZE', '1'))
+    rank = int(os.environ.get('RANK', '0'))
+    local_rank = int(os.environ.get('LOCAL_RANK', '0'))
+    if not torch.cuda.is_available():
+        raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
+    torch.cuda.set_device(local_rank)
+    dev = torch.device('cuda', local_rank)
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
+        dist.init_process_group('nccl', device_id=dev)
+
+    from lowlightenvironmentvideoobjectdetection_amd import data, engine
+    from lowlightenvironmentvideoobjectdetection_amd.synthetic import calibrate_head_on_device
+
+    B, T = args.frames_per_step, args.clip_frames
+    det, cleaner = build_models(seed=0)
+    # each rank gets its own clip (clips shard across ranks; a video's frames stay on one device)
+    clean = data.synth_clean_clip(T, args.height, args.width, seed=100 + rank)
+    dark = data.darken_and_add_noise(clean, seed=200 + rank)
+    clip, img_shape, pad_shape = data.preprocess_clip(dark, dev)
+    hp, wp = pad_shape[0], pad_shape[1]
+
+    def make_plan():
+        return engine.EnhanceDetectPlan(cleaner.state_dict(), det.state_dict(), NUM_CLASSES, B, hp, wp, dev,
+                                        detector_kwargs=dict(test_cfg=dict(det.bbox_head.test_cfg),
+                                                             img_shapes=[img_shape] * B),
+                                        use_graph=not args.no_graph)
+    # one pass with the raw seeded weights, then give the head trained-detector-like statistics so that a
+    # few thousand candidates pass score_thr and NMS has real work ("busy" variant)
+    plan = make_plan()
+    plan.den.frames.copy_(clip[:B + 4])
+    plan.plan.run()
+    torch.cuda.synchronize()
+    calibrate_head_on_device(det, plan.det)
+    del plan
+    plan = make_plan()
+    plan.prepare(clip)
+    n_windows = T - B + 1
+
+    def run_steps(k, start=0):
+        for s in range(k):
+            plan.step(clip, ((start + s) * B) % n_windows)
+
+    run_steps(args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    run_steps(args.steps, args.warmup)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    n_det = sum(len(d) for d, _ in plan.results())
+    n_cand_thr = int((plan.det.post.decode[0].scores > 0.05).sum().item())
+
+    out = None
+    if rank == 0:
+        fps = args.steps * B * world / dt
+        flops_step = plan.plan.flops
+        out = {
+            'metric': METRIC, 'value': round(fps, 3), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True,
+            'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+            'config': {
+                'workload': 'Enhance-CNN (FastDVDnet, 4 DenBlocks/frame) + RetinaNet R-50+FPN inference + decode + NMS, '
+                            f'{args.width}x{args.height} clip (padded {wp}x{hp}), {NUM_CLASSES} classes, 1xMI355X per rank',
+                'clip_frames': T, 'frames_per_step': B, 'hip_graph': not args.no_graph,
+                'algorithmic_gflop_per_frame': round(flops_step / B / 1e9, 1),
+                'candidates_above_score_thr': n_cand_thr, 'detections_last_step': n_det,
+                'parallelism': f'clip-sharded x{world}, no data-path collective',
+            },
+        }
+        # ---- roofline of the dominant kernel family (conv_igemm_kernel: every conv launch of the step)
+        if not args.no_kernel_timing:
+            timed = plan.plan.run_timed(iters=5)
+            convs = [(n, ms, fl) for (n, ms, fl, _) in timed if fl > 0]
+            conv_ms = sum(ms for _, ms, _ in convs)
+            all_ms = sum(ms for _, ms, _, _ in timed)
+            conv_fl = sum(fl for _, _, fl in convs)
+            top = max(convs, key=lambda c: c[1])
+            peak = 2500.0
+            ach = conv_fl / (conv_ms * 1e-3) / 1e12
+            out['roofline'] = {
+                'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
+                'traffic': None,
+                'kernel': 'conv_igemm_kernel (all %d conv launches of one step; algorithmic 2*MACs of the unpadded convs)' % len(convs),
+                'conv_ms_per_step': round(conv_ms, 4), 'all_kernels_ms_per_step': round(all_ms, 4),
+                'top_launch': {'name': top[0], 'ms': round(top[1], 4), 'tflops': round(top[2] / (top[1] * 1e-3) / 1e12, 2)},
+            }
+        if world == 1 and not args.no_cpu_baseline:
+            out['cpu_baseline'] = cpu_baseline(det, cleaner, clip.cpu(), img_shape)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+if __name__ == '__main__':
+    main()

@@ -68,6 +68,29 @@ class Plan:
         else:
             self.graph.replay()
 
+    def run_timed(self, iters=3):
+        """Eager replay with a HIP event pair around every launch (on the stream the launches go to).
+        Returns [(name, avg ms, flops, bytes)] per step. Diagnostic: not the throughput path."""
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        evs = []
+        for _ in range(iters):
+            row = []
+            for name, fn, args, _, _ in self.steps:
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                rc = fn(*args, stream)
+                e1.record()
+                if rc != 0:
+                    raise LlvError(f'{name}: {lib().llv_strerror(rc).decode()} ({rc})')
+                row.append((e0, e1))
+            evs.append(row)
+        torch.cuda.synchronize()
+        out = []
+        for i, (name, _, _, fl, nb) in enumerate(self.steps):
+            ms = sum(r[i][0].elapsed_time(r[i][1]) for r in evs) / iters
+            out.append((name, ms, fl, nb))
+        return out
+
     @property
     def flops(self):
         return sum(s[3] for s in self.steps)
@@ -431,3 +454,73 @@ class FastDVDnetPlan:
         srcs2 = [self.mid[s:s + batch] for s in range(3)]
         pc, x = _denblock(b, sd, p2, srcs2, batch, 'temp2')
         b.conv(f'temp2.out1', x, pc, CONV_RES_RSUB, res=srcs2[1], out=self.out)
+
+
+# ------------------------------------------------------------------------------------------------
+# enhance + detect on a clip
+# ------------------------------------------------------------------------------------------------
+class EnhanceDetectPlan:
+    """FastDVDnet -> RetinaNet over `batch` consecutive frames of a clip resident in HBM.
+
+    The denoiser writes straight into the detector's NHWC8 input buffer (no layout change, no copy).
+    clip: (T + 4, H, W, 8) fp16, frames replicated by two at each end (the window of frame t is t-2..t+2,
+    clamped at the clip ends as the reference's test-time reference sampler does).
+    step(t0): frames t0 .. t0+batch-1.
+    """
+
+    def __init__(self, cleaner_sd, detector_sd, num_classes, batch, height, width, device, detector_kwargs=None,
+                 use_graph=True):
+        self.batch, self.h, self.w, self.dev = batch, height, width, device
+        self.den = FastDVDnetPlan(cleaner_sd, batch, height, width, device)
+        self.det = RetinaNetPlan(detector_sd, num_classes, batch, height, width, device, x_in=self.den.out,
+                                 **(detector_kwargs or {}))
+        self.plan = Plan(device)
+        self.plan.extend(self.den.plan)
+        self.plan.extend(self.det.plan)
+        self.use_graph = use_graph
+        k = self.det.post.nms[0].max_num
+        # results of the step, device side, gathered into one buffer so the D2H is a single copy
+        self.res_dev = torch.zeros((batch, k, 6), device=device, dtype=torch.float32)
+        self.cnt_dev = torch.zeros((batch,), device=device, dtype=torch.int32)
+        self.res_host = torch.zeros((batch, k, 6), dtype=torch.float32).pin_memory()
+        self.cnt_host = torch.zeros((batch,), dtype=torch.int32).pin_memory()
+        self._graph = None
+
+    def _body(self, window):
+        self.den.frames.copy_(window)
+        self.plan.run()
+        for n, nb in enumerate(self.det.post.nms):
+            self.res_dev[n, :, :5].copy_(nb.dets)
+            self.res_dev[n, :, 5].copy_(nb.labels)
+            self.cnt_dev[n:n + 1].copy_(nb.count)
+        self.res_host.copy_(self.res_dev, non_blocking=True)
+        self.cnt_host.copy_(self.cnt_dev, non_blocking=True)
+
+    def prepare(self, clip):
+        """Warm up once (one-time kernel attribute calls) and capture the step into a HIP graph."""
+        self._window = torch.empty_like(self.den.frames)
+        self._window.copy_(clip[:self.batch + 4])
+        self._body(self._window)
+        torch.cuda.synchronize()
+        if self.use_graph:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._body(self._window)
+            self._graph = g
+
+    def step(self, clip, t0):
+        """Enqueue one step (no host sync). Results land in res_host/cnt_host after the stream drains."""
+        self._window.copy_(clip[t0:t0 + self.batch + 4])
+        if self._graph is not None:
+            self._graph.replay()
+        else:
+            self._body(self._window)
+
+    def results(self):
+        torch.cuda.current_stream().synchronize()
+        out = []
+        for n in range(self.batch):
+            k = int(self.cnt_host[n])
+            r = self.res_host[n, :k]
+            out.append((r[:, :5].clone(), r[:, 5].long()))
+        return out

@@ -54,6 +54,31 @@ def randomize(model, seed=0, cls_bias=-2.0):
     return model
 
 
+def calibrate_cls(det, img, target_std=1.2, target_mean=-3.0):
+    """Rescale retina_cls so that, on `img`, the logits have the spread of a trained detector (scores spread
+    over (0, 1) instead of saturating): otherwise the top-100 detections are all ~1.0 and their membership is
+    decided by rounding noise. Uses the fp32 oracle on the CPU; deterministic."""
+    from oracle.detector import retina_head_forward, retinanet_extract_feat
+    sd = det.state_dict()
+    with torch.no_grad():
+        cls, reg = retina_head_forward(sd, retinanet_extract_feat(sd, img, det.backbone.depth), det.bbox_head.stacked_convs)
+        # box deltas of a trained head are O(0.1); random ones reach the +-log(1000/16) clamp where exp() turns a
+        # 1e-3 relative logit difference into pixels
+        rflat = torch.cat([r.flatten() for r in reg])
+        rs = 0.25 / (rflat.std().item() + 1e-12)
+        det.bbox_head.retina_reg.weight.mul_(rs)
+        det.bbox_head.retina_reg.bias.mul_(rs)
+        flat = torch.cat([c.flatten() for c in cls])
+        b = det.bbox_head.retina_cls.bias
+        w = det.bbox_head.retina_cls.weight
+        scale = target_std / (flat.std().item() + 1e-12)
+        mean_wo_bias = (flat.mean().item() - b.mean().item()) * scale
+        w.mul_(scale)
+        b.copy_(torch.full_like(b, target_mean - mean_wo_bias) + (b - b.mean()) * scale)
+    det.invalidate_plans()
+    return det
+
+
 def smooth_image(n, h, w, seed=0):
     """Low-pass noise + rectangles, normalised-image statistics (zero mean, unit-ish variance), NCHW fp32."""
     g = torch.Generator().manual_seed(seed)

@@ -8,7 +8,7 @@ import numpy as np
 import pytest
 import torch
 
-from helpers import img_meta, match_detections, randomize, retinanet_cfg, smooth_image
+from helpers import calibrate_cls, img_meta, match_detections, randomize, retinanet_cfg, smooth_image
 
 pytestmark = pytest.mark.gpu
 
@@ -89,6 +89,7 @@ def test_retinanet_simple_test_vs_oracle(dev, h, w, ncls):
     from oracle.detector import retinanet_simple_test, retinanet_extract_feat
     det = randomize(reg.build_detector(retinanet_cfg(num_classes=ncls)), seed=7, cls_bias=-1.5)
     img = smooth_image(1, h, w, seed=8)
+    calibrate_cls(det, img)
     meta = img_meta(h - 8, w, h, w, scale=1.25)
     sd = {k: v.clone() for k, v in det.state_dict().items()}
     ref = retinanet_simple_test(sd, img, meta, num_classes=ncls, rescale=True)
