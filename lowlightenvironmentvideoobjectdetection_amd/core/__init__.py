@@ -1,2 +1,3 @@
 from .anchor import AnchorGenerator, anchor_inside_flags, images_to_levels  # noqa: F401
+from .assign import AssignResult, MaxIoUAssigner, PseudoSampler, SamplingResult  # noqa: F401
 from .bbox import DeltaXYWHBBoxCoder, bbox2result  # noqa: F401

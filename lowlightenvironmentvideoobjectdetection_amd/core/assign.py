@@ -1,0 +1,81 @@
+"""MaxIoUAssigner / PseudoSampler with the reference's interface
+(mmdetection/mmdet/core/bbox/assigners/max_iou_assigner.py:9-212, samplers/pseudo_sampler.py:8-41,
+assigners/assign_result.py, samplers/sampling_result.py). The k x n IoU matrix, both arg-maxes and the
+low-quality match run in llv_iou_assign (csrc/train_ops.hip) without materialising the matrix."""
+import torch
+
+from .. import ops
+from .._lib import LlvError
+from ..registry import BBOX_ASSIGNERS, BBOX_SAMPLERS
+
+
+class AssignResult:
+    def __init__(self, num_gts, gt_inds, max_overlaps, labels=None):
+        self.num_gts, self.gt_inds, self.max_overlaps, self.labels = num_gts, gt_inds, max_overlaps, labels
+
+    @property
+    def num_preds(self):
+        return len(self.gt_inds)
+
+
+class SamplingResult:
+    """sampling_result.py:7-60"""
+
+    def __init__(self, pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags):
+        self.pos_inds, self.neg_inds = pos_inds, neg_inds
+        self.pos_bboxes, self.neg_bboxes = bboxes[pos_inds], bboxes[neg_inds]
+        self.pos_is_gt = gt_flags[pos_inds]
+        self.num_gts = gt_bboxes.shape[0]
+        self.pos_assigned_gt_inds = assign_result.gt_inds[pos_inds] - 1
+        if gt_bboxes.numel() == 0:
+            assert self.pos_assigned_gt_inds.numel() == 0
+            self.pos_gt_bboxes = torch.empty_like(gt_bboxes).view(-1, 4)
+        else:
+            if len(gt_bboxes.shape) < 2:
+                gt_bboxes = gt_bboxes.view(-1, 4)
+            self.pos_gt_bboxes = gt_bboxes[self.pos_assigned_gt_inds, :]
+        self.pos_gt_labels = assign_result.labels[pos_inds] if assign_result.labels is not None else None
+
+
+@BBOX_ASSIGNERS.register_module()
+class MaxIoUAssigner(object):
+    def __init__(self, pos_iou_thr, neg_iou_thr, min_pos_iou=.0, gt_max_assign_all=True, ignore_iof_thr=-1,
+                 ignore_wrt_candidates=True, match_low_quality=True, gpu_assign_thr=-1,
+                 iou_calculator=dict(type='BboxOverlaps2D')):
+        if not isinstance(neg_iou_thr, float):
+            raise NotImplementedError('tuple neg_iou_thr is outside the dense-head hot path')
+        self.pos_iou_thr, self.neg_iou_thr, self.min_pos_iou = pos_iou_thr, neg_iou_thr, min_pos_iou
+        self.gt_max_assign_all, self.ignore_iof_thr = gt_max_assign_all, ignore_iof_thr
+        self.ignore_wrt_candidates, self.match_low_quality = ignore_wrt_candidates, match_low_quality
+        self.gpu_assign_thr = gpu_assign_thr
+
+    def assign(self, bboxes, gt_bboxes, gt_bboxes_ignore=None, gt_labels=None):
+        if self.ignore_iof_thr > 0 and gt_bboxes_ignore is not None and gt_bboxes_ignore.numel() > 0:
+            raise NotImplementedError('ignore regions (ignore_iof_thr > 0) are outside the hot path (config uses -1)')
+        n, k = bboxes.shape[0], gt_bboxes.shape[0]
+        if n == 0:
+            gt_inds = bboxes.new_full((0,), -1, dtype=torch.long)
+            labels = None if gt_labels is None else bboxes.new_full((0,), -1, dtype=torch.long)
+            return AssignResult(k, gt_inds, bboxes.new_zeros((0,)), labels)
+        gt_inds, max_ov = ops.iou_assign(gt_bboxes[:, :4], bboxes[:, :4], None, self.pos_iou_thr, self.neg_iou_thr,
+                                         self.min_pos_iou, self.match_low_quality, self.gt_max_assign_all)
+        if gt_labels is not None:
+            labels = gt_inds.new_full((n,), -1)
+            pos = torch.nonzero(gt_inds > 0, as_tuple=False).squeeze(-1)
+            if pos.numel() > 0:
+                labels[pos] = gt_labels[gt_inds[pos] - 1]
+        else:
+            labels = None
+        return AssignResult(k, gt_inds, max_ov, labels)
+
+
+@BBOX_SAMPLERS.register_module()
+class PseudoSampler(object):
+    def __init__(self, **kwargs):
+        pass
+
+    def sample(self, assign_result, bboxes, gt_bboxes, **kwargs):
+        pos_inds = torch.nonzero(assign_result.gt_inds > 0, as_tuple=False).squeeze(-1).unique()
+        neg_inds = torch.nonzero(assign_result.gt_inds == 0, as_tuple=False).squeeze(-1).unique()
+        gt_flags = bboxes.new_zeros(bboxes.shape[0], dtype=torch.uint8)
+        return SamplingResult(pos_inds, neg_inds, bboxes, gt_bboxes, assign_result, gt_flags)

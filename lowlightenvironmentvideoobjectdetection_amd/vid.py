@@ -1,0 +1,193 @@
+"""Video detectors with the reference's interface (mmtracking/mmtrack/models/vid/base.py:15-326) and the
+enhance -> detect wiring of mmtracking/mmtrack/models/vid/selsa_fastdvd_darkfarm.py:151-184,294-319, for a
+single-stage (dense head) detector.
+
+The reference's SelsaFastDVDnetDetect asserts a two-stage detector (`roi_head`, :37-38) and its single-stage test
+branches are broken, so the dense-head variant is registered here as `FastDVDnetDetect` with the
+same constructor arguments (detector, cleaner, pretrains, frozen_modules, train_cfg, test_cfg, loss_type)."""
+from collections import OrderedDict
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+from . import engine, ops
+from ._lib import LlvError
+from .core.bbox import bbox2result
+from .planned import PlannedModule
+from .registry import MODELS, build_cleaner, build_detector
+
+
+class BaseVideoDetector(PlannedModule):
+    def __init__(self):
+        super().__init__()
+
+    def init_module(self, module, pretrain=None):
+        """base.py:22-37"""
+        if pretrain is not None:
+            from .checkpoint import load_checkpoint
+            print(f'load {module} from: {pretrain}')
+            load_checkpoint(getattr(self, module), pretrain, strict=False)
+        else:
+            getattr(self, module).init_weights()
+        self.invalidate_plans()
+
+    def freeze_module(self, module):
+        """base.py:39-54"""
+        if isinstance(module, str):
+            modules = [module]
+        elif isinstance(module, (list, tuple)):
+            modules = module
+        else:
+            raise TypeError('module must be a str or a list.')
+        for name in modules:
+            m = getattr(self, name)
+            m.eval()
+            for p in m.parameters():
+                p.requires_grad = False
+
+    with_detector = property(lambda self: hasattr(self, 'detector') and self.detector is not None)
+    with_motion = property(lambda self: hasattr(self, 'motion') and self.motion is not None)
+    with_aggregator = property(lambda self: hasattr(self, 'aggregator') and self.aggregator is not None)
+    with_cleaner = property(lambda self: hasattr(self, 'cleaner') and self.cleaner is not None)
+
+    def forward_test(self, imgs, img_metas, **kwargs):
+        """base.py:97-138"""
+        if isinstance(imgs, torch.Tensor):
+            imgs = [imgs]
+        elif not isinstance(imgs, list):
+            raise TypeError(f'imgs must be a list or tensor, but got {type(imgs)}')
+        assert isinstance(img_metas, list)
+        if isinstance(img_metas[0], dict):
+            img_metas = [img_metas]
+        elif not isinstance(img_metas[0], list):
+            raise TypeError('img_metas must be a List[List[dict]] or List[dict]')
+        num_augs = len(imgs)
+        if num_augs != len(img_metas):
+            raise ValueError(f'num of augmentations ({len(imgs)}) != num of image meta ({len(img_metas)})')
+        if num_augs == 1:
+            if 'proposals' in kwargs:
+                kwargs['proposals'] = kwargs['proposals'][0]
+            return self.simple_test(imgs[0], img_metas[0], **kwargs)
+        assert imgs[0].size(0) == 1
+        assert 'proposals' not in kwargs
+        return self.aug_test(imgs, img_metas, **kwargs)
+
+    def forward(self, img, img_metas, return_loss=True, **kwargs):
+        """base.py:140-156"""
+        if return_loss:
+            return self.forward_train(img, img_metas, **kwargs)
+        return self.forward_test(img, img_metas, **kwargs)
+
+    def _parse_losses(self, losses):
+        """base.py:158-190 (same contract as the detector's)."""
+        log_vars = OrderedDict()
+        for loss_name, loss_value in losses.items():
+            if isinstance(loss_value, torch.Tensor):
+                log_vars[loss_name] = loss_value.mean()
+            elif isinstance(loss_value, list):
+                log_vars[loss_name] = sum(_loss.mean() for _loss in loss_value)
+            else:
+                raise TypeError(f'{loss_name} is not a tensor or list of tensors')
+        loss = sum(_value for _key, _value in log_vars.items() if 'loss' in _key)
+        log_vars['loss'] = loss
+        for loss_name, loss_value in log_vars.items():
+            if dist.is_available() and dist.is_initialized():
+                loss_value = loss_value.data.clone()
+                dist.all_reduce(loss_value.div_(dist.get_world_size()))
+            log_vars[loss_name] = loss_value.item()
+        return loss, log_vars
+
+    def train_step(self, data, optimizer):
+        losses = self(**data)
+        loss, log_vars = self._parse_losses(losses)
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(data['img_metas']))
+
+    def aug_test(self, imgs, img_metas, **kwargs):
+        raise NotImplementedError('test-time augmentation is outside the hot path')
+
+
+@MODELS.register_module()
+class FastDVDnetDetect(BaseVideoDetector):
+    """FastDVDnet (5-frame window) -> single-stage detector.
+
+    Test-time call, as mmtrack's data pipeline delivers it (selsa_fastdvd_darkfarm.py:262-301):
+        model(return_loss=False, img=[T(1,3,H,W)], img_metas=[[meta]], ref_img=[T(1,4,3,H,W)], ref_img_metas=...)
+    The reference caches the four reference frames at frame 0 of a video in self.memo and re-uses them for every
+    later frame (:295-301); pass ref_img with every call to slide the window instead (both are supported: a call
+    without ref_img uses the memo). Returns {'bbox_results': list[num_classes] of (k,5) float32 arrays}.
+    """
+
+    def __init__(self, detector, cleaner, pretrains=None, frozen_modules=None, train_cfg=None, test_cfg=None,
+                 loss_type=None):
+        super().__init__()
+        self.detector = build_detector(detector)
+        self.cleaner = build_cleaner(cleaner)
+        if hasattr(self.detector, 'roi_head'):
+            raise LlvError('FastDVDnetDetect drives a dense-head (single-stage) detector; two-stage is out of scope')
+        self.train_cfg, self.test_cfg, self.loss_type = train_cfg, test_cfg, loss_type
+        self.memo = None
+        self.init_weights(pretrains)
+        if frozen_modules is not None:
+            self.freeze_module(frozen_modules)
+
+    def init_weights(self, pretrain):
+        """selsa_fastdvd_darkfarm.py:47-62"""
+        if pretrain is None:
+            pretrain = dict()
+        assert isinstance(pretrain, dict), '`pretrain` must be a dict.'
+        if self.with_detector and pretrain.get('detector', False):
+            self.init_module('detector', pretrain['detector'])
+        if self.with_cleaner and pretrain.get('cleaner', False):
+            self.init_module('cleaner', pretrain['cleaner'])
+
+    def invalidate_plans(self):
+        super().invalidate_plans()
+        for m in self.children():
+            if isinstance(m, PlannedModule):
+                m.invalidate_plans()
+
+    def make_plan(self, batch, height, width, device, use_graph=False):
+        d = self.detector
+        return engine.EnhanceDetectPlan(
+            self.cleaner.state_dict(), d.state_dict(), d.bbox_head.cls_out_channels, batch, height, width, device,
+            detector_kwargs=dict(depth=d.backbone.depth, strides=d.backbone.strides, style=d.backbone.style,
+                                 out_indices=d.backbone.out_indices, start_level=d.neck.start_level, num_outs=d.neck.num_outs,
+                                 add_extra_convs=d.neck.add_extra_convs, stacked_convs=d.bbox_head.stacked_convs,
+                                 anchor_generator=d.bbox_head.anchor_generator,
+                                 test_cfg=dict(d.bbox_head.test_cfg) if d.bbox_head.test_cfg else None,
+                                 target_means=d.bbox_head.bbox_coder.means, target_stds=d.bbox_head.bbox_coder.stds),
+            use_graph=use_graph)
+
+    def forward_train(self, img, img_metas, **kwargs):
+        raise LlvError('FastDVDnetDetect.forward_train: the training path is not built yet in this round')
+
+    def simple_test(self, img, img_metas, ref_img=None, ref_img_metas=None, rescale=False, **kwargs):
+        self._check_input(img)
+        assert len(img) == 1, 'video detectors take 1 image per GPU (selsa_fastdvd_darkfarm.py:152-153)'
+        frame_id = img_metas[0].get('frame_id', -1)
+        if ref_img is not None:
+            refs = ref_img[0] if isinstance(ref_img, (list, tuple)) else ref_img
+            refs = refs[0] if refs.dim() == 5 else refs
+            assert refs.shape[0] == 4, 'FastDVDnet support frames is 4.'
+            self.memo = dict(ref_imgs=refs)
+        elif self.memo is None or frame_id == 0:
+            raise LlvError('first frame of a video needs ref_img (4 reference frames)')
+        refs = self.memo['ref_imgs']
+        n, c, h, w = img.shape
+        plan = self._plan((h, w, str(img.device)), lambda: self.make_plan(1, h, w, img.device))
+        # window order [ref0, ref1, img, ref2, ref3] (selsa_fastdvd_darkfarm.py:300)
+        window = torch.cat([refs[:2], img, refs[2:]], dim=0).float().contiguous()
+        ops.pack_input(window, 8, out=plan.den.frames)
+        dp = plan.det.post.decode[0].desc
+        m = img_metas[0]
+        dp.clip, dp.img_h, dp.img_w = 1, float(m['img_shape'][0]), float(m['img_shape'][1])
+        sf = np.asarray(m.get('scale_factor', 1.0), dtype=np.float32).reshape(-1)
+        sf = np.repeat(sf, 4) if sf.size == 1 else sf
+        for e in range(4):
+            dp.scale_factor[e] = float(sf[e])
+        dp.rescale = 1 if rescale else 0
+        plan.plan.run()
+        dets, labels = plan.det.results()[0]
+        self.memo['denoising_img'] = plan.den.out
+        return dict(bbox_results=bbox2result(dets, labels, self.detector.bbox_head.num_classes))

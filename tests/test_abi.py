@@ -1,0 +1,72 @@
+"""The C-ABI library builds, loads, and exports every symbol include/llv.h declares (no compute without a GPU)."""
+import ctypes
+import os
+import re
+
+import pytest
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _declared():
+    txt = open(os.path.join(ROOT, 'include', 'llv.h')).read()
+    txt = re.sub(r'/\*.*?\*/', '', txt, flags=re.S)
+    return sorted(set(re.findall(r'\b(llv_[a-z0-9_]+)\s*\(', txt)))
+
+
+def test_header_symbols_are_exported_and_bound():
+    import __graft_entry__ as g
+    g.build()
+    from lowlightenvironmentvideoobjectdetection_amd import _lib
+    names = _declared()
+    assert len(names) >= 20
+    h = ctypes.CDLL(_lib.LIB_PATH)
+    for n in names:
+        assert hasattr(h, n), f'{n} declared in include/llv.h but not exported by libllv.so'
+        assert n in _lib.SIGNATURES, f'{n} has no ctypes signature in _lib.py'
+    assert sorted(_lib.SIGNATURES) == names
+    assert _lib.lib().llv_abi_version() == 1
+    assert _lib.lib().llv_strerror(-1) == b'bad argument'
+
+
+def test_bad_arguments_are_rejected_before_any_launch():
+    """Argument validation happens on the host: these calls never reach the device."""
+    from lowlightenvironmentvideoobjectdetection_amd import _lib
+    L = _lib.lib()
+    assert L.llv_conv2d_nhwc_fwd(None, None) == -1
+    d = _lib.ConvDesc()
+    assert L.llv_conv2d_nhwc_fwd(ctypes.byref(d), None) == -1
+    assert L.llv_maxpool3x3s2_nhwc(None, None, 1, 8, 8, 8, None) == -1
+    assert L.llv_multiclass_nms(None, None, 10, 4, 4, 0.05, 0.5, 100, None, None, None, None, None, 0, None) == -1
+    assert L.llv_multiclass_nms_workspace_bytes(4540, 80, 100) > 0
+    assert L.llv_nms_workspace_bytes(100) > 0
+    assert L.llv_iou_assign_workspace_bytes(10, 1000) > 0
+    dd = _lib.DecodeDesc()
+    assert L.llv_retina_decode_ncand(ctypes.byref(dd)) == -1
+    dd.n_levels, dd.num_classes, dd.num_anchors, dd.nms_pre = 5, 80, 9, 1000
+    for i, (h, w) in enumerate([(92, 160), (46, 80), (23, 40), (12, 20), (6, 10)]):
+        dd.level_h[i], dd.level_w[i] = h, w
+    assert L.llv_retina_decode_ncand(ctypes.byref(dd)) == 4540          # 1000*4 + 540
+    assert L.llv_retina_decode_workspace_bytes(ctypes.byref(dd)) >= 176580 * 4 + 4540 * 4
+
+
+def test_product_has_no_cpu_path():
+    import torch
+    import lowlightenvironmentvideoobjectdetection_amd.models as M
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    from lowlightenvironmentvideoobjectdetection_amd._lib import LlvError
+    with pytest.raises(LlvError):
+        M.build_backbone(dict(type='ResNet', depth=18))(torch.rand(1, 3, 32, 32))
+    with pytest.raises(LlvError):
+        ops.multiclass_nms(torch.rand(4, 4), torch.rand(4, 3), 0.05, dict(type='nms', iou_threshold=0.5), 10)
+    with pytest.raises(LlvError):
+        ops.maxpool3x3s2(torch.zeros(1, 8, 8, 8, dtype=torch.float16))
+
+
+def test_product_does_not_import_oracle():
+    import subprocess
+    import sys
+    code = ("import sys; sys.path.insert(0, %r); import lowlightenvironmentvideoobjectdetection_amd.models, "
+            "lowlightenvironmentvideoobjectdetection_amd.engine, lowlightenvironmentvideoobjectdetection_amd.data; "
+            "assert not any(m == 'oracle' or m.startswith('oracle.') for m in sys.modules), 'product imports oracle'" % ROOT)
+    subprocess.run([sys.executable, '-c', code], check=True)

@@ -1,0 +1,54 @@
+"""N > 1 path on the CPU: world_size-2 gloo processes exercise video sharding, the result gather, the
+loss all-reduce of _parse_losses (base.py:185-218) and the coalesced gradient averaging."""
+import os
+import sys
+
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)
+    from lowlightenvironmentvideoobjectdetection_amd import dist_utils
+    from lowlightenvironmentvideoobjectdetection_amd.detectors import BaseDetector
+    lens = [4, 2, 5, 3]
+    mine = dist_utils.shard_videos(lens, rank, world)
+    part = [('frame', i, rank) for i in mine]
+    allres = dist_utils.collect_results(part, sum(lens))
+    losses = dict(loss_cls=[torch.tensor(1.0 + rank), torch.tensor(2.0)], loss_bbox=torch.tensor(0.5 * (rank + 1)), acc=torch.tensor(10.0 * rank))
+    loss, log_vars = BaseDetector._parse_losses(None, losses)
+    p = torch.nn.Parameter(torch.zeros(5))
+    p.grad = torch.full((5,), float(rank + 1))
+    p2 = torch.nn.Parameter(torch.zeros(3))
+    p2.grad = torch.full((3,), float(10 * (rank + 1)))
+    dist_utils.allreduce_grads([p, p2], coalesce=True, bucket_size_mb=-1)
+    q.put((rank, mine, allres, float(loss), dict(log_vars), p.grad.tolist(), p2.grad.tolist()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_world_size_two_gloo():
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29500 + (os.getpid() % 2000)
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    out = sorted([q.get(timeout=120) for _ in procs])
+    for p in procs:
+        p.join(60)
+        assert p.exitcode == 0
+    (r0, mine0, all0, loss0, lv0, g0, h0), (r1, mine1, all1, loss1, lv1, g1, h1) = out
+    assert mine0 == list(range(0, 6)) and mine1 == list(range(6, 14))          # videos {0,1} | {2,3}, whole videos only
+    assert all1 is None and [a[1] for a in all0] == list(range(14))
+    assert loss0 == 3.0 + 0.5 and loss1 == 4.0 + 1.0                           # local loss is NOT reduced (base.py:204-206)
+    assert lv0 == lv1                                                          # logged scalars are the rank mean
+    assert abs(lv0['loss_cls'] - 3.5) < 1e-6 and abs(lv0['loss_bbox'] - 0.75) < 1e-6 and abs(lv0['acc'] - 5.0) < 1e-6
+    assert abs(lv0['loss'] - 4.25) < 1e-6
+    assert g0 == g1 == [1.5] * 5 and h0 == h1 == [15.0] * 3

@@ -1,0 +1,180 @@
+"""Host logic on the CPU: registry/config surface, weight packing, state_dict names, sharding, preprocessing."""
+import os
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+import lowlightenvironmentvideoobjectdetection_amd.models as M
+from lowlightenvironmentvideoobjectdetection_amd import ops, registry
+from lowlightenvironmentvideoobjectdetection_amd.config import Config
+from helpers import retinanet_cfg
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_registry_build_from_cfg_errors():
+    """same failure modes as mmcv.utils.build_from_cfg (mmdetection/mmdet/models/builder.py:15-34)"""
+    with pytest.raises(TypeError):
+        registry.build_from_cfg('ResNet', registry.BACKBONES)
+    with pytest.raises(KeyError):
+        registry.build_from_cfg(dict(depth=50), registry.BACKBONES)
+    with pytest.raises(KeyError):
+        registry.build_from_cfg(dict(type='NoSuchNet'), registry.BACKBONES)
+    with pytest.raises(KeyError):
+        M.build_backbone(dict(type='ResNet', depth=51))           # resnet.py:395-396
+    seq = registry.build([dict(type='ResNet', depth=18), dict(type='ResNet', depth=18)], registry.BACKBONES)
+    assert isinstance(seq, torch.nn.Sequential) and len(seq) == 2
+    for name, reg in [('RetinaNet', registry.DETECTORS), ('ResNet', registry.BACKBONES), ('FPN', registry.NECKS),
+                      ('RetinaHead', registry.HEADS), ('AnchorHead', registry.HEADS), ('FocalLoss', registry.LOSSES),
+                      ('L1Loss', registry.LOSSES), ('SmoothL1Loss', registry.LOSSES), ('FastDVDnet', registry.CLEANER),
+                      ('FastDVDnetDetect', registry.MODELS), ('AnchorGenerator', registry.ANCHOR_GENERATORS),
+                      ('DeltaXYWHBBoxCoder', registry.BBOX_CODERS), ('MaxIoUAssigner', registry.BBOX_ASSIGNERS),
+                      ('PseudoSampler', registry.BBOX_SAMPLERS)]:
+        assert name in reg, f'{name} missing from {reg.name}'
+
+
+def test_state_dict_names_match_reference_layout():
+    """Key names follow the reference's module paths (checkpoint compatibility)."""
+    det = M.build_detector(retinanet_cfg())
+    keys = set(det.state_dict())
+    for k in ['backbone.conv1.weight', 'backbone.bn1.running_var', 'backbone.layer1.0.conv1.weight',
+              'backbone.layer1.0.bn3.weight', 'backbone.layer1.0.downsample.0.weight', 'backbone.layer1.0.downsample.1.running_mean',
+              'backbone.layer4.2.conv3.weight', 'neck.lateral_convs.0.conv.weight', 'neck.lateral_convs.2.conv.bias',
+              'neck.fpn_convs.4.conv.weight', 'bbox_head.cls_convs.3.conv.weight', 'bbox_head.reg_convs.0.conv.bias',
+              'bbox_head.retina_cls.weight', 'bbox_head.retina_reg.bias']:
+        assert k in keys, k
+    assert det.state_dict()['backbone.layer2.0.downsample.0.weight'].shape == (512, 256, 1, 1)
+    assert det.state_dict()['neck.fpn_convs.3.conv.weight'].shape == (256, 2048, 3, 3)      # P6 on C5 ('on_input')
+    assert det.state_dict()['bbox_head.retina_cls.weight'].shape == (720, 256, 3, 3)
+    n_all = sum(p.numel() for p in det.parameters())
+    n_train = sum(p.numel() for p in det.parameters() if p.requires_grad)
+    assert n_all == 37968692 and abs(n_train - 37.74e6) < 0.02e6
+    c = M.build_cleaner(dict(type='FastDVDnet'))
+    ck = set(c.state_dict())
+    for k in ['temp1.inc.convblock.0.weight', 'temp1.inc.convblock.4.running_mean', 'temp1.downc0.convblock.3.convblock.3.weight',
+              'temp2.upc2.convblock.1.weight', 'temp2.outc.convblock.3.weight']:
+        assert k in ck, k
+    assert c.state_dict()['temp1.inc.convblock.0.weight'].shape == (90, 3, 3, 3)
+    assert c.state_dict()['temp1.upc2.convblock.1.weight'].shape == (256, 128, 3, 3)
+
+
+def test_reference_init_schemes():
+    det = M.build_detector(retinanet_cfg())
+    sd = det.state_dict()
+    assert float(sd['backbone.layer1.0.bn3.weight'].abs().max()) == 0.0          # zero_init_residual, resnet.py:611-618
+    assert float(sd['backbone.layer1.0.bn1.weight'].min()) == 1.0
+    assert abs(float(sd['bbox_head.retina_cls.bias'][0]) - (-np.log(99.0))) < 1e-5   # bias_init_with_prob(0.01)
+    assert abs(float(sd['bbox_head.cls_convs.0.conv.weight'].std()) - 0.01) < 1e-3   # normal_init std 0.01
+    assert float(sd['neck.lateral_convs.0.conv.bias'].abs().max()) == 0.0
+    assert not det.backbone.conv1.weight.requires_grad and not det.backbone.layer1[0].conv1.weight.requires_grad
+    assert det.backbone.layer2[0].conv1.weight.requires_grad                        # frozen_stages=1
+    det.train()
+    assert not det.backbone.layer3[0].bn1.training                                   # norm_eval, resnet.py:642-651
+
+
+def test_config_base_inheritance_delete_and_overrides(tmp_path):
+    (tmp_path / 'base.py').write_text("model = dict(type='A', head=dict(type='H', n=1, keep=2))\nlr = 0.1\n")
+    (tmp_path / 'child.py').write_text("_base_ = './base.py'\nmodel = dict(head=dict(n=5))\n")
+    (tmp_path / 'child2.py').write_text("_base_ = ['./base.py']\nmodel = dict(head=dict(_delete_=True, type='G'))\n")
+    c = Config.fromfile(str(tmp_path / 'child.py'))
+    assert c.model.type == 'A' and c.model.head.n == 5 and c.model.head.keep == 2 and c.lr == 0.1
+    c2 = Config.fromfile(str(tmp_path / 'child2.py'))
+    assert dict(c2.model.head) == dict(type='G')
+    c.merge_from_dict({'model.head.n': 7, 'lr': 0.2})
+    assert c.model.head.n == 7 and c.lr == 0.2 and c.get('nope', 3) == 3
+
+
+def test_repo_configs_build():
+    cfg = Config.fromfile(os.path.join(ROOT, 'configs/llv/fastdvdnet_retinanet_r50_fpn_720p.py'))
+    assert cfg.dist_params.backend == 'nccl'
+    m = M.build_model(cfg.model)
+    assert type(m).__name__ == 'FastDVDnetDetect' and not any(p.requires_grad for p in m.cleaner.parameters())
+    cfg2 = Config.fromfile(os.path.join(ROOT, 'configs/llv/retinanet_r50_fpn_720p.py'))
+    d = M.build_detector(cfg2.model)
+    assert type(d.bbox_head.assigner).__name__ == 'MaxIoUAssigner'
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/mmdetection/configs'), reason='reference tree not present')
+def test_reference_config_files_load_unchanged():
+    c = Config.fromfile('/root/reference/mmdetection/configs/retinanet/retinanet_r50_fpn_1x_coco.py')
+    assert c.model.type == 'RetinaNet' and c.model.test_cfg.nms.iou_threshold == 0.5 and c.optimizer.type == 'SGD'
+    with pytest.warns(UserWarning):
+        d = M.build_detector(c.model)          # pretrained='torchvision://resnet50' cannot be fetched: warns, keeps init
+    assert d.bbox_head.num_classes == 80
+    c = Config.fromfile('/root/reference/mmdetection/configs/fp16/retinanet_r50_fpn_fp16_1x_coco.py')
+    assert c.fp16.loss_scale == 512.
+    c = Config.fromfile('/root/reference/mmtracking/configs/_base_/models/retinanet_r50_fpn.py')
+    assert c.model.detector.type == 'RetinaNet'
+
+
+def _emulate_packed_conv(x_nchw, pc):
+    """CPU emulation of what the kernel computes from the packed layout (fp16-rounded weights, fp32 math)."""
+    cin = pc.cin
+    w = pc.w[0, :pc.cout, :pc.kh * pc.kw * cin].float().reshape(pc.cout, pc.kh, pc.kw, cin).permute(0, 3, 1, 2)
+    xp = torch.zeros(x_nchw.shape[0], cin, *x_nchw.shape[2:])
+    xp[:, :x_nchw.shape[1]] = x_nchw
+    return F.conv2d(xp, w, pc.bias, pc.stride, pc.pad)
+
+
+def test_pack_conv_layout_and_bn_fold():
+    g = torch.Generator().manual_seed(0)
+    w = torch.randn(10, 6, 3, 3, generator=g) * 0.1
+    gamma, beta = torch.rand(10, generator=g) + 0.5, torch.randn(10, generator=g)
+    mean, var = torch.randn(10, generator=g), torch.rand(10, generator=g) + 0.5
+    pc = ops.pack_conv(w, None, stride=2, pad=1, bn=(gamma, beta, mean, var))
+    assert pc.cin == 8 and pc.cout == 12 and pc.w_rows == 16 and pc.k_pad == 96 and pc.w.dtype == torch.float16
+    x = torch.randn(2, 6, 9, 11, generator=g)
+    ref = F.batch_norm(F.conv2d(x, w, None, 2, 1), mean, var, gamma, beta, False, 0., 1e-5)
+    got = _emulate_packed_conv(x, pc)
+    assert (got[:, :10] - ref).abs().max() < 2e-3 and got[:, 10:].abs().max() == 0
+    a, b = ops.pack_conv(torch.randn(8, 16, 3, 3), torch.zeros(8), 1, 1), ops.pack_conv(torch.randn(8, 16, 3, 3), torch.ones(8), 1, 1)
+    s = ops.stack_groups([a, b])
+    assert s.groups == 2 and s.w.shape == (2, 16, 160) and torch.equal(s.bias[8:], torch.ones(8))
+    c = ops.concat_cout([a, b])
+    assert c.cout == 16 and c.groups == 1 and torch.equal(c.w[0, 8:16], b.w[0, :8])
+
+
+def test_clip_sharding_matches_distributed_video_sampler():
+    """mmtracking/mmtrack/datasets/samplers/distributed_video_sampler.py:24-45: contiguous whole videos per rank."""
+    from lowlightenvironmentvideoobjectdetection_amd.dist_utils import shard_videos
+    lens = [5, 3, 7, 2, 9, 4, 6]
+    for world in (1, 2, 3, 8):
+        seen = []
+        for r in range(world):
+            idx = shard_videos(lens, r, world)
+            assert idx == sorted(idx)
+            seen += idx
+        assert sorted(seen) == list(range(sum(lens)))               # every frame exactly once
+        for r in range(world):                                      # a video never straddles two ranks
+            vids = set()
+            for i in shard_videos(lens, r, world):
+                v, acc = 0, 0
+                while i >= acc + lens[v]:
+                    acc += lens[v]
+                    v += 1
+                vids.add(v)
+            for r2 in range(r + 1, world):
+                for i in shard_videos(lens, r2, world):
+                    v, acc = 0, 0
+                    while i >= acc + lens[v]:
+                        acc += lens[v]
+                        v += 1
+                    assert v not in vids
+
+
+def test_preprocess_clip_matches_reference_pipeline_math():
+    """Brighten (transforms.py:381-403), Normalize with to_rgb, Pad to /32: against a numpy restatement."""
+    from lowlightenvironmentvideoobjectdetection_amd import data
+    g = np.random.RandomState(0)
+    frames = (g.rand(3, 50, 70, 3) * 60).round().astype(np.float32)
+    out, img_shape, pad_shape = data.preprocess_clip(torch.from_numpy(frames), 'cpu', m=0.25)
+    assert img_shape == (50, 70, 3) and pad_shape == (64, 96, 3) and out.shape == (7, 64, 96, 8)
+    amp = 0.25 * 50 * 70 * 3 / (frames[0] / 255.0).sum()
+    ref = np.clip(frames[1] * amp, 0, 255).astype(np.uint8).astype(np.float32)[..., ::-1]
+    ref = (ref - np.array([123.675, 116.28, 103.53], np.float32)) / np.array([58.395, 57.12, 57.375], np.float32)
+    got = out[3, :50, :70, :3].float().numpy()
+    assert np.abs(got - ref).max() < 2e-3                      # fp16 storage of values in [-2.2, 2.7]
+    assert float(out[3, 50:].abs().max()) == 0 and float(out[3, :, 70:].abs().max()) == 0 and float(out[..., 3:].abs().max()) == 0
+    assert torch.equal(out[0], out[2]) and torch.equal(out[1], out[2]) and torch.equal(out[-1], out[4])
