@@ -126,7 +126,7 @@ def main():
     plan.den.frames.copy_(clip[:B + 4])
     plan.plan.run()
     torch.cuda.synchronize()
-    calibrate_head_on_device(det, plan.det)
+    calibrate_head_on_device(det, plan.det, target_cls_mean=-6.0, target_cls_std=1.3)
     del plan
     plan = make_plan()
     plan.prepare(clip)

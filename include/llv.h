@@ -78,6 +78,8 @@ extern "C" {
  *
  * x      : n_src tensors, NHWC fp16, x_ld channels per pixel each; the launch sees them
  *          concatenated along C (src_cvec 8-channel vectors per source). n_src == 1 normally.
+ *          With groups == n_src > 1, group g reads source tensor g instead (grouped conv over separate
+ *          tensors: FastDVDnet.py:27-28 Conv2d(9, 90, 3, groups=3) over three frames).
  * w      : per group [w_rows][k_pad] fp16, k = (r*kw + q)*cin + c, zero padded to k_pad (mult of 32)
  *          and to w_rows (mult of 16) rows; groups are consecutive.
  * bias   : fp32 [groups*cout] (folded BN shift or conv bias), never NULL.
@@ -108,7 +110,18 @@ typedef struct llv_conv_desc {
     int64_t seg_xoff[LLV_MAX_SEG], seg_yoff[LLV_MAX_SEG];
     int32_t flags;
     int32_t res_h, res_w;
-    int32_t tile; /* 0 = auto; else LLV_TILE_* to force a tile shape (tests, tuning) */
+    int32_t tile;     /* 0 = auto; else LLV_TILE_* to force a tile shape (tests, tuning) */
+    int32_t k_splits; /* 0 = auto; else force this many K splits (1 = none) */
+    void* workspace;  /* fp32 split-K partial sums; llv_conv2d_workspace_bytes(desc) bytes (0 if no split) */
+    size_t workspace_bytes;
+    /* Optional second packing of the same weights for the direct (halo-in-LDS) 3x3 stride-1 kernel:
+     * [group][chunk][n-tile][halo_bn rows][Kc_pad + 8] fp16 with Kc = 9*CK, CK = min(cin, 32), k = tap*CK + c.
+     * NULL (or tile != 0) selects the implicit-GEMM kernel. halo_bn in {16, 32, 64}. */
+    const void* w_halo;
+    int32_t halo_bn;
+    /* != 0: group g writes channels [0, cout) of its own plane y + g*y_group_stride (fp16 elements, multiple of 8)
+     * instead of channels [g*cout, (g+1)*cout) of one interleaved tensor; the consumer reads the planes as n_src sources. */
+    int64_t y_group_stride;
 } llv_conv_desc;
 
 #define LLV_TILE_AUTO 0
@@ -124,6 +137,8 @@ int llv_abi_version(void);
 const char* llv_strerror(int code);
 
 int llv_conv2d_nhwc_fwd(const llv_conv_desc* desc, void* stream);
+/* bytes of workspace the launch described by desc needs (split-K partial sums); 0 when it runs unsplit */
+size_t llv_conv2d_workspace_bytes(const llv_conv_desc* desc);
 /* algorithmic FLOPs (2*MACs, true channels) the launch described by desc performs */
 double llv_conv2d_flops(const llv_conv_desc* desc);
 

@@ -47,6 +47,12 @@ class ConvDesc(C.Structure):
         ('flags', C.c_int32),
         ('res_h', C.c_int32), ('res_w', C.c_int32),
         ('tile', C.c_int32),
+        ('k_splits', C.c_int32),
+        ('workspace', C.c_void_p),
+        ('workspace_bytes', C.c_size_t),
+        ('w_halo', C.c_void_p),
+        ('halo_bn', C.c_int32),
+        ('y_group_stride', C.c_int64),
     ]
 
 
@@ -78,6 +84,7 @@ SIGNATURES = {
     'llv_strerror': (C.c_char_p, [_I]),
     'llv_conv2d_nhwc_fwd': (_I, [C.POINTER(ConvDesc), _P]),
     'llv_conv2d_flops': (C.c_double, [C.POINTER(ConvDesc)]),
+    'llv_conv2d_workspace_bytes': (_Z, [C.POINTER(ConvDesc)]),
     'llv_maxpool3x3s2_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'llv_pack_nchw_f32_to_nhwc_f16': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     'llv_unpack_nhwc_f16_to_nchw_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

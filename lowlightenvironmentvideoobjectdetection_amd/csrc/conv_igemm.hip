@@ -44,7 +44,177 @@ struct ConvKArgs {
     int tiles_n, nblk;
     int m_total;
     long w_gstride;  // elements between groups in w
+    int src_per_group;  // groups == n_src: group g reads source tensor g
+    long y_gstride;     // != 0: group g writes its own plane y + g*y_gstride (channel index restarts at 0)
+    int stage_out;      // epilogue goes through an LDS tile so that global stores are full 16-byte vectors
+    int k_splits;       // > 1: blockIdx.z owns k-steps [z*nk_per, ...) and writes fp32 partials to ws
+    int nk_per;
+    float* ws;          // [k_splits][m_total][groups*cout] fp32 partial sums
 };
+
+// Shared epilogue: v[4] = conv sum (no bias yet) of channels gco..gco+3 of output row m.
+struct EpiCtx {
+    long opix, rpix;
+    int ox, oy, n, Ho, Wo, yo;
+};
+
+__device__ __forceinline__ void epi_locate(const ConvKArgs& a, int m, EpiCtx& c) {
+    int Ho = a.seg_ho[0], Wo = a.seg_wo[0], m0 = 0, yo = a.seg_yoff[0];
+#pragma unroll
+    for (int s = 1; s < LLV_MAX_SEG; ++s) {
+        if (s < a.n_seg && m >= a.seg_m0[s]) {
+            Ho = a.seg_ho[s]; Wo = a.seg_wo[s]; m0 = a.seg_m0[s]; yo = a.seg_yoff[s];
+        }
+    }
+    const int ml = m - m0;
+    c.opix = (long)yo + ml;  // output pixel index (dense batch x Ho x Wo per segment)
+    c.rpix = c.opix;
+    c.ox = 0; c.oy = 0; c.n = 0; c.Ho = Ho; c.Wo = Wo; c.yo = yo;
+    if (a.flags & (LLV_CONV_PIXSHUF | LLV_CONV_RES_UPS)) {
+        c.ox = ml % Wo;
+        const int t = ml / Wo;
+        c.oy = t % Ho;
+        c.n = t / Ho;
+    }
+    if (a.flags & LLV_CONV_RES_UPS) {
+        // F.interpolate(mode='nearest', size=(Ho,Wo)): src = min(floor(dst * in/out), in-1)
+        const float sy = (float)a.res_h / (float)Ho, sx = (float)a.res_w / (float)Wo;
+        int ry = (int)floorf((float)c.oy * sy); ry = ry < a.res_h - 1 ? ry : a.res_h - 1;
+        int rx = (int)floorf((float)c.ox * sx); rx = rx < a.res_w - 1 ? rx : a.res_w - 1;
+        c.rpix = ((long)c.n * a.res_h + ry) * a.res_w + rx;
+    }
+}
+
+// bias / residual / ReLU on 4 consecutive channels. With PIXSHUF the residual and ReLU are applied at the
+// shuffled output location instead (epi_store_direct / the staged store), so only the bias is added here.
+__device__ __forceinline__ void epi_compute(const ConvKArgs& a, const EpiCtx& c, int gco, float (&v)[4]) {
+    const int flags = a.flags;
+    const float4 b4 = *reinterpret_cast<const float4*>(a.bias + gco);
+    v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
+    if (flags & LLV_CONV_PIXSHUF) return;
+    if (flags & (LLV_CONV_RES_ADD | LLV_CONV_RES_RSUB)) {
+        const f16x4 r4 = *reinterpret_cast<const f16x4*>(a.res + c.rpix * a.res_ld + gco);
+        if (flags & LLV_CONV_RES_RSUB) {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] = (float)r4[e] - v[e];
+        } else {
+#pragma unroll
+            for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+        }
+    }
+    if (flags & LLV_CONV_RELU) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+    }
+}
+
+__device__ __forceinline__ void epi_store(const ConvKArgs& a, const EpiCtx& c, int gco, float v0, float v1, float v2, float v3) {
+    const int flags = a.flags;
+    float v[4] = {v0, v1, v2, v3};
+    epi_compute(a, c, gco, v);
+    if (a.y_gstride) {   // planar groups (plain fp16 store only; host checks the flags)
+        const int g = gco / a.cout, co = gco - g * a.cout;
+        f16x4 o4 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(a.y) + g * a.y_gstride + c.opix * a.y_ld + co) = o4;
+        return;
+    }
+    if (flags & LLV_CONV_PIXSHUF) {
+        // conv channel ch = 4*cc + 2*dy + dx -> out pixel (2oy+dy, 2ox+dx), channel cc
+        const int cc = gco >> 2;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int dy = e >> 1, dx = e & 1;
+            const long p = (long)c.yo + ((long)(c.n * 2 * c.Ho + 2 * c.oy + dy)) * (2 * c.Wo) + (2 * c.ox + dx);
+            float o = v[e];
+            if (flags & LLV_CONV_RES_ADD) o += (float)a.res[p * a.res_ld + cc];
+            if (flags & LLV_CONV_RELU) o = fmaxf(o, 0.f);
+            reinterpret_cast<_Float16*>(a.y)[p * a.y_ld + cc] = (_Float16)o;
+        }
+        return;
+    }
+    if (flags & LLV_CONV_OUT_F32) {
+        *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + c.opix * a.y_ld + gco) = make_float4(v[0], v[1], v[2], v[3]);
+    } else {
+        f16x4 o4 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+        *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(a.y) + c.opix * a.y_ld + gco) = o4;
+    }
+}
+
+// Phase 2 of the LDS-staged epilogue: the [BM pixels][BN couts] fp16 tile (row stride BN+8 halfs) goes to
+// global memory 16 bytes per lane, consecutive lanes = consecutive channels of a pixel. row_to_m maps a tile
+// row to the output row index m (or -1 when the row is outside the image / past the end).
+template <int BN, int BM, typename RowFn>
+__device__ __forceinline__ void staged_store(const ConvKArgs& a, const _Float16* tile, int g, int tile_n, RowFn row_to_m) {
+    constexpr int TS = BN + 8;
+    const int tid = threadIdx.x;
+    if (!(a.flags & LLV_CONV_PIXSHUF)) {
+        constexpr int CPR = BN / 8;  // 16-B chunks per tile row
+        for (int q = tid; q < BM * CPR; q += 256) {
+            const int prow = q / CPR, cc = q - prow * CPR;
+            const int m = row_to_m(prow);
+            const int co = tile_n * BN + cc * 8;
+            if (m < 0 || co >= a.cout) continue;
+            EpiCtx c;
+            epi_locate(a, m, c);
+            _Float16* dst = reinterpret_cast<_Float16*>(a.y) + (a.y_gstride ? g * a.y_gstride + c.opix * a.y_ld + co : c.opix * a.y_ld + g * a.cout + co);
+            const uint4 val = *reinterpret_cast<const uint4*>(tile + prow * TS + cc * 8);
+            if (co + 8 <= a.cout) *reinterpret_cast<uint4*>(dst) = val;
+            else *reinterpret_cast<uint2*>(dst) = make_uint2(val.x, val.y);   // cout is a multiple of 4
+        }
+    } else if constexpr (BN >= 32) {
+        // PixelShuffle(2): out pixel (2oy+dy, 2ox+dx), channel cc <- conv channel 4*cc + 2*dy + dx.
+        // One lane = 8 consecutive output channels of one of the four output pixels of a conv pixel.
+        constexpr int OC8 = BN / 32;  // groups of 8 output channels per tile row
+        for (int q = tid; q < BM * 4 * OC8; q += 256) {
+            const int o8 = q % OC8;
+            const int e = (q / OC8) & 3;
+            const int prow = q / (OC8 * 4);
+            const int m = row_to_m(prow);
+            const int co = tile_n * BN + o8 * 32;          // first conv channel of this group
+            if (m < 0 || co >= a.cout) continue;
+            EpiCtx c;
+            epi_locate(a, m, c);
+            const int dy = e >> 1, dx = e & 1;
+            const long p = (long)c.yo + ((long)(c.n * 2 * c.Ho + 2 * c.oy + dy)) * (2 * c.Wo) + (2 * c.ox + dx);
+            const int occ = (g * a.cout + co) >> 2;         // first output channel
+            const _Float16* src = tile + prow * TS + o8 * 32 + e;
+            float v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = (float)src[t * 4];
+            if (a.flags & LLV_CONV_RES_ADD) {
+                const f16x8 r8 = *reinterpret_cast<const f16x8*>(a.res + p * a.res_ld + occ);
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] += (float)r8[t];
+            }
+            if (a.flags & LLV_CONV_RELU) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] = fmaxf(v[t], 0.f);
+            }
+            f16x8 o8v;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) o8v[t] = (_Float16)v[t];
+            *reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(a.y) + p * a.y_ld + occ) = o8v;
+        }
+    }
+}
+
+// split-K second pass: sum the fp32 partial slabs, then the normal epilogue. One lane per (row, 4 channels).
+__global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvKArgs a, int ctot) {
+    const int c4 = ctot >> 2;
+    const long total = (long)a.m_total * c4;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int m = (int)(i / c4);
+        const int gco = (int)(i - (long)m * c4) * 4;
+        float4 s = make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int z = 0; z < a.k_splits; ++z) {
+            const float4 p = *reinterpret_cast<const float4*>(a.ws + ((long)z * a.m_total + m) * ctot + gco);
+            s.x += p.x; s.y += p.y; s.z += p.z; s.w += p.w;
+        }
+        EpiCtx c;
+        epi_locate(a, m, c);
+        epi_store(a, c, gco, s.x, s.y, s.z, s.w);
+    }
+}
 
 // byte offset of 16-B chunk `ch` (0..3) of row `row` inside a [rows][32 halfs] LDS tile.
 // Fragment reads take row = 16*t + (lane&15), ch = lane>>4; ds_read_b128 is served in four
@@ -65,7 +235,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     constexpr int XVEC = (BM * 4 + 255) / 256;
     constexpr int STAGE = (BN + BM) * 64;  // bytes per LDS stage
 
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    constexpr int TS = BN + 8;                    // epilogue tile row stride in halfs (+16 B: spreads rows over banks)
+    constexpr int EPI = BM * TS * 2;              // bytes of the [BM pixels][BN couts] fp16 output tile
+    constexpr int SMEM = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
     const int tid = threadIdx.x;
     const int lane = tid & 63;
@@ -119,9 +292,18 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         }
     }
 
-    // ---- K walk state: (r, q, c8) of this lane's chunk
-    int kc8 = ch, kr = 0, kq = 0;
-    while (kc8 >= cvec) { kc8 -= cvec; if (++kq == a.kw) { kq = 0; ++kr; } }
+    // ---- K walk state: (r, q, c8) of this lane's chunk, starting at this block's first k-step
+    const int ks_begin = blockIdx.z * a.nk_per;
+    int nk_all = a.k_pad >> 5;
+    const int ks_end = (ks_begin + a.nk_per < nk_all) ? ks_begin + a.nk_per : nk_all;
+    int kc8, kr, kq;
+    {
+        const int kvec = ks_begin * 4 + ch;
+        const int tap = kvec / cvec;
+        kc8 = kvec - tap * cvec;
+        kr = tap / a.kw;
+        kq = tap - kr * a.kw;
+    }
 
     uint4 wreg[WVEC], xreg[XVEC];
 
@@ -137,7 +319,10 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
         }
         const _Float16* xb;
         int cofs;
-        if (a.n_src > 1) {
+        if (a.src_per_group) {
+            xb = g == 0 ? a.x0 : (g == 1 ? a.x1 : a.x2);
+            cofs = kc8 * 8;
+        } else if (a.n_src > 1) {
             const int s = kc8 / a.src_cvec;
             xb = s == 0 ? a.x0 : (s == 1 ? a.x1 : a.x2);
             cofs = (kc8 - s * a.src_cvec) * 8;
@@ -180,15 +365,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    const int nk = a.k_pad >> 5;
-    gload(0);
+    const int nk = ks_end - ks_begin;
+    gload(ks_begin);
     lstore(0);
     __syncthreads();
 
     const int frow = lane & 15, fch = lane >> 4;
     for (int ks = 0; ks < nk; ++ks) {
         const int cur = ks & 1;
-        if (ks + 1 < nk) gload(ks + 1);
+        if (ks + 1 < nk) gload(ks_begin + ks + 1);
 
         const unsigned char* sW = smem + cur * STAGE;
         const unsigned char* sX = sW + BN * 64;
@@ -210,79 +395,248 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
     }
 
     // ---- epilogue: lane holds channels co..co+3 (rows of D) of pixel column lane&15
-    const int flags = a.flags;
+    if (a.k_splits > 1) {
+        const int ctot = (int)gridDim.y * a.cout;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = tile_m * BM + wm * WM + j * 16 + frow;
+            if (m >= a.m_total) continue;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int co = tile_n * BN + wn * WN + i * 16 + fch * 4;
+                if (co >= a.cout) continue;
+                *reinterpret_cast<float4*>(a.ws + ((long)blockIdx.z * a.m_total + m) * ctot + g * a.cout + co) =
+                    make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
+        return;
+    }
+    if (a.stage_out) {
+        // ---- phase 1: final fp16 values -> LDS tile [pixel][cout]  (the K loop ended with a barrier: LDS is free)
+        _Float16* tile = reinterpret_cast<_Float16*>(smem);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int prow = wm * WM + j * 16 + frow;
+            const int m = tile_m * BM + prow;
+            EpiCtx c;
+            const bool mok = m < a.m_total;
+            if (mok) epi_locate(a, m, c);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int col = wn * WN + i * 16 + fch * 4;
+                const int co = tile_n * BN + col;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (mok && co < a.cout) epi_compute(a, c, g * a.cout + co, v);
+                const f16x4 o4 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                *reinterpret_cast<f16x4*>(tile + prow * TS + col) = o4;
+            }
+        }
+        __syncthreads();
+        staged_store<BN, BM>(a, tile, g, tile_n, [&](int prow) { const int m = tile_m * BM + prow; return m < a.m_total ? m : -1; });
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int m = tile_m * BM + wm * WM + j * 16 + frow;
         if (m >= a.m_total) continue;
-        int Ho = a.seg_ho[0], Wo = a.seg_wo[0], m0 = 0, yo = a.seg_yoff[0];
-#pragma unroll
-        for (int s = 1; s < LLV_MAX_SEG; ++s) {
-            if (s < a.n_seg && m >= a.seg_m0[s]) {
-                Ho = a.seg_ho[s]; Wo = a.seg_wo[s]; m0 = a.seg_m0[s]; yo = a.seg_yoff[s];
-            }
-        }
-        const int ml = m - m0;
-        long opix = (long)yo + ml;  // output pixel index (dense batch x Ho x Wo per segment)
-        long rpix = opix;
-        int ox = 0, oy = 0, n = 0;
-        if (flags & (LLV_CONV_PIXSHUF | LLV_CONV_RES_UPS)) {
-            ox = ml % Wo;
-            const int t = ml / Wo;
-            oy = t % Ho;
-            n = t / Ho;
-        }
-        if (flags & LLV_CONV_RES_UPS) {
-            // F.interpolate(mode='nearest', size=(Ho,Wo)): src = min(floor(dst * in/out), in-1)
-            const float sy = (float)a.res_h / (float)Ho, sx = (float)a.res_w / (float)Wo;
-            int ry = (int)floorf((float)oy * sy); ry = ry < a.res_h - 1 ? ry : a.res_h - 1;
-            int rx = (int)floorf((float)ox * sx); rx = rx < a.res_w - 1 ? rx : a.res_w - 1;
-            rpix = ((long)n * a.res_h + ry) * a.res_w + rx;
-        }
+        EpiCtx c;
+        epi_locate(a, m, c);
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             const int co = tile_n * BN + wn * WN + i * 16 + fch * 4;
             if (co >= a.cout) continue;
-            const int gco = g * a.cout + co;
-            const float4 b4 = *reinterpret_cast<const float4*>(a.bias + gco);
-            float v[4] = {acc[i][j][0] + b4.x, acc[i][j][1] + b4.y, acc[i][j][2] + b4.z, acc[i][j][3] + b4.w};
-            if (flags & LLV_CONV_PIXSHUF) {
-                // conv channel c = 4*cc + 2*dy + dx -> out pixel (2oy+dy, 2ox+dx), channel cc
-                const int cc = gco >> 2;
+            epi_store(a, c, g * a.cout + co, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    }
+}
+
+
+// ------------------------------------------------------------------------------------------------
+// conv3x3_halo_kernel: direct 3x3 / stride 1 / pad 1 convolution for the full-resolution, few-channel layers
+// (FastDVDnet.py:22-74). One workgroup = an 8 x 32 pixel output tile x BN output channels. Per 32-channel
+// chunk of the input it stages the (8+2) x (32+2) pixel halo tile AND that chunk's weights in LDS once; all
+// nine taps are then formed from LDS (MFMA B fragments read at shifted pixel addresses), so every input byte
+// crosses L1 once instead of nine times and a chunk is 9 barrier-free MFMA k-steps.
+// K order inside a chunk: k = tap*CK + c (CK = min(Cin, 32) channels), weights packed per (chunk, n-tile) as
+// [BN rows][wrow halfs] with wrow = Kc_pad + 8 (the +16 B spreads the 16 fragment rows over all LDS slots).
+// ------------------------------------------------------------------------------------------------
+struct HaloArgs {
+    const _Float16* w;   // halo-packed weights
+    int H, W;            // image size (= output size)
+    int tiles_x, tiles_y;
+    int n_chunks, ck, kc_pad, wrow;
+    int ntiles_n;
+    int nblk;
+    long w_gstride;      // halfs between groups
+};
+
+constexpr int HALO_TH = 8, HALO_TW = 32, HALO_PX = (HALO_TH + 2) * (HALO_TW + 2);
+
+__device__ __forceinline__ int halo_off(int px, int c8, int ck) {
+    // byte offset of 16-B piece c8 of halo pixel px. For 64-B pixels XOR piece bit 1 with pixel bit 2: the 16
+    // consecutive pixels of a fragment read then hit 16 distinct LDS slots whatever their alignment.
+    if (ck == 32) return px * 64 + ((c8 ^ (((px >> 2) & 1) << 1)) << 4);
+    return px * (ck * 2) + (c8 << 4);
+}
+
+template <int BN>
+__global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a, const HaloArgs h) {
+    constexpr int TN = BN / 16, TM = 4;
+    constexpr int HV = (HALO_PX * 4 + 255) / 256;            // halo 16-B vectors per lane (CK = 32)
+    constexpr int WV = (BN * 37 + 255) / 256;                // weight vectors per lane (wrow = 296 halfs = 37 vectors)
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    unsigned char* s_halo = hsm;
+    unsigned char* s_w = hsm + HALO_PX * 64;
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    {
+        const int nblk = h.nblk;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tx0 = (bid % h.tiles_x) * HALO_TW;
+    const int t1 = bid / h.tiles_x;
+    const int ty0 = (t1 % h.tiles_y) * HALO_TH;
+    const int n = t1 / h.tiles_y;
+    const int tile_n = blockIdx.y % h.ntiles_n;
+    const int g = blockIdx.y / h.ntiles_n;
+
+    const _Float16* xb = a.src_per_group ? (g == 0 ? a.x0 : (g == 1 ? a.x1 : a.x2)) : a.x0;
+    const int xc0 = a.src_per_group ? 0 : g * a.cin;
+    const bool multi = a.n_src > 1 && !a.src_per_group;   // sources concatenated along C, a chunk lies in one source
+    const int cvec = h.ck >> 3;
+    const int nvec_h = HALO_PX * cvec;
+    const int wvec_row = h.wrow >> 3;
+    const int nvec_w = BN * wvec_row;
+    const long img_base = (long)a.seg_xoff[0] + (long)n * h.H * h.W;
+
+    f32x4 acc[TN][TM];
 #pragma unroll
-                for (int e = 0; e < 4; ++e) {
-                    const int dy = e >> 1, dx = e & 1;
-                    const long p = (long)yo + ((long)(n * 2 * Ho + 2 * oy + dy)) * (2 * Wo) + (2 * ox + dx);
-                    float o = v[e];
-                    if (flags & LLV_CONV_RES_ADD) o += (float)a.res[p * a.res_ld + cc];
-                    if (flags & LLV_CONV_RELU) o = fmaxf(o, 0.f);
-                    reinterpret_cast<_Float16*>(a.y)[p * a.y_ld + cc] = (_Float16)o;
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int frow = lane & 15, fch = lane >> 4;
+    int pbase[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) pbase[j] = (2 * wave + (j >> 1)) * (HALO_TW + 2) + (j & 1) * 16 + frow;
+
+    const int nks = h.kc_pad >> 5;
+    for (int ci = 0; ci < h.n_chunks; ++ci) {
+        // ---- stage halo + weights of this chunk (all loads issued before the first LDS write)
+        uint4 hreg[HV], wreg[WV];
+#pragma unroll
+        for (int i = 0; i < HV; ++i) {
+            const int v = tid + i * 256;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (v < nvec_h) {
+                const int px = v / cvec, c8 = v - px * cvec;
+                const int hy = px / (HALO_TW + 2), hx = px - hy * (HALO_TW + 2);
+                const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+                if ((unsigned)gy < (unsigned)h.H && (unsigned)gx < (unsigned)h.W) {
+                    const _Float16* xs = xb;
+                    int coff = xc0 + ci * h.ck + c8 * 8;
+                    if (multi) {
+                        const int cv = (ci * h.ck >> 3) + c8, sidx = cv / a.src_cvec;
+                        xs = sidx == 0 ? a.x0 : (sidx == 1 ? a.x1 : a.x2);
+                        coff = (cv - sidx * a.src_cvec) * 8;
+                    }
+                    val = *reinterpret_cast<const uint4*>(xs + (img_base + (long)gy * h.W + gx) * a.x_ld + coff);
                 }
-                continue;
             }
-            if (flags & (LLV_CONV_RES_ADD | LLV_CONV_RES_RSUB)) {
-                const f16x4 r4 = *reinterpret_cast<const f16x4*>(a.res + rpix * a.res_ld + gco);
-                if (flags & LLV_CONV_RES_RSUB) {
+            hreg[i] = val;
+        }
+        const _Float16* wsrc = h.w + (long)g * h.w_gstride + ((long)(ci * h.ntiles_n + tile_n) * BN) * h.wrow;
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] = (float)r4[e] - v[e];
-                } else {
+        for (int i = 0; i < WV; ++i) {
+            const int v = tid + i * 256;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (v < nvec_w) val = *reinterpret_cast<const uint4*>(wsrc + (long)v * 8);
+            wreg[i] = val;
+        }
+        if (ci > 0) __syncthreads();   // previous chunk's fragment reads are done
 #pragma unroll
-                    for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
-                }
+        for (int i = 0; i < HV; ++i) {
+            const int v = tid + i * 256;
+            if (v < nvec_h) {
+                const int px = v / cvec, c8 = v - px * cvec;
+                *reinterpret_cast<uint4*>(s_halo + halo_off(px, c8, h.ck)) = hreg[i];
             }
-            if (flags & LLV_CONV_RELU) {
+        }
 #pragma unroll
-                for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
-            }
-            if (flags & LLV_CONV_OUT_F32) {
-                *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + opix * a.y_ld + gco) =
-                    make_float4(v[0], v[1], v[2], v[3]);
-            } else {
-                f16x4 o4 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
-                *reinterpret_cast<f16x4*>(reinterpret_cast<_Float16*>(a.y) + opix * a.y_ld + gco) = o4;
+        for (int i = 0; i < WV; ++i) {
+            const int v = tid + i * 256;
+            if (v < nvec_w) *reinterpret_cast<uint4*>(s_w + v * 16) = wreg[i];
+        }
+        __syncthreads();
+        // ---- nks barrier-free k-steps out of LDS
+        for (int ks = 0; ks < nks; ++ks) {
+            const int kvec = ks * 4 + fch;
+            int tap = kvec / cvec;
+            const int c8 = kvec - tap * cvec;
+            tap = tap > 8 ? 8 : tap;                           // k beyond 9*CK: weights are zero, keep the read in range
+            const int tr = tap / 3, tq = tap - tr * 3;
+            const int poff = tr * (HALO_TW + 2) + tq;
+            f16x8 af[TN], bf[TM];
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                af[i] = *reinterpret_cast<const f16x8*>(s_w + ((i * 16 + frow) * h.wrow + ks * 32 + fch * 8) * 2);
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                bf[j] = *reinterpret_cast<const f16x8*>(s_halo + halo_off(pbase[j] + poff, c8, h.ck));
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue through the LDS tile (rows = ty*32 + tx)
+    auto row_to_m = [&](int prow) {
+        const int oy = ty0 + (prow >> 5), ox = tx0 + (prow & 31);
+        return (oy < h.H && ox < h.W) ? (int)(((long)n * h.H + oy) * h.W + ox) : -1;
+    };
+    constexpr int TS = BN + 8;
+    _Float16* tile = reinterpret_cast<_Float16*>(hsm);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int prow = (2 * wave + (j >> 1)) * 32 + (j & 1) * 16 + frow;
+        const int m = row_to_m(prow);
+        EpiCtx c;
+        if (m >= 0) epi_locate(a, m, c);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int col = i * 16 + fch * 4;
+            const int co = tile_n * BN + col;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (a.stage_out) {
+                if (m >= 0 && co < a.cout) epi_compute(a, c, g * a.cout + co, v);
+                const f16x4 o4 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                *reinterpret_cast<f16x4*>(tile + prow * TS + col) = o4;
+            } else if (m >= 0 && co < a.cout) {
+                epi_store(a, c, g * a.cout + co, v[0], v[1], v[2], v[3]);
             }
         }
     }
+    if (a.stage_out) {
+        __syncthreads();
+        staged_store<BN, 256>(a, tile, g, tile_n, row_to_m);
+    }
+}
+
+template <int BN>
+int launch_halo(ConvKArgs& k, HaloArgs& h, int groups, int batch, hipStream_t st) {
+    h.ntiles_n = (k.cout + BN - 1) / BN;
+    h.nblk = h.tiles_x * h.tiles_y * batch;
+    const size_t lds_main = (size_t)HALO_PX * 64 + (size_t)BN * h.wrow * 2;
+    const size_t lds_epi = (size_t)256 * (BN + 8) * 2;
+    const size_t lds = lds_main > lds_epi ? lds_main : lds_epi;
+    dim3 grid(h.nblk, h.ntiles_n * groups, 1);
+    hipLaunchKernelGGL((conv3x3_halo_kernel<BN>), grid, dim3(256), lds, st, k, h);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
 template <int BN, int BM, int WN, int WM>
@@ -290,14 +644,42 @@ int launch(ConvKArgs& k, int groups, hipStream_t st) {
     k.tiles_n = (k.cout + BN - 1) / BN;
     const int tiles_m = (k.m_total + BM - 1) / BM;
     k.nblk = k.tiles_n * tiles_m;
-    dim3 grid(k.nblk, groups, 1);
+    dim3 grid(k.nblk, groups, k.k_splits);
     hipLaunchKernelGGL((conv_igemm_kernel<BN, BM, WN, WM>), grid, dim3(256), 0, st, k);
+    if (k.k_splits > 1) {
+        const int ctot = groups * k.cout;
+        long work = (long)k.m_total * (ctot >> 2);
+        long gsz = (work + 255) / 256;
+        gsz = gsz > 2048 ? 2048 : (gsz < 1 ? 1 : gsz);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((int)gsz), dim3(256), 0, st, k, ctot);
+    }
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
-int pick_tile(const ConvKArgs& k, int groups) {
-    const int co = k.cout;
-    const long m = k.m_total;
+void tile_dims(int tile, int& bn, int& bm) {
+    switch (tile) {
+        case LLV_TILE_128x128: bn = 128; bm = 128; break;
+        case LLV_TILE_64x256: bn = 64; bm = 256; break;
+        case LLV_TILE_32x256: bn = 32; bm = 256; break;
+        case LLV_TILE_16x256: bn = 16; bm = 256; break;
+        default: bn = 64; bm = 64; break;
+    }
+}
+
+// Split K when the launch cannot fill the chip: few tiles and a long K loop (ResNet layer3/4, FPN P5-P7).
+int pick_splits(int tile, int cout, long m, int groups, int nk, int flags) {
+    if (flags & LLV_CONV_PIXSHUF) return 1;
+    int bn, bm;
+    tile_dims(tile, bn, bm);
+    const long blocks = ((cout + bn - 1) / bn) * ((m + bm - 1) / bm) * groups;
+    if (blocks >= 256 || nk < 16) return 1;
+    long s = (512 + blocks - 1) / blocks;
+    if (s > nk / 8) s = nk / 8;
+    if (s > 32) s = 32;
+    return s < 2 ? 1 : (int)s;
+}
+
+int pick_tile(int co, long m, int groups) {
     if (co <= 16) return LLV_TILE_16x256;
     if (co <= 32) return LLV_TILE_32x256;
     if (co <= 64) return m >= 64 * 1024 ? LLV_TILE_64x256 : LLV_TILE_64x64;
@@ -308,6 +690,31 @@ int pick_tile(const ConvKArgs& k, int groups) {
 }
 
 }  // namespace
+
+struct LaunchPlan { int tile, splits, nk_per; long m; };
+
+static int plan_launch(const llv_conv_desc* d, LaunchPlan& lp) {
+    long m = 0;
+    for (int s = 0; s < d->n_seg; ++s) m += (long)d->batch * d->seg_ho[s] * d->seg_wo[s];
+    lp.m = m;
+    lp.tile = d->tile ? d->tile : pick_tile(d->cout, m, d->groups);
+    const int nk = d->k_pad >> 5;
+    lp.splits = d->k_splits > 0 ? d->k_splits : pick_splits(lp.tile, d->cout, m, d->groups, nk, d->flags);
+    if (lp.splits > nk) lp.splits = nk;
+    if (lp.splits < 1) lp.splits = 1;
+    lp.nk_per = (nk + lp.splits - 1) / lp.splits;
+    lp.splits = (nk + lp.nk_per - 1) / lp.nk_per;
+    return LLV_OK;
+}
+
+extern "C" size_t llv_conv2d_workspace_bytes(const llv_conv_desc* d) {
+    if (!d || d->n_seg < 1 || d->n_seg > LLV_MAX_SEG || d->cout <= 0 || d->groups < 1 || d->k_pad < 32) return 0;
+    if (d->w_halo && !d->tile) return 0;
+    LaunchPlan lp;
+    plan_launch(d, lp);
+    if (lp.splits <= 1) return 0;
+    return (size_t)lp.splits * (size_t)lp.m * (size_t)d->groups * d->cout * sizeof(float);
+}
 
 extern "C" double llv_conv2d_flops(const llv_conv_desc* d) {
     if (!d) return 0.0;
@@ -325,7 +732,11 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
     if ((d->k_pad & 31) || d->k_pad < d->kh * d->kw * d->cin) return LLV_E_BADARG;
     if (d->kh < 1 || d->kw < 1 || d->stride < 1 || d->pad < 0 || d->groups < 1 || d->batch < 1) return LLV_E_BADARG;
     if ((d->x_ld & 7) || (d->y_ld & 3)) return LLV_E_BADARG;
-    if (d->n_src > 1) {
+    if (d->n_src > 1 && d->groups == d->n_src) {
+        if (d->src_cvec * 8 != d->cin || d->x_ld < d->cin) return LLV_E_BADARG;   // group g reads source g
+        for (int s = 0; s < d->n_src; ++s)
+            if (!d->x[s]) return LLV_E_BADARG;
+    } else if (d->n_src > 1) {
         if (d->groups != 1 || d->src_cvec < 1 || d->src_cvec * 8 * d->n_src != d->cin) return LLV_E_BADARG;
         for (int s = 0; s < d->n_src; ++s)
             if (!d->x[s]) return LLV_E_BADARG;
@@ -342,7 +753,7 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
     if (f & LLV_CONV_PIXSHUF) {
         if (d->n_seg != 1 || (f & (LLV_CONV_OUT_F32 | LLV_CONV_RES_RSUB))) return LLV_E_BADARG;
         if (d->y_ld < d->groups * d->cout / 4) return LLV_E_BADARG;
-    } else if (d->y_ld < d->groups * d->cout) {
+    } else if (d->y_ld < (d->y_group_stride ? 1 : d->groups) * d->cout) {
         return LLV_E_BADARG;
     }
 
@@ -382,9 +793,61 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
     k.m_total = (int)m;
     k.flags = f; k.res_h = d->res_h; k.res_w = d->res_w;
     k.w_gstride = (long)d->w_rows * d->k_pad;
+    k.src_per_group = (d->n_src > 1 && d->groups == d->n_src) ? 1 : 0;
+    k.y_gstride = d->y_group_stride;
+    if (d->y_group_stride) {
+        if (d->y_group_stride < 0 || (f & (LLV_CONV_OUT_F32 | LLV_CONV_PIXSHUF)) || d->y_ld < d->cout || (d->y_group_stride & 7)) return LLV_E_BADARG;
+    }
+    // LDS-staged stores need 16-byte aligned channel runs in y (and in res for the shuffled skip add)
+    k.stage_out = 0;
+    if (!(f & LLV_CONV_OUT_F32) && (d->y_ld & 7) == 0) {
+        if (f & LLV_CONV_PIXSHUF) {
+            const bool res_ok = !(f & LLV_CONV_RES_ADD) || (d->res_ld & 7) == 0;
+            if ((d->cout & 31) == 0 && res_ok) k.stage_out = 1;
+        } else if ((d->cout & 7) == 0 || d->groups == 1 || d->y_group_stride) {
+            k.stage_out = 1;
+        }
+    }
+    LaunchPlan lp;
+    plan_launch(d, lp);
+    k.k_splits = lp.splits;
+    k.nk_per = lp.nk_per;
+    k.ws = (float*)d->workspace;
+    if (lp.splits > 1 && !(d->w_halo && !d->tile)) {
+        if (f & LLV_CONV_PIXSHUF) return LLV_E_BADARG;
+        if (!d->workspace || d->workspace_bytes < llv_conv2d_workspace_bytes(d)) return LLV_E_WORKSPACE;
+    }
 
     hipStream_t st = (hipStream_t)stream;
-    int tile = d->tile ? d->tile : pick_tile(k, d->groups);
+    if (d->w_halo && !d->tile) {
+        // direct (halo-in-LDS) path: 3x3 / stride 1 / pad 1, one segment, Cin in {8,16,24} or a multiple of 32
+        if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->n_seg != 1) return LLV_E_BADARG;
+        if (!(d->cin == 8 || d->cin == 16 || d->cin == 24 || (d->cin & 31) == 0)) return LLV_E_BADARG;
+        if (d->n_src > 1 && d->groups != d->n_src && (d->groups != 1 || (d->src_cvec * 8) % (d->cin < 32 ? d->cin : 32) != 0)) return LLV_E_BADARG;
+        if (d->halo_bn != 16 && d->halo_bn != 32 && d->halo_bn != 64) return LLV_E_BADARG;
+        HaloArgs h;
+        h.w = (const _Float16*)d->w_halo;
+        h.H = d->seg_h[0]; h.W = d->seg_w[0];
+        if (d->seg_ho[0] != h.H || d->seg_wo[0] != h.W) return LLV_E_BADARG;
+        h.tiles_x = (h.W + HALO_TW - 1) / HALO_TW;
+        h.tiles_y = (h.H + HALO_TH - 1) / HALO_TH;
+        h.ck = d->cin < 32 ? d->cin : 32;
+        h.n_chunks = d->cin / h.ck;
+        h.kc_pad = (9 * h.ck + 31) & ~31;
+        h.wrow = h.kc_pad + 8;
+        const int bn = d->halo_bn;
+        const int nt = (d->cout + bn - 1) / bn;
+        h.w_gstride = (long)h.n_chunks * nt * bn * h.wrow;
+        if ((f & LLV_CONV_PIXSHUF) && bn < 32) k.stage_out = 0;
+        k.k_splits = 1;
+        switch (bn) {
+            case 16: return launch_halo<16>(k, h, d->groups, d->batch, st);
+            case 32: return launch_halo<32>(k, h, d->groups, d->batch, st);
+            default: return launch_halo<64>(k, h, d->groups, d->batch, st);
+        }
+    }
+    const int tile = lp.tile;
+    if ((f & LLV_CONV_PIXSHUF) && tile == LLV_TILE_16x256) k.stage_out = 0;
     switch (tile) {
         case LLV_TILE_128x128: return launch<128, 128, 64, 64>(k, d->groups, st);
         case LLV_TILE_64x256:  return launch<64, 256, 64, 64>(k, d->groups, st);

@@ -21,6 +21,10 @@ from . import ops
 from ._lib import (CONV_OUT_F32, CONV_PIXSHUF, CONV_RELU, CONV_RES_ADD, CONV_RES_RSUB, CONV_RES_UPS, LlvError, lib)
 
 BN_EPS = 1e-5
+# direct (halo-in-LDS) 3x3 kernel for the FastDVDnet layers: on by default; LLV_HALO=0 falls back to implicit GEMM
+import os as _os
+HALO = _os.environ.get('LLV_HALO', '1') != '0'
+HALO_MAX_COUT = int(_os.environ.get('LLV_HALO_MAX_COUT', '128'))
 ARCH = {18: ('basic', (2, 2, 2, 2)), 34: ('basic', (3, 4, 6, 3)), 50: ('bottleneck', (3, 4, 6, 3)),
         101: ('bottleneck', (3, 4, 23, 3)), 152: ('bottleneck', (3, 8, 36, 3))}
 
@@ -104,6 +108,8 @@ class Builder:
         self.dev = device
         self.plan = Plan(device)
         self._fn_conv = lib().llv_conv2d_nhwc_fwd
+        self._ws = None              # one split-K workspace shared by all launches of the plan (they run in order)
+        self._ws_descs = []
 
     def buf(self, *shape, dtype=torch.float16):
         t = torch.zeros(shape, device=self.dev, dtype=dtype)
@@ -111,14 +117,23 @@ class Builder:
         return t
 
     def conv_desc(self, name, pc: ops.PackedConv, xs, y, batch, segs, x_ld, y_ld, res=None, res_ld=0, flags=0,
-                  res_hw=(0, 0), tile=0):
+                  res_hw=(0, 0), tile=0, y_group_stride=0):
         pc.to(self.dev)
-        d = ops.make_conv_desc(pc, xs, y, batch, segs, x_ld, y_ld, res, res_ld, flags, res_hw, tile)
+        d = ops.make_conv_desc(pc, xs, y, batch, segs, x_ld, y_ld, res, res_ld, flags, res_hw, tile, 0, y_group_stride)
         m = sum(batch * s[2] * s[3] for s in segs)
         flops = 2.0 * m * pc.true_macs_per_pixel
         nbytes = 2.0 * (sum(batch * s[0] * s[1] for s in segs) * pc.cin * pc.groups + m * pc.cout * pc.groups) + \
             pc.w.numel() * 2.0
-        self.plan.keep += [pc.w, pc.bias, d] + list(xs) + [y] + ([res] if res is not None else [])
+        wsb = ops.conv_workspace_bytes(d)
+        if wsb:
+            if self._ws is None or self._ws.numel() < wsb:
+                self._ws = torch.empty((wsb,), device=self.dev, dtype=torch.uint8)
+                self.plan.keep.append(self._ws)
+                for od in self._ws_descs:
+                    od.workspace = self._ws.data_ptr()
+            d.workspace, d.workspace_bytes = self._ws.data_ptr(), wsb
+            self._ws_descs.append(d)
+        self.plan.keep += [pc, pc.w, pc.bias, d] + list(xs) + [y] + ([res] if res is not None else [])
         self.plan.add(name, self._fn_conv, (C.byref(d),), flops, nbytes)
         return d
 
@@ -386,26 +401,42 @@ def _denblock(b: Builder, sd, p, srcs, batch, tag):
     """One DenBlock over `batch` images whose three input frames are srcs[0..2] (each a view (batch,H,W,8):
     image n of source s is frame n+s of a clip, so consecutive windows share memory). FastDVDnet.py:102-116."""
     f = CONV_RELU
-    # inc: Conv2d(9, 90, 3, groups=3) as a block-diagonal dense conv reading the three NHWC8 frames directly
+    # inc: Conv2d(9, 90, 3, groups=3) over three separate NHWC8 frames: a grouped launch whose group g reads
+    # source tensor g (3 real + 5 zero channels) and writes channels [32g, 32g+30) (+2 zero) of a 96-wide buffer
     wg = sd[p + 'inc.convblock.0.weight']                    # (90, 3, 3, 3)
     ng = 3
     og = wg.shape[0] // ng
-    dense = torch.zeros(wg.shape[0], 3 * ng, 3, 3)
+    og_pad = ops.round_up(og, 4)
+    bnp = _bn(sd, p + 'inc.convblock.1')
+    pcs = []
+    for g in range(ng):
+        sl = slice(og * g, og * (g + 1))
+        pcs.append(ops.pack_conv(wg[sl], None, 1, 1, in_map=[0, 1, 2, -1, -1, -1, -1, -1], cout_store=og_pad,
+                                 bn=tuple(t[sl] for t in bnp), eps=BN_EPS))
+    pc = ops.stack_groups(pcs)
+    pc.n_src, pc.src_cvec = ng, 1
+    if HALO:
+        ops.add_halo_packing(pc)
+    # each group writes its own (batch, H, W, 32) plane (full cache lines); inc1 reads the three planes as three sources
+    n, hh, ww, _ = srcs[0].shape
+    planes = b.buf(ng, n, hh, ww, og_pad)
+    b.conv_desc(f'{tag}.inc0', pc, list(srcs), planes, n, [(hh, ww, hh, ww, 0, 0)], srcs[0].shape[-1], og_pad, flags=f,
+                y_group_stride=n * hh * ww * og_pad)
+    x = [planes[g] for g in range(ng)]
+    w2 = sd[p + 'inc.convblock.3.weight']
     in_map = []
     for g in range(ng):
-        dense[og * g:og * (g + 1), 3 * g:3 * g + 3] = wg[og * g:og * (g + 1)]
-        in_map += [3 * g, 3 * g + 1, 3 * g + 2, -1, -1, -1, -1, -1]
-    c_mid = ops.round_up(wg.shape[0], 8)
-    pc = ops.pack_conv(dense, None, 1, 1, in_map=in_map, cout_store=c_mid, n_src=3, bn=_bn(sd, p + 'inc.convblock.1'), eps=BN_EPS)
-    pc.true_macs_per_pixel = wg.shape[0] * wg.shape[1] * 9          # grouped conv: count the true MACs
-    x = b.conv(f'{tag}.inc0', list(srcs), pc, f)
-    w2 = sd[p + 'inc.convblock.3.weight']
-    pc = ops.pack_conv(w2, None, 1, 1, in_map=list(range(w2.shape[1])) + [-1] * (c_mid - w2.shape[1]),
-                       bn=_bn(sd, p + 'inc.convblock.4'), eps=BN_EPS)
+        in_map += [og * g + j if j < og else -1 for j in range(og_pad)]
+    pc = ops.pack_conv(w2, None, 1, 1, in_map=in_map, n_src=ng, bn=_bn(sd, p + 'inc.convblock.4'), eps=BN_EPS)
+    if HALO:
+        ops.add_halo_packing(pc)
     x0 = b.conv(f'{tag}.inc1', x, pc, f)
 
     def cbr(name, x, conv, bn, stride=1, flags=f, res=None):
-        return b.conv(name, x, ops.pack_conv(sd[conv + '.weight'], None, stride, 1, bn=_bn(sd, bn), eps=BN_EPS), flags, res=res)
+        pc = ops.pack_conv(sd[conv + '.weight'], None, stride, 1, bn=_bn(sd, bn), eps=BN_EPS)
+        if HALO and stride == 1 and pc.cout <= HALO_MAX_COUT:
+            ops.add_halo_packing(pc)
+        return b.conv(name, x, pc, flags, res=res)
 
     def down(x, q, t):                                       # DownBlock, FastDVDnet.py:39-49
         x = cbr(f'{tag}.{t}.0', x, q + 'convblock.0', q + 'convblock.1', 2)
@@ -416,6 +447,8 @@ def _denblock(b: Builder, sd, p, srcs, batch, tag):
         x = cbr(f'{tag}.{t}.0', x, q + 'convblock.0.convblock.0', q + 'convblock.0.convblock.1')   # :111-113 is fused
         x = cbr(f'{tag}.{t}.1', x, q + 'convblock.0.convblock.3', q + 'convblock.0.convblock.4')
         pc = ops.pack_conv(sd[q + 'convblock.1.weight'], None, 1, 1)
+        if HALO and pc.cout <= HALO_MAX_COUT:
+            ops.add_halo_packing(pc)
         return b.conv(f'{tag}.{t}.2', x, pc, CONV_PIXSHUF | CONV_RES_ADD, res=skip)
 
     x1 = down(x0, p + 'downc0.', 'down0')
@@ -424,6 +457,8 @@ def _denblock(b: Builder, sd, p, srcs, batch, tag):
     x0s = up(x1s, p + 'upc1.', 'up1', x0)                    # = x0 + upc1(x1 + x2)
     x = cbr(f'{tag}.out0', x0s, p + 'outc.convblock.0', p + 'outc.convblock.1')
     pc = ops.pack_conv(sd[p + 'outc.convblock.3.weight'], None, 1, 1, cout_store=8)
+    if HALO:
+        ops.add_halo_packing(pc)
     return pc, x
 
 

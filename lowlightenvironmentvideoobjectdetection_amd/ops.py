@@ -54,11 +54,52 @@ class PackedConv:
     n_src: int = 1
     src_cvec: int = 0
     true_macs_per_pixel: int = 0   # unpadded Cout*Cin/g*kh*kw, for FLOP accounting
+    w_halo: Optional[torch.Tensor] = None   # second packing for the direct 3x3 kernel (add_halo_packing)
+    halo_bn: int = 0
 
     def to(self, device):
         self.w = self.w.to(device)
         self.bias = self.bias.to(device)
+        if self.w_halo is not None:
+            self.w_halo = self.w_halo.to(device)
         return self
+
+
+def halo_eligible(pc: 'PackedConv') -> bool:
+    if not (pc.kh == 3 and pc.kw == 3 and pc.stride == 1 and pc.pad == 1):
+        return False
+    if not (pc.cin in (8, 16, 24) or pc.cin % 32 == 0):
+        return False
+    if pc.n_src > 1 and pc.groups != pc.n_src:
+        # sources concatenated along C: every 32-channel chunk must lie inside one source
+        if pc.groups != 1 or (pc.src_cvec * 8) % min(pc.cin, 32) != 0:
+            return False
+    return True
+
+
+def add_halo_packing(pc: 'PackedConv') -> 'PackedConv':
+    """Second packing of the same (already folded, fp16) weights for conv3x3_halo_kernel:
+    [group][chunk][n-tile][bn rows][Kc_pad + 8], Kc = 9*CK, CK = min(cin, 32), k = tap*CK + c (see include/llv.h)."""
+    if not halo_eligible(pc):
+        return pc
+    cin, g = pc.cin, pc.groups
+    ck = min(cin, 32)
+    nch = cin // ck
+    kc = 9 * ck
+    kc_pad = round_up(kc, 32)
+    wrow = kc_pad + 8
+    bn = 16 if pc.cout <= 16 else (32 if pc.cout <= 32 else 64)
+    nt = (pc.cout + bn - 1) // bn
+    w = pc.w.cpu()[:, :, :9 * cin].reshape(g, pc.w_rows, 9, cin)
+    out = torch.zeros(g, nch, nt, bn, wrow, dtype=torch.float16)
+    for ci in range(nch):
+        for t in range(nt):
+            r0, r1 = t * bn, min((t + 1) * bn, pc.w_rows)
+            if r1 > r0:
+                out[:, ci, t, :r1 - r0, :kc] = w[:, r0:r1, :, ci * ck:(ci + 1) * ck].reshape(g, r1 - r0, kc)
+    pc.w_halo = out.contiguous().to(pc.w.device)
+    pc.halo_bn = bn
+    return pc
 
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], stride=1, pad=0,
@@ -139,7 +180,8 @@ def conv_out_size(h, w, pc: PackedConv):
 
 def make_conv_desc(pc: PackedConv, xs: Sequence[torch.Tensor], y: torch.Tensor, batch: int,
                    segs: Sequence[tuple], x_ld: int, y_ld: int, res: Optional[torch.Tensor] = None,
-                   res_ld: int = 0, flags: int = 0, res_hw=(0, 0), tile: int = 0) -> ConvDesc:
+                   res_ld: int = 0, flags: int = 0, res_hw=(0, 0), tile: int = 0, k_splits: int = 0,
+                   y_group_stride: int = 0) -> ConvDesc:
     """segs: [(h, w, ho, wo, x_pixel_off, y_pixel_off), ...]"""
     d = ConvDesc()
     for i in range(_lib.LLV_MAX_SRC):
@@ -160,15 +202,34 @@ def make_conv_desc(pc: PackedConv, xs: Sequence[torch.Tensor], y: torch.Tensor, 
     d.flags = flags
     d.res_h, d.res_w = res_hw
     d.tile = tile
+    d.k_splits = k_splits
+    d.workspace, d.workspace_bytes = 0, 0
+    d.y_group_stride = y_group_stride
+    if pc.w_halo is not None and len(segs) == 1 and tile == 0 and segs[0][0] == segs[0][2] and segs[0][1] == segs[0][3]:
+        d.w_halo, d.halo_bn = pc.w_halo.data_ptr(), pc.halo_bn
+    else:
+        d.w_halo, d.halo_bn = 0, 0
     return d
 
 
+def conv_workspace_bytes(desc: ConvDesc) -> int:
+    return int(lib().llv_conv2d_workspace_bytes(C.byref(desc)))
+
+
 def launch_conv(desc: ConvDesc):
+    ws = None
+    if not desc.workspace:
+        wsb = conv_workspace_bytes(desc)
+        if wsb:          # split-K launch without a caller workspace: allocate one for this call
+            ws = torch.empty((wsb,), device=torch.device('cuda', torch.cuda.current_device()), dtype=torch.uint8)
+            desc.workspace, desc.workspace_bytes = ws.data_ptr(), wsb
     check(lib().llv_conv2d_nhwc_fwd(C.byref(desc), _stream()), 'llv_conv2d_nhwc_fwd')
+    if ws is not None:
+        desc.workspace, desc.workspace_bytes = 0, 0
 
 
 def conv2d(x, pc: PackedConv, res: Optional[torch.Tensor] = None, flags: int = 0, out: Optional[torch.Tensor] = None,
-           tile: int = 0) -> torch.Tensor:
+           tile: int = 0, k_splits: int = 0) -> torch.Tensor:
     """Single-segment convenience: x is (N,H,W,C) fp16 NHWC, or a list of n_src such tensors."""
     xs = list(x) if isinstance(x, (list, tuple)) else [x]
     _need_gpu(*xs, pc.w, pc.bias, res, out)
@@ -191,7 +252,11 @@ def conv2d(x, pc: PackedConv, res: Optional[torch.Tensor] = None, flags: int = 0
         if flags & CONV_RES_UPS:
             res_hw = (res.shape[1], res.shape[2])
     d = make_conv_desc(pc, xs, out, n, [(h, w, ho, wo, 0, 0)], cx, out.shape[3], res,
-                       res.shape[3] if res is not None else 0, flags, res_hw, tile)
+                       res.shape[3] if res is not None else 0, flags, res_hw, tile, k_splits)
+    wsb = conv_workspace_bytes(d)
+    if wsb:
+        ws = torch.empty((wsb,), device=xs[0].device, dtype=torch.uint8)
+        d.workspace, d.workspace_bytes = ws.data_ptr(), wsb
     launch_conv(d)
     return out
 

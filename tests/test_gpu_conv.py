@@ -193,3 +193,163 @@ def test_maxpool_and_pack(dev):
     m = ops.maxpool3x3s2(xf.permute(0, 2, 3, 1).contiguous().to(dev))
     refm = F.max_pool2d(xf.float(), 3, 2, 1)
     assert torch.equal(m.float().cpu().permute(0, 3, 1, 2), refm)
+
+
+@pytest.mark.parametrize('splits', [2, 5, 16])
+def test_conv_split_k(dev, splits):
+    """Small-M / long-K launch (ResNet layer4, FPN P6): K split over blockIdx.z, fp32 partial slabs, fused epilogue."""
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    g = torch.Generator().manual_seed(20 + splits)
+    x = torch.randn(1, 512, 6, 10, generator=g).half().float()
+    wt = (torch.randn(96, 512, 3, 3, generator=g) / 68.0).half().float()
+    b = torch.randn(96, generator=g)
+    res = torch.randn(1, 3, 5, 96, generator=g).half()
+    pc = ops.pack_conv(wt, b, stride=2, pad=1).to(dev)
+    y = ops.conv2d(_nhwc(x).half().to(dev), pc, res=res.to(dev), flags=ops.CONV_RELU | ops.CONV_RES_ADD, k_splits=splits)
+    ref = F.relu(F.conv2d(x, wt, b, 2, 1) + res.float().permute(0, 3, 1, 2))
+    _check(y, ref, 96)
+
+
+def test_conv_split_k_auto_matches_unsplit(dev):
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    g = torch.Generator().manual_seed(31)
+    x = torch.randn(1, 2048, 12, 20, generator=g).half()
+    wt = (torch.randn(256, 2048, 1, 1, generator=g) / 45.0).half().float()
+    pc = ops.pack_conv(wt, torch.zeros(256)).to(dev)
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    d = ops.make_conv_desc(pc, [xd], torch.empty(1, 12, 20, 256, dtype=torch.float16, device=dev), 1, [(12, 20, 12, 20, 0, 0)], 2048, 256)
+    assert ops.conv_workspace_bytes(d) > 0                     # the heuristic splits this one
+    y_auto = ops.conv2d(xd, pc)
+    y_one = ops.conv2d(xd, pc, k_splits=1)
+    ref = F.conv2d(x.float(), wt)
+    _check(y_auto, ref, 256)
+    _check(y_one, ref, 256)
+
+
+def test_conv_grouped_over_separate_sources(dev):
+    """FastDVDnet input conv as the engine issues it: groups == n_src == 3, group g reads frame g (NHWC8)."""
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    g = torch.Generator().manual_seed(41)
+    frames = [torch.randn(2, 3, 18, 22, generator=g).half().float() for _ in range(3)]
+    wg = (torch.randn(90, 3, 3, 3, generator=g) / 5.0).half().float()
+    pcs = [ops.pack_conv(wg[30 * i:30 * i + 30], None, 1, 1, in_map=[0, 1, 2, -1, -1, -1, -1, -1], cout_store=32) for i in range(3)]
+    pc = ops.stack_groups(pcs)
+    pc.n_src, pc.src_cvec = 3, 1
+    pc.to(dev)
+    xs = []
+    for f in frames:
+        t = torch.zeros(2, 18, 22, 8, dtype=torch.float16)
+        t[..., :3] = _nhwc(f).half()
+        xs.append(t.to(dev))
+    y = ops.conv2d(xs, pc, flags=ops.CONV_RELU)
+    assert y.shape == (2, 18, 22, 96)
+    ref = F.relu(F.conv2d(torch.cat(frames, 1), wg, None, 1, 1, 1, 3))
+    got = y.float().cpu().reshape(2, 18, 22, 3, 32)
+    assert got[..., 30:].abs().max() == 0
+    got = got[..., :30].reshape(2, 18, 22, 90).permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() / ref.abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize('cfg', [
+    # n, cin, cout, h, w, flags-kind
+    (1, 32, 32, 20, 45, 'relu'),
+    (2, 96, 32, 17, 33, 'relu'),
+    (1, 64, 64, 9, 70, 'relu'),
+    (1, 64, 128, 16, 40, 'pixshuf'),
+    (1, 32, 3, 24, 31, 'rsub'),
+    (1, 128, 128, 8, 32, 'res'),
+    (3, 8, 20, 13, 21, 'none'),
+    (1, 24, 90, 16, 24, 'relu'),
+])
+def test_conv3x3_halo_kernel(dev, cfg):
+    """Direct (halo-in-LDS) 3x3 kernel vs torch, same tolerance as the implicit-GEMM path, and bit-compatible
+    results are NOT required between the two kernels (different summation order)."""
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    n, cin, cout, h, w, kind = cfg
+    g = torch.Generator().manual_seed(cin * 7 + cout)
+    x = torch.randn(n, cin, h, w, generator=g).half().float()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).half().float()
+    b = torch.randn(cout, generator=g)
+    pc = ops.add_halo_packing(ops.pack_conv(wt, b, 1, 1, cout_store=8 if cout == 3 else None)).to(dev)
+    assert pc.w_halo is not None
+    cin_pad = pc.cin
+    xp = torch.zeros(n, h, w, cin_pad, dtype=torch.float16)
+    xp[..., :cin] = _nhwc(x).half()
+    ref = F.conv2d(x, wt, b, 1, 1)
+    flags, res = 0, None
+    if kind == 'relu':
+        flags, ref = ops.CONV_RELU, F.relu(ref)
+    elif kind == 'res':
+        res = torch.randn(n, h, w, pc.cout, generator=g).half()
+        flags, ref = ops.CONV_RELU | ops.CONV_RES_ADD, F.relu(ref + res.float().permute(0, 3, 1, 2)[:, :cout])
+    elif kind == 'rsub':
+        res = torch.zeros(n, h, w, 8, dtype=torch.float16)
+        res[..., :3] = torch.randn(n, h, w, 3, generator=g).half()
+        flags, ref = ops.CONV_RES_RSUB, res.float().permute(0, 3, 1, 2)[:, :3] - ref
+    elif kind == 'pixshuf':
+        res = torch.randn(n, 2 * h, 2 * w, cout // 4, generator=g).half()
+        flags, ref = ops.CONV_PIXSHUF | ops.CONV_RES_ADD, F.pixel_shuffle(ref, 2) + res.float().permute(0, 3, 1, 2)
+    y = ops.conv2d(xp.to(dev), pc, res=res.to(dev) if res is not None else None, flags=flags)
+    _check(y, ref, ref.shape[1])
+
+
+def test_conv3x3_halo_grouped_sources(dev):
+    """FastDVDnet input conv through the halo kernel: groups == n_src == 3, CK = 8."""
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    g = torch.Generator().manual_seed(51)
+    frames = [torch.randn(2, 3, 19, 37, generator=g).half().float() for _ in range(3)]
+    wg = (torch.randn(90, 3, 3, 3, generator=g) / 5.0).half().float()
+    pcs = [ops.pack_conv(wg[30 * i:30 * i + 30], None, 1, 1, in_map=[0, 1, 2, -1, -1, -1, -1, -1], cout_store=32) for i in range(3)]
+    pc = ops.stack_groups(pcs)
+    pc.n_src, pc.src_cvec = 3, 1
+    ops.add_halo_packing(pc).to(dev)
+    assert pc.w_halo is not None and pc.halo_bn == 32
+    xs = []
+    for f in frames:
+        t = torch.zeros(2, 19, 37, 8, dtype=torch.float16)
+        t[..., :3] = _nhwc(f).half()
+        xs.append(t.to(dev))
+    y = ops.conv2d(xs, pc, flags=ops.CONV_RELU)
+    ref = F.relu(F.conv2d(torch.cat(frames, 1), wg, None, 1, 1, 1, 3))
+    got = y.float().cpu().reshape(2, 19, 37, 3, 32)[..., :30].reshape(2, 19, 37, 90).permute(0, 3, 1, 2)
+    assert (got - ref).abs().max().item() / ref.abs().max().item() < 2e-3
+
+
+@pytest.mark.parametrize('use_halo', [True, False])
+def test_conv_grouped_planar_outputs_then_multi_source(dev, use_halo):
+    """inc0 -> inc1 as the FastDVDnet plan issues them: three groups each write their own plane
+    (y_group_stride), the next conv reads the three planes as three concatenated sources."""
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    g = torch.Generator().manual_seed(61)
+    n, h, w = 2, 18, 37
+    frames = [torch.randn(n, 3, h, w, generator=g).half().float() for _ in range(3)]
+    wg = (torch.randn(90, 3, 3, 3, generator=g) / 5.0).half().float()
+    w2 = (torch.randn(32, 90, 3, 3, generator=g) / 28.0).half().float()
+    pcs = [ops.pack_conv(wg[30 * i:30 * i + 30], None, 1, 1, in_map=[0, 1, 2, -1, -1, -1, -1, -1], cout_store=32) for i in range(3)]
+    pc = ops.stack_groups(pcs)
+    pc.n_src, pc.src_cvec = 3, 1
+    in_map = []
+    for gi in range(3):
+        in_map += [30 * gi + j if j < 30 else -1 for j in range(32)]
+    pc2 = ops.pack_conv(w2, None, 1, 1, in_map=in_map, n_src=3)
+    if use_halo:
+        ops.add_halo_packing(pc)
+        ops.add_halo_packing(pc2)
+        assert pc.w_halo is not None and pc2.w_halo is not None
+    pc.to(dev)
+    pc2.to(dev)
+    xs = []
+    for f in frames:
+        t = torch.zeros(n, h, w, 8, dtype=torch.float16)
+        t[..., :3] = _nhwc(f).half()
+        xs.append(t.to(dev))
+    planes = torch.zeros(3, n, h, w, 32, dtype=torch.float16, device=dev)
+    d = ops.make_conv_desc(pc, xs, planes, n, [(h, w, h, w, 0, 0)], 8, 32, flags=ops.CONV_RELU, y_group_stride=n * h * w * 32)
+    ops.launch_conv(d)
+    ref1 = F.relu(F.conv2d(torch.cat(frames, 1), wg, None, 1, 1, 1, 3))
+    got1 = planes.float().cpu()[..., :30].permute(1, 0, 4, 2, 3).reshape(n, 90, h, w)
+    assert (got1 - ref1).abs().max().item() / ref1.abs().max().item() < 2e-3
+    assert planes.float().cpu()[..., 30:].abs().max().item() == 0
+    y2 = ops.conv2d([planes[0], planes[1], planes[2]], pc2, flags=ops.CONV_RELU)
+    ref2 = F.relu(F.conv2d(got1, w2, None, 1, 1))
+    _check(y2, ref2, 32)
