@@ -36,6 +36,12 @@ struct DecK {
     int* cand_anchor;
     float* ms;  // workspace: max score per anchor
     int* sel;   // workspace: selected global anchor per candidate slot
+    unsigned* hist;   // [n_levels][4096] score histogram (zeroed by the launcher)
+    int* meta;        // [n_levels][4]: b*, #above b*, |A|, |T|  (zeroed by the launcher)
+    uint64_t* listA;  // [n_levels][capA] keys above b*
+    uint64_t* listT;  // [total anchors] keys inside b* (level l at a0[l])
+    int capA;
+    int blk0[LLV_MAX_SEG + 1];  // first class_max block of each level
 };
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
@@ -51,110 +57,212 @@ __device__ __forceinline__ int level_of_anchor(const DecK& k, int g) {
     return l;
 }
 
-template <typename T>
-__global__ void class_max_kernel(const DecK k) {
-    const int total = k.a0[k.n_levels];
-    for (int g = blockIdx.x * blockDim.x + threadIdx.x; g < total; g += gridDim.x * blockDim.x) {
-        const int l = level_of_anchor(k, g);
-        const int loc = g - k.a0[l];
-        const int cell = loc / k.A, an = loc - cell * k.A;
-        const long base = (k.cls_off[l] + cell) * (long)k.cls_ld + (long)an * k.C;
-        float m = 0.f;  // sigmoid > 0
-        const T* p = reinterpret_cast<const T*>(k.cls) + base;
-        for (int c = 0; c < k.C; ++c) m = fmaxf(m, sigmoidf_((float)p[c]));
-        k.ms[g] = m;
+constexpr int kBins = 4096;      // linear score histogram: bin = min(4095, int(score * 4096)), monotone in the score
+constexpr int kSortCap = 8192;   // ties-list size the final kernel sorts in LDS; longer lists take the radix path
+
+__device__ __forceinline__ int score_bin(float m) {
+    int b = (int)(m * (float)kBins);
+    return b < 0 ? 0 : (b > kBins - 1 ? kBins - 1 : b);
+}
+
+// wave-aggregated atomicAdd(&base[key], 1): lanes with equal key issue one atomic
+__device__ __forceinline__ void wave_hist_add(unsigned* base, unsigned key, bool valid) {
+    unsigned long long active = __ballot(valid);
+    const int lane = threadIdx.x & 63;
+    while (active) {
+        const int leader = __ffsll((long long)active) - 1;
+        const unsigned kb = __shfl(key, leader);
+        const unsigned long long same = __ballot(valid && key == kb);
+        if (lane == leader) atomicAdd(&base[kb], (unsigned)__popcll(same));
+        active &= ~same;
     }
 }
 
-// one block (1024 threads) per level
-__global__ __launch_bounds__(1024) void topk_select_kernel(const DecK k) {
+// K1: per anchor max_c sigmoid(logit) (every logit read once) + per-level score histogram.
+// A block works inside ONE level (blk0[] = first block of each level), so its histogram lives in LDS and is
+// flushed with at most one global atomic per non-empty bin.
+constexpr int kAnchorsPerBlock = 512;
+template <typename T>
+__global__ __launch_bounds__(256) void class_max_kernel(const DecK k) {
+    __shared__ unsigned lh[kBins];
+    int l = 0;
+#pragma unroll
+    for (int s = 1; s < LLV_MAX_SEG; ++s)
+        if (s < k.n_levels && (int)blockIdx.x >= k.blk0[s]) l = s;
+    for (int i = threadIdx.x; i < kBins; i += 256) lh[i] = 0;
+    __syncthreads();
+    const int n = k.a0[l + 1] - k.a0[l];
+    const int first = (blockIdx.x - k.blk0[l]) * kAnchorsPerBlock;
+    for (int loc = first + threadIdx.x; loc < first + kAnchorsPerBlock && loc < n; loc += 256) {
+        const int cell = loc / k.A, an = loc - cell * k.A;
+        const T* p = reinterpret_cast<const T*>(k.cls) + (k.cls_off[l] + cell) * (long)k.cls_ld + (long)an * k.C;
+        float m = 0.f;  // sigmoid > 0
+        for (int c = 0; c < k.C; ++c) m = fmaxf(m, sigmoidf_((float)p[c]));
+        k.ms[k.a0[l] + loc] = m;
+        atomicAdd(&lh[score_bin(m)], 1u);
+    }
+    __syncthreads();
+    unsigned* gh = k.hist + l * kBins;
+    for (int i = threadIdx.x; i < kBins; i += 256) {
+        const unsigned v = lh[i];
+        if (v) atomicAdd(&gh[i], v);
+    }
+}
+
+// K2: one block per level: the bin b* in which the k-th largest score falls, and how many scores lie above it
+__global__ __launch_bounds__(256) void topk_threshold_kernel(const DecK k) {
     const int l = blockIdx.x;
     const int n = k.a0[l + 1] - k.a0[l];
     const int kk = k.c0[l + 1] - k.c0[l];
-    const float* ms = k.ms + k.a0[l];
+    int* meta = k.meta + l * 4;
+    if (kk >= n) {
+        if (threadIdx.x == 0) { meta[0] = -1; meta[1] = 0; }
+        return;
+    }
+    __shared__ unsigned part[256];
+    const unsigned* h = k.hist + l * kBins;
+    constexpr int PER = kBins / 256;
+    const int top = kBins - 1 - threadIdx.x * PER;   // this thread owns bins top, top-1, ..., top-PER+1
+    unsigned s = 0;
+    for (int i = 0; i < PER; ++i) s += h[top - i];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        unsigned cum = 0;
+        int t = 0;
+        for (; t < 255; ++t) {
+            if (cum + part[t] >= (unsigned)kk) break;
+            cum += part[t];
+        }
+        int b = kBins - 1 - t * PER;
+        const int lo = b - PER + 1;
+        for (; b > lo; --b) {
+            if (cum + h[b] >= (unsigned)kk) break;
+            cum += h[b];
+        }
+        meta[0] = b;           // b*
+        meta[1] = (int)cum;    // scores in bins above b*  (< kk)
+    }
+}
+
+// K3: scores above b* go to list A, scores inside b* to list T (unordered appends; the 64-bit keys are distinct)
+__global__ void topk_compact_kernel(const DecK k) {
+    const int total = k.a0[k.n_levels];
+    const int stride = gridDim.x * blockDim.x;
+    const int lane = threadIdx.x & 63;
+    for (int g0 = blockIdx.x * blockDim.x; g0 < total; g0 += stride) {
+        const int g = g0 + threadIdx.x;
+        int l = 0, which = 0;   // 1 = A, 2 = T
+        uint64_t key = 0;
+        if (g < total) {
+            l = level_of_anchor(k, g);
+            const int bstar = k.meta[l * 4];
+            if (bstar >= 0) {
+                const float m = k.ms[g];
+                const int b = score_bin(m);
+                which = b > bstar ? 1 : (b == bstar ? 2 : 0);
+                key = llv::make_key(m, (unsigned)(g - k.a0[l]));
+            }
+        }
+        // one atomic per (wave, level, list)
+        for (int w = 1; w <= 2; ++w) {
+            unsigned long long active = __ballot(which == w);
+            while (active) {
+                const int leader = __ffsll((long long)active) - 1;
+                const int ll = __shfl(l, leader);
+                const unsigned long long same = __ballot(which == w && l == ll);
+                int base = 0;
+                if (lane == leader) base = atomicAdd(&k.meta[ll * 4 + 1 + w], (int)__popcll(same));
+                base = __shfl(base, leader);
+                if (which == w && l == ll) {
+                    const int pos = base + __popcll(same & ((1ull << lane) - 1ull));
+                    if (w == 1) k.listA[(long)ll * k.capA + pos] = key;
+                    else k.listT[k.a0[ll] + pos] = key;
+                }
+                active &= ~same;
+            }
+        }
+    }
+}
+
+// K4: one block per level: top (k - |A|) keys of T, merged with A, sorted -> sel (score desc, anchor asc)
+__global__ __launch_bounds__(1024) void topk_final_kernel(const DecK k) {
+    const int l = blockIdx.x;
+    const int n = k.a0[l + 1] - k.a0[l];
+    const int kk = k.c0[l + 1] - k.c0[l];
     int* sel = k.sel + k.c0[l];
     const int tid = threadIdx.x;
     if (kk >= n) {  // no top-k on this level: anchor order is kept (anchor_head.py:657-658)
         for (int i = tid; i < n; i += blockDim.x) sel[i] = k.a0[l] + i;
         return;
     }
+    extern __shared__ __attribute__((aligned(16))) uint64_t lds[];
+    const int np2k = llv::next_pow2(kk);
+    uint64_t* fin = lds;             // [np2k]
+    uint64_t* tbuf = lds + np2k;     // [kSortCap]
     __shared__ unsigned hist[256];
-    __shared__ unsigned sh_prefix, sh_need;
-    __shared__ int wcnt_gt[16], wcnt_eq[16];
-    extern __shared__ __attribute__((aligned(16))) uint64_t keys[];  // next_pow2(kk)
-
-    unsigned prefix = 0, need = (unsigned)kk;
-    for (int pass = 0; pass < 4; ++pass) {
-        const int shift = 24 - 8 * pass;
-        for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
-        __syncthreads();
-        for (int i = tid; i < n; i += blockDim.x) {
-            const unsigned key = llv::f32_ordered(ms[i]);
-            const bool match = pass == 0 ? true : ((key >> (shift + 8)) == prefix);
-            if (match) atomicAdd(&hist[(key >> shift) & 255u], 1u);
-        }
-        __syncthreads();
-        if (tid == 0) {
-            unsigned cum = 0, nd = need;
-            int b = 255;
-            for (; b > 0; --b) {
-                if (cum + hist[b] >= nd) break;
-                cum += hist[b];
-            }
-            sh_need = nd - cum;
-            sh_prefix = (prefix << 8) | (unsigned)b;
-        }
-        __syncthreads();
-        prefix = sh_prefix;
-        need = sh_need;
-        __syncthreads();
-    }
-    const unsigned T = prefix;  // key of the kk-th largest score; take `need` of its ties, lowest index first
-
-    const int np2 = llv::next_pow2(kk);
-    for (int i = tid; i < np2; i += blockDim.x) keys[i] = 0;
+    __shared__ uint64_t sh_prefix;
+    __shared__ unsigned sh_need, sh_cnt;
+    const int* meta = k.meta + l * 4;
+    const int nA = meta[2], nT = meta[3];
+    const int m = kk - nA;           // keys still needed, all from T (nT >= m by construction)
+    const uint64_t* A = k.listA + (long)l * k.capA;
+    const uint64_t* Tl = k.listT + k.a0[l];
+    for (int i = tid; i < np2k; i += blockDim.x) fin[i] = i < nA ? A[i] : 0ull;
     __syncthreads();
-
-    const int lane = tid & 63, wave = tid >> 6, nw = blockDim.x >> 6;
-    int run_take = 0, run_eq = 0;
-    for (int base = 0; base < n; base += blockDim.x) {
-        const int i = base + tid;
-        unsigned key = 0;
-        bool gt = false, eq = false;
-        if (i < n) {
-            key = llv::f32_ordered(ms[i]);
-            gt = key > T;
-            eq = key == T;
-        }
-        const unsigned long long bgt = __ballot(gt), beq = __ballot(eq);
-        if (lane == 0) { wcnt_gt[wave] = __popcll(bgt); wcnt_eq[wave] = __popcll(beq); }
+    if (nT <= kSortCap) {
+        const int np2t = llv::next_pow2(nT > 1 ? nT : 1);
+        for (int i = tid; i < np2t; i += blockDim.x) tbuf[i] = i < nT ? Tl[i] : 0ull;
         __syncthreads();
-        int pos = run_take, eqr = run_eq, tot_take = run_take, tot_eq = run_eq;
-        for (int w = 0; w < nw; ++w) {
-            const int e = wcnt_eq[w], g2 = wcnt_gt[w];
-            int avail = (int)need - tot_eq;
-            avail = avail < 0 ? 0 : avail;
-            const int te = e < avail ? e : avail;
-            if (w < wave) { pos += g2 + te; eqr += e; }
-            tot_take += g2 + te;
-            tot_eq += e;
+        llv::bitonic_sort_desc(tbuf, np2t);
+        for (int i = tid; i < m; i += blockDim.x) fin[nA + i] = tbuf[i];
+        __syncthreads();
+    } else {
+        // long tie list (e.g. a blank frame: every score equal): 8 x 8-bit radix select on the distinct 64-bit keys
+        uint64_t prefix = 0;
+        unsigned need = (unsigned)m;
+        for (int pass = 0; pass < 8; ++pass) {
+            const int shift = 56 - 8 * pass;
+            for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
+            __syncthreads();
+            for (int i0 = 0; i0 < nT; i0 += blockDim.x) {
+                const int i = i0 + tid;
+                bool ok = false;
+                unsigned d = 0;
+                if (i < nT) {
+                    const uint64_t key = Tl[i];
+                    ok = pass == 0 ? true : ((key >> (shift + 8)) == prefix);
+                    d = (unsigned)((key >> shift) & 255ull);
+                }
+                wave_hist_add(hist, d, ok);
+            }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned cum = 0;
+                int b = 255;
+                for (; b > 0; --b) {
+                    if (cum + hist[b] >= need) break;
+                    cum += hist[b];
+                }
+                sh_need = need - cum;
+                sh_prefix = (prefix << 8) | (uint64_t)b;
+            }
+            __syncthreads();
+            prefix = sh_prefix;
+            need = sh_need;
+            __syncthreads();
         }
-        const unsigned long long below = (1ull << lane) - 1ull;
-        const int my_eq_rank = eqr + __popcll(beq & below);
-        const bool take_eq = eq && my_eq_rank < (int)need;
-        // lanes of this wave taken before me: gt lanes below + taken-eq lanes below
-        int avail_w = (int)need - eqr;
-        avail_w = avail_w < 0 ? 0 : avail_w;
-        int eq_below = __popcll(beq & below);
-        eq_below = eq_below < avail_w ? eq_below : avail_w;
-        const int my_pos = pos + __popcll(bgt & below) + eq_below;
-        if (gt || take_eq) keys[my_pos] = ((uint64_t)key << 32) | (uint64_t)(0xffffffffu - (unsigned)i);
-        run_take = tot_take;
-        run_eq = tot_eq;
+        // prefix is now the m-th largest key; keys are distinct, so exactly m keys are >= it
+        if (tid == 0) sh_cnt = 0;
+        __syncthreads();
+        for (int i = tid; i < nT; i += blockDim.x) {
+            const uint64_t key = Tl[i];
+            if (key >= prefix) fin[nA + atomicAdd(&sh_cnt, 1u)] = key;
+        }
         __syncthreads();
     }
-    llv::bitonic_sort_desc(keys, np2);
-    for (int i = tid; i < kk; i += blockDim.x) sel[i] = k.a0[l] + (int)llv::key_index(keys[i]);
+    llv::bitonic_sort_desc(fin, np2k);
+    for (int i = tid; i < kk; i += blockDim.x) sel[i] = k.a0[l] + (int)llv::key_index(fin[i]);
 }
 
 template <typename T>
@@ -233,12 +341,27 @@ extern "C" int llv_retina_decode_ncand(const llv_decode_desc* d) {
     return rc < 0 ? rc : k.c0[d->n_levels];
 }
 
+namespace {
+struct WsLayout { size_t ms, sel, hist, meta, listA, listT, total; };
+WsLayout ws_layout(const DecK& k, int n_levels, int nms_pre) {
+    auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
+    WsLayout w;
+    size_t o = 0;
+    w.hist = o; o += al((size_t)n_levels * kBins * 4);
+    w.meta = o; o += al((size_t)n_levels * 4 * 4);          // hist + meta are contiguous: one memset
+    w.ms = o; o += al((size_t)k.a0[n_levels] * 4);
+    w.sel = o; o += al((size_t)k.c0[n_levels] * 4);
+    w.listA = o; o += al((size_t)n_levels * (size_t)(nms_pre > 0 ? nms_pre : 1) * 8);
+    w.listT = o; o += al((size_t)k.a0[n_levels] * 8);
+    w.total = o;
+    return w;
+}
+}  // namespace
+
 extern "C" size_t llv_retina_decode_workspace_bytes(const llv_decode_desc* d) {
     DecK k;
     if (fill(d, k) < 0) return 0;
-    const size_t a = ((size_t)k.a0[d->n_levels] * 4 + 255) & ~(size_t)255;
-    const size_t c = ((size_t)k.c0[d->n_levels] * 4 + 255) & ~(size_t)255;
-    return a + c;
+    return ws_layout(k, d->n_levels, d->nms_pre).total;
 }
 
 extern "C" int llv_retina_decode_topk(const llv_decode_desc* d, void* stream) {
@@ -255,18 +378,34 @@ extern "C" int llv_retina_decode_topk(const llv_decode_desc* d, void* stream) {
     for (int e = 0; e < 4; ++e) { k.means[e] = d->means[e]; k.stds[e] = d->stds[e]; k.sf[e] = d->scale_factor[e]; }
     k.max_ratio = d->max_ratio; k.clip = d->clip; k.img_h = d->img_h; k.img_w = d->img_w; k.rescale = d->rescale;
     k.boxes = d->boxes; k.scores = d->scores; k.cand_anchor = d->cand_anchor;
-    const size_t a = ((size_t)k.a0[d->n_levels] * 4 + 255) & ~(size_t)255;
-    k.ms = (float*)d->workspace;
-    k.sel = (int*)((char*)d->workspace + a);
+    const WsLayout w = ws_layout(k, d->n_levels, d->nms_pre);
+    char* ws = (char*)d->workspace;
+    k.hist = (unsigned*)(ws + w.hist); k.meta = (int*)(ws + w.meta);
+    k.ms = (float*)(ws + w.ms); k.sel = (int*)(ws + w.sel);
+    k.listA = (uint64_t*)(ws + w.listA); k.listT = (uint64_t*)(ws + w.listT);
+    k.capA = d->nms_pre > 0 ? d->nms_pre : 1;
     hipStream_t st = (hipStream_t)stream;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_final_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+        attr_done = true;
+    }
+    if (hipMemsetAsync(ws + w.hist, 0, w.ms - w.hist, st) != hipSuccess) return LLV_E_LAUNCH;
     const int total = k.a0[d->n_levels];
     int grid = (total + 255) / 256;
-    grid = grid > 4096 ? 4096 : grid;
-    if (k.f32) hipLaunchKernelGGL((class_max_kernel<float>), dim3(grid), dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((class_max_kernel<_Float16>), dim3(grid), dim3(256), 0, st, k);
+    grid = grid > 2048 ? 2048 : grid;
+    int nb = 0;
+    for (int l = 0; l <= LLV_MAX_SEG; ++l) {
+        k.blk0[l] = nb;
+        if (l < d->n_levels) nb += (k.a0[l + 1] - k.a0[l] + kAnchorsPerBlock - 1) / kAnchorsPerBlock;
+    }
+    if (k.f32) hipLaunchKernelGGL((class_max_kernel<float>), dim3(nb), dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((class_max_kernel<_Float16>), dim3(nb), dim3(256), 0, st, k);
+    hipLaunchKernelGGL(topk_threshold_kernel, dim3(d->n_levels), dim3(256), 0, st, k);
+    hipLaunchKernelGGL(topk_compact_kernel, dim3(grid), dim3(256), 0, st, k);
     int np2 = 1;
     while (np2 < (d->nms_pre > 0 ? d->nms_pre : 1)) np2 <<= 1;
-    hipLaunchKernelGGL(topk_select_kernel, dim3(d->n_levels), dim3(1024), (size_t)np2 * 8, st, k);
+    hipLaunchKernelGGL(topk_final_kernel, dim3(d->n_levels), dim3(1024), (size_t)(np2 + kSortCap) * 8, st, k);
     if (k.f32) hipLaunchKernelGGL((gather_decode_kernel<float>), dim3(d->n_cand), dim3(128), 0, st, k);
     else hipLaunchKernelGGL((gather_decode_kernel<_Float16>), dim3(d->n_cand), dim3(128), 0, st, k);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;

@@ -43,23 +43,23 @@ __device__ __forceinline__ bool iou_gt(const float4 a, const float4 b, float thr
     return inter / (sa + sb - inter) > thr;
 }
 
-// max coordinate over boxes that have at least one class above the threshold
-__global__ __launch_bounds__(1024) void nms_prepare_kernel(const float* __restrict__ boxes,
-                                                           const float* __restrict__ scores, int n, int C,
-                                                           int c_ld, float thr, unsigned* maxc_u, int* any,
-                                                           int* cls_cnt) {
-    __shared__ unsigned smax[16];
-    __shared__ int sany[16];
+// Pass 1 (multi-block, coalesced over the n x C score matrix): every (box i, class c) with score > thr is
+// appended to class c's candidate list as a 64-bit (score, flat index) key, and the maximum coordinate of
+// the boxes that own a candidate is reduced (boxes.max() of batched_nms). Appends are unordered; the keys are
+// distinct, so the per-class sort that follows is deterministic.
+__global__ __launch_bounds__(256) void nms_scan_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                      int n, int C, int c_ld, float thr, unsigned* maxc_u,
+                                                      int* cnt_in, uint64_t* cand) {
+    const long total = (long)n * C;
     unsigned m = 0;
-    int a = 0;
-    for (int i = threadIdx.x; i < n; i += blockDim.x) {
-        bool v = false;
-        for (int c = 0; c < C; ++c) v |= scores[(long)i * c_ld + c] > thr;
-        if (v) {
-            a = 1;
+    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(e / C), c = (int)(e - (long)i * C);
+        const float s = scores[(long)i * c_ld + c];
+        if (s > thr) {
+            const int slot = atomicAdd(&cnt_in[c], 1);
+            cand[(long)c * n + slot] = llv::make_key(s, (unsigned)e);
             const float4 b = reinterpret_cast<const float4*>(boxes)[i];
-            const float mm = fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w));
-            const unsigned u = llv::f32_ordered(mm);
+            const unsigned u = llv::f32_ordered(fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
             m = u > m ? u : m;
         }
     }
@@ -67,16 +67,8 @@ __global__ __launch_bounds__(1024) void nms_prepare_kernel(const float* __restri
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned t = __shfl_xor(m, o);
         m = t > m ? t : m;
-        a |= __shfl_xor(a, o);
     }
-    if ((threadIdx.x & 63) == 0) { smax[threadIdx.x >> 6] = m; sany[threadIdx.x >> 6] = a; }
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        for (int w = 1; w < (int)(blockDim.x >> 6); ++w) { m = smax[w] > m ? smax[w] : m; a |= sany[w]; }
-        *maxc_u = m;
-        *any = a;
-    }
-    for (int c = threadIdx.x; c < C; c += blockDim.x) cls_cnt[c] = 0;
+    if ((threadIdx.x & 63) == 0 && m) atomicMax(maxc_u, m);
 }
 
 // Greedy scan over `cnt` sorted keys (LDS) by wave 0. box_of(idx) gives the (offset) box of
@@ -119,41 +111,24 @@ __device__ inline int greedy_scan(const uint64_t* keys, int cnt, float thr, int 
     return nkept;
 }
 
-// one workgroup per class
-__global__ __launch_bounds__(256) void nms_class_kernel(const float* __restrict__ boxes,
-                                                        const float* __restrict__ scores, int n, int C, int c_ld,
-                                                        float score_thr, float iou_thr, int max_num,
-                                                        const unsigned* maxc_u, const int* any, int* cls_cnt,
-                                                        uint64_t* cls_keys) {
-    if (!*any) return;
+// one workgroup per class: sort its candidate list in LDS, greedy scan by wave 0
+__global__ __launch_bounds__(256) void nms_class_kernel(const float* __restrict__ boxes, int n, int C, float iou_thr,
+                                                        int max_num, const unsigned* maxc_u, const int* cnt_in,
+                                                        const uint64_t* cand, int* cls_cnt, uint64_t* cls_keys) {
     const int c = blockIdx.x;
+    const int cnt = cnt_in[c];
+    if (cnt == 0) {
+        if (threadIdx.x == 0) cls_cnt[c] = 0;
+        return;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(sm);                     // [np2]
-    const int np2_max = llv::next_pow2(n);
-    float4* kept = reinterpret_cast<float4*>(sm + (size_t)np2_max * 8);   // [max_num]
-    int* scratch = reinterpret_cast<int*>(sm + (size_t)np2_max * 8 + (size_t)max_num * 16);  // [17]
-
-    // ordered compaction of candidates of this class
-    int cnt = 0;
-    for (int base = 0; base < n; base += blockDim.x) {
-        const int i = base + threadIdx.x;
-        float s = 0.f;
-        bool v = false;
-        if (i < n) {
-            s = scores[(long)i * c_ld + c];
-            v = s > score_thr;
-        }
-        int tot;
-        const int pos = llv::block_exclusive_scan(v ? 1 : 0, scratch, &tot);
-        if (v) keys[cnt + pos] = llv::make_key(s, (unsigned)i * (unsigned)C + (unsigned)c);
-        cnt += tot;
-    }
-    if (cnt == 0) return;
     const int np2 = llv::next_pow2(cnt);
-    for (int i = cnt + threadIdx.x; i < np2; i += blockDim.x) keys[i] = 0;
+    float4* kept = reinterpret_cast<float4*>(sm + (size_t)np2 * 8);       // [max_num]
+    const uint64_t* src = cand + (long)c * n;
+    for (int i = threadIdx.x; i < np2; i += blockDim.x) keys[i] = i < cnt ? src[i] : 0ull;
     __syncthreads();
     llv::bitonic_sort_desc(keys, np2);
-
     if (threadIdx.x < 64) {
         // boxes_for_nms = boxes + idxs.to(boxes) * (max_coordinate + 1)   (mmcv batched_nms)
         const float off = (float)c * (llv::f32_unordered(*maxc_u) + 1.0f);
@@ -169,13 +144,9 @@ __global__ __launch_bounds__(256) void nms_class_kernel(const float* __restrict_
 
 // one workgroup: merge the per-class kept lists, global (score desc, flat asc) order, top max_num
 __global__ __launch_bounds__(1024) void nms_merge_kernel(const float* __restrict__ boxes, int C, int max_num,
-                                                         const int* any, const int* cls_cnt,
+                                                         const int* cls_cnt,
                                                          const uint64_t* cls_keys, float* dets, int64_t* labels,
                                                          int* count, int* keep_flat) {
-    if (!*any) {
-        if (threadIdx.x == 0) *count = 0;
-        return;
-    }
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(sm);
     __shared__ int s_off[1025];
@@ -252,7 +223,9 @@ inline void nms_init_once() {
 
 extern "C" size_t llv_multiclass_nms_workspace_bytes(int n, int num_classes, int max_num) {
     if (n < 0 || num_classes < 1 || max_num < 1) return 0;
-    return al(16) + al((size_t)num_classes * 4) + al((size_t)num_classes * max_num * 8);
+    // [maxc | cnt_in[C]] (memset together) | cls_cnt[C] | cls_keys[C][max_num] | cand[C][n]
+    return al(16 + (size_t)num_classes * 4) + al((size_t)num_classes * 4) + al((size_t)num_classes * max_num * 8) +
+           al((size_t)num_classes * (size_t)(n > 0 ? n : 1) * 8);
 }
 
 extern "C" int llv_multiclass_nms(const float* boxes, const float* scores, int n, int num_classes, int c_ld,
@@ -268,22 +241,29 @@ extern "C" int llv_multiclass_nms(const float* boxes, const float* scores, int n
     hipStream_t st = (hipStream_t)stream;
     nms_init_once();
     char* ws = (char*)workspace;
+    const size_t o_cnt = al(16 + (size_t)num_classes * 4);
+    const size_t o_keys = o_cnt + al((size_t)num_classes * 4);
+    const size_t o_cand = o_keys + al((size_t)num_classes * max_num * 8);
     unsigned* maxc_u = (unsigned*)ws;
-    int* any = (int*)(ws + 8);
-    int* cls_cnt = (int*)(ws + al(16));
-    uint64_t* cls_keys = (uint64_t*)(ws + al(16) + al((size_t)num_classes * 4));
-    hipLaunchKernelGGL(nms_prepare_kernel, dim3(1), dim3(1024), 0, st, boxes, scores, n, num_classes, c_ld,
-                       score_thr, maxc_u, any, cls_cnt);
+    int* cnt_in = (int*)(ws + 16);
+    int* cls_cnt = (int*)(ws + o_cnt);
+    uint64_t* cls_keys = (uint64_t*)(ws + o_keys);
+    uint64_t* cand = (uint64_t*)(ws + o_cand);
+    if (hipMemsetAsync(ws, 0, o_cnt + al((size_t)num_classes * 4), st) != hipSuccess) return LLV_E_LAUNCH;
     if (n > 0) {
+        long g = ((long)n * num_classes + 255) / 256;
+        g = g > 1024 ? 1024 : g;
+        hipLaunchKernelGGL(nms_scan_kernel, dim3((int)g), dim3(256), 0, st, boxes, scores, n, num_classes, c_ld, score_thr,
+                           maxc_u, cnt_in, cand);
         int np2 = 1;
         while (np2 < n) np2 <<= 1;
-        const size_t lds = (size_t)np2 * 8 + (size_t)max_num * 16 + 17 * 4;
-        hipLaunchKernelGGL(nms_class_kernel, dim3(num_classes), dim3(256), lds, st, boxes, scores, n, num_classes,
-                           c_ld, score_thr, iou_thr, max_num, maxc_u, any, cls_cnt, cls_keys);
+        const size_t lds = (size_t)np2 * 8 + (size_t)max_num * 16;
+        hipLaunchKernelGGL(nms_class_kernel, dim3(num_classes), dim3(256), lds, st, boxes, n, num_classes, iou_thr, max_num,
+                           maxc_u, cnt_in, cand, cls_cnt, cls_keys);
     }
     int mp2 = 1;
     while (mp2 < num_classes * max_num) mp2 <<= 1;
-    hipLaunchKernelGGL(nms_merge_kernel, dim3(1), dim3(1024), (size_t)mp2 * 8, st, boxes, num_classes, max_num, any,
+    hipLaunchKernelGGL(nms_merge_kernel, dim3(1), dim3(1024), (size_t)mp2 * 8, st, boxes, num_classes, max_num,
                        cls_cnt, cls_keys, dets, labels, count, keep_flat);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
