@@ -153,7 +153,7 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     n_det = sum(len(d) for d, _ in plan.results())
-    n_cand_thr = int((plan.det.post.decode[0].scores > 0.05).sum().item())
+    n_cand_thr = int((plan.det.post.dp.scores.reshape(B, -1)[0] > 0.05).sum().item())
 
     out = None
     if rank == 0:

@@ -61,6 +61,7 @@ extern "C" {
 
 #define LLV_MAX_SEG 5 /* pyramid levels batched into one conv launch */
 #define LLV_MAX_SRC 3 /* input tensors concatenated along C by one conv launch */
+#define LLV_MAX_BATCH 16 /* images decoded / suppressed by one batched post-processing launch */
 
 /* llv_conv_desc.flags */
 #define LLV_CONV_RELU 1        /* y = max(y, 0) last */
@@ -186,6 +187,12 @@ typedef struct llv_decode_desc {
     int32_t* cand_anchor;         /* [n_cand] global anchor index (level offset + cell*A + a) */
     int32_t n_cand;               /* sum over levels of min(nms_pre, h*w*A), filled by llv_retina_decode_ncand */
     void* workspace; size_t workspace_bytes;
+    /* batch > 1: images n = 0..batch-1 in one set of launches. Level l of image n starts n*level_h*level_w pixels
+     * after cls_off[l] / reg_off[l] (the pyramid layout of engine.Pyramid); outputs are [batch][n_cand][...];
+     * img_h_b / img_w_b / scale_factor_b replace img_h / img_w / scale_factor. batch <= LLV_MAX_BATCH. 0 means 1. */
+    int32_t batch;
+    float img_h_b[LLV_MAX_BATCH], img_w_b[LLV_MAX_BATCH];
+    float scale_factor_b[LLV_MAX_BATCH][4];
 } llv_decode_desc;
 
 int llv_retina_decode_ncand(const llv_decode_desc* desc);
@@ -202,6 +209,14 @@ int llv_multiclass_nms(const float* boxes, const float* scores, int n, int num_c
                        float score_thr, float iou_thr, int max_num, float* dets, int64_t* labels,
                        int32_t* count, int32_t* keep_flat, void* workspace, size_t workspace_bytes,
                        void* stream);
+
+/* The same for `batch` images in one set of launches: boxes [batch][n][4], scores [batch][n][c_ld],
+ * dets [batch][max_num][5], labels / keep_flat [batch][max_num], count [batch]. */
+size_t llv_multiclass_nms_batched_workspace_bytes(int batch, int n, int num_classes, int max_num);
+int llv_multiclass_nms_batched(const float* boxes, const float* scores, int batch, int n, int num_classes, int c_ld,
+                               float score_thr, float iou_thr, int max_num, float* dets, int64_t* labels,
+                               int32_t* count, int32_t* keep_flat, void* workspace, size_t workspace_bytes,
+                               void* stream);
 
 /* Plain single-class NMS: keep [n] int64 (score-descending kept indices), count[1] int32. n <= 8192. */
 size_t llv_nms_workspace_bytes(int n);

@@ -11,6 +11,7 @@ LIB_PATH = os.path.join(_HERE, 'libllv.so')
 
 LLV_MAX_SEG = 5
 LLV_MAX_SRC = 3
+LLV_MAX_BATCH = 16
 
 # llv_conv_desc.flags
 CONV_RELU = 1
@@ -74,6 +75,9 @@ class DecodeDesc(C.Structure):
         ('boxes', C.c_void_p), ('scores', C.c_void_p), ('cand_anchor', C.c_void_p),
         ('n_cand', C.c_int32),
         ('workspace', C.c_void_p), ('workspace_bytes', C.c_size_t),
+        ('batch', C.c_int32),
+        ('img_h_b', C.c_float * LLV_MAX_BATCH), ('img_w_b', C.c_float * LLV_MAX_BATCH),
+        ('scale_factor_b', (C.c_float * 4) * LLV_MAX_BATCH),
     ]
 
 
@@ -94,6 +98,8 @@ SIGNATURES = {
     'llv_retina_decode_topk': (_I, [C.POINTER(DecodeDesc), _P]),
     'llv_multiclass_nms_workspace_bytes': (_Z, [_I, _I, _I]),
     'llv_multiclass_nms': (_I, [_P, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    'llv_multiclass_nms_batched_workspace_bytes': (_Z, [_I, _I, _I, _I]),
+    'llv_multiclass_nms_batched': (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
     'llv_nms_workspace_bytes': (_Z, [_I]),
     'llv_nms': (_I, [_P, _P, _I, _F, _P, _P, _P, _Z, _P]),
     'llv_embed_aggregate': (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P]),

@@ -42,7 +42,21 @@ struct DecK {
     uint64_t* listT;  // [total anchors] keys inside b* (level l at a0[l])
     int capA;
     int blk0[LLV_MAX_SEG + 1];  // first class_max block of each level
+    int batch;                  // images (blockIdx.y); level l of image n starts n*h*w pixels after cls_off[l]
+    float img_h_b[LLV_MAX_BATCH], img_w_b[LLV_MAX_BATCH], sf_b[LLV_MAX_BATCH][4];
 };
+
+// per-image views of the workspace / outputs (image = blockIdx.y)
+#define IMG_SETUP(k) \
+    const int img = blockIdx.y; \
+    const int A_tot = (k).a0[(k).n_levels], N_cand = (k).c0[(k).n_levels]; \
+    float* const ms_i = (k).ms + (long)img * A_tot; \
+    int* const sel_i = (k).sel + (long)img * N_cand; \
+    unsigned* const hist_i = (k).hist + (long)img * (k).n_levels * kBins; \
+    int* const meta_i = (k).meta + (long)img * (k).n_levels * 4; \
+    uint64_t* const listA_i = (k).listA + (long)img * (k).n_levels * (k).capA; \
+    uint64_t* const listT_i = (k).listT + (long)img * A_tot; \
+    (void)ms_i; (void)sel_i; (void)hist_i; (void)meta_i; (void)listA_i; (void)listT_i;
 
 __device__ __forceinline__ float sigmoidf_(float x) { return 1.f / (1.f + expf(-x)); }
 
@@ -89,20 +103,22 @@ __global__ __launch_bounds__(256) void class_max_kernel(const DecK k) {
 #pragma unroll
     for (int s = 1; s < LLV_MAX_SEG; ++s)
         if (s < k.n_levels && (int)blockIdx.x >= k.blk0[s]) l = s;
+    IMG_SETUP(k)
     for (int i = threadIdx.x; i < kBins; i += 256) lh[i] = 0;
     __syncthreads();
     const int n = k.a0[l + 1] - k.a0[l];
+    const long cls_l = k.cls_off[l] + (long)img * k.h[l] * k.w[l];
     const int first = (blockIdx.x - k.blk0[l]) * kAnchorsPerBlock;
     for (int loc = first + threadIdx.x; loc < first + kAnchorsPerBlock && loc < n; loc += 256) {
         const int cell = loc / k.A, an = loc - cell * k.A;
-        const T* p = reinterpret_cast<const T*>(k.cls) + (k.cls_off[l] + cell) * (long)k.cls_ld + (long)an * k.C;
+        const T* p = reinterpret_cast<const T*>(k.cls) + (cls_l + cell) * (long)k.cls_ld + (long)an * k.C;
         float m = 0.f;  // sigmoid > 0
         for (int c = 0; c < k.C; ++c) m = fmaxf(m, sigmoidf_((float)p[c]));
-        k.ms[k.a0[l] + loc] = m;
+        ms_i[k.a0[l] + loc] = m;
         atomicAdd(&lh[score_bin(m)], 1u);
     }
     __syncthreads();
-    unsigned* gh = k.hist + l * kBins;
+    unsigned* gh = hist_i + l * kBins;
     for (int i = threadIdx.x; i < kBins; i += 256) {
         const unsigned v = lh[i];
         if (v) atomicAdd(&gh[i], v);
@@ -114,13 +130,14 @@ __global__ __launch_bounds__(256) void topk_threshold_kernel(const DecK k) {
     const int l = blockIdx.x;
     const int n = k.a0[l + 1] - k.a0[l];
     const int kk = k.c0[l + 1] - k.c0[l];
-    int* meta = k.meta + l * 4;
+    IMG_SETUP(k)
+    int* meta = meta_i + l * 4;
     if (kk >= n) {
         if (threadIdx.x == 0) { meta[0] = -1; meta[1] = 0; }
         return;
     }
     __shared__ unsigned part[256];
-    const unsigned* h = k.hist + l * kBins;
+    const unsigned* h = hist_i + l * kBins;
     constexpr int PER = kBins / 256;
     const int top = kBins - 1 - threadIdx.x * PER;   // this thread owns bins top, top-1, ..., top-PER+1
     unsigned s = 0;
@@ -150,15 +167,16 @@ __global__ void topk_compact_kernel(const DecK k) {
     const int total = k.a0[k.n_levels];
     const int stride = gridDim.x * blockDim.x;
     const int lane = threadIdx.x & 63;
+    IMG_SETUP(k)
     for (int g0 = blockIdx.x * blockDim.x; g0 < total; g0 += stride) {
         const int g = g0 + threadIdx.x;
         int l = 0, which = 0;   // 1 = A, 2 = T
         uint64_t key = 0;
         if (g < total) {
             l = level_of_anchor(k, g);
-            const int bstar = k.meta[l * 4];
+            const int bstar = meta_i[l * 4];
             if (bstar >= 0) {
-                const float m = k.ms[g];
+                const float m = ms_i[g];
                 const int b = score_bin(m);
                 which = b > bstar ? 1 : (b == bstar ? 2 : 0);
                 key = llv::make_key(m, (unsigned)(g - k.a0[l]));
@@ -172,12 +190,12 @@ __global__ void topk_compact_kernel(const DecK k) {
                 const int ll = __shfl(l, leader);
                 const unsigned long long same = __ballot(which == w && l == ll);
                 int base = 0;
-                if (lane == leader) base = atomicAdd(&k.meta[ll * 4 + 1 + w], (int)__popcll(same));
+                if (lane == leader) base = atomicAdd(&meta_i[ll * 4 + 1 + w], (int)__popcll(same));
                 base = __shfl(base, leader);
                 if (which == w && l == ll) {
                     const int pos = base + __popcll(same & ((1ull << lane) - 1ull));
-                    if (w == 1) k.listA[(long)ll * k.capA + pos] = key;
-                    else k.listT[k.a0[ll] + pos] = key;
+                    if (w == 1) listA_i[(long)ll * k.capA + pos] = key;
+                    else listT_i[k.a0[ll] + pos] = key;
                 }
                 active &= ~same;
             }
@@ -190,7 +208,8 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const DecK k) {
     const int l = blockIdx.x;
     const int n = k.a0[l + 1] - k.a0[l];
     const int kk = k.c0[l + 1] - k.c0[l];
-    int* sel = k.sel + k.c0[l];
+    IMG_SETUP(k)
+    int* sel = sel_i + k.c0[l];
     const int tid = threadIdx.x;
     if (kk >= n) {  // no top-k on this level: anchor order is kept (anchor_head.py:657-658)
         for (int i = tid; i < n; i += blockDim.x) sel[i] = k.a0[l] + i;
@@ -203,11 +222,11 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const DecK k) {
     __shared__ unsigned hist[256];
     __shared__ uint64_t sh_prefix;
     __shared__ unsigned sh_need, sh_cnt;
-    const int* meta = k.meta + l * 4;
+    const int* meta = meta_i + l * 4;
     const int nA = meta[2], nT = meta[3];
     const int m = kk - nA;           // keys still needed, all from T (nT >= m by construction)
-    const uint64_t* A = k.listA + (long)l * k.capA;
-    const uint64_t* Tl = k.listT + k.a0[l];
+    const uint64_t* A = listA_i + (long)l * k.capA;
+    const uint64_t* Tl = listT_i + k.a0[l];
     for (int i = tid; i < np2k; i += blockDim.x) fin[i] = i < nA ? A[i] : 0ull;
     __syncthreads();
     if (nT <= kSortCap) {
@@ -272,18 +291,21 @@ __global__ void gather_decode_kernel(const DecK k) {
 #pragma unroll
     for (int s = 1; s < LLV_MAX_SEG; ++s)
         if (s < k.n_levels && slot >= k.c0[s]) l = s;
-    const int g = k.sel[slot];
+    IMG_SETUP(k)
+    const int g = sel_i[slot];
     const int loc = g - k.a0[l];
     const int cell = loc / k.A, an = loc - cell * k.A;
-    const T* pc = reinterpret_cast<const T*>(k.cls) + (k.cls_off[l] + cell) * (long)k.cls_ld + (long)an * k.C;
-    for (int c = threadIdx.x; c < k.C; c += blockDim.x) k.scores[(long)slot * k.C + c] = sigmoidf_((float)pc[c]);
+    const long ipix = (long)img * k.h[l] * k.w[l];
+    const long oslot = (long)img * N_cand + slot;
+    const T* pc = reinterpret_cast<const T*>(k.cls) + (k.cls_off[l] + ipix + cell) * (long)k.cls_ld + (long)an * k.C;
+    for (int c = threadIdx.x; c < k.C; c += blockDim.x) k.scores[oslot * k.C + c] = sigmoidf_((float)pc[c]);
     if (threadIdx.x == 0) {
-        k.cand_anchor[slot] = g;
+        k.cand_anchor[oslot] = g;
         const int cy = cell / k.w[l], cx = cell - cy * k.w[l];
         const float shx = (float)(cx * k.sw[l]), shy = (float)(cy * k.sh[l]);
         const float* b = k.base + ((long)l * k.A + an) * 4;
         const float ax1 = b[0] + shx, ay1 = b[1] + shy, ax2 = b[2] + shx, ay2 = b[3] + shy;
-        const T* pr = reinterpret_cast<const T*>(k.reg) + (k.reg_off[l] + cell) * (long)k.reg_ld + (long)an * 4;
+        const T* pr = reinterpret_cast<const T*>(k.reg) + (k.reg_off[l] + ipix + cell) * (long)k.reg_ld + (long)an * 4;
         const float dx = (float)pr[0] * k.stds[0] + k.means[0];
         const float dy = (float)pr[1] * k.stds[1] + k.means[1];
         float dw = (float)pr[2] * k.stds[2] + k.means[2];
@@ -296,7 +318,7 @@ __global__ void gather_decode_kernel(const DecK k) {
         const float gx = px + pw * dx, gy = py + ph * dy;
         float o[4] = {gx - gw * 0.5f, gy - gh * 0.5f, gx + gw * 0.5f, gy + gh * 0.5f};
         if (k.clip) {
-            const float mx[4] = {k.img_w, k.img_h, k.img_w, k.img_h};
+            const float mx[4] = {k.img_w_b[img], k.img_h_b[img], k.img_w_b[img], k.img_h_b[img]};
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 o[e] = o[e] < 0.f ? 0.f : o[e];
@@ -305,10 +327,10 @@ __global__ void gather_decode_kernel(const DecK k) {
         }
         if (k.rescale) {
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = o[e] / k.sf[e];
+            for (int e = 0; e < 4; ++e) o[e] = o[e] / k.sf_b[img][e];
         }
 #pragma unroll
-        for (int e = 0; e < 4; ++e) k.boxes[(long)slot * 4 + e] = o[e];
+        for (int e = 0; e < 4; ++e) k.boxes[oslot * 4 + e] = o[e];
     }
 }
 
@@ -343,16 +365,17 @@ extern "C" int llv_retina_decode_ncand(const llv_decode_desc* d) {
 
 namespace {
 struct WsLayout { size_t ms, sel, hist, meta, listA, listT, total; };
-WsLayout ws_layout(const DecK& k, int n_levels, int nms_pre) {
+WsLayout ws_layout(const DecK& k, int n_levels, int nms_pre, int batch) {
     auto al = [](size_t v) { return (v + 255) & ~(size_t)255; };
     WsLayout w;
     size_t o = 0;
-    w.hist = o; o += al((size_t)n_levels * kBins * 4);
-    w.meta = o; o += al((size_t)n_levels * 4 * 4);          // hist + meta are contiguous: one memset
-    w.ms = o; o += al((size_t)k.a0[n_levels] * 4);
-    w.sel = o; o += al((size_t)k.c0[n_levels] * 4);
-    w.listA = o; o += al((size_t)n_levels * (size_t)(nms_pre > 0 ? nms_pre : 1) * 8);
-    w.listT = o; o += al((size_t)k.a0[n_levels] * 8);
+    const size_t b = (size_t)(batch > 0 ? batch : 1);
+    w.hist = o; o += al(b * n_levels * kBins * 4);
+    w.meta = o; o += al(b * n_levels * 4 * 4);               // hist + meta are contiguous: one memset
+    w.ms = o; o += al(b * k.a0[n_levels] * 4);
+    w.sel = o; o += al(b * k.c0[n_levels] * 4);
+    w.listA = o; o += al(b * n_levels * (size_t)(nms_pre > 0 ? nms_pre : 1) * 8);
+    w.listT = o; o += al(b * k.a0[n_levels] * 8);
     w.total = o;
     return w;
 }
@@ -361,7 +384,7 @@ WsLayout ws_layout(const DecK& k, int n_levels, int nms_pre) {
 extern "C" size_t llv_retina_decode_workspace_bytes(const llv_decode_desc* d) {
     DecK k;
     if (fill(d, k) < 0) return 0;
-    return ws_layout(k, d->n_levels, d->nms_pre).total;
+    return ws_layout(k, d->n_levels, d->nms_pre, d->batch).total;
 }
 
 extern "C" int llv_retina_decode_topk(const llv_decode_desc* d, void* stream) {
@@ -378,7 +401,16 @@ extern "C" int llv_retina_decode_topk(const llv_decode_desc* d, void* stream) {
     for (int e = 0; e < 4; ++e) { k.means[e] = d->means[e]; k.stds[e] = d->stds[e]; k.sf[e] = d->scale_factor[e]; }
     k.max_ratio = d->max_ratio; k.clip = d->clip; k.img_h = d->img_h; k.img_w = d->img_w; k.rescale = d->rescale;
     k.boxes = d->boxes; k.scores = d->scores; k.cand_anchor = d->cand_anchor;
-    const WsLayout w = ws_layout(k, d->n_levels, d->nms_pre);
+    const int batch = d->batch > 0 ? d->batch : 1;
+    if (batch > LLV_MAX_BATCH) return LLV_E_UNSUPPORTED;
+    k.batch = batch;
+    for (int n = 0; n < batch; ++n) {
+        const bool per = d->batch > 1;
+        k.img_h_b[n] = per ? d->img_h_b[n] : d->img_h;
+        k.img_w_b[n] = per ? d->img_w_b[n] : d->img_w;
+        for (int e = 0; e < 4; ++e) k.sf_b[n][e] = per ? d->scale_factor_b[n][e] : d->scale_factor[e];
+    }
+    const WsLayout w = ws_layout(k, d->n_levels, d->nms_pre, batch);
     char* ws = (char*)d->workspace;
     k.hist = (unsigned*)(ws + w.hist); k.meta = (int*)(ws + w.meta);
     k.ms = (float*)(ws + w.ms); k.sel = (int*)(ws + w.sel);
@@ -399,14 +431,14 @@ extern "C" int llv_retina_decode_topk(const llv_decode_desc* d, void* stream) {
         k.blk0[l] = nb;
         if (l < d->n_levels) nb += (k.a0[l + 1] - k.a0[l] + kAnchorsPerBlock - 1) / kAnchorsPerBlock;
     }
-    if (k.f32) hipLaunchKernelGGL((class_max_kernel<float>), dim3(nb), dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((class_max_kernel<_Float16>), dim3(nb), dim3(256), 0, st, k);
-    hipLaunchKernelGGL(topk_threshold_kernel, dim3(d->n_levels), dim3(256), 0, st, k);
-    hipLaunchKernelGGL(topk_compact_kernel, dim3(grid), dim3(256), 0, st, k);
+    if (k.f32) hipLaunchKernelGGL((class_max_kernel<float>), dim3(nb, batch), dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((class_max_kernel<_Float16>), dim3(nb, batch), dim3(256), 0, st, k);
+    hipLaunchKernelGGL(topk_threshold_kernel, dim3(d->n_levels, batch), dim3(256), 0, st, k);
+    hipLaunchKernelGGL(topk_compact_kernel, dim3(grid, batch), dim3(256), 0, st, k);
     int np2 = 1;
     while (np2 < (d->nms_pre > 0 ? d->nms_pre : 1)) np2 <<= 1;
-    hipLaunchKernelGGL(topk_final_kernel, dim3(d->n_levels), dim3(1024), (size_t)(np2 + kSortCap) * 8, st, k);
-    if (k.f32) hipLaunchKernelGGL((gather_decode_kernel<float>), dim3(d->n_cand), dim3(128), 0, st, k);
-    else hipLaunchKernelGGL((gather_decode_kernel<_Float16>), dim3(d->n_cand), dim3(128), 0, st, k);
+    hipLaunchKernelGGL(topk_final_kernel, dim3(d->n_levels, batch), dim3(1024), (size_t)(np2 + kSortCap) * 8, st, k);
+    if (k.f32) hipLaunchKernelGGL((gather_decode_kernel<float>), dim3(d->n_cand, batch), dim3(128), 0, st, k);
+    else hipLaunchKernelGGL((gather_decode_kernel<_Float16>), dim3(d->n_cand, batch), dim3(128), 0, st, k);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }

@@ -49,8 +49,16 @@ __device__ __forceinline__ bool iou_gt(const float4 a, const float4 b, float thr
 // distinct, so the per-class sort that follows is deterministic.
 __global__ __launch_bounds__(256) void nms_scan_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                       int n, int C, int c_ld, float thr, unsigned* maxc_u,
-                                                      int* cnt_in, uint64_t* cand) {
+                                                      int* cnt_in, uint64_t* cand, long ws_stride) {
     const long total = (long)n * C;
+    {   // image = blockIdx.y: inputs are [batch][n][...], the workspace repeats every ws_stride bytes
+        const int img = blockIdx.y;
+        boxes += (long)img * n * 4;
+        scores += (long)img * n * c_ld;
+        maxc_u = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(maxc_u) + img * ws_stride);
+        cnt_in = reinterpret_cast<int*>(reinterpret_cast<char*>(cnt_in) + img * ws_stride);
+        cand = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(cand) + img * ws_stride);
+    }
     unsigned m = 0;
     for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
         const int i = (int)(e / C), c = (int)(e - (long)i * C);
@@ -114,8 +122,17 @@ __device__ inline int greedy_scan(const uint64_t* keys, int cnt, float thr, int 
 // one workgroup per class: sort its candidate list in LDS, greedy scan by wave 0
 __global__ __launch_bounds__(256) void nms_class_kernel(const float* __restrict__ boxes, int n, int C, float iou_thr,
                                                         int max_num, const unsigned* maxc_u, const int* cnt_in,
-                                                        const uint64_t* cand, int* cls_cnt, uint64_t* cls_keys) {
+                                                        const uint64_t* cand, int* cls_cnt, uint64_t* cls_keys, long ws_stride) {
     const int c = blockIdx.x;
+    {
+        const int img = blockIdx.y;
+        boxes += (long)img * n * 4;
+        maxc_u = reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(maxc_u) + img * ws_stride);
+        cnt_in = reinterpret_cast<const int*>(reinterpret_cast<const char*>(cnt_in) + img * ws_stride);
+        cand = reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(cand) + img * ws_stride);
+        cls_cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(cls_cnt) + img * ws_stride);
+        cls_keys = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(cls_keys) + img * ws_stride);
+    }
     const int cnt = cnt_in[c];
     if (cnt == 0) {
         if (threadIdx.x == 0) cls_cnt[c] = 0;
@@ -143,10 +160,20 @@ __global__ __launch_bounds__(256) void nms_class_kernel(const float* __restrict_
 }
 
 // one workgroup: merge the per-class kept lists, global (score desc, flat asc) order, top max_num
-__global__ __launch_bounds__(1024) void nms_merge_kernel(const float* __restrict__ boxes, int C, int max_num,
+__global__ __launch_bounds__(1024) void nms_merge_kernel(const float* __restrict__ boxes, int n, int C, int max_num,
                                                          const int* cls_cnt,
                                                          const uint64_t* cls_keys, float* dets, int64_t* labels,
-                                                         int* count, int* keep_flat) {
+                                                         int* count, int* keep_flat, long ws_stride) {
+    {
+        const int img = blockIdx.y;
+        boxes += (long)img * n * 4;
+        cls_cnt = reinterpret_cast<const int*>(reinterpret_cast<const char*>(cls_cnt) + img * ws_stride);
+        cls_keys = reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(cls_keys) + img * ws_stride);
+        dets += (long)img * max_num * 5;
+        labels += (long)img * max_num;
+        keep_flat += (long)img * max_num;
+        count += img;
+    }
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(sm);
     __shared__ int s_off[1025];
@@ -221,26 +248,35 @@ inline void nms_init_once() {
 
 }  // namespace
 
-extern "C" size_t llv_multiclass_nms_workspace_bytes(int n, int num_classes, int max_num) {
-    if (n < 0 || num_classes < 1 || max_num < 1) return 0;
-    // [maxc | cnt_in[C]] (memset together) | cls_cnt[C] | cls_keys[C][max_num] | cand[C][n]
+static size_t mnms_ws_one(int n, int num_classes, int max_num) {
+    // [maxc | cnt_in[C]] | cls_cnt[C] (memset together) | cls_keys[C][max_num] | cand[C][n]
     return al(16 + (size_t)num_classes * 4) + al((size_t)num_classes * 4) + al((size_t)num_classes * max_num * 8) +
            al((size_t)num_classes * (size_t)(n > 0 ? n : 1) * 8);
 }
 
-extern "C" int llv_multiclass_nms(const float* boxes, const float* scores, int n, int num_classes, int c_ld,
-                                  float score_thr, float iou_thr, int max_num, float* dets, int64_t* labels,
-                                  int32_t* count, int32_t* keep_flat, void* workspace, size_t workspace_bytes,
-                                  void* stream) {
+extern "C" size_t llv_multiclass_nms_batched_workspace_bytes(int batch, int n, int num_classes, int max_num) {
+    if (batch < 1 || n < 0 || num_classes < 1 || max_num < 1) return 0;
+    return (size_t)batch * mnms_ws_one(n, num_classes, max_num);
+}
+
+extern "C" size_t llv_multiclass_nms_workspace_bytes(int n, int num_classes, int max_num) {
+    return llv_multiclass_nms_batched_workspace_bytes(1, n, num_classes, max_num);
+}
+
+extern "C" int llv_multiclass_nms_batched(const float* boxes, const float* scores, int batch, int n, int num_classes, int c_ld,
+                                          float score_thr, float iou_thr, int max_num, float* dets, int64_t* labels,
+                                          int32_t* count, int32_t* keep_flat, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
     if (!dets || !labels || !count || !keep_flat || !workspace || num_classes < 1 || num_classes > 1024 || max_num < 1 ||
-        n < 0 || c_ld < num_classes)
+        n < 0 || c_ld < num_classes || batch < 1)
         return LLV_E_BADARG;
     if (n > 0 && (!boxes || !scores)) return LLV_E_BADARG;
-    if (workspace_bytes < llv_multiclass_nms_workspace_bytes(n, num_classes, max_num)) return LLV_E_WORKSPACE;
-    if (n > kMaxN || (long)num_classes * max_num > kMaxMerge || (long)n * num_classes > 0x7fffffffL) return LLV_E_UNSUPPORTED;
+    if (workspace_bytes < llv_multiclass_nms_batched_workspace_bytes(batch, n, num_classes, max_num)) return LLV_E_WORKSPACE;
+    if (n > kMaxN || (long)num_classes * max_num > kMaxMerge || (long)n * num_classes > 0x7fffffffL || batch > 65535) return LLV_E_UNSUPPORTED;
     hipStream_t st = (hipStream_t)stream;
     nms_init_once();
     char* ws = (char*)workspace;
+    const long stride = (long)mnms_ws_one(n, num_classes, max_num);
     const size_t o_cnt = al(16 + (size_t)num_classes * 4);
     const size_t o_keys = o_cnt + al((size_t)num_classes * 4);
     const size_t o_cand = o_keys + al((size_t)num_classes * max_num * 8);
@@ -249,23 +285,32 @@ extern "C" int llv_multiclass_nms(const float* boxes, const float* scores, int n
     int* cls_cnt = (int*)(ws + o_cnt);
     uint64_t* cls_keys = (uint64_t*)(ws + o_keys);
     uint64_t* cand = (uint64_t*)(ws + o_cand);
-    if (hipMemsetAsync(ws, 0, o_cnt + al((size_t)num_classes * 4), st) != hipSuccess) return LLV_E_LAUNCH;
+    for (int b = 0; b < batch; ++b)   // counters of every image (small, contiguous per image)
+        if (hipMemsetAsync(ws + (size_t)b * stride, 0, o_keys, st) != hipSuccess) return LLV_E_LAUNCH;
     if (n > 0) {
         long g = ((long)n * num_classes + 255) / 256;
         g = g > 1024 ? 1024 : g;
-        hipLaunchKernelGGL(nms_scan_kernel, dim3((int)g), dim3(256), 0, st, boxes, scores, n, num_classes, c_ld, score_thr,
-                           maxc_u, cnt_in, cand);
+        hipLaunchKernelGGL(nms_scan_kernel, dim3((int)g, batch), dim3(256), 0, st, boxes, scores, n, num_classes, c_ld, score_thr,
+                           maxc_u, cnt_in, cand, stride);
         int np2 = 1;
         while (np2 < n) np2 <<= 1;
         const size_t lds = (size_t)np2 * 8 + (size_t)max_num * 16;
-        hipLaunchKernelGGL(nms_class_kernel, dim3(num_classes), dim3(256), lds, st, boxes, n, num_classes, iou_thr, max_num,
-                           maxc_u, cnt_in, cand, cls_cnt, cls_keys);
+        hipLaunchKernelGGL(nms_class_kernel, dim3(num_classes, batch), dim3(256), lds, st, boxes, n, num_classes, iou_thr, max_num,
+                           maxc_u, cnt_in, cand, cls_cnt, cls_keys, stride);
     }
     int mp2 = 1;
     while (mp2 < num_classes * max_num) mp2 <<= 1;
-    hipLaunchKernelGGL(nms_merge_kernel, dim3(1), dim3(1024), (size_t)mp2 * 8, st, boxes, num_classes, max_num,
-                       cls_cnt, cls_keys, dets, labels, count, keep_flat);
+    hipLaunchKernelGGL(nms_merge_kernel, dim3(1, batch), dim3(1024), (size_t)mp2 * 8, st, boxes, n, num_classes, max_num,
+                       cls_cnt, cls_keys, dets, labels, count, keep_flat, stride);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_multiclass_nms(const float* boxes, const float* scores, int n, int num_classes, int c_ld,
+                                  float score_thr, float iou_thr, int max_num, float* dets, int64_t* labels,
+                                  int32_t* count, int32_t* keep_flat, void* workspace, size_t workspace_bytes,
+                                  void* stream) {
+    return llv_multiclass_nms_batched(boxes, scores, 1, n, num_classes, c_ld, score_thr, iou_thr, max_num, dets, labels, count,
+                                      keep_flat, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t llv_nms_workspace_bytes(int n) {

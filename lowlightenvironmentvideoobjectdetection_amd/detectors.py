@@ -174,20 +174,7 @@ class SingleStageDetector(BaseDetector):
         """single_stage.py:98-129: one pack, one plan replay, one D2H of <= max_per_img rows per image."""
         self._check_input(img)
         plan = self._get_plan(img)
-        post = plan.post
-        clip = self.bbox_head.bbox_coder.clip_border
-        for n, dp in enumerate(post.decode):
-            m = img_metas[n]
-            d = dp.desc
-            if clip:
-                d.clip, d.img_h, d.img_w = 1, float(m['img_shape'][0]), float(m['img_shape'][1])
-            else:
-                d.clip = 0
-            sf = np.asarray(m['scale_factor'], dtype=np.float32).reshape(-1)
-            sf = np.repeat(sf, 4) if sf.size == 1 else sf
-            for e in range(4):
-                d.scale_factor[e] = float(sf[e])
-            d.rescale = 1 if rescale else 0
+        plan.post.set_metas(img_metas, rescale)
         ops.pack_input(img.float().contiguous(), 8, out=plan.x_in)
         plan.plan.run()
         return [bbox2result(d, l, self.bbox_head.num_classes) for d, l in plan.results()]

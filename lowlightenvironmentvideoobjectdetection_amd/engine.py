@@ -329,30 +329,38 @@ class PostProcess:
         iou_thr = nms_cfg.get('iou_threshold', nms_cfg.get('iou_thr'))
         A = anchor_generator.num_base_anchors[0]
         assert cls_buf.shape[-1] >= A * num_classes and reg_buf.shape[-1] >= A * 4
-        self.decode, self.nms, self.num_classes = [], [], num_classes
-        for n in range(pyr.batch):
-            offs = [pyr.level_off[i] + n * h * w for i, (h, w) in enumerate(pyr.level_hw)]
-            img_shape = img_shapes[n] if (img_shapes is not None and clip_border) else None
-            sf = scale_factors[n] if scale_factors is not None else (1., 1., 1., 1.)
-            dp = ops.make_decode_plan(cls_buf, reg_buf, pyr.level_hw, anchor_generator.strides, offs, offs,
-                                      cls_buf.shape[-1], reg_buf.shape[-1], num_classes, A, anchor_generator.base_anchors,
-                                      tc.get('nms_pre', -1), target_means, target_stds, 16 / 1000, img_shape, sf, rescale)
-            nb = ops.NmsBuffers(dp.n_cand, num_classes, tc['max_per_img'], b.dev)
-            self.decode.append(dp)
-            self.nms.append(nb)
-            b.plan.keep += [dp, nb]
-            b.plan.add(f'decode{n}', lib().llv_retina_decode_topk, (C.byref(dp.desc),), 0.0,
-                       float(cls_buf.element_size() * cls_buf.numel()) / pyr.batch)
-            b.plan.add(f'nms{n}', lib().llv_multiclass_nms,
-                       (C.c_void_p(dp.boxes.data_ptr()), C.c_void_p(dp.scores.data_ptr()), dp.n_cand, num_classes, num_classes,
-                        C.c_float(tc['score_thr']), C.c_float(iou_thr), tc['max_per_img'], C.c_void_p(nb.dets.data_ptr()),
-                        C.c_void_p(nb.labels.data_ptr()), C.c_void_p(nb.count.data_ptr()), C.c_void_p(nb.keep_flat.data_ptr()),
-                        C.c_void_p(nb.ws.data_ptr()), C.c_size_t(nb.ws_bytes)), 0.0, 0.0)
+        self.num_classes, self.batch, self.clip_border = num_classes, pyr.batch, clip_border
+        nb_ = pyr.batch
+        shapes = list(img_shapes) if (img_shapes is not None and clip_border) else None
+        sfs = list(scale_factors) if scale_factors is not None else [(1., 1., 1., 1.)] * nb_
+        # ONE batched decode and ONE batched NMS for all images of the step (image = blockIdx.y)
+        self.dp = ops.make_decode_plan(cls_buf, reg_buf, pyr.level_hw, anchor_generator.strides, pyr.level_off, pyr.level_off,
+                                       cls_buf.shape[-1], reg_buf.shape[-1], num_classes, A, anchor_generator.base_anchors,
+                                       tc.get('nms_pre', -1), target_means, target_stds, 16 / 1000, shapes, sfs, rescale, batch=nb_)
+        self.nb = ops.NmsBuffers(self.dp.n_cand, num_classes, tc['max_per_img'], b.dev, batch=nb_)
+        b.plan.keep += [self.dp, self.nb]
+        b.plan.add('decode', lib().llv_retina_decode_topk, (C.byref(self.dp.desc),), 0.0,
+                   float(cls_buf.element_size() * cls_buf.numel()))
+        b.plan.add('nms', lib().llv_multiclass_nms_batched,
+                   (C.c_void_p(self.dp.boxes.data_ptr()), C.c_void_p(self.dp.scores.data_ptr()), nb_, self.dp.n_cand, num_classes,
+                    num_classes, C.c_float(tc['score_thr']), C.c_float(iou_thr), tc['max_per_img'],
+                    C.c_void_p(self.nb.dets.data_ptr()), C.c_void_p(self.nb.labels.data_ptr()), C.c_void_p(self.nb.count.data_ptr()),
+                    C.c_void_p(self.nb.keep_flat.data_ptr()), C.c_void_p(self.nb.ws.data_ptr()), C.c_size_t(self.nb.ws_bytes)), 0.0, 0.0)
+
+    def set_metas(self, img_metas, rescale):
+        """Per-call image geometry (img_shape clip, scale_factor): a host-side edit of the descriptor."""
+        ops.set_decode_image_params(self.dp.desc, [m['img_shape'] for m in img_metas[:self.batch]],
+                                    [m.get('scale_factor', 1.0) for m in img_metas[:self.batch]], rescale, self.clip_border)
+
+    def dets(self, n=0):
+        return self.nb.dets if self.batch == 1 else self.nb.dets[n]
 
     def results(self):
         """D2H of the detections: [(dets (k,5), labels (k,)), ...] per image."""
-        counts = torch.cat([nb.count for nb in self.nms]).cpu().tolist()
-        return [(nb.dets[:k].cpu(), nb.labels[:k].cpu()) for nb, k in zip(self.nms, counts)]
+        counts = self.nb.count.cpu().tolist()
+        d = self.nb.dets.cpu().reshape(self.batch, -1, 5)
+        l = self.nb.labels.cpu().reshape(self.batch, -1)
+        return [(d[n, :k], l[n, :k]) for n, k in enumerate(counts)]
 
 
 DEFAULT_TEST_CFG = dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05, nms=dict(type='nms', iou_threshold=0.5), max_per_img=100)
@@ -513,7 +521,7 @@ class EnhanceDetectPlan:
         self.plan.extend(self.den.plan)
         self.plan.extend(self.det.plan)
         self.use_graph = use_graph
-        k = self.det.post.nms[0].max_num
+        k = self.det.post.nb.max_num
         # results of the step, device side, gathered into one buffer so the D2H is a single copy
         self.res_dev = torch.zeros((batch, k, 6), device=device, dtype=torch.float32)
         self.cnt_dev = torch.zeros((batch,), device=device, dtype=torch.int32)
@@ -524,10 +532,10 @@ class EnhanceDetectPlan:
     def _body(self, window):
         self.den.frames.copy_(window)
         self.plan.run()
-        for n, nb in enumerate(self.det.post.nms):
-            self.res_dev[n, :, :5].copy_(nb.dets)
-            self.res_dev[n, :, 5].copy_(nb.labels)
-            self.cnt_dev[n:n + 1].copy_(nb.count)
+        nb = self.det.post.nb
+        self.res_dev[:, :, :5].copy_(nb.dets.reshape(self.batch, -1, 5))
+        self.res_dev[:, :, 5].copy_(nb.labels.reshape(self.batch, -1))
+        self.cnt_dev.copy_(nb.count)
         self.res_host.copy_(self.res_dev, non_blocking=True)
         self.cnt_host.copy_(self.cnt_dev, non_blocking=True)
 

@@ -323,9 +323,31 @@ class DecodePlan:
     keep: list = field(default_factory=list)
 
 
+def set_decode_image_params(d: DecodeDesc, img_shapes, scale_factors, rescale, clip=True):
+    """Per-image clip size / scale factor of a (batched) decode descriptor; host-side struct edit, no launch."""
+    batch = max(int(d.batch), 1)
+    for n in range(batch):
+        shp = img_shapes[n] if img_shapes is not None else None
+        sf = np.asarray(scale_factors[n] if scale_factors is not None else 1.0, dtype=np.float32).reshape(-1)
+        if sf.size == 1:
+            sf = np.repeat(sf, 4)
+        d.img_h_b[n] = float(shp[0]) if shp is not None else 0.0
+        d.img_w_b[n] = float(shp[1]) if shp is not None else 0.0
+        for e in range(4):
+            d.scale_factor_b[n][e] = float(sf[e])
+        if n == 0:
+            d.img_h, d.img_w = d.img_h_b[0], d.img_w_b[0]
+            for e in range(4):
+                d.scale_factor[e] = float(sf[e])
+    d.clip = 1 if (clip and img_shapes is not None) else 0
+    d.rescale = 1 if rescale else 0
+
+
 def make_decode_plan(cls: torch.Tensor, reg: torch.Tensor, level_hw, strides, cls_off, reg_off, cls_ld, reg_ld,
                      num_classes, num_anchors, base_anchors, nms_pre, means, stds, wh_ratio_clip, img_shape,
-                     scale_factor, rescale) -> DecodePlan:
+                     scale_factor, rescale, batch: int = 1) -> DecodePlan:
+    """batch > 1: img_shape / scale_factor are per-image lists; level l of image n starts n*h*w pixels after cls_off[l];
+    outputs are (batch, n_cand, ...)."""
     _need_gpu(cls, reg)
     d = DecodeDesc()
     d.n_levels = len(level_hw)
@@ -344,28 +366,27 @@ def make_decode_plan(cls: torch.Tensor, reg: torch.Tensor, level_hw, strides, cl
     for e in range(4):
         d.means[e], d.stds[e] = float(means[e]), float(stds[e])
     d.max_ratio = float(np.float32(np.abs(np.log(wh_ratio_clip))))
-    if img_shape is not None:
-        d.clip, d.img_h, d.img_w = 1, float(img_shape[0]), float(img_shape[1])
+    d.batch = batch
+    if batch == 1 and (img_shape is None or not isinstance(img_shape[0], (tuple, list, np.ndarray))):
+        shapes = [img_shape] if img_shape is not None else None
+        sfs = [scale_factor]
     else:
-        d.clip, d.img_h, d.img_w = 0, 0.0, 0.0
-    sf = np.asarray(scale_factor, dtype=np.float32).reshape(-1)
-    if sf.size == 1:
-        sf = np.repeat(sf, 4)
-    for e in range(4):
-        d.scale_factor[e] = float(sf[e])
-    d.rescale = 1 if rescale else 0
+        shapes, sfs = img_shape, scale_factor
+    set_decode_image_params(d, shapes, sfs, rescale)
     n_cand = lib().llv_retina_decode_ncand(C.byref(d))
     if n_cand < 0:
         check(n_cand, 'llv_retina_decode_ncand')
     d.n_cand = n_cand
     dev = cls.device
-    boxes = torch.empty((n_cand, 4), device=dev, dtype=torch.float32)
-    scores = torch.empty((n_cand, num_classes), device=dev, dtype=torch.float32)
-    cand = torch.empty((n_cand,), device=dev, dtype=torch.int32)
+    boxes = torch.empty((batch, n_cand, 4), device=dev, dtype=torch.float32)
+    scores = torch.empty((batch, n_cand, num_classes), device=dev, dtype=torch.float32)
+    cand = torch.empty((batch, n_cand), device=dev, dtype=torch.int32)
     wsb = lib().llv_retina_decode_workspace_bytes(C.byref(d))
     ws = torch.empty((max(wsb, 256),), device=dev, dtype=torch.uint8)
     d.boxes, d.scores, d.cand_anchor = boxes.data_ptr(), scores.data_ptr(), cand.data_ptr()
     d.workspace, d.workspace_bytes = ws.data_ptr(), wsb
+    if batch == 1:
+        boxes, scores, cand = boxes[0], scores[0], cand[0]
     return DecodePlan(d, boxes, scores, cand, ws, ba, n_cand, keep=[cls, reg])
 
 
@@ -375,28 +396,32 @@ def retina_decode_topk(plan: DecodePlan):
 
 
 class NmsBuffers:
-    def __init__(self, n, num_classes, max_num, device):
-        self.n, self.num_classes, self.max_num = n, num_classes, max_num
-        self.dets = torch.zeros((max_num, 5), device=device, dtype=torch.float32)
-        self.labels = torch.zeros((max_num,), device=device, dtype=torch.int64)
-        self.count = torch.zeros((1,), device=device, dtype=torch.int32)
-        self.keep_flat = torch.zeros((max_num,), device=device, dtype=torch.int32)
-        self.ws_bytes = lib().llv_multiclass_nms_workspace_bytes(n, num_classes, max_num)
+    def __init__(self, n, num_classes, max_num, device, batch: int = 1):
+        self.n, self.num_classes, self.max_num, self.batch = n, num_classes, max_num, batch
+        self.dets = torch.zeros((batch, max_num, 5), device=device, dtype=torch.float32)
+        self.labels = torch.zeros((batch, max_num), device=device, dtype=torch.int64)
+        self.count = torch.zeros((batch,), device=device, dtype=torch.int32)
+        self.keep_flat = torch.zeros((batch, max_num), device=device, dtype=torch.int32)
+        self.ws_bytes = lib().llv_multiclass_nms_batched_workspace_bytes(batch, n, num_classes, max_num)
         self.ws = torch.empty((max(self.ws_bytes, 256),), device=device, dtype=torch.uint8)
+        if batch == 1:
+            self.dets, self.labels, self.keep_flat = self.dets[0], self.labels[0], self.keep_flat[0]
 
 
 def multiclass_nms_into(boxes, scores, score_thr, iou_thr, bufs: NmsBuffers, num_classes=None):
-    """Stream-ordered, no host sync; results land in bufs (dets, labels, count, keep_flat)."""
+    """Stream-ordered, no host sync; results land in bufs (dets, labels, count, keep_flat).
+    boxes (n,4)/(batch,n,4), scores (n,c_ld)/(batch,n,c_ld)."""
     _need_gpu(boxes, scores)
     assert boxes.dtype == torch.float32 and scores.dtype == torch.float32
     assert boxes.is_contiguous() and scores.is_contiguous()
-    n = boxes.shape[0]
-    ncls = num_classes if num_classes is not None else scores.shape[1]
+    n = boxes.shape[-2]
+    ncls = num_classes if num_classes is not None else scores.shape[-1]
     assert n <= bufs.n and ncls == bufs.num_classes
-    check(lib().llv_multiclass_nms(_ptr(boxes), _ptr(scores), n, ncls, scores.shape[1], float(score_thr),
-                                   float(iou_thr), bufs.max_num, _ptr(bufs.dets), _ptr(bufs.labels), _ptr(bufs.count),
-                                   _ptr(bufs.keep_flat), _ptr(bufs.ws), bufs.ws_bytes, _stream()),
-          'llv_multiclass_nms')
+    assert (boxes.dim() == 3 and boxes.shape[0] == bufs.batch) or (boxes.dim() == 2 and bufs.batch == 1)
+    check(lib().llv_multiclass_nms_batched(_ptr(boxes), _ptr(scores), bufs.batch, n, ncls, scores.shape[-1], float(score_thr),
+                                           float(iou_thr), bufs.max_num, _ptr(bufs.dets), _ptr(bufs.labels), _ptr(bufs.count),
+                                           _ptr(bufs.keep_flat), _ptr(bufs.ws), bufs.ws_bytes, _stream()),
+          'llv_multiclass_nms_batched')
 
 
 def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, return_inds=False):

@@ -179,14 +179,7 @@ class FastDVDnetDetect(BaseVideoDetector):
         # window order [ref0, ref1, img, ref2, ref3] (selsa_fastdvd_darkfarm.py:300)
         window = torch.cat([refs[:2], img, refs[2:]], dim=0).float().contiguous()
         ops.pack_input(window, 8, out=plan.den.frames)
-        dp = plan.det.post.decode[0].desc
-        m = img_metas[0]
-        dp.clip, dp.img_h, dp.img_w = 1, float(m['img_shape'][0]), float(m['img_shape'][1])
-        sf = np.asarray(m.get('scale_factor', 1.0), dtype=np.float32).reshape(-1)
-        sf = np.repeat(sf, 4) if sf.size == 1 else sf
-        for e in range(4):
-            dp.scale_factor[e] = float(sf[e])
-        dp.rescale = 1 if rescale else 0
+        plan.det.post.set_metas(img_metas, rescale)
         plan.plan.run()
         dets, labels = plan.det.results()[0]
         self.memo['denoising_img'] = plan.den.out

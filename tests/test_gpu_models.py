@@ -150,3 +150,23 @@ def test_cpu_input_raises(dev):
     m = reg.build_backbone(dict(type='ResNet', depth=18))
     with pytest.raises(LlvError):
         m(torch.rand(1, 3, 32, 32))
+
+
+def test_retinanet_batch_of_images_matches_single_image_runs(dev):
+    """Batched post-processing (one decode + one NMS launch set for all images, image = blockIdx.y) returns, per
+    image, exactly what a batch-1 run of that image returns (same kernels, same order of operations)."""
+    reg = _registry()
+    ncls, h, w = 4, 96, 128
+    det = randomize(reg.build_detector(retinanet_cfg(num_classes=ncls, depth=18, in_channels=(64, 128, 256, 512), feat=64)),
+                    seed=17, cls_bias=-1.5)
+    imgs = smooth_image(3, h, w, seed=18)
+    calibrate_cls(det, imgs[:1])
+    metas = [img_meta(h - 8 * i, w - 16 * i, h, w, scale=1.0 + 0.25 * i) for i in range(3)]
+    det = det.to(dev).eval()
+    res_b = det(img=[imgs.to(dev)], img_metas=[metas], return_loss=False, rescale=True)
+    assert len(res_b) == 3
+    for i in range(3):
+        res_1 = det(img=[imgs[i:i + 1].to(dev)], img_metas=[[metas[i]]], return_loss=False, rescale=True)[0]
+        assert sum(len(r) for r in res_1) > 5
+        for a, b in zip(res_b[i], res_1):
+            assert a.shape == b.shape and np.array_equal(a, b)

@@ -15,7 +15,7 @@ calibrate_head_on_device(det, plan.det, target_cls_mean=-6.0, target_cls_std=1.3
 plan = engine.EnhanceDetectPlan(cleaner.state_dict(), det.state_dict(), 80, B, 736, 1280, dev, use_graph=False)
 plan.den.frames.copy_(clip[:B + 4])
 plan.plan.run(); torch.cuda.synchronize()
-print('candidates above thr:', int((plan.det.post.decode[0].scores > 0.05).sum()), 'dets:', int(plan.det.post.nms[0].count.item()))
+print('candidates above thr:', int((plan.det.post.dp.scores.reshape(B, -1)[0] > 0.05).sum()), 'dets:', int(plan.det.post.nb.count[0].item()))
 t = plan.plan.run_timed(iters=5)
 tot = sum(x[1] for x in t)
 print(f'total {tot:.3f} ms, flops {plan.plan.flops/1e9:.1f} G')
