@@ -6,11 +6,13 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path over `--frames-per-step` consecutive frames of a clip that is already
-resident in HBM (preprocessed: Brighten -> Normalize -> Pad, as the reference's test pipeline does before
-the model; the reference's benchmark.py excludes data loading too). Timed: window copy, 4 DenBlocks per frame
-(3 temp1 + 1 temp2, no reuse across steps), ResNet-50, FPN, RetinaHead, decode/top-k, NMS and the D2H copy
-of the detections. Rank 0 prints ONE JSON line.
+A step = one pass of the hot path over `--frames-per-step` (default 4) consecutive frames of a clip that is
+already resident in HBM (preprocessed: Brighten -> Normalize -> Pad, as the reference's test pipeline does
+before the model; the reference's benchmark.py excludes data loading too). Timed: window copy, FastDVDnet
+(B+2 temp1 DenBlocks + B temp2 DenBlocks for the B frames of the step: every distinct temp1 result is computed
+once per step, nothing is carried between steps; B=1 is the reference's 3+1 per frame), ResNet-50, FPN,
+RetinaHead, decode/top-k, NMS and the D2H copy of the detections. The JSON line also carries the batch-1
+("latency mode", 4 DenBlocks per frame) rate. Rank 0 prints ONE JSON line.
 """
 import argparse
 import json
@@ -61,7 +63,12 @@ def cpu_baseline(det, cleaner, clip_cpu, img_shape):
     (5-frame window -> FastDVDnet -> RetinaNet -> decode -> NMS), all cores."""
     from oracle.cleaner import fastdvdnet_forward
     from oracle.detector import retinanet_simple_test
-    cores = os.cpu_count() or 1
+    # the GPU box gives one GPU job a 16-core share of the host; use what the affinity mask allows, at most 16
+    try:
+        avail = len(os.sched_getaffinity(0))
+    except AttributeError:
+        avail = os.cpu_count() or 1
+    cores = max(1, min(avail, 16))
     torch.set_num_threads(cores)
     sd_c = {k: v.detach().float().cpu() for k, v in cleaner.state_dict().items()}
     sd_d = {k: v.detach().float().cpu() for k, v in det.state_dict().items()}
@@ -78,18 +85,32 @@ def cpu_baseline(det, cleaner, clip_cpu, img_shape):
                        f'RetinaNet R-50+FPN/decode/NMS {t2 - t1:.2f} s, torch fp32, {cores} threads')
 
 
+def _profiled_traffic(frames_per_step):
+    """HBM bytes of the conv launches of one step, from the committed rocprofv3 PMC passes (profiles/*_traffic.json:
+    FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate --pmc passes), if they were taken at this frames_per_step."""
+    path = os.path.join(ROOT, 'profiles', 'traffic.json')
+    try:
+        t = json.load(open(path))
+        if int(t.get('frames_per_step', -1)) == int(frames_per_step):
+            return t['conv_hbm_bytes_per_step']
+    except Exception:
+        pass
+    return None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
     ap.add_argument('--steps', type=int, default=30)
     ap.add_argument('--warmup', type=int, default=5)
-    ap.add_argument('--frames-per-step', type=int, default=1)
+    ap.add_argument('--frames-per-step', type=int, default=4)
     ap.add_argument('--clip-frames', type=int, default=32)
     ap.add_argument('--height', type=int, default=720)
     ap.add_argument('--width', type=int, default=1280)
     ap.add_argument('--no-graph', action='store_true')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
+    ap.add_argument('--no-latency-mode', action='store_true')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -153,6 +174,24 @@ def main():
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
     n_det = sum(len(d) for d, _ in plan.results())
+    # batch-1 latency mode (the reference's per-frame protocol: 3 temp1 + 1 temp2 DenBlocks per frame)
+    lat = None
+    if rank == 0 and world == 1 and B != 1 and not args.no_latency_mode:
+        p1 = engine.EnhanceDetectPlan(cleaner.state_dict(), det.state_dict(), NUM_CLASSES, 1, hp, wp, dev,
+                                      detector_kwargs=dict(test_cfg=dict(det.bbox_head.test_cfg), img_shapes=[img_shape]),
+                                      use_graph=not args.no_graph)
+        p1.prepare(clip)
+        for s_ in range(args.warmup):
+            p1.step(clip, s_ % T)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        for s_ in range(args.steps):
+            p1.step(clip, (args.warmup + s_) % T)
+        torch.cuda.synchronize()
+        d1 = time.perf_counter() - t1
+        lat = {'frames_per_step': 1, 'denblocks_per_frame': 4, 'value': round(args.steps / d1, 3), 'unit': 'frames/s',
+               'ms_per_frame': round(d1 / args.steps * 1e3, 4), 'algorithmic_gflop_per_frame': round(p1.plan.flops / 1e9, 1)}
+        del p1
     n_cand_thr = int((plan.det.post.dp.scores.reshape(B, -1)[0] > 0.05).sum().item())
 
     out = None
@@ -164,9 +203,10 @@ def main():
             'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True,
             'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
             'config': {
-                'workload': 'Enhance-CNN (FastDVDnet, 4 DenBlocks/frame) + RetinaNet R-50+FPN inference + decode + NMS, '
+                'workload': 'Enhance-CNN (FastDVDnet 5-frame window) + RetinaNet R-50+FPN inference + decode + NMS, '
                             f'{args.width}x{args.height} clip (padded {wp}x{hp}), {NUM_CLASSES} classes, 1xMI355X per rank',
-                'clip_frames': T, 'frames_per_step': B, 'hip_graph': not args.no_graph,
+                'clip_frames': T, 'frames_per_step': B, 'denblocks_per_frame': round((2 * B + 2) / B, 3),
+                'hip_graph': not args.no_graph,
                 'algorithmic_gflop_per_frame': round(flops_step / B / 1e9, 1),
                 'candidates_above_score_thr': n_cand_thr, 'detections_last_step': n_det,
                 'parallelism': f'clip-sharded x{world}, no data-path collective',
@@ -184,11 +224,14 @@ def main():
             ach = conv_fl / (conv_ms * 1e-3) / 1e12
             out['roofline'] = {
                 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                'traffic': None,
-                'kernel': 'conv_igemm_kernel (all %d conv launches of one step; algorithmic 2*MACs of the unpadded convs)' % len(convs),
+                'traffic': _profiled_traffic(B),
+                'kernel': 'conv kernels (conv_igemm_kernel + conv3x3_halo_kernel): all %d conv launches of one step; '
+                          'algorithmic 2*MACs of the unpadded convs' % len(convs),
                 'conv_ms_per_step': round(conv_ms, 4), 'all_kernels_ms_per_step': round(all_ms, 4),
                 'top_launch': {'name': top[0], 'ms': round(top[1], 4), 'tflops': round(top[2] / (top[1] * 1e-3) / 1e12, 2)},
             }
+        if lat is not None:
+            out['latency_mode'] = lat
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(det, cleaner, clip.cpu(), img_shape)
         print(json.dumps(out), flush=True)
