@@ -1,11 +1,101 @@
-"""Training-side head code (targets, losses). Built after the inference path; see DESIGN.md scope table."""
+"""Training side of the dense head: targets + losses on the device kernels.
+
+  AnchorHead.get_anchors / get_targets / _get_targets_single / loss_single / loss
+        mmdetection/mmdet/models/dense_heads/anchor_head.py:145-493
+  heavy parts -> kernels: MaxIoUAssigner (llv_iou_assign: k x n IoU, both arg-maxes, low-quality match, no Python loop
+  over gts) and the sigmoid focal loss over (N*anchors, C) logits (llv_sigmoid_focal_loss_fwd/bwd, autograd Function).
+  The remaining glue touches only the positives (a few hundred rows) and stays in torch.
+Backbone/neck/head convolution backward kernels are not built yet: SingleStageDetector.forward_train raises.
+"""
+import torch
+
+from . import ops
 from ._lib import LlvError
+from .core.anchor import anchor_inside_flags, images_to_levels
 
 
-def anchor_head_loss(head, *args, **kwargs):
-    raise LlvError('AnchorHead.loss: the training path (row a11-a13 of the scope table) is not built yet in this round; '
-                   'the focal-loss and IoU-assign kernels exist (ops.sigmoid_focal_loss_*, ops.iou_assign)')
+def _bbox2delta(proposals, gt, means, stds):
+    """mmdetection/mmdet/core/bbox/coder/delta_xywh_bbox_coder.py:88-130 (positives only: tiny)"""
+    proposals, gt = proposals.float(), gt.float()
+    px = (proposals[..., 0] + proposals[..., 2]) * 0.5
+    py = (proposals[..., 1] + proposals[..., 3]) * 0.5
+    pw = proposals[..., 2] - proposals[..., 0]
+    ph = proposals[..., 3] - proposals[..., 1]
+    gx = (gt[..., 0] + gt[..., 2]) * 0.5
+    gy = (gt[..., 1] + gt[..., 3]) * 0.5
+    gw = gt[..., 2] - gt[..., 0]
+    gh = gt[..., 3] - gt[..., 1]
+    deltas = torch.stack([(gx - px) / pw, (gy - py) / ph, torch.log(gw / pw), torch.log(gh / ph)], dim=-1)
+    return deltas.sub_(deltas.new_tensor(means).unsqueeze(0)).div_(deltas.new_tensor(stds).unsqueeze(0))
+
+
+def get_targets_single(head, flat_anchors, valid_flags, gt_bboxes, gt_labels, img_meta):
+    """anchor_head.py:175-271 with PseudoSampler; assignment over the inside anchors via a validity mask
+    (identical to assigning the subset and unmapping: outside anchors neither win a gt nor get a label)."""
+    tc = head.train_cfg
+    inside = anchor_inside_flags(flat_anchors, valid_flags, img_meta['img_shape'][:2], tc['allowed_border'])
+    if not bool(inside.any()):
+        return (None,) * 6
+    a = head.assigner
+    gt_inds, _ = ops.iou_assign(gt_bboxes, flat_anchors, inside, a.pos_iou_thr, a.neg_iou_thr, a.min_pos_iou,
+                                a.match_low_quality, a.gt_max_assign_all)
+    n = flat_anchors.shape[0]
+    pos_inds = torch.nonzero(gt_inds > 0, as_tuple=False).squeeze(-1)
+    neg_inds = torch.nonzero(gt_inds == 0, as_tuple=False).squeeze(-1)
+    bbox_targets = torch.zeros_like(flat_anchors)
+    bbox_weights = torch.zeros_like(flat_anchors)
+    labels = flat_anchors.new_full((n,), head.num_classes, dtype=torch.long)
+    label_weights = flat_anchors.new_zeros(n, dtype=torch.float)
+    if len(pos_inds) > 0:
+        pos_gt = gt_inds[pos_inds] - 1
+        if head.reg_decoded_bbox:
+            raise LlvError('reg_decoded_bbox (IoU-family losses) is not wired yet')
+        bbox_targets[pos_inds, :] = _bbox2delta(flat_anchors[pos_inds], gt_bboxes[pos_gt, :], head.bbox_coder.means,
+                                                head.bbox_coder.stds)
+        bbox_weights[pos_inds, :] = 1.0
+        labels[pos_inds] = gt_labels[pos_gt] if gt_labels is not None else 0
+        label_weights[pos_inds] = 1.0 if tc['pos_weight'] <= 0 else tc['pos_weight']
+    if len(neg_inds) > 0:
+        label_weights[neg_inds] = 1.0
+    return labels, label_weights, bbox_targets, bbox_weights, pos_inds, neg_inds
+
+
+def anchor_head_loss(head, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None):
+    """AnchorHead.loss (anchor_head.py:425-493). cls_scores / bbox_preds: per-level NCHW GPU tensors."""
+    if head.train_cfg is None:
+        raise LlvError('AnchorHead.loss needs train_cfg (assigner, allowed_border, pos_weight)')
+    featmap_sizes = [f.size()[-2:] for f in cls_scores]
+    assert len(featmap_sizes) == head.anchor_generator.num_levels
+    device = cls_scores[0].device
+    if device.type != 'cuda':
+        raise LlvError('the loss path runs on the MI355X (iou-assign and focal-loss kernels); no CPU fallback')
+    mlvl_anchors = head.anchor_generator.grid_anchors(featmap_sizes, device)
+    num_level_anchors = [a.size(0) for a in mlvl_anchors]
+    flat_anchors = torch.cat(mlvl_anchors)
+    per_img = []
+    for i, meta in enumerate(img_metas):
+        flags = torch.cat(head.anchor_generator.valid_flags(featmap_sizes, meta['pad_shape'], device))
+        per_img.append(get_targets_single(head, flat_anchors, flags, gt_bboxes[i].to(device),
+                                          gt_labels[i].to(device) if gt_labels is not None else None, meta))
+    if any(r[0] is None for r in per_img):
+        return None
+    num_total_pos = sum(max(r[4].numel(), 1) for r in per_img)
+    num_total_neg = sum(max(r[5].numel(), 1) for r in per_img)
+    num_total_samples = num_total_pos + num_total_neg if head.sampling else num_total_pos
+    labels_list = images_to_levels([r[0] for r in per_img], num_level_anchors)
+    label_weights_list = images_to_levels([r[1] for r in per_img], num_level_anchors)
+    bbox_targets_list = images_to_levels([r[2] for r in per_img], num_level_anchors)
+    bbox_weights_list = images_to_levels([r[3] for r in per_img], num_level_anchors)
+    losses_cls, losses_bbox = [], []
+    for cls, reg, lab, lw, bt, bw in zip(cls_scores, bbox_preds, labels_list, label_weights_list, bbox_targets_list,
+                                         bbox_weights_list):          # loss_single, anchor_head.py:375-423
+        cls = cls.permute(0, 2, 3, 1).reshape(-1, head.cls_out_channels)
+        losses_cls.append(head.loss_cls(cls, lab.reshape(-1), lw.reshape(-1), avg_factor=num_total_samples))
+        reg = reg.permute(0, 2, 3, 1).reshape(-1, 4)
+        losses_bbox.append(head.loss_bbox(reg, bt.reshape(-1, 4), bw.reshape(-1, 4), avg_factor=num_total_samples))
+    return dict(loss_cls=losses_cls, loss_bbox=losses_bbox)
 
 
 def single_stage_forward_train(det, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None):
-    raise LlvError('SingleStageDetector.forward_train: conv backward kernels are not built yet in this round')
+    raise LlvError('SingleStageDetector.forward_train: convolution backward (dgrad/wgrad) kernels are not built yet; '
+                   'the head loss itself runs (bbox_head.loss on given head outputs)')
