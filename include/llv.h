@@ -230,6 +230,11 @@ int llv_nms(const float* boxes, const float* scores, int n, float iou_thr, int64
 int llv_embed_aggregate(const void* x_embed, const void* ref_embed, const void* ref, void* out, int n_ref,
                         int64_t hw, int c, int embed_ld, int ref_ld, int out_ld, void* stream);
 
+/* Ring-buffer form: embed / feat hold n_slots frames [slot][hw][c]; the key frame is slot key_slot and is excluded
+ * from the references (mmtracking/mmtrack/models/vid/llvod.py:201-206). */
+int llv_embed_aggregate_ring(const void* embed, const void* feat, void* out, int n_slots, int key_slot, int64_t hw,
+                             int c, int embed_ld, int feat_ld, int out_ld, void* stream);
+
 /* flow_warp_feats: x NHWC fp16 (n,h,w,c), flow NCHW fp32 (n,2,hf,wf) -> y NHWC fp16. */
 int llv_flow_warp(const void* x, const float* flow, void* y, int n, int h, int w, int c, int ld, int hf,
                   int wf, void* stream);

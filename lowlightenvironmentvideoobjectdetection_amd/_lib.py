@@ -103,6 +103,7 @@ SIGNATURES = {
     'llv_nms_workspace_bytes': (_Z, [_I]),
     'llv_nms': (_I, [_P, _P, _I, _F, _P, _P, _P, _Z, _P]),
     'llv_embed_aggregate': (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
+    'llv_embed_aggregate_ring': (_I, [_P, _P, _P, _I, _I, _L, _I, _I, _I, _I, _P]),
     'llv_flow_warp': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'llv_sigmoid_focal_loss_fwd': (_I, [_P, _P, _P, _L, _I, _F, _F, _P]),
     'llv_sigmoid_focal_loss_bwd': (_I, [_P, _P, _P, _L, _I, _F, _F, _P]),

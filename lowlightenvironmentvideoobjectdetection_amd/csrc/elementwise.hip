@@ -88,9 +88,13 @@ __global__ void unpack_kernel(const T* __restrict__ x, float* __restrict__ y, in
 // EmbedAggregator tail (embed_aggregator.py:70-81). One wave per pixel: lanes stride the channels.
 //   xe = x_embed / ||x_embed||, re_n = ref_embed_n / ||ref_embed_n||, w_n = softmax_n(sum_c re_n*xe),
 //   out = sum_n w_n * ref_n.
+// key_slot >= 0 selects the ring form: re/ref hold n_ref slots of a ring buffer, the key frame is slot key_slot
+// (its embedding is read from re, xe is ignored) and is excluded from the references, as LLVOD does
+// (mmtracking/mmtrack/models/vid/llvod.py:201-206).
 __global__ void embed_aggregate_kernel(const _Float16* __restrict__ xe, const _Float16* __restrict__ re,
                                        const _Float16* __restrict__ ref, _Float16* __restrict__ out, int n_ref,
-                                       long hw, int c, int embed_ld, int ref_ld, int out_ld) {
+                                       long hw, int c, int embed_ld, int ref_ld, int out_ld, int key_slot) {
+    if (key_slot >= 0) xe = re + (long)key_slot * hw * embed_ld;
     const int lane = threadIdx.x & 63;
     const long wave = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
     const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
@@ -109,6 +113,7 @@ __global__ void embed_aggregate_kernel(const _Float16* __restrict__ xe, const _F
         const float xn = sqrtf(xx);
         float mx = -INFINITY;
         for (int n = 0; n < n_ref; ++n) {
+            if (n == key_slot) { if (lane == 0) myw[n] = -INFINITY; continue; }
             float rr = 0.f, rx = 0.f;
             for (int ch = lane * 8; ch < c; ch += 512) {
                 const f16x8 v = *reinterpret_cast<const f16x8*>(re + ((long)n * hw + p) * embed_ld + ch);
@@ -124,10 +129,12 @@ __global__ void embed_aggregate_kernel(const _Float16* __restrict__ xe, const _F
         }
         __builtin_amdgcn_wave_barrier();
         float den = 0.f;
-        for (int n = 0; n < n_ref; ++n) den += expf(myw[n] - mx);
+        for (int n = 0; n < n_ref; ++n)
+            if (n != key_slot) den += expf(myw[n] - mx);
         for (int ch = lane * 8; ch < c; ch += 512) {
             float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
             for (int n = 0; n < n_ref; ++n) {
+                if (n == key_slot) continue;
                 const float wgt = expf(myw[n] - mx) / den;
                 const f16x8 v = *reinterpret_cast<const f16x8*>(ref + ((long)n * hw + p) * ref_ld + ch);
 #pragma unroll
@@ -253,7 +260,20 @@ extern "C" int llv_embed_aggregate(const void* x_embed, const void* ref_embed, c
     if (blocks > 256L * 8) blocks = 256L * 8;
     hipLaunchKernelGGL(embed_aggregate_kernel, dim3((int)blocks), dim3(256), 4 * n_ref * sizeof(float),
                        (hipStream_t)stream, (const _Float16*)x_embed, (const _Float16*)ref_embed,
-                       (const _Float16*)ref, (_Float16*)out, n_ref, (long)hw, c, embed_ld, ref_ld, out_ld);
+                       (const _Float16*)ref, (_Float16*)out, n_ref, (long)hw, c, embed_ld, ref_ld, out_ld, -1);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_embed_aggregate_ring(const void* embed, const void* feat, void* out, int n_slots, int key_slot,
+                                        int64_t hw, int c, int embed_ld, int feat_ld, int out_ld, void* stream) {
+    if (!embed || !feat || !out || n_slots < 2 || n_slots > 256 || key_slot < 0 || key_slot >= n_slots || hw < 1 || c < 8 || (c & 7))
+        return LLV_E_BADARG;
+    if ((embed_ld & 7) || (feat_ld & 7) || (out_ld & 7) || embed_ld < c || feat_ld < c || out_ld < c) return LLV_E_BADARG;
+    long blocks = ((long)hw + 3) / 4;
+    if (blocks > 256L * 8) blocks = 256L * 8;
+    hipLaunchKernelGGL(embed_aggregate_kernel, dim3((int)blocks), dim3(256), 4 * n_slots * sizeof(float), (hipStream_t)stream,
+                       (const _Float16*)embed, (const _Float16*)embed, (const _Float16*)feat, (_Float16*)out, n_slots, (long)hw,
+                       c, embed_ld, feat_ld, out_ld, key_slot);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 

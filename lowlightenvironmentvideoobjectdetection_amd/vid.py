@@ -184,3 +184,123 @@ class FastDVDnetDetect(BaseVideoDetector):
         dets, labels = plan.det.results()[0]
         self.memo['denoising_img'] = plan.den.out
         return dict(bbox_results=bbox2result(dets, labels, self.detector.bbox_head.num_classes))
+
+
+@MODELS.register_module()
+class LLVOD(BaseVideoDetector):
+    """Temporal feature aggregation without optical flow (mmtracking/mmtrack/models/vid/llvod.py:17-254), for a
+    dense-head detector: the pyramid features of the last `memo_len` frames (reference: 32, llvod.py:163) live in a
+    device ring buffer together with their embeddings; each new frame costs one backbone+FPN pass and one embedding
+    conv, then per level `EmbedAggregator(x_key, refs)` (key excluded from the references, llvod.py:201-206), the
+    RetinaHead on the aggregated pyramid, decode and NMS.
+
+    Call (test): model(return_loss=False, img=[T(1,3,H,W)], img_metas=[[meta]], ref_img=[T(1,N,3,H,W)] or None).
+    `ref_img` frames are pushed into the ring before `img`; frame_id == 0 resets it. The reference's own control
+    flow for this class cannot run (assert frame_id == 1 next to `if frame_id == 0`, NameError on
+    general_clean_noise_pairs), so the window bookkeeping here is the plain sliding one.
+    """
+
+    def __init__(self, detector, aggregator, pretrains=None, frozen_modules=None, train_cfg=None, test_cfg=None,
+                 memo_len=32):
+        super().__init__()
+        from .registry import build_aggregator
+        self.detector = build_detector(detector)
+        self.aggregator = build_aggregator(aggregator)
+        if hasattr(self.detector, 'roi_head'):
+            raise LlvError('LLVOD here drives a dense-head (single-stage) detector; two-stage is out of scope')
+        self.train_cfg, self.test_cfg, self.memo_len = train_cfg, test_cfg, memo_len
+        self.memo = None
+        self.init_weights(pretrains)
+        if frozen_modules is not None:
+            self.freeze_module(frozen_modules)
+
+    def init_weights(self, pretrain):
+        if pretrain is None:
+            pretrain = dict()
+        assert isinstance(pretrain, dict), '`pretrain` must be a dict.'
+        if self.with_detector and pretrain.get('detector', False):
+            self.init_module('detector', pretrain['detector'])
+        if self.with_aggregator and pretrain.get('aggregator', False):
+            self.init_module('aggregator', pretrain['aggregator'])
+
+    def invalidate_plans(self):
+        super().invalidate_plans()
+        self.memo = None
+        for m in self.children():
+            if isinstance(m, PlannedModule):
+                m.invalidate_plans()
+
+    def forward_train(self, img, img_metas, **kwargs):
+        raise LlvError('LLVOD.forward_train: the training path is not built yet in this round')
+
+    def _make_plan(self, h, w, device):
+        from .aggregators import embed_packed_convs
+        d, ag = self.detector, self.aggregator
+        sd = engine._cpu_sd(d.state_dict())
+        bb, neck, head = d.backbone, d.neck, d.bbox_head
+        # stage A: backbone + FPN + embedding convs of ONE frame
+        ba = engine.Builder(device)
+        x_in = ba.buf(1, h, w, 8)
+        feats = engine.build_resnet(ba, sd, x_in, p='backbone.', **bb.plan_kwargs())
+        pyr = engine.build_fpn(ba, sd, feats, p='neck.', **neck.plan_kwargs())
+        emb = pyr.buf
+        for i, (pc, flags) in enumerate(embed_packed_convs(engine._cpu_sd(ag.state_dict()), ag.num_convs)):
+            nxt = ba.buf(pyr.total, pc.cout)
+            ba.conv_desc(f'embed{i}', pc, [emb], nxt, 1, pyr.segs(), emb.shape[-1], nxt.shape[-1], flags=flags)
+            emb = nxt
+        # ring buffers per level: features and embeddings of the last memo_len frames
+        c = pyr.buf.shape[-1]
+        ring_f = [torch.zeros((self.memo_len, hh, ww, c), device=device, dtype=torch.float16) for hh, ww in pyr.level_hw]
+        ring_e = [torch.zeros((self.memo_len, hh, ww, emb.shape[-1]), device=device, dtype=torch.float16) for hh, ww in pyr.level_hw]
+        # stage B: head + decode + NMS on the aggregated pyramid
+        bbld = engine.Builder(device)
+        agg = engine.Pyramid(bbld.buf(pyr.total, c), pyr.level_hw, pyr.level_off, 1)
+        cls_buf, reg_buf = engine.build_retina_head(bbld, sd, agg, head.stacked_convs, True, p='bbox_head.')
+        post = engine.PostProcess(bbld, cls_buf, reg_buf, agg, head.cls_out_channels, head.anchor_generator,
+                                  dict(head.test_cfg) if head.test_cfg else engine.DEFAULT_TEST_CFG, head.bbox_coder.means,
+                                  head.bbox_coder.stds, [(h, w, 3)], None, False, head.bbox_coder.clip_border)
+        return dict(a=ba.plan, b=bbld.plan, x_in=x_in, pyr=pyr, emb=emb, ring_f=ring_f, ring_e=ring_e, agg=agg, post=post)
+
+    def _push(self, plan, frame):
+        """One frame (1,3,H,W) through stage A into the next ring slot; returns the slot."""
+        ops.pack_input(frame.float().contiguous(), 8, out=plan['x_in'])
+        plan['a'].run()
+        m = self.memo
+        slot = m['next']
+        pyr = plan['pyr']
+        for l in range(len(pyr.level_hw)):
+            plan['ring_f'][l][slot].copy_(pyr.level(l)[0])
+            plan['ring_e'][l][slot].copy_(pyr.level(l, plan['emb'])[0])
+        m['next'] = (slot + 1) % self.memo_len
+        m['valid'] = min(m['valid'] + 1, self.memo_len)
+        return slot
+
+    def simple_test(self, img, img_metas, ref_img=None, ref_img_metas=None, rescale=False, **kwargs):
+        self._check_input(img)
+        assert len(img) == 1, 'video detectors take 1 image per GPU (llvod.py:65)'
+        n, c, h, w = img.shape
+        plan = self._plan((h, w, str(img.device)), lambda: self._make_plan(h, w, img.device))
+        frame_id = img_metas[0].get('frame_id', -1)
+        if self.memo is None or frame_id == 0:
+            self.memo = dict(next=0, valid=0)
+        if ref_img is not None:
+            refs = ref_img[0] if isinstance(ref_img, (list, tuple)) else ref_img
+            refs = refs[0] if refs.dim() == 5 else refs
+            for i in range(refs.shape[0]):
+                self._push(plan, refs[i:i + 1])
+        key = self._push(plan, img)
+        pyr, agg = plan['pyr'], plan['agg']
+        nv = self.memo['valid']
+        for l, (hh, ww) in enumerate(pyr.level_hw):
+            out = agg.level(l)
+            if nv < 2:
+                out.copy_(plan['ring_f'][l][key:key + 1])           # no references yet: the frame's own features
+            else:
+                ops.check(ops.lib().llv_embed_aggregate_ring(ops._ptr(plan['ring_e'][l]), ops._ptr(plan['ring_f'][l]), ops._ptr(out),
+                                                             nv, key, hh * ww, out.shape[-1], plan['ring_e'][l].shape[-1],
+                                                             plan['ring_f'][l].shape[-1], out.shape[-1], ops._stream()),
+                          'llv_embed_aggregate_ring')
+        plan['post'].set_metas(img_metas, rescale)
+        plan['b'].run()
+        dets, labels = plan['post'].results()[0]
+        return dict(bbox_results=bbox2result(dets, labels, self.detector.bbox_head.num_classes))
