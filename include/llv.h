@@ -143,6 +143,22 @@ size_t llv_conv2d_workspace_bytes(const llv_conv_desc* desc);
 /* algorithmic FLOPs (2*MACs, true channels) the launch described by desc performs */
 double llv_conv2d_flops(const llv_conv_desc* desc);
 
+/*
+ * FastDVDnet InputCvBlock in one launch (mmtracking/mmtrack/models/cleaners/FastDVDnet.py:22-36):
+ *   Conv2d(9, 90, 3, groups=3) + BN + ReLU -> Conv2d(90, 32, 3) + BN + ReLU; the 90-channel intermediate stays in LDS.
+ * conv  : the SECOND conv as an llv_conv_desc: x[0..2] = the three NHWC8 frame tensors (n_src = 3, x_ld >= 8),
+ *         cin = 96 (three groups of 30 + 2 zero channels), cout <= 32 (multiple of 8), w_halo = its halo packing
+ *         ([3 chunks][32 rows][296]), bias, y, flags in {0, LLV_CONV_RELU}, one segment, 3x3 / stride 1 / pad 1.
+ * w_pre : the FIRST (grouped) conv, halo packing [3 groups][32 rows][104] fp16 (k = tap*8 + c, rows 30,31 zero).
+ * bias_pre : fp32 [96] (folded BN shift, 0 for the pad channels).
+ */
+typedef struct llv_inputcv_desc {
+    llv_conv_desc conv;
+    const void* w_pre;
+    const float* bias_pre;
+} llv_inputcv_desc;
+int llv_inputcvblock_fwd(const llv_inputcv_desc* desc, void* stream);
+
 /* 3x3 stride-2 pad-1 max pooling, NHWC fp16, c multiple of 8. */
 int llv_maxpool3x3s2_nhwc(const void* x, void* y, int batch, int h, int w, int c, void* stream);
 

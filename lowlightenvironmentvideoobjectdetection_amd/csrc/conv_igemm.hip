@@ -627,6 +627,176 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a, co
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// inputcv_kernel: FastDVDnet's InputCvBlock in one launch (FastDVDnet.py:22-36):
+//   Conv2d(3F, 30F, 3, groups=F) + BN + ReLU  ->  Conv2d(30F, 32, 3) + BN + ReLU        (F = 3 frames)
+// One workgroup = 8 x 32 output pixels x 32 channels. For each frame g it loads the (8+4) x (32+4) pixel patch of
+// frame g (NHWC8) and the group's weights, computes the FIRST conv for the (8+2) x (32+2) halo tile with MFMA and
+// writes it (bias + ReLU, zero outside the image = the second conv's zero padding) into the LDS halo buffer,
+// then runs the second conv's 9 k-steps for that 32-channel chunk exactly like conv3x3_halo_kernel.
+// The 90-channel full-resolution intermediate never exists in HBM.
+// ------------------------------------------------------------------------------------------------
+struct PreArgs {
+    const _Float16* w;    // [group][32 rows][wrow] halo packing of the grouped conv (K = tap*8 + c, padded to 96)
+    const float* bias;    // [groups*32]
+    int wrow;             // 104
+};
+constexpr int PATCH_W = HALO_TW + 4, PATCH_H = HALO_TH + 4, PATCH_PX = PATCH_W * PATCH_H;   // 36 x 12
+
+__global__ __launch_bounds__(256) void inputcv_kernel(const ConvKArgs a, const HaloArgs h, const PreArgs pre) {
+    constexpr int BN = 32, TN = 2, TM = 4;
+    constexpr int NMT = (HALO_PX + 15) / 16;                 // 22 M-tiles of 16 halo pixels
+    extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
+    unsigned char* s_halo = hsm;                             // 340 x 64 B   (also the epilogue tile later)
+    unsigned char* s_w = s_halo + HALO_PX * 64;              // 32 x wrow halfs (second conv, this chunk)
+    unsigned char* s_in = s_w + BN * h.wrow * 2;             // 432 x 16 B   (frame patch)
+    unsigned char* s_w0 = s_in + PATCH_PX * 16;              // 32 x pre.wrow halfs (first conv, this group)
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    int bid = blockIdx.x;
+    {
+        const int nblk = h.nblk;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tx0 = (bid % h.tiles_x) * HALO_TW;
+    const int t1 = bid / h.tiles_x;
+    const int ty0 = (t1 % h.tiles_y) * HALO_TH;
+    const int n = t1 / h.tiles_y;
+    const long img_base = (long)a.seg_xoff[0] + (long)n * h.H * h.W;
+    const int frow = lane & 15, fch = lane >> 4;
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    int pbase[TM];
+#pragma unroll
+    for (int j = 0; j < TM; ++j) pbase[j] = (2 * wave + (j >> 1)) * (HALO_TW + 2) + (j & 1) * 16 + frow;
+
+    const int nvec_w = BN * (h.wrow >> 3);
+    const int nvec_w0 = BN * (pre.wrow >> 3);
+    for (int g = 0; g < h.n_chunks; ++g) {
+        const _Float16* xg = g == 0 ? a.x0 : (g == 1 ? a.x1 : a.x2);
+        // ---- loads of this group: frame patch, first-conv weights, second-conv chunk weights
+        uint4 preg[2], w0reg[2], wreg[5];
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int v = tid + i * 256;
+            uint4 val = make_uint4(0, 0, 0, 0);
+            if (v < PATCH_PX) {
+                const int py = v / PATCH_W, px = v - py * PATCH_W;
+                const int gy = ty0 + py - 2, gx = tx0 + px - 2;
+                if ((unsigned)gy < (unsigned)h.H && (unsigned)gx < (unsigned)h.W)
+                    val = *reinterpret_cast<const uint4*>(xg + (img_base + (long)gy * h.W + gx) * a.x_ld);
+            }
+            preg[i] = val;
+        }
+        const _Float16* w0src = pre.w + (long)g * BN * pre.wrow;
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int v = tid + i * 256;
+            w0reg[i] = v < nvec_w0 ? *reinterpret_cast<const uint4*>(w0src + (long)v * 8) : make_uint4(0, 0, 0, 0);
+        }
+        const _Float16* wsrc = h.w + ((long)g * BN) * h.wrow;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int v = tid + i * 256;
+            wreg[i] = v < nvec_w ? *reinterpret_cast<const uint4*>(wsrc + (long)v * 8) : make_uint4(0, 0, 0, 0);
+        }
+        if (g > 0) __syncthreads();                            // previous chunk's fragment reads are done
+#pragma unroll
+        for (int i = 0; i < 2; ++i) {
+            const int v = tid + i * 256;
+            if (v < PATCH_PX) *reinterpret_cast<uint4*>(s_in + v * 16) = preg[i];
+            if (v < nvec_w0) *reinterpret_cast<uint4*>(s_w0 + v * 16) = w0reg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int v = tid + i * 256;
+            if (v < nvec_w) *reinterpret_cast<uint4*>(s_w + v * 16) = wreg[i];
+        }
+        __syncthreads();
+        // ---- stage A: first conv on the halo tile (22 M-tiles of 16 halo pixels, K = 9 taps x 8 ch -> 3 k-steps)
+        for (int mt = wave; mt < NMT; mt += 4) {
+            const int hp = mt * 16 + frow;                     // halo pixel of this lane's B column
+            const int hpc = hp < HALO_PX ? hp : HALO_PX - 1;
+            const int hy = hpc / (HALO_TW + 2), hx = hpc - hy * (HALO_TW + 2);
+            f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+            for (int ks = 0; ks < 3; ++ks) {
+                int tap = ks * 4 + fch;
+                tap = tap > 8 ? 8 : tap;                       // k >= 72: zero weights
+                const int tr = tap / 3, tq = tap - tr * 3;
+                const f16x8 bf = *reinterpret_cast<const f16x8*>(s_in + ((hy + tr) * PATCH_W + hx + tq) * 16);
+                const f16x8 a0 = *reinterpret_cast<const f16x8*>(s_w0 + ((frow) * pre.wrow + ks * 32 + fch * 8) * 2);
+                const f16x8 a1 = *reinterpret_cast<const f16x8*>(s_w0 + ((16 + frow) * pre.wrow + ks * 32 + fch * 8) * 2);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bf, c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bf, c1, 0, 0, 0);
+            }
+            // lane holds channels fch*4..+3 (c0) and 16+fch*4..+3 (c1) of halo pixel hp
+            if (hp < HALO_PX) {
+                const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+                const bool inside = (unsigned)gy < (unsigned)h.H && (unsigned)gx < (unsigned)h.W;
+                const float4 b0 = *reinterpret_cast<const float4*>(pre.bias + g * BN + fch * 4);
+                const float4 b1 = *reinterpret_cast<const float4*>(pre.bias + g * BN + 16 + fch * 4);
+                f16x4 o0, o1;
+                o0[0] = (_Float16)(inside ? fmaxf(c0[0] + b0.x, 0.f) : 0.f); o0[1] = (_Float16)(inside ? fmaxf(c0[1] + b0.y, 0.f) : 0.f);
+                o0[2] = (_Float16)(inside ? fmaxf(c0[2] + b0.z, 0.f) : 0.f); o0[3] = (_Float16)(inside ? fmaxf(c0[3] + b0.w, 0.f) : 0.f);
+                o1[0] = (_Float16)(inside ? fmaxf(c1[0] + b1.x, 0.f) : 0.f); o1[1] = (_Float16)(inside ? fmaxf(c1[1] + b1.y, 0.f) : 0.f);
+                o1[2] = (_Float16)(inside ? fmaxf(c1[2] + b1.z, 0.f) : 0.f); o1[3] = (_Float16)(inside ? fmaxf(c1[3] + b1.w, 0.f) : 0.f);
+                // channel ch lives in 16-B piece ch/8, byte (ch%8)*2 of the halo pixel (same swizzle as the reads)
+                *reinterpret_cast<f16x4*>(s_halo + halo_off(hp, fch >> 1, 32) + (fch & 1) * 8) = o0;
+                *reinterpret_cast<f16x4*>(s_halo + halo_off(hp, 2 + (fch >> 1), 32) + (fch & 1) * 8) = o1;
+            }
+        }
+        __syncthreads();
+        // ---- stage B: second conv, chunk g (9 barrier-free k-steps)
+        for (int ks = 0; ks < 9; ++ks) {
+            const int tr = ks / 3, tq = ks - tr * 3;
+            const int poff = tr * (HALO_TW + 2) + tq;
+            f16x8 af[TN], bf[TM];
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+                af[i] = *reinterpret_cast<const f16x8*>(s_w + ((i * 16 + frow) * h.wrow + ks * 32 + fch * 8) * 2);
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                bf[j] = *reinterpret_cast<const f16x8*>(s_halo + halo_off(pbase[j] + poff, fch, 32));
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+    // ---- epilogue through the LDS tile
+    auto row_to_m = [&](int prow) {
+        const int oy = ty0 + (prow >> 5), ox = tx0 + (prow & 31);
+        return (oy < h.H && ox < h.W) ? (int)(((long)n * h.H + oy) * h.W + ox) : -1;
+    };
+    constexpr int TS = BN + 8;
+    _Float16* tile = reinterpret_cast<_Float16*>(hsm);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int prow = (2 * wave + (j >> 1)) * 32 + (j & 1) * 16 + frow;
+        const int m = row_to_m(prow);
+        EpiCtx c;
+        if (m >= 0) epi_locate(a, m, c);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int col = i * 16 + fch * 4;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (m >= 0 && col < a.cout) epi_compute(a, c, col, v);
+            const f16x4 o4 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            *reinterpret_cast<f16x4*>(tile + prow * TS + col) = o4;
+        }
+    }
+    __syncthreads();
+    staged_store<BN, 256>(a, tile, 0, 0, row_to_m);
+}
+
 template <int BN>
 int launch_halo(ConvKArgs& k, HaloArgs& h, int groups, int batch, hipStream_t st) {
     h.ntiles_n = (k.cout + BN - 1) / BN;
@@ -856,4 +1026,39 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
         case LLV_TILE_64x64:   return launch<64, 64, 32, 32>(k, d->groups, st);
         default: return LLV_E_UNSUPPORTED;
     }
+}
+
+
+extern "C" int llv_inputcvblock_fwd(const llv_inputcv_desc* p, void* stream) {
+    if (!p || !p->w_pre || !p->bias_pre) return LLV_E_BADARG;
+    const llv_conv_desc* d = &p->conv;
+    if (!d->w_halo || !d->bias || !d->y || d->n_seg != 1 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1) return LLV_E_BADARG;
+    if (d->n_src != 3 || !d->x[0] || !d->x[1] || !d->x[2] || d->x_ld < 8 || (d->x_ld & 7)) return LLV_E_BADARG;
+    if (d->cin != 96 || d->cout < 4 || d->cout > 32 || (d->cout & 7) || d->groups != 1 || (d->y_ld & 7) || d->y_ld < d->cout) return LLV_E_BADARG;
+    if (d->flags & ~(LLV_CONV_RELU)) return LLV_E_BADARG;
+    if (d->seg_h[0] < 1 || d->seg_w[0] < 1 || d->seg_ho[0] != d->seg_h[0] || d->seg_wo[0] != d->seg_w[0] || d->batch < 1) return LLV_E_BADARG;
+    const long px = (long)d->batch * d->seg_h[0] * d->seg_w[0];
+    if (d->seg_xoff[0] < 0 || d->seg_yoff[0] < 0 || d->seg_xoff[0] + px > 0x7fffffffL || d->seg_yoff[0] + px > 0x7fffffffL) return LLV_E_BADARG;
+    ConvKArgs k = {};
+    k.x0 = (const _Float16*)d->x[0]; k.x1 = (const _Float16*)d->x[1]; k.x2 = (const _Float16*)d->x[2];
+    k.bias = d->bias; k.y = d->y; k.res = nullptr;
+    k.n_src = 3; k.src_cvec = 1; k.x_ld = d->x_ld; k.y_ld = d->y_ld; k.res_ld = 0;
+    k.cin = 96; k.cout = d->cout; k.kh = 3; k.kw = 3; k.stride = 1; k.pad = 1; k.n_seg = 1;
+    for (int s = 0; s < LLV_MAX_SEG; ++s) {
+        k.seg_h[s] = d->seg_h[0]; k.seg_w[s] = d->seg_w[0]; k.seg_ho[s] = d->seg_h[0]; k.seg_wo[s] = d->seg_w[0];
+        k.seg_xoff[s] = (int)d->seg_xoff[0]; k.seg_yoff[s] = (int)d->seg_yoff[0]; k.seg_m0[s] = 0;
+    }
+    k.seg_m0[LLV_MAX_SEG] = (int)px; k.m_total = (int)px;
+    k.flags = d->flags; k.stage_out = 1; k.k_splits = 1; k.y_gstride = 0; k.src_per_group = 0;
+    HaloArgs h;
+    h.w = (const _Float16*)d->w_halo;
+    h.H = d->seg_h[0]; h.W = d->seg_w[0];
+    h.tiles_x = (h.W + HALO_TW - 1) / HALO_TW; h.tiles_y = (h.H + HALO_TH - 1) / HALO_TH;
+    h.ck = 32; h.n_chunks = 3; h.kc_pad = 288; h.wrow = 296; h.ntiles_n = 1;
+    h.nblk = h.tiles_x * h.tiles_y * d->batch; h.w_gstride = 0;
+    PreArgs pre;
+    pre.w = (const _Float16*)p->w_pre; pre.bias = p->bias_pre; pre.wrow = 104;
+    const size_t lds = (size_t)HALO_PX * 64 + (size_t)32 * h.wrow * 2 + (size_t)PATCH_PX * 16 + (size_t)32 * pre.wrow * 2;
+    hipLaunchKernelGGL(inputcv_kernel, dim3(h.nblk), dim3(256), lds, (hipStream_t)stream, k, h, pre);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }

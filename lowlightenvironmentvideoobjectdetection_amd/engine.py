@@ -25,6 +25,7 @@ BN_EPS = 1e-5
 import os as _os
 HALO = _os.environ.get('LLV_HALO', '1') != '0'
 HALO_MAX_COUT = int(_os.environ.get('LLV_HALO_MAX_COUT', '128'))
+FUSE_INPUTCV = _os.environ.get('LLV_FUSE_INPUTCV', '1') != '0'
 ARCH = {18: ('basic', (2, 2, 2, 2)), 34: ('basic', (3, 4, 6, 3)), 50: ('bottleneck', (3, 4, 6, 3)),
         101: ('bottleneck', (3, 4, 23, 3)), 152: ('bottleneck', (3, 8, 36, 3))}
 
@@ -425,20 +426,33 @@ def _denblock(b: Builder, sd, p, srcs, batch, tag):
     pc.n_src, pc.src_cvec = ng, 1
     if HALO:
         ops.add_halo_packing(pc)
-    # each group writes its own (batch, H, W, 32) plane (full cache lines); inc1 reads the three planes as three sources
     n, hh, ww, _ = srcs[0].shape
-    planes = b.buf(ng, n, hh, ww, og_pad)
-    b.conv_desc(f'{tag}.inc0', pc, list(srcs), planes, n, [(hh, ww, hh, ww, 0, 0)], srcs[0].shape[-1], og_pad, flags=f,
-                y_group_stride=n * hh * ww * og_pad)
-    x = [planes[g] for g in range(ng)]
     w2 = sd[p + 'inc.convblock.3.weight']
     in_map = []
     for g in range(ng):
         in_map += [og * g + j if j < og else -1 for j in range(og_pad)]
-    pc = ops.pack_conv(w2, None, 1, 1, in_map=in_map, n_src=ng, bn=_bn(sd, p + 'inc.convblock.4'), eps=BN_EPS)
+    pc2 = ops.pack_conv(w2, None, 1, 1, in_map=in_map, n_src=ng, bn=_bn(sd, p + 'inc.convblock.4'), eps=BN_EPS)
     if HALO:
-        ops.add_halo_packing(pc)
-    x0 = b.conv(f'{tag}.inc1', x, pc, f)
+        ops.add_halo_packing(pc2)
+    if HALO and FUSE_INPUTCV and og_pad == 32 and pc2.cout == 32 and pc.w_halo is not None and pc2.w_halo is not None:
+        # the whole InputCvBlock as one launch: the 90-channel intermediate never leaves LDS (llv_inputcvblock_fwd)
+        from ._lib import InputCvDesc
+        x0 = b.buf(n, hh, ww, pc2.cout)
+        pc.to(b.dev)
+        pc2.to(b.dev)
+        d = InputCvDesc()
+        d.conv = ops.make_conv_desc(pc2, list(srcs), x0, n, [(hh, ww, hh, ww, 0, 0)], srcs[0].shape[-1], pc2.cout, flags=f)
+        d.w_pre, d.bias_pre = pc.w_halo.data_ptr(), pc.bias.data_ptr()
+        m = n * hh * ww
+        b.plan.keep += [pc, pc2, d, x0] + list(srcs)
+        b.plan.add(f'{tag}.inputcv', lib().llv_inputcvblock_fwd, (C.byref(d),), 2.0 * m * (pc.true_macs_per_pixel + pc2.true_macs_per_pixel),
+                   2.0 * m * (24 + pc2.cout))
+    else:
+        # each group writes its own (batch, H, W, 32) plane (full cache lines); inc1 reads the three planes as three sources
+        planes = b.buf(ng, n, hh, ww, og_pad)
+        b.conv_desc(f'{tag}.inc0', pc, list(srcs), planes, n, [(hh, ww, hh, ww, 0, 0)], srcs[0].shape[-1], og_pad, flags=f,
+                    y_group_stride=n * hh * ww * og_pad)
+        x0 = b.conv(f'{tag}.inc1', [planes[g] for g in range(ng)], pc2, f)
 
     def cbr(name, x, conv, bn, stride=1, flags=f, res=None):
         pc = ops.pack_conv(sd[conv + '.weight'], None, stride, 1, bn=_bn(sd, bn), eps=BN_EPS)

@@ -353,3 +353,41 @@ def test_conv_grouped_planar_outputs_then_multi_source(dev, use_halo):
     y2 = ops.conv2d([planes[0], planes[1], planes[2]], pc2, flags=ops.CONV_RELU)
     ref2 = F.relu(F.conv2d(got1, w2, None, 1, 1))
     _check(y2, ref2, 32)
+
+
+@pytest.mark.parametrize('n,h,w', [(1, 16, 32), (2, 19, 45), (3, 8, 70)])
+def test_fused_inputcvblock(dev, n, h, w):
+    """llv_inputcvblock_fwd == Conv2d(9,90,3,groups=3)+BN+ReLU -> Conv2d(90,32,3)+BN+ReLU (FastDVDnet.py:22-36),
+    with the first conv's output rounded to fp16 as the two-launch path does."""
+    import ctypes as C
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    from lowlightenvironmentvideoobjectdetection_amd._lib import InputCvDesc, check, lib
+    g = torch.Generator().manual_seed(71 + n)
+    frames = [torch.randn(n, 3, h, w, generator=g).half().float() for _ in range(3)]
+    wg = (torch.randn(90, 3, 3, 3, generator=g) / 5.0).half().float()
+    b0 = torch.randn(90, generator=g) * 0.1
+    w2 = (torch.randn(32, 90, 3, 3, generator=g) / 28.0).half().float()
+    b2 = torch.randn(32, generator=g) * 0.1
+    pcs = [ops.pack_conv(wg[30 * i:30 * i + 30], b0[30 * i:30 * i + 30], 1, 1, in_map=[0, 1, 2, -1, -1, -1, -1, -1], cout_store=32)
+           for i in range(3)]
+    pc = ops.stack_groups(pcs)
+    pc.n_src, pc.src_cvec = 3, 1
+    in_map = []
+    for gi in range(3):
+        in_map += [30 * gi + j if j < 30 else -1 for j in range(32)]
+    pc2 = ops.pack_conv(w2, b2, 1, 1, in_map=in_map, n_src=3)
+    ops.add_halo_packing(pc).to(dev)
+    ops.add_halo_packing(pc2).to(dev)
+    xs = []
+    for f in frames:
+        t = torch.zeros(n, h, w, 8, dtype=torch.float16)
+        t[..., :3] = _nhwc(f).half()
+        xs.append(t.to(dev))
+    y = torch.zeros(n, h, w, 32, dtype=torch.float16, device=dev)
+    d = InputCvDesc()
+    d.conv = ops.make_conv_desc(pc2, xs, y, n, [(h, w, h, w, 0, 0)], 8, 32, flags=ops.CONV_RELU)
+    d.w_pre, d.bias_pre = pc.w_halo.data_ptr(), pc.bias.data_ptr()
+    check(lib().llv_inputcvblock_fwd(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'llv_inputcvblock_fwd')
+    mid = F.relu(F.conv2d(torch.cat(frames, 1), wg, b0, 1, 1, 1, 3)).half().float()
+    ref = F.relu(F.conv2d(mid, w2, b2, 1, 1))
+    _check(y, ref, 32)
