@@ -158,6 +158,11 @@ typedef struct llv_inputcv_desc {
     const float* bias_pre;
 } llv_inputcv_desc;
 int llv_inputcvblock_fwd(const llv_inputcv_desc* desc, void* stream);
+/* FastDVDnet OutputCvBlock in one launch (FastDVDnet.py:64-74): Conv2d(32,32,3)+BN+ReLU -> Conv2d(32,3,3), with the
+ * DenBlock residual `in1 - x` (FastDVDnet.py:115) as LLV_CONV_RES_RSUB. conv = the second conv (x[0] = the 32-channel
+ * input tensor, cin = 32, cout <= 16 multiple of 8, w_halo [16 rows][296], res = in1); w_pre = first conv, halo packing
+ * [32 rows][296]; bias_pre fp32 [32]. */
+int llv_outputcvblock_fwd(const llv_inputcv_desc* desc, void* stream);
 
 /* 3x3 stride-2 pad-1 max pooling, NHWC fp16, c multiple of 8. */
 int llv_maxpool3x3s2_nhwc(const void* x, void* y, int batch, int h, int w, int c, void* stream);

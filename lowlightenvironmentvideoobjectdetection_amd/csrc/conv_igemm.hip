@@ -643,14 +643,22 @@ struct PreArgs {
 };
 constexpr int PATCH_W = HALO_TW + 4, PATCH_H = HALO_TH + 4, PATCH_PX = PATCH_W * PATCH_H;   // 36 x 12
 
-__global__ __launch_bounds__(256) void inputcv_kernel(const ConvKArgs a, const HaloArgs h, const PreArgs pre) {
-    constexpr int BN = 32, TN = 2, TM = 4;
+// CK0 = channels per pixel of the first conv's input (8: one NHWC8 frame per group, InputCvBlock;
+//       32: one 32-channel tensor, OutputCvBlock FastDVDnet.py:64-74), BN2 = output tile of the second conv.
+template <int CK0, int BN2>
+__global__ __launch_bounds__(256) void convpair_kernel(const ConvKArgs a, const HaloArgs h, const PreArgs pre) {
+    constexpr int BN = 32;                                   // channels of the intermediate per chunk
+    constexpr int TN2 = BN2 / 16, TM = 4;
     constexpr int NMT = (HALO_PX + 15) / 16;                 // 22 M-tiles of 16 halo pixels
+    constexpr int PV = (PATCH_PX * (CK0 / 8) + 255) / 256;   // patch vectors per lane
+    constexpr int NKS0 = (9 * CK0 + 31) / 32;                // k-steps of the first conv
+    constexpr int W0V = (BN * (NKS0 * 32 + 8) / 8 + 255) / 256;
+    constexpr int W1V = (BN2 * 37 + 255) / 256;
     extern __shared__ __attribute__((aligned(16))) unsigned char hsm[];
     unsigned char* s_halo = hsm;                             // 340 x 64 B   (also the epilogue tile later)
-    unsigned char* s_w = s_halo + HALO_PX * 64;              // 32 x wrow halfs (second conv, this chunk)
-    unsigned char* s_in = s_w + BN * h.wrow * 2;             // 432 x 16 B   (frame patch)
-    unsigned char* s_w0 = s_in + PATCH_PX * 16;              // 32 x pre.wrow halfs (first conv, this group)
+    unsigned char* s_w = s_halo + HALO_PX * 64;              // BN2 x wrow halfs (second conv, this chunk)
+    unsigned char* s_in = s_w + BN2 * h.wrow * 2;            // 432 x CK0*2 B (input patch)
+    unsigned char* s_w0 = s_in + PATCH_PX * CK0 * 2;         // 32 x pre.wrow halfs (first conv, this group)
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
     int bid = blockIdx.x;
@@ -666,70 +674,81 @@ __global__ __launch_bounds__(256) void inputcv_kernel(const ConvKArgs a, const H
     const long img_base = (long)a.seg_xoff[0] + (long)n * h.H * h.W;
     const int frow = lane & 15, fch = lane >> 4;
 
-    f32x4 acc[TN][TM];
+    f32x4 acc[TN2][TM];
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+    for (int i = 0; i < TN2; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
     int pbase[TM];
 #pragma unroll
     for (int j = 0; j < TM; ++j) pbase[j] = (2 * wave + (j >> 1)) * (HALO_TW + 2) + (j & 1) * 16 + frow;
 
-    const int nvec_w = BN * (h.wrow >> 3);
+    constexpr int cv0 = CK0 / 8;
+    const int nvec_w = BN2 * (h.wrow >> 3);
     const int nvec_w0 = BN * (pre.wrow >> 3);
     for (int g = 0; g < h.n_chunks; ++g) {
         const _Float16* xg = g == 0 ? a.x0 : (g == 1 ? a.x1 : a.x2);
-        // ---- loads of this group: frame patch, first-conv weights, second-conv chunk weights
-        uint4 preg[2], w0reg[2], wreg[5];
+        // ---- loads of this group: input patch, first-conv weights, second-conv chunk weights
+        uint4 preg[PV], w0reg[W0V], wreg[W1V];
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < PV; ++i) {
             const int v = tid + i * 256;
             uint4 val = make_uint4(0, 0, 0, 0);
-            if (v < PATCH_PX) {
-                const int py = v / PATCH_W, px = v - py * PATCH_W;
+            if (v < PATCH_PX * cv0) {
+                const int pp = v / cv0, c8 = v - pp * cv0;
+                const int py = pp / PATCH_W, px = pp - py * PATCH_W;
                 const int gy = ty0 + py - 2, gx = tx0 + px - 2;
                 if ((unsigned)gy < (unsigned)h.H && (unsigned)gx < (unsigned)h.W)
-                    val = *reinterpret_cast<const uint4*>(xg + (img_base + (long)gy * h.W + gx) * a.x_ld);
+                    val = *reinterpret_cast<const uint4*>(xg + (img_base + (long)gy * h.W + gx) * a.x_ld + c8 * 8);
             }
             preg[i] = val;
         }
         const _Float16* w0src = pre.w + (long)g * BN * pre.wrow;
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < W0V; ++i) {
             const int v = tid + i * 256;
             w0reg[i] = v < nvec_w0 ? *reinterpret_cast<const uint4*>(w0src + (long)v * 8) : make_uint4(0, 0, 0, 0);
         }
-        const _Float16* wsrc = h.w + ((long)g * BN) * h.wrow;
+        const _Float16* wsrc = h.w + ((long)g * BN2) * h.wrow;
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < W1V; ++i) {
             const int v = tid + i * 256;
             wreg[i] = v < nvec_w ? *reinterpret_cast<const uint4*>(wsrc + (long)v * 8) : make_uint4(0, 0, 0, 0);
         }
         if (g > 0) __syncthreads();                            // previous chunk's fragment reads are done
 #pragma unroll
-        for (int i = 0; i < 2; ++i) {
+        for (int i = 0; i < PV; ++i) {
             const int v = tid + i * 256;
-            if (v < PATCH_PX) *reinterpret_cast<uint4*>(s_in + v * 16) = preg[i];
+            if (v < PATCH_PX * cv0) {
+                const int pp = v / cv0, c8 = v - pp * cv0;
+                *reinterpret_cast<uint4*>(s_in + halo_off(pp, c8, CK0)) = preg[i];
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < W0V; ++i) {
+            const int v = tid + i * 256;
             if (v < nvec_w0) *reinterpret_cast<uint4*>(s_w0 + v * 16) = w0reg[i];
         }
 #pragma unroll
-        for (int i = 0; i < 5; ++i) {
+        for (int i = 0; i < W1V; ++i) {
             const int v = tid + i * 256;
             if (v < nvec_w) *reinterpret_cast<uint4*>(s_w + v * 16) = wreg[i];
         }
         __syncthreads();
-        // ---- stage A: first conv on the halo tile (22 M-tiles of 16 halo pixels, K = 9 taps x 8 ch -> 3 k-steps)
+        // ---- stage A: first conv on the halo tile (22 M-tiles of 16 halo pixels), k = tap*CK0 + c
         for (int mt = wave; mt < NMT; mt += 4) {
             const int hp = mt * 16 + frow;                     // halo pixel of this lane's B column
             const int hpc = hp < HALO_PX ? hp : HALO_PX - 1;
             const int hy = hpc / (HALO_TW + 2), hx = hpc - hy * (HALO_TW + 2);
             f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
-            for (int ks = 0; ks < 3; ++ks) {
-                int tap = ks * 4 + fch;
-                tap = tap > 8 ? 8 : tap;                       // k >= 72: zero weights
+            for (int ks = 0; ks < NKS0; ++ks) {
+                const int kvec = ks * 4 + fch;
+                int tap = kvec / cv0;
+                const int c8 = kvec - tap * cv0;
+                tap = tap > 8 ? 8 : tap;                       // k beyond 9*CK0: zero weights
                 const int tr = tap / 3, tq = tap - tr * 3;
-                const f16x8 bf = *reinterpret_cast<const f16x8*>(s_in + ((hy + tr) * PATCH_W + hx + tq) * 16);
+                const f16x8 bf = *reinterpret_cast<const f16x8*>(s_in + halo_off((hy + tr) * PATCH_W + hx + tq, c8, CK0));
                 const f16x8 a0 = *reinterpret_cast<const f16x8*>(s_w0 + ((frow) * pre.wrow + ks * 32 + fch * 8) * 2);
                 const f16x8 a1 = *reinterpret_cast<const f16x8*>(s_w0 + ((16 + frow) * pre.wrow + ks * 32 + fch * 8) * 2);
                 c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bf, c0, 0, 0, 0);
@@ -756,15 +775,15 @@ __global__ __launch_bounds__(256) void inputcv_kernel(const ConvKArgs a, const H
         for (int ks = 0; ks < 9; ++ks) {
             const int tr = ks / 3, tq = ks - tr * 3;
             const int poff = tr * (HALO_TW + 2) + tq;
-            f16x8 af[TN], bf[TM];
+            f16x8 af[TN2], bf[TM];
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
+            for (int i = 0; i < TN2; ++i)
                 af[i] = *reinterpret_cast<const f16x8*>(s_w + ((i * 16 + frow) * h.wrow + ks * 32 + fch * 8) * 2);
 #pragma unroll
             for (int j = 0; j < TM; ++j)
                 bf[j] = *reinterpret_cast<const f16x8*>(s_halo + halo_off(pbase[j] + poff, fch, 32));
 #pragma unroll
-            for (int i = 0; i < TN; ++i)
+            for (int i = 0; i < TN2; ++i)
 #pragma unroll
                 for (int j = 0; j < TM; ++j)
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
@@ -776,7 +795,7 @@ __global__ __launch_bounds__(256) void inputcv_kernel(const ConvKArgs a, const H
         const int oy = ty0 + (prow >> 5), ox = tx0 + (prow & 31);
         return (oy < h.H && ox < h.W) ? (int)(((long)n * h.H + oy) * h.W + ox) : -1;
     };
-    constexpr int TS = BN + 8;
+    constexpr int TS = BN2 + 8;
     _Float16* tile = reinterpret_cast<_Float16*>(hsm);
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
@@ -785,7 +804,7 @@ __global__ __launch_bounds__(256) void inputcv_kernel(const ConvKArgs a, const H
         EpiCtx c;
         if (m >= 0) epi_locate(a, m, c);
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
+        for (int i = 0; i < TN2; ++i) {
             const int col = i * 16 + fch * 4;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (m >= 0 && col < a.cout) epi_compute(a, c, col, v);
@@ -794,7 +813,7 @@ __global__ __launch_bounds__(256) void inputcv_kernel(const ConvKArgs a, const H
         }
     }
     __syncthreads();
-    staged_store<BN, 256>(a, tile, 0, 0, row_to_m);
+    staged_store<BN2, 256>(a, tile, 0, 0, row_to_m);
 }
 
 template <int BN>
@@ -1029,21 +1048,29 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
 }
 
 
-extern "C" int llv_inputcvblock_fwd(const llv_inputcv_desc* p, void* stream) {
+static int convpair_launch(const llv_inputcv_desc* p, void* stream, bool output_block) {
     if (!p || !p->w_pre || !p->bias_pre) return LLV_E_BADARG;
     const llv_conv_desc* d = &p->conv;
     if (!d->w_halo || !d->bias || !d->y || d->n_seg != 1 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1) return LLV_E_BADARG;
-    if (d->n_src != 3 || !d->x[0] || !d->x[1] || !d->x[2] || d->x_ld < 8 || (d->x_ld & 7)) return LLV_E_BADARG;
-    if (d->cin != 96 || d->cout < 4 || d->cout > 32 || (d->cout & 7) || d->groups != 1 || (d->y_ld & 7) || d->y_ld < d->cout) return LLV_E_BADARG;
-    if (d->flags & ~(LLV_CONV_RELU)) return LLV_E_BADARG;
+    if (d->groups != 1 || (d->y_ld & 7) || d->y_ld < d->cout || (d->cout & 7) || d->cout < 8) return LLV_E_BADARG;
     if (d->seg_h[0] < 1 || d->seg_w[0] < 1 || d->seg_ho[0] != d->seg_h[0] || d->seg_wo[0] != d->seg_w[0] || d->batch < 1) return LLV_E_BADARG;
     const long px = (long)d->batch * d->seg_h[0] * d->seg_w[0];
     if (d->seg_xoff[0] < 0 || d->seg_yoff[0] < 0 || d->seg_xoff[0] + px > 0x7fffffffL || d->seg_yoff[0] + px > 0x7fffffffL) return LLV_E_BADARG;
     ConvKArgs k = {};
-    k.x0 = (const _Float16*)d->x[0]; k.x1 = (const _Float16*)d->x[1]; k.x2 = (const _Float16*)d->x[2];
-    k.bias = d->bias; k.y = d->y; k.res = nullptr;
-    k.n_src = 3; k.src_cvec = 1; k.x_ld = d->x_ld; k.y_ld = d->y_ld; k.res_ld = 0;
-    k.cin = 96; k.cout = d->cout; k.kh = 3; k.kw = 3; k.stride = 1; k.pad = 1; k.n_seg = 1;
+    if (!output_block) {
+        if (d->n_src != 3 || !d->x[0] || !d->x[1] || !d->x[2] || d->x_ld < 8 || (d->x_ld & 7)) return LLV_E_BADARG;
+        if (d->cin != 96 || d->cout != 32 || (d->flags & ~(LLV_CONV_RELU))) return LLV_E_BADARG;
+    } else {
+        if (d->n_src != 1 || !d->x[0] || d->x_ld < 32 || (d->x_ld & 7)) return LLV_E_BADARG;
+        if (d->cin != 32 || d->cout > 16 || (d->flags & ~(LLV_CONV_RELU | LLV_CONV_RES_RSUB | LLV_CONV_RES_ADD))) return LLV_E_BADARG;
+        if ((d->flags & (LLV_CONV_RES_RSUB | LLV_CONV_RES_ADD)) && (!d->res || (d->res_ld & 3) || d->res_ld < d->cout)) return LLV_E_BADARG;
+    }
+    k.x0 = (const _Float16*)d->x[0];
+    k.x1 = (const _Float16*)(output_block ? d->x[0] : d->x[1]);
+    k.x2 = (const _Float16*)(output_block ? d->x[0] : d->x[2]);
+    k.bias = d->bias; k.y = d->y; k.res = (const _Float16*)d->res;
+    k.n_src = d->n_src; k.src_cvec = 1; k.x_ld = d->x_ld; k.y_ld = d->y_ld; k.res_ld = d->res_ld;
+    k.cin = d->cin; k.cout = d->cout; k.kh = 3; k.kw = 3; k.stride = 1; k.pad = 1; k.n_seg = 1;
     for (int s = 0; s < LLV_MAX_SEG; ++s) {
         k.seg_h[s] = d->seg_h[0]; k.seg_w[s] = d->seg_w[0]; k.seg_ho[s] = d->seg_h[0]; k.seg_wo[s] = d->seg_w[0];
         k.seg_xoff[s] = (int)d->seg_xoff[0]; k.seg_yoff[s] = (int)d->seg_yoff[0]; k.seg_m0[s] = 0;
@@ -1054,11 +1081,24 @@ extern "C" int llv_inputcvblock_fwd(const llv_inputcv_desc* p, void* stream) {
     h.w = (const _Float16*)d->w_halo;
     h.H = d->seg_h[0]; h.W = d->seg_w[0];
     h.tiles_x = (h.W + HALO_TW - 1) / HALO_TW; h.tiles_y = (h.H + HALO_TH - 1) / HALO_TH;
-    h.ck = 32; h.n_chunks = 3; h.kc_pad = 288; h.wrow = 296; h.ntiles_n = 1;
+    h.ck = 32; h.n_chunks = output_block ? 1 : 3; h.kc_pad = 288; h.wrow = 296; h.ntiles_n = 1;
     h.nblk = h.tiles_x * h.tiles_y * d->batch; h.w_gstride = 0;
     PreArgs pre;
-    pre.w = (const _Float16*)p->w_pre; pre.bias = p->bias_pre; pre.wrow = 104;
-    const size_t lds = (size_t)HALO_PX * 64 + (size_t)32 * h.wrow * 2 + (size_t)PATCH_PX * 16 + (size_t)32 * pre.wrow * 2;
-    hipLaunchKernelGGL(inputcv_kernel, dim3(h.nblk), dim3(256), lds, (hipStream_t)stream, k, h, pre);
+    pre.w = (const _Float16*)p->w_pre; pre.bias = p->bias_pre; pre.wrow = output_block ? 296 : 104;
+    const int ck0 = output_block ? 32 : 8, bn2 = output_block ? 16 : 32;
+    size_t lds = (size_t)HALO_PX * 64 + (size_t)bn2 * h.wrow * 2 + (size_t)PATCH_PX * ck0 * 2 + (size_t)32 * pre.wrow * 2;
+    const size_t epi = (size_t)256 * (bn2 + 8) * 2;
+    if (lds < epi) lds = epi;
+    static bool attr_done = false;
+    if (!attr_done) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convpair_kernel<32, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convpair_kernel<8, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
+        attr_done = true;
+    }
+    if (output_block) hipLaunchKernelGGL((convpair_kernel<32, 16>), dim3(h.nblk), dim3(256), lds, (hipStream_t)stream, k, h, pre);
+    else hipLaunchKernelGGL((convpair_kernel<8, 32>), dim3(h.nblk), dim3(256), lds, (hipStream_t)stream, k, h, pre);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
+
+extern "C" int llv_inputcvblock_fwd(const llv_inputcv_desc* p, void* stream) { return convpair_launch(p, stream, false); }
+extern "C" int llv_outputcvblock_fwd(const llv_inputcv_desc* p, void* stream) { return convpair_launch(p, stream, true); }

@@ -26,6 +26,7 @@ import os as _os
 HALO = _os.environ.get('LLV_HALO', '1') != '0'
 HALO_MAX_COUT = int(_os.environ.get('LLV_HALO_MAX_COUT', '128'))
 FUSE_INPUTCV = _os.environ.get('LLV_FUSE_INPUTCV', '1') != '0'
+FUSE_OUTPUTCV = _os.environ.get('LLV_FUSE_OUTPUTCV', '1') != '0'
 ARCH = {18: ('basic', (2, 2, 2, 2)), 34: ('basic', (3, 4, 6, 3)), 50: ('bottleneck', (3, 4, 6, 3)),
         101: ('bottleneck', (3, 4, 23, 3)), 152: ('bottleneck', (3, 8, 36, 3))}
 
@@ -406,7 +407,7 @@ class RetinaNetPlan:
 # ------------------------------------------------------------------------------------------------
 # FastDVDnet
 # ------------------------------------------------------------------------------------------------
-def _denblock(b: Builder, sd, p, srcs, batch, tag):
+def _denblock(b: Builder, sd, p, srcs, batch, tag, out):
     """One DenBlock over `batch` images whose three input frames are srcs[0..2] (each a view (batch,H,W,8):
     image n of source s is frame n+s of a clip, so consecutive windows share memory). FastDVDnet.py:102-116."""
     f = CONV_RELU
@@ -477,11 +478,29 @@ def _denblock(b: Builder, sd, p, srcs, batch, tag):
     x2 = down(x1, p + 'downc1.', 'down1')
     x1s = up(x2, p + 'upc2.', 'up2', x1)                     # = x1 + upc2(x2)
     x0s = up(x1s, p + 'upc1.', 'up1', x0)                    # = x0 + upc1(x1 + x2)
-    x = cbr(f'{tag}.out0', x0s, p + 'outc.convblock.0', p + 'outc.convblock.1')
-    pc = ops.pack_conv(sd[p + 'outc.convblock.3.weight'], None, 1, 1, cout_store=8)
+    # OutputCvBlock (FastDVDnet.py:64-74) + the DenBlock residual in1 - x (:115)
+    pc0 = ops.pack_conv(sd[p + 'outc.convblock.0.weight'], None, 1, 1, bn=_bn(sd, p + 'outc.convblock.1'), eps=BN_EPS)
+    pc1 = ops.pack_conv(sd[p + 'outc.convblock.3.weight'], None, 1, 1, cout_store=8)
     if HALO:
-        ops.add_halo_packing(pc)
-    return pc, x
+        ops.add_halo_packing(pc0)
+        ops.add_halo_packing(pc1)
+    res = srcs[1]
+    if HALO and FUSE_OUTPUTCV and pc0.cin == 32 and pc0.cout == 32 and pc1.halo_bn == 16 and pc0.halo_bn == 32:
+        from ._lib import InputCvDesc
+        n, hh, ww, _ = x0s.shape
+        pc0.to(b.dev)
+        pc1.to(b.dev)
+        d = InputCvDesc()
+        d.conv = ops.make_conv_desc(pc1, [x0s], out, n, [(hh, ww, hh, ww, 0, 0)], x0s.shape[-1], out.shape[-1], res, res.shape[-1],
+                                    CONV_RES_RSUB)
+        d.w_pre, d.bias_pre = pc0.w_halo.data_ptr(), pc0.bias.data_ptr()
+        m = n * hh * ww
+        b.plan.keep += [pc0, pc1, d, x0s, out, res]
+        b.plan.add(f'{tag}.outputcv', lib().llv_outputcvblock_fwd, (C.byref(d),), 2.0 * m * (pc0.true_macs_per_pixel + pc1.true_macs_per_pixel),
+                   2.0 * m * (32 + 8 + 8))
+    else:
+        x = b.conv(f'{tag}.out0', x0s, pc0, f)
+        b.conv(f'{tag}.out1', x, pc1, CONV_RES_RSUB, res=res, out=out)
 
 
 class FastDVDnetPlan:
@@ -506,11 +525,9 @@ class FastDVDnetPlan:
         self.out = out if out is not None else b.buf(batch, height, width, 8)
         p1, p2 = prefix + 'temp1.', prefix + 'temp2.'
         srcs = [self.frames[s:s + n1] for s in range(3)]
-        pc, x = _denblock(b, sd, p1, srcs, n1, 'temp1')
-        b.conv(f'temp1.out1', x, pc, CONV_RES_RSUB, res=srcs[1], out=self.mid)      # in1 - x   (:115)
+        _denblock(b, sd, p1, srcs, n1, 'temp1', self.mid)
         srcs2 = [self.mid[s:s + batch] for s in range(3)]
-        pc, x = _denblock(b, sd, p2, srcs2, batch, 'temp2')
-        b.conv(f'temp2.out1', x, pc, CONV_RES_RSUB, res=srcs2[1], out=self.out)
+        _denblock(b, sd, p2, srcs2, batch, 'temp2', self.out)
 
 
 # ------------------------------------------------------------------------------------------------

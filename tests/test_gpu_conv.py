@@ -391,3 +391,31 @@ def test_fused_inputcvblock(dev, n, h, w):
     mid = F.relu(F.conv2d(torch.cat(frames, 1), wg, b0, 1, 1, 1, 3)).half().float()
     ref = F.relu(F.conv2d(mid, w2, b2, 1, 1))
     _check(y, ref, 32)
+
+
+@pytest.mark.parametrize('n,h,w', [(1, 16, 32), (2, 21, 50)])
+def test_fused_outputcvblock(dev, n, h, w):
+    """llv_outputcvblock_fwd == in1 - Conv2d(32,3,3)(ReLU(BN(Conv2d(32,32,3)(x)))) (FastDVDnet.py:64-74,115)."""
+    import ctypes as C
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    from lowlightenvironmentvideoobjectdetection_amd._lib import InputCvDesc, check, lib
+    g = torch.Generator().manual_seed(81 + n)
+    x = torch.randn(n, 32, h, w, generator=g).half().float()
+    w0 = (torch.randn(32, 32, 3, 3, generator=g) / 17.0).half().float()
+    b0 = torch.randn(32, generator=g) * 0.1
+    w1 = (torch.randn(3, 32, 3, 3, generator=g) / 17.0).half().float()
+    in1 = torch.zeros(n, h, w, 8, dtype=torch.float16)
+    in1[..., :3] = torch.randn(n, h, w, 3, generator=g).half()
+    pc0 = ops.add_halo_packing(ops.pack_conv(w0, b0, 1, 1)).to(dev)
+    pc1 = ops.add_halo_packing(ops.pack_conv(w1, None, 1, 1, cout_store=8)).to(dev)
+    xd = _nhwc(x).half().to(dev)
+    y = torch.zeros(n, h, w, 8, dtype=torch.float16, device=dev)
+    d = InputCvDesc()
+    d.conv = ops.make_conv_desc(pc1, [xd], y, n, [(h, w, h, w, 0, 0)], 32, 8, in1.to(dev), 8, ops.CONV_RES_RSUB)
+    res_keep = in1.to(dev)
+    d.conv.res = res_keep.data_ptr()
+    d.w_pre, d.bias_pre = pc0.w_halo.data_ptr(), pc0.bias.data_ptr()
+    check(lib().llv_outputcvblock_fwd(C.byref(d), C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'llv_outputcvblock_fwd')
+    mid = F.relu(F.conv2d(x, w0, b0, 1, 1)).half().float()
+    ref = in1.float().permute(0, 3, 1, 2)[:, :3] - F.conv2d(mid, w1, None, 1, 1)
+    _check(y, ref, 3)
