@@ -70,7 +70,7 @@ extern "C" {
 #define LLV_CONV_PIXSHUF 8     /* store through nn.PixelShuffle(2): out (2Ho,2Wo,cout/4) */
 #define LLV_CONV_RES_UPS 16    /* res is (res_h,res_w), nearest-upsampled to (Ho,Wo) (fpn.py:185-191) */
 #define LLV_CONV_OUT_F32 32    /* y is fp32 instead of fp16 */
-#define LLV_CONV_RELU_IN_RES 64 /* reserved */
+#define LLV_CONV_LEAKY 64      /* y = y > 0 ? y : act_slope*y last (FlowNetSimple LeakyReLU(0.1), flownet_simple.py:66-68) */
 
 /*
  * One convolution launch, implicit GEMM on MFMA (fp16 in, fp32 accumulate).
@@ -123,6 +123,9 @@ typedef struct llv_conv_desc {
     /* != 0: group g writes channels [0, cout) of its own plane y + g*y_group_stride (fp16 elements, multiple of 8)
      * instead of channels [g*cout, (g+1)*cout) of one interleaved tensor; the consumer reads the planes as n_src sources. */
     int64_t y_group_stride;
+    float act_slope;               /* negative slope for LLV_CONV_LEAKY */
+    int32_t ps_out_h, ps_out_w;    /* LLV_CONV_PIXSHUF: stored extent (<= 2Ho x 2Wo; 0 = full). A 4x4/stride-2/pad-1 transposed conv is
+                                      a 3x3 conv to 4*Cout channels + this shuffle; the crop is FlowNetSimple.crop_like (flownet_simple.py:246-251) */
 } llv_conv_desc;
 
 #define LLV_TILE_AUTO 0
@@ -255,6 +258,15 @@ int llv_embed_aggregate(const void* x_embed, const void* ref_embed, const void* 
  * from the references (mmtracking/mmtrack/models/vid/llvod.py:201-206). */
 int llv_embed_aggregate_ring(const void* embed, const void* feat, void* out, int n_slots, int key_slot, int64_t hw,
                              int c, int embed_ld, int feat_ld, int out_ld, void* stream);
+
+/* FlowNetSimple.prepare_imgs (flownet_simple.py:149-190) for image pairs: x (n,6,h,w) NCHW fp32 normalised images ->
+ * y (n, ho, wo, 8) NHWC fp16: v = x*scale[c] + shift[c] (de-normalise, /255, -flow mean folded by the caller), zero for
+ * rows >= img_h / cols >= img_w, bilinear resize (align_corners=False) by scale_factor = wo/w; channels 6,7 zero. */
+int llv_flow_prepare(const float* x, void* y, int n, int h, int w, int ho, int wo, int img_h, int img_w,
+                     const float* scale, const float* shift, float resize_scale, void* stream);
+/* F.interpolate(x, scale_factor=s, mode='bilinear', align_corners=False) * mul on NCHW fp32 (flownet_simple.py:236-242). */
+int llv_bilinear_resize_f32(const float* x, float* y, int nc, int h, int w, int ho, int wo, float scale_factor, float mul,
+                            void* stream);
 
 /* flow_warp_feats: x NHWC fp16 (n,h,w,c), flow NCHW fp32 (n,2,hf,wf) -> y NHWC fp16. */
 int llv_flow_warp(const void* x, const float* flow, void* y, int n, int h, int w, int c, int ld, int hf,

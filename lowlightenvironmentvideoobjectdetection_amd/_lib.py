@@ -20,6 +20,7 @@ CONV_RES_RSUB = 4
 CONV_PIXSHUF = 8
 CONV_RES_UPS = 16
 CONV_OUT_F32 = 32
+CONV_LEAKY = 64
 
 TILE_AUTO, TILE_128x128, TILE_64x256, TILE_32x256, TILE_16x256, TILE_64x64 = 0, 1, 2, 3, 4, 5
 TILE_256x128, TILE_128x256 = 6, 7
@@ -54,6 +55,8 @@ class ConvDesc(C.Structure):
         ('w_halo', C.c_void_p),
         ('halo_bn', C.c_int32),
         ('y_group_stride', C.c_int64),
+        ('act_slope', C.c_float),
+        ('ps_out_h', C.c_int32), ('ps_out_w', C.c_int32),
     ]
 
 
@@ -110,6 +113,8 @@ SIGNATURES = {
     'llv_nms': (_I, [_P, _P, _I, _F, _P, _P, _P, _Z, _P]),
     'llv_embed_aggregate': (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
     'llv_embed_aggregate_ring': (_I, [_P, _P, _P, _I, _I, _L, _I, _I, _I, _I, _P]),
+    'llv_flow_prepare': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P]),
+    'llv_bilinear_resize_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P]),
     'llv_flow_warp': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'llv_sigmoid_focal_loss_fwd': (_I, [_P, _P, _P, _L, _I, _F, _F, _P]),
     'llv_sigmoid_focal_loss_bwd': (_I, [_P, _P, _P, _L, _I, _F, _F, _P]),

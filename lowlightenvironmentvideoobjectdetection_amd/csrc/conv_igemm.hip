@@ -45,6 +45,8 @@ struct ConvKArgs {
     int m_total;
     long w_gstride;  // elements between groups in w
     int src_per_group;  // groups == n_src: group g reads source tensor g
+    float act_slope;    // LLV_CONV_LEAKY: y = y > 0 ? y : act_slope * y
+    int ps_h, ps_w;     // PIXSHUF: stored output extent (<= 2Ho, 2Wo): crop_like of a transposed conv
     long y_gstride;     // != 0: group g writes its own plane y + g*y_gstride (channel index restarts at 0)
     int stage_out;      // epilogue goes through an LDS tile so that global stores are full 16-byte vectors
     int k_splits;       // > 1: blockIdx.z owns k-steps [z*nk_per, ...) and writes fp32 partials to ws
@@ -85,6 +87,12 @@ __device__ __forceinline__ void epi_locate(const ConvKArgs& a, int m, EpiCtx& c)
     }
 }
 
+__device__ __forceinline__ float act_fn(const ConvKArgs& a, float v) {
+    if (a.flags & LLV_CONV_RELU) return fmaxf(v, 0.f);
+    if (a.flags & LLV_CONV_LEAKY) return v > 0.f ? v : a.act_slope * v;
+    return v;
+}
+
 // bias / residual / ReLU on 4 consecutive channels. With PIXSHUF the residual and ReLU are applied at the
 // shuffled output location instead (epi_store_direct / the staged store), so only the bias is added here.
 __device__ __forceinline__ void epi_compute(const ConvKArgs& a, const EpiCtx& c, int gco, float (&v)[4]) {
@@ -102,9 +110,9 @@ __device__ __forceinline__ void epi_compute(const ConvKArgs& a, const EpiCtx& c,
             for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
         }
     }
-    if (flags & LLV_CONV_RELU) {
+    if (flags & (LLV_CONV_RELU | LLV_CONV_LEAKY)) {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) v[e] = fmaxf(v[e], 0.f);
+        for (int e = 0; e < 4; ++e) v[e] = act_fn(a, v[e]);
     }
 }
 
@@ -124,10 +132,11 @@ __device__ __forceinline__ void epi_store(const ConvKArgs& a, const EpiCtx& c, i
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
             const int dy = e >> 1, dx = e & 1;
-            const long p = (long)c.yo + ((long)(c.n * 2 * c.Ho + 2 * c.oy + dy)) * (2 * c.Wo) + (2 * c.ox + dx);
+            if (2 * c.oy + dy >= a.ps_h || 2 * c.ox + dx >= a.ps_w) continue;
+            const long p = (long)c.yo + ((long)(c.n * a.ps_h + 2 * c.oy + dy)) * a.ps_w + (2 * c.ox + dx);
             float o = v[e];
             if (flags & LLV_CONV_RES_ADD) o += (float)a.res[p * a.res_ld + cc];
-            if (flags & LLV_CONV_RELU) o = fmaxf(o, 0.f);
+            o = act_fn(a, o);
             reinterpret_cast<_Float16*>(a.y)[p * a.y_ld + cc] = (_Float16)o;
         }
         return;
@@ -175,7 +184,8 @@ __device__ __forceinline__ void staged_store(const ConvKArgs& a, const _Float16*
             EpiCtx c;
             epi_locate(a, m, c);
             const int dy = e >> 1, dx = e & 1;
-            const long p = (long)c.yo + ((long)(c.n * 2 * c.Ho + 2 * c.oy + dy)) * (2 * c.Wo) + (2 * c.ox + dx);
+            if (2 * c.oy + dy >= a.ps_h || 2 * c.ox + dx >= a.ps_w) continue;
+            const long p = (long)c.yo + ((long)(c.n * a.ps_h + 2 * c.oy + dy)) * a.ps_w + (2 * c.ox + dx);
             const int occ = (g * a.cout + co) >> 2;         // first output channel
             const _Float16* src = tile + prow * TS + o8 * 32 + e;
             float v[8];
@@ -186,9 +196,9 @@ __device__ __forceinline__ void staged_store(const ConvKArgs& a, const _Float16*
 #pragma unroll
                 for (int t = 0; t < 8; ++t) v[t] += (float)r8[t];
             }
-            if (a.flags & LLV_CONV_RELU) {
+            if (a.flags & (LLV_CONV_RELU | LLV_CONV_LEAKY)) {
 #pragma unroll
-                for (int t = 0; t < 8; ++t) v[t] = fmaxf(v[t], 0.f);
+                for (int t = 0; t < 8; ++t) v[t] = act_fn(a, v[t]);
             }
             f16x8 o8v;
 #pragma unroll
@@ -969,7 +979,7 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
             // range or predicated off, but the output extent must not exceed the conv formula.
             if (Ho > (H + 2 * d->pad - d->kh) / d->stride + 1 || Wo > (W + 2 * d->pad - d->kw) / d->stride + 1) return LLV_E_BADARG;
             const long xend = d->seg_xoff[s] + (long)d->batch * H * W;
-            const long yend = d->seg_yoff[s] + (long)d->batch * Ho * Wo * ((f & LLV_CONV_PIXSHUF) ? 4 : 1);
+            const long yend = d->seg_yoff[s] + (long)d->batch * Ho * Wo * ((f & LLV_CONV_PIXSHUF) ? 4 : 1);  // upper bound (cropped shuffle stores fewer)
             if (d->seg_xoff[s] < 0 || d->seg_yoff[s] < 0 || xend > 0x7fffffffL || yend > 0x7fffffffL) return LLV_E_BADARG;
         }
         k.seg_h[s] = H; k.seg_w[s] = W; k.seg_ho[s] = Ho; k.seg_wo[s] = Wo;
@@ -983,6 +993,13 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
     k.flags = f; k.res_h = d->res_h; k.res_w = d->res_w;
     k.w_gstride = (long)d->w_rows * d->k_pad;
     k.src_per_group = (d->n_src > 1 && d->groups == d->n_src) ? 1 : 0;
+    k.act_slope = d->act_slope;
+    k.ps_h = 2 * d->seg_ho[0]; k.ps_w = 2 * d->seg_wo[0];
+    if ((f & LLV_CONV_PIXSHUF) && d->ps_out_h > 0 && d->ps_out_w > 0) {
+        if (d->ps_out_h > k.ps_h || d->ps_out_w > k.ps_w) return LLV_E_BADARG;
+        k.ps_h = d->ps_out_h; k.ps_w = d->ps_out_w;
+    }
+    if ((f & LLV_CONV_RELU) && (f & LLV_CONV_LEAKY)) return LLV_E_BADARG;
     k.y_gstride = d->y_group_stride;
     if (d->y_group_stride) {
         if (d->y_group_stride < 0 || (f & (LLV_CONV_OUT_F32 | LLV_CONV_PIXSHUF)) || d->y_ld < d->cout || (d->y_group_stride & 7)) return LLV_E_BADARG;
@@ -1077,6 +1094,7 @@ static int convpair_launch(const llv_inputcv_desc* p, void* stream, bool output_
     }
     k.seg_m0[LLV_MAX_SEG] = (int)px; k.m_total = (int)px;
     k.flags = d->flags; k.stage_out = 1; k.k_splits = 1; k.y_gstride = 0; k.src_per_group = 0;
+    k.act_slope = 0.f; k.ps_h = 0; k.ps_w = 0;
     HaloArgs h;
     h.w = (const _Float16*)d->w_halo;
     h.H = d->seg_h[0]; h.W = d->seg_w[0];

@@ -210,7 +210,87 @@ __global__ void flow_warp_kernel(const _Float16* __restrict__ x, const float* __
     }
 }
 
+// bilinear sample of plane f (h x w) at PyTorch's align_corners=False source coordinate of output (oy, ox)
+__device__ __forceinline__ float bilerp_plane(const float* f, int h, int w, float sy, float sx) {
+    sy = sy < 0.f ? 0.f : sy;
+    sx = sx < 0.f ? 0.f : sx;
+    int y0 = (int)sy, x0 = (int)sx;
+    y0 = y0 < h - 1 ? y0 : h - 1;
+    x0 = x0 < w - 1 ? x0 : w - 1;
+    const int y1 = y0 < h - 1 ? y0 + 1 : y0, x1 = x0 < w - 1 ? x0 + 1 : x0;
+    const float ly = sy - (float)y0, lx = sx - (float)x0;
+    const float hy = 1.f - ly, hx = 1.f - lx;
+    return hy * (hx * f[y0 * w + x0] + lx * f[y0 * w + x1]) + ly * (hx * f[y1 * w + x0] + lx * f[y1 * w + x1]);
+}
+
+__global__ void bilinear_resize_kernel(const float* __restrict__ x, float* __restrict__ y, int nc, int h, int w, int ho,
+                                       int wo, float rscale, float mul) {
+    const long total = (long)nc * ho * wo;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % wo);
+        const long t = i / wo;
+        const int oy = (int)(t % ho);
+        const long p = t / ho;
+        const float sy = ((float)oy + 0.5f) * rscale - 0.5f, sx = ((float)ox + 0.5f) * rscale - 0.5f;
+        y[i] = bilerp_plane(x + p * h * w, h, w, sy, sx) * mul;
+    }
+}
+
+// FlowNetSimple.prepare_imgs: affine per channel, zero outside the un-padded image, bilinear resize, NHWC8 fp16
+__global__ void flow_prepare_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int n, int h, int w, int ho,
+                                    int wo, int img_h, int img_w, const float* __restrict__ scale,
+                                    const float* __restrict__ shift, float rscale) {
+    const long total = (long)n * ho * wo;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int ox = (int)(i % wo);
+        const long t = i / wo;
+        const int oy = (int)(t % ho);
+        const long b = t / ho;
+        float sy = ((float)oy + 0.5f) * rscale - 0.5f, sx = ((float)ox + 0.5f) * rscale - 0.5f;
+        sy = sy < 0.f ? 0.f : sy;
+        sx = sx < 0.f ? 0.f : sx;
+        int y0 = (int)sy, x0 = (int)sx;
+        y0 = y0 < h - 1 ? y0 : h - 1;
+        x0 = x0 < w - 1 ? x0 : w - 1;
+        const int y1 = y0 < h - 1 ? y0 + 1 : y0, x1 = x0 < w - 1 ? x0 + 1 : x0;
+        const float ly = sy - (float)y0, lx = sx - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+        f16x8 o;
+#pragma unroll
+        for (int c = 0; c < 8; ++c) {
+            float v = 0.f;
+            if (c < 6) {
+                const float* f = x + (b * 6 + c) * (long)h * w;
+                const float sc = scale[c], sh = shift[c];
+                auto px = [&](int yy, int xx) { return (yy < img_h && xx < img_w) ? f[yy * w + xx] * sc + sh : 0.f; };
+                v = hy * (hx * px(y0, x0) + lx * px(y0, x1)) + ly * (hx * px(y1, x0) + lx * px(y1, x1));
+            }
+            o[c] = (_Float16)v;
+        }
+        *reinterpret_cast<f16x8*>(y + i * 8) = o;
+    }
+}
+
 }  // namespace
+
+extern "C" int llv_flow_prepare(const float* x, void* y, int n, int h, int w, int ho, int wo, int img_h, int img_w,
+                                const float* scale, const float* shift, float resize_scale, void* stream) {
+    if (!x || !y || !scale || !shift || n < 1 || h < 1 || w < 1 || ho < 1 || wo < 1 || !(resize_scale > 0.f)) return LLV_E_BADARG;
+    if ((int)floor((double)h * (double)resize_scale) != ho || (int)floor((double)w * (double)resize_scale) != wo) return LLV_E_BADARG;
+    const long total = (long)n * ho * wo;
+    hipLaunchKernelGGL(flow_prepare_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, x, (_Float16*)y, n, h, w,
+                       ho, wo, img_h, img_w, scale, shift, 1.f / resize_scale);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_bilinear_resize_f32(const float* x, float* y, int nc, int h, int w, int ho, int wo, float scale_factor,
+                                       float mul, void* stream) {
+    if (!x || !y || nc < 1 || h < 1 || w < 1 || ho < 1 || wo < 1 || !(scale_factor > 0.f)) return LLV_E_BADARG;
+    if ((int)floor((double)h * (double)scale_factor) != ho || (int)floor((double)w * (double)scale_factor) != wo) return LLV_E_BADARG;
+    const long total = (long)nc * ho * wo;
+    hipLaunchKernelGGL(bilinear_resize_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, x, y, nc, h, w, ho, wo,
+                       1.f / scale_factor, mul);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
 
 extern "C" int llv_maxpool3x3s2_nhwc(const void* x, void* y, int batch, int h, int w, int c, void* stream) {
     if (!x || !y || batch < 1 || h < 1 || w < 1 || c < 8 || (c & 7)) return LLV_E_BADARG;

@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import ops
-from ._lib import (CONV_OUT_F32, CONV_PIXSHUF, CONV_RELU, CONV_RES_ADD, CONV_RES_RSUB, CONV_RES_UPS, LlvError, lib)
+from ._lib import (CONV_LEAKY, CONV_OUT_F32, CONV_PIXSHUF, CONV_RELU, CONV_RES_ADD, CONV_RES_RSUB, CONV_RES_UPS, LlvError, lib)
 
 BN_EPS = 1e-5
 # direct (halo-in-LDS) 3x3 kernel for the FastDVDnet layers: on by default; LLV_HALO=0 falls back to implicit GEMM
@@ -119,9 +119,10 @@ class Builder:
         return t
 
     def conv_desc(self, name, pc: ops.PackedConv, xs, y, batch, segs, x_ld, y_ld, res=None, res_ld=0, flags=0,
-                  res_hw=(0, 0), tile=0, y_group_stride=0):
+                  res_hw=(0, 0), tile=0, y_group_stride=0, act_slope=0.0, ps_out=(0, 0)):
         pc.to(self.dev)
-        d = ops.make_conv_desc(pc, xs, y, batch, segs, x_ld, y_ld, res, res_ld, flags, res_hw, tile, 0, y_group_stride)
+        d = ops.make_conv_desc(pc, xs, y, batch, segs, x_ld, y_ld, res, res_ld, flags, res_hw, tile, 0, y_group_stride,
+                               act_slope, ps_out)
         m = sum(batch * s[2] * s[3] for s in segs)
         flops = 2.0 * m * pc.true_macs_per_pixel
         nbytes = 2.0 * (sum(batch * s[0] * s[1] for s in segs) * pc.cin * pc.groups + m * pc.cout * pc.groups) + \
@@ -598,3 +599,110 @@ class EnhanceDetectPlan:
             r = self.res_host[n, :k]
             out.append((r[:, :5].clone(), r[:, 5].long()))
         return out
+
+
+# ------------------------------------------------------------------------------------------------
+# FlowNetSimple
+# ------------------------------------------------------------------------------------------------
+class FlowNetPlan:
+    """FlowNetSimple.forward (mmtracking/mmtrack/models/motion/flownet_simple.py:192-244) for `batch` image pairs of
+    size (h, w): prepare (de-normalise, mask, bilinear x img_scale_factor) -> 9 strided/plain convs with LeakyReLU(0.1)
+    -> 4 refinement levels (predict_flow, 4x4/s2 transposed convs as 3x3 conv + PixelShuffle with crop_like, concat by
+    writing into channel slices of one buffer) -> predict_flow -> bilinear x(4/img_scale_factor), x flow scale.
+    Input: self.pairs (batch, 6, h, w) fp32 NCHW (img, ref stacked on C, as dff.py:211 builds it). Output: self.flow
+    (batch, 2, h', w') fp32 NCHW with h' = floor(floor(h*s)/4 ... ) as the reference's arithmetic gives."""
+    CONV = dict(inplanes=(6, 64, 128, 256, 512, 512), kernel_size=(7, 5, 5, 3, 3, 3), num_convs=(1, 1, 2, 2, 2, 2))
+    DECONV_IN = (386, 770, 1026, 1024)
+
+    def __init__(self, sd, batch, height, width, device, img_scale_factor=0.5, flow_scale_factor=5.0,
+                 flow_img_norm_std=(255.0, 255.0, 255.0), flow_img_norm_mean=(0.411, 0.432, 0.450),
+                 img_norm_mean=(123.675, 116.28, 103.53), img_norm_std=(58.395, 57.12, 57.375), img_shape=None):
+        import math
+        b = Builder(device)
+        self.builder, self.plan, self.batch = b, b.plan, batch
+        sd = _cpu_sd(sd)
+        s = float(img_scale_factor)
+        ho, wo = int(math.floor(height * s)), int(math.floor(width * s))
+        self.pairs = b.buf(batch, 6, height, width, dtype=torch.float32)
+        # flow_img = (x*std + mean)/flow_std - flow_mean  ==  x*scale + shift   (flownet_simple.py:178-179)
+        sc = [img_norm_std[c % 3] / flow_img_norm_std[c % 3] for c in range(6)]
+        sh = [img_norm_mean[c % 3] / flow_img_norm_std[c % 3] - flow_img_norm_mean[c % 3] for c in range(6)]
+        self.scale = torch.tensor(sc, device=device, dtype=torch.float32)
+        self.shift = torch.tensor(sh, device=device, dtype=torch.float32)
+        x0 = b.buf(batch, ho, wo, 8)
+        ih, iw = (img_shape[0], img_shape[1]) if img_shape is not None else (height, width)
+        self._prep_args = [C.c_void_p(self.pairs.data_ptr()), C.c_void_p(x0.data_ptr()), batch, height, width, ho, wo, ih, iw,
+                           C.c_void_p(self.scale.data_ptr()), C.c_void_p(self.shift.data_ptr()), C.c_float(s)]
+        b.plan.keep += [self.scale, self.shift]
+        b.plan.add('flow.prepare', lib().llv_flow_prepare, tuple(self._prep_args), 0.0, 4.0 * self.pairs.numel())
+        self._prep_step = len(b.plan.steps) - 1
+        leaky = dict(flags=CONV_LEAKY, act_slope=0.1)
+        # ---- encoder; conv2..conv6 outputs are skip connections: each is written straight into the channel slice
+        # [0, C) of the concat buffer its refinement level reads (concat = cat(conv_out, deconv_out, upflow))
+        inpl, ks, ncv = self.CONV['inplanes'], self.CONV['kernel_size'], self.CONV['num_convs']
+        planes_of = [inpl[i + 1] if i < 5 else 2 * inpl[5] for i in range(6)]         # 64,128,256,512,512,1024
+        deconv_planes = {2: 64, 3: 128, 4: 256, 5: 512}                                 # deconv{i} output channels
+        x, xh, xw, xc = x0, ho, wo, 8
+        skips = {}
+        for i in range(6):
+            pl = planes_of[i]
+            for j in range(ncv[i]):
+                k = ks[i] if (j == 0 or i != 2) else 3
+                k = ks[i] if j == 0 else (3 if i == 2 else ks[i])
+                stride = 2 if j == 0 else 1
+                wt = sd[f'conv{i + 1}.{j}.conv.weight']
+                in_map = None
+                if i == 0 and j == 0:
+                    in_map = [0, 1, 2, 3, 4, 5, -1, -1]
+                pc = ops.pack_conv(wt, sd.get(f'conv{i + 1}.{j}.conv.bias'), stride, (k - 1) // 2, in_map=in_map)
+                oh, ow = ops.conv_out_size(xh, xw, pc)
+                last = j == ncv[i] - 1
+                if last and 1 <= i <= 4:          # conv2..conv5 outputs head a concat buffer: [conv | deconv | upflow(2->8)]
+                    tot = pl + deconv_planes[i + 1] + 8
+                    out = b.buf(batch, oh, ow, tot)
+                else:
+                    tot = pl
+                    out = b.buf(batch, oh, ow, pl)
+                b.conv_desc(f'flow.conv{i + 1}.{j}', pc, [x], out, batch, [(xh, xw, oh, ow, 0, 0)], xc, tot, **leaky)
+                x, xh, xw, xc = out, oh, ow, tot
+            skips[i + 1] = (x, xh, xw, pl, xc)      # conv{i+1}: buffer, h, w, real channels, ld
+        # ---- refinement (flownet_simple.py:217-233): i = 4..1 over conv_outs = (conv2..conv6)
+        cat_buf, ch, cw, c_real, cld = skips[6]
+        cat_map = list(range(1024))                 # padded channel -> original channel of concat_out
+        for lvl in (5, 4, 3, 2):                    # deconv5..deconv2 / predict_flow6..3 / upsample_flow5..2
+            tgt, th, tw, tc, tld = skips[lvl]       # conv_outs[i-1]
+            dpl = deconv_planes[lvl]
+            # flow = predict_flow{lvl+1}(concat_out): 3x3, no bias, no activation -> 8-channel buffer (2 real)
+            pcf = ops.pack_conv(sd[f'predict_flow{lvl + 1}.conv.weight'], None, 1, 1, in_map=cat_map, cout_store=8)
+            fl = b.buf(batch, ch, cw, 8)
+            b.conv_desc(f'flow.predict_flow{lvl + 1}', pcf, [cat_buf], fl, batch, [(ch, cw, ch, cw, 0, 0)], cld, 8)
+            # upflow = crop_like(upsample_flow{lvl}(flow)) -> channels [tc+dpl, tc+dpl+2) of the target's concat buffer
+            pcu = ops.pack_deconv4x4s2(sd[f'upsample_flow{lvl}.conv.weight'], None, in_map=[0, 1, -1, -1, -1, -1, -1, -1])
+            b.conv_desc(f'flow.upsample_flow{lvl}', pcu, [fl], tgt[..., tc + dpl:], batch, [(ch, cw, ch, cw, 0, 0)], 8, tld,
+                        flags=CONV_PIXSHUF, ps_out=(th, tw))
+            # deconv_out = crop_like(deconv{lvl}(concat_out)) + LeakyReLU -> channels [tc, tc+dpl)
+            pcd = ops.pack_deconv4x4s2(sd[f'deconv{lvl}.conv.weight'], None, in_map=cat_map)
+            b.conv_desc(f'flow.deconv{lvl}', pcd, [cat_buf], tgt[..., tc:], batch, [(ch, cw, ch, cw, 0, 0)], cld, tld,
+                        flags=CONV_PIXSHUF | CONV_LEAKY, act_slope=0.1, ps_out=(th, tw))
+            cat_buf, ch, cw, cld = tgt, th, tw, tld
+            cat_map = list(range(tc + dpl)) + [tc + dpl, tc + dpl + 1] + [-1] * 6
+        pcf = ops.pack_conv(sd['predict_flow.conv.weight'], None, 1, 1, in_map=cat_map, cout_store=8)
+        fl = b.buf(batch, ch, cw, 8)
+        b.conv_desc('flow.predict_flow', pcf, [cat_buf], fl, batch, [(ch, cw, ch, cw, 0, 0)], cld, 8)
+        # ---- NHWC fp16 (2 real channels) -> NCHW fp32, bilinear x(4/s), x(4/s)*flow_scale (flownet_simple.py:235-242)
+        fl32 = b.buf(batch, 2, ch, cw, dtype=torch.float32)
+        b.plan.add('flow.unpack', lib().llv_unpack_nhwc_f16_to_nchw_f32,
+                   (C.c_void_p(fl.data_ptr()), C.c_void_p(fl32.data_ptr()), batch, 2, ch, cw, 8), 0.0, 0.0)
+        up = 4.0 / s
+        fh, fw = int(math.floor(ch * up)), int(math.floor(cw * up))
+        self.flow = b.buf(batch, 2, fh, fw, dtype=torch.float32)
+        b.plan.add('flow.upsample', lib().llv_bilinear_resize_f32,
+                   (C.c_void_p(fl32.data_ptr()), C.c_void_p(self.flow.data_ptr()), batch * 2, ch, cw, fh, fw, C.c_float(up),
+                    C.c_float(up * flow_scale_factor)), 0.0, 0.0)
+
+    def set_img_shape(self, img_shape):
+        """The un-padded image extent masks the flow image (flownet_simple.py:180-181): host-side edit of the launch args."""
+        a = list(self._prep_args)
+        a[7], a[8] = int(img_shape[0]), int(img_shape[1])
+        name, fn, _, fl, nb = self.plan.steps[self._prep_step]
+        self.plan.steps[self._prep_step] = (name, fn, tuple(a), fl, nb)

@@ -11,7 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
-from ._lib import (CONV_OUT_F32, CONV_PIXSHUF, CONV_RELU, CONV_RES_ADD, CONV_RES_RSUB, CONV_RES_UPS,
+from ._lib import (CONV_LEAKY, CONV_OUT_F32, CONV_PIXSHUF, CONV_RELU, CONV_RES_ADD, CONV_RES_RSUB, CONV_RES_UPS,
                    ConvDesc, DecodeDesc, LlvError, check, lib)
 
 
@@ -181,7 +181,7 @@ def conv_out_size(h, w, pc: PackedConv):
 def make_conv_desc(pc: PackedConv, xs: Sequence[torch.Tensor], y: torch.Tensor, batch: int,
                    segs: Sequence[tuple], x_ld: int, y_ld: int, res: Optional[torch.Tensor] = None,
                    res_ld: int = 0, flags: int = 0, res_hw=(0, 0), tile: int = 0, k_splits: int = 0,
-                   y_group_stride: int = 0) -> ConvDesc:
+                   y_group_stride: int = 0, act_slope: float = 0.0, ps_out=(0, 0)) -> ConvDesc:
     """segs: [(h, w, ho, wo, x_pixel_off, y_pixel_off), ...]"""
     d = ConvDesc()
     for i in range(_lib.LLV_MAX_SRC):
@@ -205,6 +205,8 @@ def make_conv_desc(pc: PackedConv, xs: Sequence[torch.Tensor], y: torch.Tensor, 
     d.k_splits = k_splits
     d.workspace, d.workspace_bytes = 0, 0
     d.y_group_stride = y_group_stride
+    d.act_slope = act_slope
+    d.ps_out_h, d.ps_out_w = ps_out
     if pc.w_halo is not None and len(segs) == 1 and tile == 0 and segs[0][0] == segs[0][2] and segs[0][1] == segs[0][3]:
         d.w_halo, d.halo_bn = pc.w_halo.data_ptr(), pc.halo_bn
     else:
@@ -538,3 +540,25 @@ def iou_assign(gt_bboxes, anchors, valid=None, pos_iou_thr=0.5, neg_iou_thr=0.4,
                                int(match_low_quality), int(gt_max_assign_all), _ptr(assigned), _ptr(max_ov), _ptr(ws), wsb,
                                _stream()), 'llv_iou_assign')
     return assigned, max_ov
+
+
+def pack_deconv4x4s2(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, in_map=None) -> PackedConv:
+    """nn.ConvTranspose2d(Cin, Cout, 4, stride=2, padding=1) as a 3x3/pad-1 conv to 4*Cout channels followed by
+    PixelShuffle(2) (LLV_CONV_PIXSHUF): output (2y+dy, 2x+dx) only sees inputs y-1..y+1, x-1..x+1, with
+    tap r (input row y+r-1) <- kernel row {dy=0: r0->3, r1->1; dy=1: r1->2, r2->0} (same for columns), zero elsewhere.
+    weight: (Cin, Cout, 4, 4) as torch stores it (flownet_simple.py:95-104 deconv layers)."""
+    cin, cout = weight.shape[0], weight.shape[1]
+    w = weight.detach().double().cpu()
+    w3 = torch.zeros(cout * 4, cin, 3, 3, dtype=torch.float64)
+    kmap = {0: {0: 3, 1: 1}, 1: {1: 2, 2: 0}}       # parity -> {3x3 tap: 4x4 kernel index}
+    for dy in (0, 1):
+        for dx in (0, 1):
+            for r, ky in kmap[dy].items():
+                for q, kx in kmap[dx].items():
+                    w3[dy * 2 + dx::4, :, r, q] = w[:, :, ky, kx].t()
+    b3 = None
+    if bias is not None:
+        b3 = bias.detach().double().cpu().repeat_interleave(4)
+    pc = pack_conv(w3.float(), b3.float() if b3 is not None else None, 1, 1, in_map=in_map)
+    pc.true_macs_per_pixel = cout * cin * 16 // 4 * 4   # per INPUT pixel: 16 taps x Cin x Cout (4 outputs x 4 taps each)
+    return pc

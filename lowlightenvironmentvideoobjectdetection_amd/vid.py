@@ -304,3 +304,206 @@ class LLVOD(BaseVideoDetector):
         plan['b'].run()
         dets, labels = plan['post'].results()[0]
         return dict(bbox_results=bbox2result(dets, labels, self.detector.bbox_head.num_classes))
+
+
+class _StagePlans:
+    """Plan pieces shared by the flow-based video detectors: stage A = backbone + FPN of `batch` frames into a pyramid,
+    stage B = RetinaHead + decode + NMS reading ONE frame's pyramid from `cur`."""
+
+    def __init__(self, det, h, w, device, batch_a):
+        sd = engine._cpu_sd(det.state_dict())
+        bb, neck, head = det.backbone, det.neck, det.bbox_head
+        self.a = {}
+        for n in sorted(set(batch_a)):
+            ba = engine.Builder(device)
+            x_in = ba.buf(n, h, w, 8)
+            feats = engine.build_resnet(ba, sd, x_in, p='backbone.', **bb.plan_kwargs())
+            pyr = engine.build_fpn(ba, sd, feats, p='neck.', **neck.plan_kwargs())
+            self.a[n] = (ba.plan, x_in, pyr)
+        p1 = self.a[min(self.a)][2]
+        bh = engine.Builder(device)
+        self.cur = engine.Pyramid(bh.buf(sum(hh * ww for hh, ww in p1.level_hw), p1.buf.shape[-1]), p1.level_hw,
+                                  [sum(a * b for a, b in p1.level_hw[:i]) for i in range(len(p1.level_hw))], 1)
+        cls_buf, reg_buf = engine.build_retina_head(bh, sd, self.cur, head.stacked_convs, True, p='bbox_head.')
+        self.post = engine.PostProcess(bh, cls_buf, reg_buf, self.cur, head.cls_out_channels, head.anchor_generator,
+                                       dict(head.test_cfg) if head.test_cfg else engine.DEFAULT_TEST_CFG, head.bbox_coder.means,
+                                       head.bbox_coder.stds, [(h, w, 3)], None, False, head.bbox_coder.clip_border)
+        self.b = bh.plan
+        self.num_classes = head.num_classes
+
+    def extract(self, frames):
+        """frames (n,3,H,W) fp32 GPU -> the stage-A pyramid of batch n (valid until the next extract of that batch)."""
+        n = frames.shape[0]
+        plan, x_in, pyr = self.a[n]
+        ops.pack_input(frames.float().contiguous(), 8, out=x_in)
+        plan.run()
+        return pyr
+
+    def detect(self, img_metas, rescale):
+        self.post.set_metas(img_metas, rescale)
+        self.b.run()
+        dets, labels = self.post.results()[0]
+        return dict(bbox_results=bbox2result(dets, labels, self.num_classes))
+
+
+def _warp_pyramid(src_levels, flow, dst_levels):
+    """flow_warp_feats per FPN level (mmtracking/mmtrack/core/motion/flow.py:4-41): src/dst lists of (n,h,w,C) fp16."""
+    for s, d in zip(src_levels, dst_levels):
+        n, hh, ww, c = s.shape
+        ops.check(ops.lib().llv_flow_warp(ops._ptr(s), ops._ptr(flow), ops._ptr(d), n, hh, ww, c, c, flow.shape[2], flow.shape[3],
+                                          ops._stream()), 'llv_flow_warp')
+
+
+@MODELS.register_module()
+class DFF(BaseVideoDetector):
+    """Deep Feature Flow (mmtracking/mmtrack/models/vid/dff.py:11-282) for a dense-head detector: every
+    `test_cfg.key_frame_interval`-th frame runs backbone + FPN and caches image and pyramid; the frames in between
+    run FlowNetSimple on (frame, key frame) and warp the cached pyramid (dff.py:205-216), then the head."""
+
+    def __init__(self, detector, motion, pretrains=None, frozen_modules=None, train_cfg=None, test_cfg=None):
+        super().__init__()
+        from .registry import build_motion
+        self.detector = build_detector(detector)
+        self.motion = build_motion(motion)
+        if hasattr(self.detector, 'roi_head'):
+            raise LlvError('DFF here drives a dense-head (single-stage) detector; two-stage is out of scope')
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg or dict()
+        self.memo = None
+        self.init_weights(pretrains)
+        if frozen_modules is not None:
+            self.freeze_module(frozen_modules)
+
+    def init_weights(self, pretrain):
+        if pretrain is None:
+            pretrain = dict()
+        assert isinstance(pretrain, dict), '`pretrain` must be a dict.'
+        if self.with_detector and pretrain.get('detector', False):
+            self.init_module('detector', pretrain['detector'])
+        if self.with_motion:
+            self.init_module('motion', pretrain.get('motion', None))
+
+    def invalidate_plans(self):
+        super().invalidate_plans()
+        self.memo = None
+        for m in self.children():
+            if isinstance(m, PlannedModule):
+                m.invalidate_plans()
+
+    def forward_train(self, img, img_metas, **kwargs):
+        raise LlvError('DFF.forward_train: the training path is not built yet in this round')
+
+    def simple_test(self, img, img_metas, ref_img=None, ref_img_metas=None, rescale=False, **kwargs):
+        self._check_input(img)
+        assert len(img) == 1, 'Dff video detectors only support 1 batch size per gpu for now.'
+        n, c, h, w = img.shape
+        st = self._plan(('stages', h, w, str(img.device)), lambda: _StagePlans(self.detector, h, w, img.device, [1]))
+        key_frame_interval = self.test_cfg.get('key_frame_interval', 10)
+        frame_id = img_metas[0].get('frame_id', -1)
+        assert frame_id >= 0
+        is_key_frame = frame_id % key_frame_interval == 0
+        if is_key_frame or self.memo is None:
+            pyr = st.extract(img)
+            self.memo = dict(img=img.float().clone(), feats=[pyr.level(l).clone() for l in range(len(pyr.level_hw))])
+            st.cur.buf.copy_(pyr.buf)
+        else:
+            flow_img = torch.cat((img.float(), self.memo['img']), dim=1)          # dff.py:211
+            flow = self.motion(flow_img, img_metas)
+            _warp_pyramid(self.memo['feats'], flow.contiguous(), [st.cur.level(l) for l in range(len(st.cur.level_hw))])
+        return st.detect(img_metas, rescale)
+
+
+@MODELS.register_module()
+class FGFA(BaseVideoDetector):
+    """Flow-Guided Feature Aggregation (mmtracking/mmtrack/models/vid/fgfa.py:12-384) for a dense-head detector,
+    test-time adaptive-stride branch (`frame_stride < 1`, fgfa.py:222-231,266-283): the reference frames given with
+    frame 0 stay in the memo; every frame: backbone + FPN, FlowNetSimple on (frame, each memo frame), warp the memo
+    pyramids, EmbedAggregator(x, cat(x, warped)) per level, head."""
+
+    def __init__(self, detector, motion, aggregator, pretrains=None, frozen_modules=None, train_cfg=None, test_cfg=None):
+        super().__init__()
+        from .registry import build_aggregator, build_motion
+        self.detector = build_detector(detector)
+        self.motion = build_motion(motion)
+        self.aggregator = build_aggregator(aggregator)
+        if hasattr(self.detector, 'roi_head'):
+            raise LlvError('FGFA here drives a dense-head (single-stage) detector; two-stage is out of scope')
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.memo = None
+        self.init_weights(pretrains)
+        if frozen_modules is not None:
+            self.freeze_module(frozen_modules)
+
+    def init_weights(self, pretrain):
+        if pretrain is None:
+            pretrain = dict()
+        assert isinstance(pretrain, dict), '`pretrain` must be a dict.'
+        if self.with_detector and pretrain.get('detector', False):
+            self.init_module('detector', pretrain['detector'])
+        if self.with_motion:
+            self.init_module('motion', pretrain.get('motion', None))
+        if self.with_aggregator and pretrain.get('aggregator', False):
+            self.init_module('aggregator', pretrain['aggregator'])
+
+    def invalidate_plans(self):
+        super().invalidate_plans()
+        self.memo = None
+        for m in self.children():
+            if isinstance(m, PlannedModule):
+                m.invalidate_plans()
+
+    def forward_train(self, img, img_metas, **kwargs):
+        raise LlvError('FGFA.forward_train: the training path is not built yet in this round')
+
+    def _agg_plan(self, st, n_ref, device):
+        """Embedding convs over the (1 + n_ref) frames of every level in one multi-segment launch + the tail per level."""
+        from .aggregators import embed_packed_convs
+        ag = self.aggregator
+        nb = n_ref + 1
+        hw = st.cur.level_hw
+        b = engine.Builder(device)
+        offs, tot = [], 0
+        for hh, ww in hw:
+            offs.append(tot)
+            tot += nb * hh * ww
+        c = st.cur.buf.shape[-1]
+        stack = engine.Pyramid(b.buf(tot, c), hw, offs, nb)       # per level: slot 0 = x, 1.. = warped references
+        emb = stack.buf
+        for i, (pc, flags) in enumerate(embed_packed_convs(engine._cpu_sd(ag.state_dict()), ag.num_convs)):
+            nxt = b.buf(tot, pc.cout)
+            b.conv_desc(f'embed{i}', pc, [emb], nxt, nb, stack.segs(), emb.shape[-1], nxt.shape[-1], flags=flags)
+            emb = nxt
+        for l, (hh, ww) in enumerate(hw):
+            e_l, s_l = stack.level(l, emb), stack.level(l)
+            b.plan.add(f'aggregate{l}', ops.lib().llv_embed_aggregate,
+                       (ops._ptr(e_l[0:1]), ops._ptr(e_l), ops._ptr(s_l), ops._ptr(st.cur.level(l)), nb, hh * ww, c, emb.shape[-1], c, c))
+        b.plan.keep += [emb]
+        return b.plan, stack
+
+    def simple_test(self, img, img_metas, ref_img=None, ref_img_metas=None, rescale=False, **kwargs):
+        self._check_input(img)
+        assert len(img) == 1, 'fgfa video detectors only support 1 batch size per gpu for now.'
+        n, c, h, w = img.shape
+        frame_id = img_metas[0].get('frame_id', -1)
+        assert frame_id >= 0
+        if img_metas[0].get('frame_stride', -1) >= 1:
+            raise LlvError('FGFA fixed-stride test mode (frame_stride >= 1) is not built; use the adaptive-stride sampler')
+        if frame_id == 0 or self.memo is None:
+            if ref_img is None:
+                raise LlvError('frame 0 of a video needs ref_img (fgfa.py:224-230)')
+            refs = ref_img[0] if isinstance(ref_img, (list, tuple)) else ref_img
+            refs = (refs[0] if refs.dim() == 5 else refs).float().contiguous()
+            nr = refs.shape[0]
+            st = self._plan(('stages', h, w, nr, str(img.device)), lambda: _StagePlans(self.detector, h, w, img.device, [1, nr]))
+            pyr = st.extract(refs)
+            self.memo = dict(img=refs, nr=nr, feats=[pyr.level(l).clone() for l in range(len(pyr.level_hw))])
+        nr = self.memo['nr']
+        st = self._plan(('stages', h, w, nr, str(img.device)), lambda: _StagePlans(self.detector, h, w, img.device, [1, nr]))
+        agg_plan, stack = self._plan(('agg', h, w, nr, str(img.device)), lambda: self._agg_plan(st, nr, img.device))
+        x = st.extract(img)
+        flow_imgs = torch.cat((img.float().repeat(nr, 1, 1, 1), self.memo['img']), dim=1)      # fgfa.py:270-272
+        flows = self.motion(flow_imgs, img_metas).contiguous()
+        for l in range(len(x.level_hw)):
+            stack.level(l)[0:1].copy_(x.level(l))
+        _warp_pyramid(self.memo['feats'], flows, [stack.level(l)[1:] for l in range(len(x.level_hw))])
+        agg_plan.run()
+        return st.detect(img_metas, rescale)

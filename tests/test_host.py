@@ -29,7 +29,8 @@ def test_registry_build_from_cfg_errors():
     for name, reg in [('RetinaNet', registry.DETECTORS), ('ResNet', registry.BACKBONES), ('FPN', registry.NECKS),
                       ('RetinaHead', registry.HEADS), ('AnchorHead', registry.HEADS), ('FocalLoss', registry.LOSSES),
                       ('L1Loss', registry.LOSSES), ('SmoothL1Loss', registry.LOSSES), ('FastDVDnet', registry.CLEANER),
-                      ('FastDVDnetDetect', registry.MODELS), ('LLVOD', registry.MODELS), ('EmbedAggregator', registry.AGGREGATORS),
+                      ('FastDVDnetDetect', registry.MODELS), ('LLVOD', registry.MODELS), ('DFF', registry.MODELS), ('FGFA', registry.MODELS), ('EmbedAggregator', registry.AGGREGATORS),
+                      ('FlowNetSimple', registry.MOTION),
                       ('AnchorGenerator', registry.ANCHOR_GENERATORS),
                       ('DeltaXYWHBBoxCoder', registry.BBOX_CODERS), ('MaxIoUAssigner', registry.BBOX_ASSIGNERS),
                       ('PseudoSampler', registry.BBOX_SAMPLERS)]:
