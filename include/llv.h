@@ -134,8 +134,7 @@ typedef struct llv_conv_desc {
 #define LLV_TILE_32x256 3
 #define LLV_TILE_16x256 4
 #define LLV_TILE_64x64 5
-#define LLV_TILE_256x128 6
-#define LLV_TILE_128x256 7
+#define LLV_TILE_128x128_REGSTAGE 6 /* 128x128 with register-staged loads (the round's first kernel; kept for A/B) */
 
 int llv_abi_version(void);
 const char* llv_strerror(int code);

@@ -23,7 +23,7 @@ CONV_OUT_F32 = 32
 CONV_LEAKY = 64
 
 TILE_AUTO, TILE_128x128, TILE_64x256, TILE_32x256, TILE_16x256, TILE_64x64 = 0, 1, 2, 3, 4, 5
-TILE_256x128, TILE_128x256 = 6, 7
+TILE_128x128_REGSTAGE = 6
 
 
 class LlvError(RuntimeError):

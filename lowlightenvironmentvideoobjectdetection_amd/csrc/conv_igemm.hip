@@ -462,6 +462,219 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
 
 
 // ------------------------------------------------------------------------------------------------
+// conv_igemm_glds_kernel<BN,BM,WN,WM>: the implicit GEMM every plan uses (BN x BM x 32 tile), with the operand tiles written
+// straight into LDS by global_load_lds_dwordx4 (no VGPR staging, no ds_write pass). The LDS image of one
+// wave-instruction is lane-linear (16 rows x 4 chunks of 16 B), so the bank swizzle is applied to the SOURCE
+// address: lane (row = l>>2, physical chunk = l&3) fetches logical chunk (l&3) ^ f(row). Padding taps and
+// tail rows read a 16-byte zero page. Next k-step's loads are in flight while this one's MFMAs run.
+// ------------------------------------------------------------------------------------------------
+__device__ __attribute__((aligned(16))) const unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
+
+template <int BN, int BM, int WN, int WM>
+__global__ __launch_bounds__(256, (BN * BM >= 128 * 128 ? 3 : 4)) void conv_igemm_glds_kernel(const ConvKArgs a) {
+    constexpr int WAVES_N = BN / WN;
+    constexpr int WAVES_M = BM / WM;
+    static_assert(WAVES_N * WAVES_M == 4, "4 waves per workgroup");
+    constexpr int TN = WN / 16, TM = WM / 16;
+    constexpr int STAGE = (BN + BM) * 64;
+    constexpr int TS = BN + 8;
+    constexpr int EPI = BM * TS * 2;
+    constexpr int SMEM = 2 * STAGE > EPI ? 2 * STAGE : EPI;
+    constexpr int NWI = BN / 16, NPI = BM / 16;              // wave-instructions per k-step: weights, pixels (16 rows each)
+    constexpr int WPW = (NWI + 3) / 4, PPW = (NPI + 3) / 4;  // per wave (wave w takes instructions w, w+4, ...)
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int wn = wave % WAVES_N, wm = wave / WAVES_N;
+    int bid = blockIdx.x;
+    {
+        const int nblk = a.nblk;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    const int tile_n = bid % a.tiles_n, tile_m = bid / a.tiles_n;
+    const int g = blockIdx.y;
+    const _Float16* wbase = a.w + (long)g * a.w_gstride;
+    const int cvec = a.cin >> 3;
+
+    // this lane's slot inside a wave-instruction: row l>>2, physical chunk l&3 -> logical chunk
+    const int lrow = lane >> 2;
+    const int ch = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
+    const _Float16* zero = reinterpret_cast<const _Float16*>(g_zero_page);
+
+    int px_iy0[PPW], px_ix0[PPW], px_base[PPW], px_hw[PPW];
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int row = (wave + 4 * i) * 16 + lrow;
+        const int m = tile_m * BM + row;
+        px_iy0[i] = 0; px_ix0[i] = 0; px_base[i] = 0; px_hw[i] = 0;
+        if (wave + 4 * i < NPI && m < a.m_total) {
+            int H = a.seg_h[0], W = a.seg_w[0], Ho = a.seg_ho[0], Wo = a.seg_wo[0], m0 = 0, xo = a.seg_xoff[0];
+#pragma unroll
+            for (int s = 1; s < LLV_MAX_SEG; ++s) {
+                if (s < a.n_seg && m >= a.seg_m0[s]) {
+                    H = a.seg_h[s]; W = a.seg_w[s]; Ho = a.seg_ho[s]; Wo = a.seg_wo[s];
+                    m0 = a.seg_m0[s]; xo = a.seg_xoff[s];
+                }
+            }
+            const int ml = m - m0;
+            const int ox = ml % Wo;
+            const int t = ml / Wo;
+            const int oy = t % Ho;
+            const int n = t / Ho;
+            px_iy0[i] = oy * a.stride - a.pad;
+            px_ix0[i] = ox * a.stride - a.pad;
+            px_base[i] = xo + n * H * W;
+            px_hw[i] = (H << 16) | W;
+        }
+    }
+    const _Float16* wrow[WPW];
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+        const int grow = tile_n * BN + (wave + 4 * i) * 16 + lrow;
+        wrow[i] = (wave + 4 * i < NWI && grow < a.w_rows) ? wbase + (long)grow * a.k_pad + ch * 8 : nullptr;
+    }
+
+    const int ks_begin = blockIdx.z * a.nk_per;
+    const int nk_all = a.k_pad >> 5;
+    const int ks_end = (ks_begin + a.nk_per < nk_all) ? ks_begin + a.nk_per : nk_all;
+    int kc8, kr, kq;
+    {
+        const int kvec = ks_begin * 4 + ch;
+        const int tap = kvec / cvec;
+        kc8 = kvec - tap * cvec;
+        kr = tap / a.kw;
+        kq = tap - kr * a.kw;
+    }
+
+    auto issue = [&](int ks, int buf) {
+        unsigned char* sW = smem + buf * STAGE;
+        unsigned char* sX = sW + BN * 64;
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            if (wave + 4 * i < NWI) {       // wave-uniform
+                const _Float16* src = wrow[i] ? wrow[i] + ks * 32 : zero;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
+                                                 (__attribute__((address_space(3))) void*)(sW + (wave + 4 * i) * 1024), 16, 0, 0);
+            }
+        }
+        const _Float16* xb;
+        int cofs;
+        if (a.src_per_group) {
+            xb = g == 0 ? a.x0 : (g == 1 ? a.x1 : a.x2);
+            cofs = kc8 * 8;
+        } else if (a.n_src > 1) {
+            const int s = kc8 / a.src_cvec;
+            xb = s == 0 ? a.x0 : (s == 1 ? a.x1 : a.x2);
+            cofs = (kc8 - s * a.src_cvec) * 8;
+        } else {
+            xb = a.x0;
+            cofs = g * a.cin + kc8 * 8;
+        }
+        const bool tap_ok = kr < a.kh;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            if (wave + 4 * i < NPI) {
+                const int H = px_hw[i] >> 16, W = px_hw[i] & 0xffff;
+                const int y = px_iy0[i] + kr, x = px_ix0[i] + kq;
+                const _Float16* src = zero;
+                if (tap_ok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
+                    src = xb + (long)(px_base[i] + y * W + x) * a.x_ld + cofs;
+                __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
+                                                 (__attribute__((address_space(3))) void*)(sX + (wave + 4 * i) * 1024), 16, 0, 0);
+            }
+        }
+        kc8 += 4;
+        while (kc8 >= cvec) { kc8 -= cvec; if (++kq == a.kw) { kq = 0; ++kr; } }
+    };
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    const int nk = ks_end - ks_begin;
+    issue(ks_begin, 0);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    const int frow = lane & 15, fch = lane >> 4;
+    for (int ks = 0; ks < nk; ++ks) {
+        const int cur = ks & 1;
+        if (ks + 1 < nk) issue(ks_begin + ks + 1, cur ^ 1);
+        const unsigned char* sW = smem + cur * STAGE;
+        const unsigned char* sX = sW + BN * 64;
+        f16x8 af[TN], bf[TM];
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+            af[i] = *reinterpret_cast<const f16x8*>(sW + lds_off(wn * WN + i * 16 + frow, fch));
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+            bf[j] = *reinterpret_cast<const f16x8*>(sX + lds_off(wm * WM + j * 16 + frow, fch));
+#pragma unroll
+        for (int i = 0; i < TN; ++i)
+#pragma unroll
+            for (int j = 0; j < TM; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+    }
+
+    if (a.k_splits > 1) {
+        const int ctot = (int)gridDim.y * a.cout;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int m = tile_m * BM + wm * WM + j * 16 + frow;
+            if (m >= a.m_total) continue;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int co = tile_n * BN + wn * WN + i * 16 + fch * 4;
+                if (co >= a.cout) continue;
+                *reinterpret_cast<float4*>(a.ws + ((long)blockIdx.z * a.m_total + m) * ctot + g * a.cout + co) =
+                    make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+            }
+        }
+        return;
+    }
+    if (a.stage_out) {
+        _Float16* tile = reinterpret_cast<_Float16*>(smem);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int prow = wm * WM + j * 16 + frow;
+            const int m = tile_m * BM + prow;
+            EpiCtx c;
+            const bool mok = m < a.m_total;
+            if (mok) epi_locate(a, m, c);
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int col = wn * WN + i * 16 + fch * 4;
+                const int co = tile_n * BN + col;
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+                if (mok && co < a.cout) epi_compute(a, c, g * a.cout + co, v);
+                const f16x4 o4 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                *reinterpret_cast<f16x4*>(tile + prow * TS + col) = o4;
+            }
+        }
+        __syncthreads();
+        staged_store<BN, BM>(a, tile, g, tile_n, [&](int prow) { const int m = tile_m * BM + prow; return m < a.m_total ? m : -1; });
+        return;
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int m = tile_m * BM + wm * WM + j * 16 + frow;
+        if (m >= a.m_total) continue;
+        EpiCtx c;
+        epi_locate(a, m, c);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int co = tile_n * BN + wn * WN + i * 16 + fch * 4;
+            if (co >= a.cout) continue;
+            epi_store(a, c, g * a.cout + co, acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+        }
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // conv3x3_halo_kernel: direct 3x3 / stride 1 / pad 1 convolution for the full-resolution, few-channel layers
 // (FastDVDnet.py:22-74). One workgroup = an 8 x 32 pixel output tile x BN output channels. Per 32-channel
 // chunk of the input it stages the (8+2) x (32+2) pixel halo tile AND that chunk's weights in LDS once; all
@@ -855,9 +1068,26 @@ int launch(ConvKArgs& k, int groups, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
+template <int BN, int BM, int WN, int WM>
+int launch_glds(ConvKArgs& k, int groups, hipStream_t st) {
+    k.tiles_n = (k.cout + BN - 1) / BN;
+    const int tiles_m = (k.m_total + BM - 1) / BM;
+    k.nblk = k.tiles_n * tiles_m;
+    dim3 grid(k.nblk, groups, k.k_splits);
+    hipLaunchKernelGGL((conv_igemm_glds_kernel<BN, BM, WN, WM>), grid, dim3(256), 0, st, k);
+    if (k.k_splits > 1) {
+        const int ctot = groups * k.cout;
+        long work = (long)k.m_total * (ctot >> 2);
+        long gsz = (work + 255) / 256;
+        gsz = gsz > 2048 ? 2048 : (gsz < 1 ? 1 : gsz);
+        hipLaunchKernelGGL(splitk_epilogue_kernel, dim3((int)gsz), dim3(256), 0, st, k, ctot);
+    }
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
 void tile_dims(int tile, int& bn, int& bm) {
     switch (tile) {
-        case LLV_TILE_128x128: bn = 128; bm = 128; break;
+        case LLV_TILE_128x128: case LLV_TILE_128x128_REGSTAGE: bn = 128; bm = 128; break;
         case LLV_TILE_64x256: bn = 64; bm = 256; break;
         case LLV_TILE_32x256: bn = 32; bm = 256; break;
         case LLV_TILE_16x256: bn = 16; bm = 256; break;
@@ -1055,11 +1285,12 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
     const int tile = lp.tile;
     if ((f & LLV_CONV_PIXSHUF) && tile == LLV_TILE_16x256) k.stage_out = 0;
     switch (tile) {
-        case LLV_TILE_128x128: return launch<128, 128, 64, 64>(k, d->groups, st);
-        case LLV_TILE_64x256:  return launch<64, 256, 64, 64>(k, d->groups, st);
-        case LLV_TILE_32x256:  return launch<32, 256, 32, 64>(k, d->groups, st);
-        case LLV_TILE_16x256:  return launch<16, 256, 16, 64>(k, d->groups, st);
-        case LLV_TILE_64x64:   return launch<64, 64, 32, 32>(k, d->groups, st);
+        case LLV_TILE_128x128: return launch_glds<128, 128, 64, 64>(k, d->groups, st);
+        case LLV_TILE_64x256:  return launch_glds<64, 256, 64, 64>(k, d->groups, st);
+        case LLV_TILE_32x256:  return launch_glds<32, 256, 32, 64>(k, d->groups, st);
+        case LLV_TILE_16x256:  return launch_glds<16, 256, 16, 64>(k, d->groups, st);
+        case LLV_TILE_64x64:   return launch_glds<64, 64, 32, 32>(k, d->groups, st);
+        case LLV_TILE_128x128_REGSTAGE: return launch<128, 128, 64, 64>(k, d->groups, st);   // register-staged loop, kept for A/B
         default: return LLV_E_UNSUPPORTED;
     }
 }
