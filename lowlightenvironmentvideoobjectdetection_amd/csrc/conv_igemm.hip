@@ -14,6 +14,7 @@
 // Replaces torch.nn.Conv2d (+BN/ReLU/add/upsample/PixelShuffle) in the reference; see include/llv.h.
 
 #include <hip/hip_runtime.h>
+#include <type_traits>
 #include <hip/hip_fp16.h>
 #include "llv.h"
 
@@ -470,18 +471,35 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
 // ------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) const unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
 
-template <int BN, int BM, int WN, int WM>
-__global__ __launch_bounds__(256, (BN * BM >= 128 * 128 ? 3 : 4)) void conv_igemm_glds_kernel(const ConvKArgs a) {
+#ifndef GLDS_STAGES
+#define GLDS_STAGES 2
+#endif
+// LDS image of a BK-wide operand tile: row-major rows of BK halfs, 16-byte chunks XOR-swizzled so that both the
+// lane-linear DMA writes and the MFMA-fragment ds_read_b128 (16 rows x one chunk per 16-lane group) are conflict-free.
+template <int BK>
+__device__ __forceinline__ int glds_swz(int row) {
+    if constexpr (BK == 32) return (0 - (row >> 2)) & 3;
+    else return (row >> 1) & 7;
+}
+template <int BK>
+__device__ __forceinline__ int glds_off(int row, int ch) { return row * (BK * 2) + ((ch ^ glds_swz<BK>(row)) << 4); }
+
+template <int BN, int BM, int WN, int WM, int BK>
+__global__ __launch_bounds__(256, (BK == 64 ? 2 : (BN * BM >= 128 * 128 ? 3 : 4))) void conv_igemm_glds_kernel(const ConvKArgs a) {
     constexpr int WAVES_N = BN / WN;
     constexpr int WAVES_M = BM / WM;
     static_assert(WAVES_N * WAVES_M == 4, "4 waves per workgroup");
     constexpr int TN = WN / 16, TM = WM / 16;
-    constexpr int STAGE = (BN + BM) * 64;
+    constexpr int RB = BK * 2;                               // bytes per LDS row
+    constexpr int CPR = BK / 8;                              // 16-byte chunks per row
+    constexpr int RPP = 1024 / RB;                           // rows per wave-instruction ("piece" = 1 KiB)
+    constexpr int STAGE = (BN + BM) * RB;
     constexpr int TS = BN + 8;
     constexpr int EPI = BM * TS * 2;
-    constexpr int SMEM = 2 * STAGE > EPI ? 2 * STAGE : EPI;
-    constexpr int NWI = BN / 16, NPI = BM / 16;              // wave-instructions per k-step: weights, pixels (16 rows each)
-    constexpr int WPW = (NWI + 3) / 4, PPW = (NPI + 3) / 4;  // per wave (wave w takes instructions w, w+4, ...)
+    constexpr int NST = GLDS_STAGES;                         // LDS ring depth: NST-1 k-steps of loads in flight
+    constexpr int SMEM = NST * STAGE > EPI ? NST * STAGE : EPI;
+    constexpr int NWI = BN / RPP, NPI = BM / RPP;            // pieces per k-step: weights, pixels
+    constexpr int WPW = (NWI + 3) / 4, PPW = (NPI + 3) / 4;  // per wave (wave w takes pieces w, w+4, ...)
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
@@ -497,15 +515,15 @@ __global__ __launch_bounds__(256, (BN * BM >= 128 * 128 ? 3 : 4)) void conv_igem
     const _Float16* wbase = a.w + (long)g * a.w_gstride;
     const int cvec = a.cin >> 3;
 
-    // this lane's slot inside a wave-instruction: row l>>2, physical chunk l&3 -> logical chunk
-    const int lrow = lane >> 2;
-    const int ch = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
+    // this lane's slot inside a piece: row lane/CPR, physical chunk lane%CPR; the swizzle is applied to the SOURCE
+    // chunk (pieces start at multiples of RPP rows, and glds_swz of row q*RPP + r depends on q only through q&1 for BK=64)
+    const int lrow = lane / CPR;
     const _Float16* zero = reinterpret_cast<const _Float16*>(g_zero_page);
 
     int px_iy0[PPW], px_ix0[PPW], px_base[PPW], px_hw[PPW];
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
-        const int row = (wave + 4 * i) * 16 + lrow;
+        const int row = (wave + 4 * i) * RPP + lrow;
         const int m = tile_m * BM + row;
         px_iy0[i] = 0; px_ix0[i] = 0; px_base[i] = 0; px_hw[i] = 0;
         if (wave + 4 * i < NPI && m < a.m_total) {
@@ -528,19 +546,21 @@ __global__ __launch_bounds__(256, (BN * BM >= 128 * 128 ? 3 : 4)) void conv_igem
             px_hw[i] = (H << 16) | W;
         }
     }
+    // every piece a wave owns has the same (piece & 1) when pieces are dealt w, w+4, ...: one logical chunk per lane
+    const int ch = (lane % CPR) ^ glds_swz<BK>(wave * RPP + lrow);
     const _Float16* wrow[WPW];
 #pragma unroll
     for (int i = 0; i < WPW; ++i) {
-        const int grow = tile_n * BN + (wave + 4 * i) * 16 + lrow;
+        const int grow = tile_n * BN + (wave + 4 * i) * RPP + lrow;
         wrow[i] = (wave + 4 * i < NWI && grow < a.w_rows) ? wbase + (long)grow * a.k_pad + ch * 8 : nullptr;
     }
 
     const int ks_begin = blockIdx.z * a.nk_per;
-    const int nk_all = a.k_pad >> 5;
+    const int nk_all = (a.k_pad + BK - 1) / BK;
     const int ks_end = (ks_begin + a.nk_per < nk_all) ? ks_begin + a.nk_per : nk_all;
     int kc8, kr, kq;
     {
-        const int kvec = ks_begin * 4 + ch;
+        const int kvec = ks_begin * CPR + ch;
         const int tap = kvec / cvec;
         kc8 = kvec - tap * cvec;
         kr = tap / a.kw;
@@ -549,11 +569,12 @@ __global__ __launch_bounds__(256, (BN * BM >= 128 * 128 ? 3 : 4)) void conv_igem
 
     auto issue = [&](int ks, int buf) {
         unsigned char* sW = smem + buf * STAGE;
-        unsigned char* sX = sW + BN * 64;
+        unsigned char* sX = sW + BN * RB;
+        const bool k_in = ks * BK + ch * 8 < a.k_pad;          // BK = 64 with k_pad = 32 (mod 64): the last half-step is zero
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
             if (wave + 4 * i < NWI) {       // wave-uniform
-                const _Float16* src = wrow[i] ? wrow[i] + ks * 32 : zero;
+                const _Float16* src = (wrow[i] && k_in) ? wrow[i] + ks * BK : zero;
                 __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src),
                                                  (__attribute__((address_space(3))) void*)(sW + (wave + 4 * i) * 1024), 16, 0, 0);
             }
@@ -584,7 +605,7 @@ __global__ __launch_bounds__(256, (BN * BM >= 128 * 128 ? 3 : 4)) void conv_igem
                                                  (__attribute__((address_space(3))) void*)(sX + (wave + 4 * i) * 1024), 16, 0, 0);
             }
         }
-        kc8 += 4;
+        kc8 += CPR;
         while (kc8 >= cvec) { kc8 -= cvec; if (++kq == a.kw) { kq = 0; ++kr; } }
     };
 
@@ -594,31 +615,49 @@ __global__ __launch_bounds__(256, (BN * BM >= 128 * 128 ? 3 : 4)) void conv_igem
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+    // vmcnt counts this wave's loads in issue order, so "all but the youngest stage's pieces" = stage ks has landed
+    constexpr int PIECES_FULL = WPW + PPW;
+    const bool short_wave = (NWI & 3) != 0 && wave >= (NWI & 3);   // waves that own one weight piece fewer
     const int nk = ks_end - ks_begin;
-    issue(ks_begin, 0);
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    int cur = 0, nxt = 0;
+#pragma unroll
+    for (int s = 0; s < NST - 1; ++s)
+        if (s < nk) { issue(ks_begin + s, nxt); nxt = nxt + 1 == NST ? 0 : nxt + 1; }
     const int frow = lane & 15, fch = lane >> 4;
     for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
-        if (ks + 1 < nk) issue(ks_begin + ks + 1, cur ^ 1);
+        // stages ks .. min(ks+NST-2, nk-1) are outstanding; wait until only those after ks remain
+        const int ahead = nk - 1 - ks < NST - 2 ? nk - 1 - ks : NST - 2;
+        if (ahead == 0) {
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        } else if (NST == 3 || ahead == 1) {
+            if (short_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES_FULL - 1) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PIECES_FULL) : "memory");
+        } else {
+            if (short_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PIECES_FULL - 1)) : "memory");
+            else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES_FULL) : "memory");
+        }
+        __syncthreads();                                     // stage ks visible to all; everyone is done reading stage ks-1
+        if (ks + NST - 1 < nk) { issue(ks_begin + ks + NST - 1, nxt); nxt = nxt + 1 == NST ? 0 : nxt + 1; }
         const unsigned char* sW = smem + cur * STAGE;
-        const unsigned char* sX = sW + BN * 64;
-        f16x8 af[TN], bf[TM];
+        const unsigned char* sX = sW + BN * RB;
+        cur = cur + 1 == NST ? 0 : cur + 1;
 #pragma unroll
-        for (int i = 0; i < TN; ++i)
-            af[i] = *reinterpret_cast<const f16x8*>(sW + lds_off(wn * WN + i * 16 + frow, fch));
+        for (int kk = 0; kk < BK / 32; ++kk) {
+            f16x8 af[TN], bf[TM];
 #pragma unroll
-        for (int j = 0; j < TM; ++j)
-            bf[j] = *reinterpret_cast<const f16x8*>(sX + lds_off(wm * WM + j * 16 + frow, fch));
-#pragma unroll
-        for (int i = 0; i < TN; ++i)
+            for (int i = 0; i < TN; ++i)
+                af[i] = *reinterpret_cast<const f16x8*>(sW + glds_off<BK>(wn * WN + i * 16 + frow, kk * 4 + fch));
 #pragma unroll
             for (int j = 0; j < TM; ++j)
-                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
+                bf[j] = *reinterpret_cast<const f16x8*>(sX + glds_off<BK>(wm * WM + j * 16 + frow, kk * 4 + fch));
+#pragma unroll
+            for (int i = 0; i < TN; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
     }
+    __syncthreads();                                         // LDS is reused by the staged epilogue
 
     if (a.k_splits > 1) {
         const int ctot = (int)gridDim.y * a.cout;
@@ -851,6 +890,209 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// conv3x3_tap_kernel<BN>: 3x3 / stride 1 / pad 1 convolution, Cin a multiple of 32, any number of segments
+// (FastDVDnet inner layers FastDVDnet.py:39-74, RetinaNet head towers retina_head.py:50-81, FPN output convs
+// fpn.py:139-150, bottleneck conv2 resnet.py:151-167). The implicit GEMM above fetches every input pixel nine
+// times (once per tap), which makes it L1/L2-throughput bound at ~64 flop per fetched byte. Here one workgroup
+// owns an 8 x 32 output-pixel tile x BN output channels; per 32-channel chunk the (8+2) x (32+2) halo tile is
+// brought into LDS ONCE by global_load_lds, and the k loop runs chunk-major, tap-minor: each (chunk, tap) step
+// DMAs only that step's BN x 32 weight slice (8 KiB for BN = 128) and forms the pixel operand from the resident
+// halo at a shifted address. ~200 flop per fetched byte, 32 MFMAs per wave per barrier.
+//   ring: 2 halo buffers (22 KiB each; chunk c+1 streams in one piece per wave per step while chunk c computes)
+//         2 weight buffers (BN x 64 B); everything issued in step s has landed before step s+1 starts (vmcnt(0)).
+// Weights are the ordinary [row][k_pad] packing with k = tap*Cin + c (same buffer the implicit GEMM reads).
+// ------------------------------------------------------------------------------------------------
+struct TapArgs {
+    int tiles_x[LLV_MAX_SEG], tiles_y[LLV_MAX_SEG], blk0[LLV_MAX_SEG + 1];
+    int nblk, n_chunks;
+    unsigned x_bytes, w_bytes;   // sizes of the source tensors / weight buffer (buffer-resource bounds, < 2 GiB)
+};
+
+constexpr int TAP_HPIECES = (HALO_PX * 4 + 63) / 64;        // 1-KiB pieces per halo tile (64-B pixels): 22
+constexpr int TAP_HBYTES = TAP_HPIECES * 1024;
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+// one wave-instruction of LDS DMA: lane l's 16 bytes at base + voff + soff land at lds + 16*l; an offset at or
+// past the resource's size reads as zero (how padding taps, tile edges and tail rows are produced)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned char* lds, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
+// halo image: pixel (hy, hx) of the (8+2) x (32+2) tile at byte (hy*34 + hx)*64, its 16-B channel piece c8 in slot
+// c8 ^ (((hx>>2)&1)<<1). Keyed on the COLUMN only, so a tap's row shift is a pure immediate offset, and the 16
+// consecutive pixels of an MFMA fragment hit 16 distinct LDS slots at any column alignment.
+__device__ __forceinline__ int tap_halo_off(int hy, int hx, int c8) {
+    return (hy * (HALO_TW + 2) + hx) * 64 + ((c8 ^ (((hx >> 2) & 1) << 1)) << 4);
+}
+
+template <int BN>
+__global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, const TapArgs h) {
+    constexpr int TN = BN / 16, TM = 4;
+    constexpr int WBYTES = BN * 64;
+    constexpr int WPW = BN / 64;                             // weight pieces per wave per step
+    constexpr int HPW = (TAP_HPIECES + 3) / 4;               // halo pieces per wave per chunk (<= 6)
+    constexpr int TS = BN + 8;
+    constexpr int RING = 2 * TAP_HBYTES + 2 * WBYTES;
+    constexpr int EPI = 256 * TS * 2;
+    constexpr int SMEM = RING > EPI ? RING : EPI;
+    constexpr int ROWB = (HALO_TW + 2) * 64;                 // bytes per halo row
+    static_assert(HPW <= 8, "halo pieces are dealt one per tap step, with one step to spare");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    {
+        const int nblk = h.nblk;
+        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
+    }
+    int seg = 0;
+#pragma unroll
+    for (int s = 1; s < LLV_MAX_SEG; ++s)
+        if (s < a.n_seg && bid >= h.blk0[s]) seg = s;
+    const int local = bid - h.blk0[seg];
+    const int H = a.seg_h[seg], W = a.seg_w[seg];
+    const int tx0 = (local % h.tiles_x[seg]) * HALO_TW;
+    const int t1 = local / h.tiles_x[seg];
+    const int ty0 = (t1 % h.tiles_y[seg]) * HALO_TH;
+    const int n = t1 / h.tiles_y[seg];
+    const int tile_n = blockIdx.y;
+    const int g = 0;
+    const int img_base = a.seg_xoff[seg] + n * H * W;        // pixel index of this image's (0, 0)
+
+    const __amdgpu_buffer_rsrc_t rW = make_rsrc(a.w, h.w_bytes);
+    const __amdgpu_buffer_rsrc_t rX0 = make_rsrc(a.x0, h.x_bytes);
+    const __amdgpu_buffer_rsrc_t rX1 = make_rsrc(a.n_src > 1 ? a.x1 : a.x0, h.x_bytes);
+    const __amdgpu_buffer_rsrc_t rX2 = make_rsrc(a.n_src > 2 ? a.x2 : a.x0, h.x_bytes);
+
+    // ---- per-lane DMA offsets, fixed for the whole k loop (the chunk / tap part is a scalar offset)
+    int hv[HPW];
+#pragma unroll
+    for (int i = 0; i < HPW; ++i) {
+        const int px = (wave + 4 * i) * 16 + (lane >> 2);
+        hv[i] = (int)h.x_bytes;                              // out of range: zeros
+        if (px < HALO_PX) {
+            const int hy = px / (HALO_TW + 2), hx = px - hy * (HALO_TW + 2);
+            const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+            const int c8 = (lane & 3) ^ (((hx >> 2) & 1) << 1);
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) hv[i] = ((img_base + gy * W + gx) * a.x_ld + c8 * 8) * 2;
+        }
+    }
+    const int wch = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
+    int wv[WPW];
+#pragma unroll
+    for (int i = 0; i < WPW; ++i) {
+        const int grow = tile_n * BN + (wave + 4 * i) * 16 + (lane >> 2);
+        wv[i] = grow < a.w_rows ? (grow * a.k_pad + wch * 8) * 2 : (int)h.w_bytes;
+    }
+
+    const int frow = lane & 15, fch = lane >> 4;
+    // MFMA fragment read addresses: weights row i*16 + frow -> wa + i*1024; halo pixel (2*wave + (j>>1) + tr,
+    // (j&1)*16 + frow + tq) -> hb[j][tq] + tr*ROWB
+    const int wa = lds_off(frow, fch);
+    int hb[TM][3];
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int tq = 0; tq < 3; ++tq) hb[j][tq] = tap_halo_off(2 * wave + (j >> 1), (j & 1) * 16 + frow + tq, fch);
+
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    unsigned char* const sHalo = smem;
+    unsigned char* const sWgt = smem + 2 * TAP_HBYTES;
+
+    auto issue_w = [&](int c, int t, int buf) __attribute__((always_inline)) {   // weights of step (chunk c, tap t): k offset t*Cin + 32c
+        const int soff = (t * a.cin + c * 32) * 2;
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) dma16(rW, sWgt + buf * WBYTES + (wave + 4 * i) * 1024, wv[i], soff);
+    };
+    auto issue_h = [&](int c, int i, int buf) __attribute__((always_inline)) {   // piece wave + 4i of chunk c's halo (i static)
+        if (wave + 4 * i >= TAP_HPIECES) return;              // wave-uniform
+        int cv = c * 4;
+        unsigned char* dst = sHalo + buf * TAP_HBYTES + (wave + 4 * i) * 1024;
+        if (a.n_src > 1) {
+            const int sidx = cv / a.src_cvec;
+            cv -= sidx * a.src_cvec;
+            if (sidx == 1) { dma16(rX1, dst, hv[i], cv * 16); return; }
+            if (sidx == 2) { dma16(rX2, dst, hv[i], cv * 16); return; }
+        }
+        dma16(rX0, dst, hv[i], cv * 16);
+    };
+
+    // one (chunk, tap) step with static tap T, halo buffer HB and weight buffer WB. A macro, not a lambda: with the
+    // accumulators captured by reference the compiler leaves the 512-byte array of the BN = 128 variant in scratch.
+#define TAP_STEP(T, HB, WB, c, more)                                                                          \
+    {                                                                                                         \
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
+        __syncthreads(); /* this step's operands are in LDS; the other buffers are free */                    \
+        if ((T) < 8) issue_w((c), (T) + 1, (WB) ^ 1);                                                         \
+        else if (more) issue_w((c) + 1, 0, (WB) ^ 1);                                                         \
+        if ((T) < HPW && (more)) issue_h((c) + 1, (T), (HB) ^ 1);                                             \
+        f16x8 af[TN], bf[TM];                                                                                 \
+        _Pragma("unroll") for (int j = 0; j < TM; ++j)                                                        \
+            bf[j] = *reinterpret_cast<const f16x8*>(sHalo + (HB) * TAP_HBYTES + ((T) / 3) * ROWB + hb[j][(T) % 3]); \
+        _Pragma("unroll") for (int i = 0; i < TN; ++i)                                                        \
+            af[i] = *reinterpret_cast<const f16x8*>(sWgt + (WB) * WBYTES + i * 1024 + wa);                    \
+        _Pragma("unroll") for (int i = 0; i < TN; ++i)                                                        \
+            _Pragma("unroll") for (int j = 0; j < TM; ++j)                                                    \
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);         \
+    }
+#define TAP_CHUNK(HB, W0, W1, c, more)                                                                        \
+    TAP_STEP(0, HB, W0, c, more) TAP_STEP(1, HB, W1, c, more) TAP_STEP(2, HB, W0, c, more)                    \
+    TAP_STEP(3, HB, W1, c, more) TAP_STEP(4, HB, W0, c, more) TAP_STEP(5, HB, W1, c, more)                    \
+    TAP_STEP(6, HB, W0, c, more) TAP_STEP(7, HB, W1, c, more) TAP_STEP(8, HB, W0, c, more)
+
+#pragma unroll
+    for (int i = 0; i < HPW; ++i) issue_h(0, i, 0);
+    issue_w(0, 0, 0);
+    for (int c = 0; c < h.n_chunks; c += 2) {
+        { const bool more = c + 1 < h.n_chunks; TAP_CHUNK(0, 0, 1, c, more) }
+        if (c + 1 < h.n_chunks) { const bool more = c + 2 < h.n_chunks; TAP_CHUNK(1, 1, 0, c + 1, more) }
+    }
+#undef TAP_STEP
+#undef TAP_CHUNK
+    __syncthreads();
+
+    // ---- epilogue through the LDS tile (rows = ty*32 + tx)
+    const int Wo = W;
+    auto row_to_m = [&](int prow) {
+        const int oy = ty0 + (prow >> 5), ox = tx0 + (prow & 31);
+        return (oy < H && ox < Wo) ? a.seg_m0[seg] + (n * H + oy) * Wo + ox : -1;
+    };
+    _Float16* tile = reinterpret_cast<_Float16*>(smem);
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int prow = (2 * wave + (j >> 1)) * 32 + (j & 1) * 16 + frow;
+        const int m = row_to_m(prow);
+        EpiCtx ec;
+        if (m >= 0) epi_locate(a, m, ec);
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int col = i * 16 + fch * 4;
+            const int co = tile_n * BN + col;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (a.stage_out) {
+                if (m >= 0 && co < a.cout) epi_compute(a, ec, g * a.cout + co, v);
+                const f16x4 o4 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                *reinterpret_cast<f16x4*>(tile + prow * TS + col) = o4;
+            } else if (m >= 0 && co < a.cout) {
+                epi_store(a, ec, g * a.cout + co, v[0], v[1], v[2], v[3]);
+            }
+        }
+    }
+    if (a.stage_out) {
+        __syncthreads();
+        staged_store<BN, 256>(a, tile, g, tile_n, row_to_m);
+    }
+}
+
+// ------------------------------------------------------------------------------------------------
 // inputcv_kernel: FastDVDnet's InputCvBlock in one launch (FastDVDnet.py:22-36):
 //   Conv2d(3F, 30F, 3, groups=F) + BN + ReLU  ->  Conv2d(30F, 32, 3) + BN + ReLU        (F = 3 frames)
 // One workgroup = 8 x 32 output pixels x 32 channels. For each frame g it loads the (8+4) x (32+4) pixel patch of
@@ -1051,6 +1293,50 @@ int launch_halo(ConvKArgs& k, HaloArgs& h, int groups, int batch, hipStream_t st
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
+// bytes spanned by one source tensor (all sources of a launch share the geometry): the buffer-resource bound
+static size_t tap_x_bytes(const llv_conv_desc* d) {
+    size_t px = 0;
+    for (int s = 0; s < d->n_seg; ++s) {
+        const size_t e = (size_t)d->seg_xoff[s] + (size_t)d->batch * d->seg_h[s] * d->seg_w[s];
+        px = e > px ? e : px;
+    }
+    return px * (size_t)d->x_ld * 2;
+}
+
+template <int BN>
+int launch_tap(ConvKArgs& k, const llv_conv_desc* d, hipStream_t st) {
+    TapArgs h;
+    int blk = 0;
+    for (int s = 0; s < LLV_MAX_SEG; ++s) {
+        h.tiles_x[s] = h.tiles_y[s] = 0;
+        h.blk0[s] = blk;
+        if (s < d->n_seg) {
+            h.tiles_x[s] = (d->seg_w[s] + HALO_TW - 1) / HALO_TW;
+            h.tiles_y[s] = (d->seg_h[s] + HALO_TH - 1) / HALO_TH;
+            blk += h.tiles_x[s] * h.tiles_y[s] * d->batch;
+        }
+    }
+    h.blk0[LLV_MAX_SEG] = blk;
+    h.nblk = blk;
+    h.n_chunks = d->cin / 32;
+    h.x_bytes = (unsigned)tap_x_bytes(d);
+    h.w_bytes = (unsigned)((size_t)d->w_rows * d->k_pad * 2);
+    k.k_splits = 1;
+    dim3 grid(h.nblk, (d->cout + BN - 1) / BN, 1);
+    hipLaunchKernelGGL((conv3x3_tap_kernel<BN>), grid, dim3(256), 0, st, k, h);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+static bool tap_eligible(const llv_conv_desc* d) {
+    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->groups != 1 || (d->cin & 31)) return false;
+    if (d->n_src > 1 && (d->src_cvec & 3)) return false;     // a 32-channel chunk must lie in one source
+    for (int s = 0; s < d->n_seg; ++s)
+        if (d->seg_ho[s] != d->seg_h[s] || d->seg_wo[s] != d->seg_w[s]) return false;
+    // 32-bit buffer offsets, with room for the scalar k offset on top of an out-of-range marker
+    if (tap_x_bytes(d) >= (1ull << 31) || (size_t)d->w_rows * d->k_pad * 2 >= (1ull << 31)) return false;
+    return true;
+}
+
 template <int BN, int BM, int WN, int WM>
 int launch(ConvKArgs& k, int groups, hipStream_t st) {
     k.tiles_n = (k.cout + BN - 1) / BN;
@@ -1068,13 +1354,13 @@ int launch(ConvKArgs& k, int groups, hipStream_t st) {
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
-template <int BN, int BM, int WN, int WM>
+template <int BN, int BM, int WN, int WM, int BK = 32>
 int launch_glds(ConvKArgs& k, int groups, hipStream_t st) {
     k.tiles_n = (k.cout + BN - 1) / BN;
     const int tiles_m = (k.m_total + BM - 1) / BM;
     k.nblk = k.tiles_n * tiles_m;
     dim3 grid(k.nblk, groups, k.k_splits);
-    hipLaunchKernelGGL((conv_igemm_glds_kernel<BN, BM, WN, WM>), grid, dim3(256), 0, st, k);
+    hipLaunchKernelGGL((conv_igemm_glds_kernel<BN, BM, WN, WM, BK>), grid, dim3(256), 0, st, k);
     if (k.k_splits > 1) {
         const int ctot = groups * k.cout;
         long work = (long)k.m_total * (ctot >> 2);
@@ -1087,8 +1373,10 @@ int launch_glds(ConvKArgs& k, int groups, hipStream_t st) {
 
 void tile_dims(int tile, int& bn, int& bm) {
     switch (tile) {
-        case LLV_TILE_128x128: case LLV_TILE_128x128_REGSTAGE: bn = 128; bm = 128; break;
-        case LLV_TILE_64x256: bn = 64; bm = 256; break;
+        case LLV_TILE_128x128: case LLV_TILE_128x128_REGSTAGE: case LLV_TILE_128x128_K64: bn = 128; bm = 128; break;
+        case LLV_TILE_TAP128: bn = 128; bm = 256; break;
+        case LLV_TILE_TAP64: bn = 64; bm = 256; break;
+        case LLV_TILE_64x256: case LLV_TILE_64x256_K64: bn = 64; bm = 256; break;
         case LLV_TILE_32x256: bn = 32; bm = 256; break;
         case LLV_TILE_16x256: bn = 16; bm = 256; break;
         default: bn = 64; bm = 64; break;
@@ -1122,12 +1410,29 @@ int pick_tile(int co, long m, int groups) {
 
 struct LaunchPlan { int tile, splits, nk_per; long m; };
 
+static int tile_bk(int tile) { return (tile == LLV_TILE_128x128_K64 || tile == LLV_TILE_64x256_K64) ? 64 : 32; }
+
 static int plan_launch(const llv_conv_desc* d, LaunchPlan& lp) {
     long m = 0;
     for (int s = 0; s < d->n_seg; ++s) m += (long)d->batch * d->seg_ho[s] * d->seg_wo[s];
     lp.m = m;
     lp.tile = d->tile ? d->tile : pick_tile(d->cout, m, d->groups);
-    const int nk = d->k_pad >> 5;
+    if (!d->tile && d->k_splits <= 1 && tap_eligible(d)) {
+        // 3x3 / stride 1: the tap-streamed kernel, unless the launch is too small to give every CU a workgroup
+        // (then the implicit GEMM with split K fills the chip better)
+        long blocks = 0;
+        for (int s = 0; s < d->n_seg; ++s)
+            blocks += (long)d->batch * ((d->seg_h[s] + HALO_TH - 1) / HALO_TH) * ((d->seg_w[s] + HALO_TW - 1) / HALO_TW);
+        blocks *= (d->cout + 63) / 64;
+        if (blocks >= 160) {
+            lp.tile = LLV_TILE_TAP64;
+            lp.splits = 1;
+            lp.nk_per = (d->k_pad + 31) / 32;
+            return LLV_OK;
+        }
+    }
+    const int bk = tile_bk(lp.tile);
+    const int nk = (d->k_pad + bk - 1) / bk;
     lp.splits = d->k_splits > 0 ? d->k_splits : pick_splits(lp.tile, d->cout, m, d->groups, nk, d->flags);
     if (lp.splits > nk) lp.splits = nk;
     if (lp.splits < 1) lp.splits = 1;
@@ -1291,6 +1596,10 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
         case LLV_TILE_16x256:  return launch_glds<16, 256, 16, 64>(k, d->groups, st);
         case LLV_TILE_64x64:   return launch_glds<64, 64, 32, 32>(k, d->groups, st);
         case LLV_TILE_128x128_REGSTAGE: return launch<128, 128, 64, 64>(k, d->groups, st);   // register-staged loop, kept for A/B
+        case LLV_TILE_128x128_K64: return launch_glds<128, 128, 64, 64, 64>(k, d->groups, st);
+        case LLV_TILE_TAP128: return tap_eligible(d) ? launch_tap<128>(k, d, st) : LLV_E_BADARG;
+        case LLV_TILE_TAP64:  return tap_eligible(d) ? launch_tap<64>(k, d, st) : LLV_E_BADARG;
+        case LLV_TILE_64x256_K64:  return launch_glds<64, 256, 64, 64, 64>(k, d->groups, st);
         default: return LLV_E_UNSUPPORTED;
     }
 }

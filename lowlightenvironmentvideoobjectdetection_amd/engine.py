@@ -458,8 +458,8 @@ def _denblock(b: Builder, sd, p, srcs, batch, tag, out):
 
     def cbr(name, x, conv, bn, stride=1, flags=f, res=None):
         pc = ops.pack_conv(sd[conv + '.weight'], None, stride, 1, bn=_bn(sd, bn), eps=BN_EPS)
-        if HALO and stride == 1 and pc.cout <= HALO_MAX_COUT:
-            ops.add_halo_packing(pc)
+        if HALO and stride == 1 and pc.cout <= HALO_MAX_COUT and pc.cin % 32:
+            ops.add_halo_packing(pc)        # Cin a multiple of 32 goes to the tap-streamed kernel instead
         return b.conv(name, x, pc, flags, res=res)
 
     def down(x, q, t):                                       # DownBlock, FastDVDnet.py:39-49
@@ -471,7 +471,7 @@ def _denblock(b: Builder, sd, p, srcs, batch, tag, out):
         x = cbr(f'{tag}.{t}.0', x, q + 'convblock.0.convblock.0', q + 'convblock.0.convblock.1')   # :111-113 is fused
         x = cbr(f'{tag}.{t}.1', x, q + 'convblock.0.convblock.3', q + 'convblock.0.convblock.4')
         pc = ops.pack_conv(sd[q + 'convblock.1.weight'], None, 1, 1)
-        if HALO and pc.cout <= HALO_MAX_COUT:
+        if HALO and pc.cout <= HALO_MAX_COUT and pc.cin % 32:
             ops.add_halo_packing(pc)
         return b.conv(f'{tag}.{t}.2', x, pc, CONV_PIXSHUF | CONV_RES_ADD, res=skip)
 

@@ -37,7 +37,7 @@ def _check(y, ref, cout, tol=2e-3):
         assert y.float().cpu()[..., cout:].abs().max().item() == 0.0
 
 
-@pytest.mark.parametrize('tile', [1, 2, 3, 4, 5, 6])
+@pytest.mark.parametrize('tile', [1, 2, 3, 4, 5, 6, 7, 8])
 @pytest.mark.parametrize('cfg', [
     # n, cin, cout, h, w, k, stride, pad
     (1, 64, 64, 20, 33, 3, 1, 1),
@@ -419,3 +419,79 @@ def test_fused_outputcvblock(dev, n, h, w):
     mid = F.relu(F.conv2d(x, w0, b0, 1, 1)).half().float()
     ref = in1.float().permute(0, 3, 1, 2)[:, :3] - F.conv2d(mid, w1, None, 1, 1)
     _check(y, ref, 3)
+
+
+# ---- tap-streamed 3x3 kernel (halo resident in LDS, weights streamed per tap); tiles 9 (BN=128) and 10 (BN=64)
+@pytest.mark.parametrize('tile', [9, 10])
+@pytest.mark.parametrize('cfg', [
+    # n, cin, cout, h, w   (3x3 / stride 1 / pad 1)
+    (1, 64, 64, 20, 33),      # ragged tile edges in both directions
+    (2, 128, 128, 16, 64),    # exact tiles, two images
+    (1, 32, 36, 9, 40),       # one chunk; cout not a multiple of 16
+    (1, 256, 200, 8, 32),     # eight chunks, two n-tiles with a ragged second one
+    (3, 96, 720, 5, 7),       # tile larger than the image
+])
+def test_conv3x3_tap_kernel(dev, cfg, tile):
+    n, cin, cout, h, w = cfg
+    y, ref, _ = _run_conv(dev, n, cin, cout, h, w, 3, 1, 1, tile=tile)
+    _check(y, ref, cout)
+
+
+@pytest.mark.parametrize('tile', [9, 10])
+def test_conv3x3_tap_segments_shared_weights(dev, tile):
+    """One launch over three pyramid levels with shared weights (the RetinaNet tower layout)."""
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    g = torch.Generator().manual_seed(21)
+    levels = [(23, 40), (12, 20), (6, 10)]
+    wt = (torch.randn(96, 64, 3, 3, generator=g) / 24.0).half().float()
+    b = torch.randn(96, generator=g)
+    pc = ops.pack_conv(wt, b, 1, 1).to(dev)
+    xs = [torch.randn(2, 64, h, w, generator=g).half().float() for h, w in levels]
+    tot = sum(2 * h * w for h, w in levels)
+    xbuf = torch.cat([_nhwc(x).reshape(-1, 64) for x in xs]).half().to(dev)
+    ybuf = torch.zeros(tot, 96, dtype=torch.float16, device=dev)
+    segs, off = [], 0
+    for h, w in levels:
+        segs.append((h, w, h, w, off, off))
+        off += 2 * h * w
+    d = ops.make_conv_desc(pc, [xbuf], ybuf, 2, segs, 64, 96, flags=ops.CONV_RELU, tile=tile)
+    ops.launch_conv(d)
+    torch.cuda.synchronize()
+    off = 0
+    for (h, w), x in zip(levels, xs):
+        got = ybuf[off:off + 2 * h * w].float().cpu().reshape(2, h, w, 96).permute(0, 3, 1, 2)
+        ref = F.relu(F.conv2d(x, wt, b, 1, 1))
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-3, (h, w, err)
+        off += 2 * h * w
+
+
+@pytest.mark.parametrize('tile', [9, 10])
+def test_conv3x3_tap_pixel_shuffle_residual_and_sources(dev, tile):
+    """PixelShuffle + skip add epilogue (UpBlock, FastDVDnet.py:52-61) and three concatenated 32-channel sources."""
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    g = torch.Generator().manual_seed(22)
+    x = torch.randn(2, 64, 10, 44, generator=g).half().float()
+    wt = (torch.randn(128, 64, 3, 3, generator=g) / 24.0).half().float()
+    pc = ops.pack_conv(wt, None, stride=1, pad=1).to(dev)
+    res = torch.randn(2, 20, 88, 32, generator=g).half()
+    y = ops.conv2d(_nhwc(x).half().to(dev), pc, res=res.to(dev), flags=ops.CONV_PIXSHUF | ops.CONV_RES_ADD, tile=tile)
+    ref = F.pixel_shuffle(F.conv2d(x, wt, None, 1, 1), 2) + res.float().permute(0, 3, 1, 2)
+    _check(y, ref, 32)
+
+    srcs = [torch.randn(1, 32, 13, 37, generator=g).half().float() for _ in range(3)]
+    w2 = (torch.randn(32, 96, 3, 3, generator=g) / 30.0).half().float()
+    b2 = torch.randn(32, generator=g)
+    pc2 = ops.pack_conv(w2, b2, 1, 1, n_src=3).to(dev)
+    y2 = ops.conv2d([_nhwc(s).half().to(dev) for s in srcs], pc2, flags=ops.CONV_RELU, tile=tile)
+    ref2 = F.relu(F.conv2d(torch.cat(srcs, 1), w2, b2, 1, 1))
+    _check(y2, ref2, 32)
+
+
+def test_conv3x3_tap_rejects_ineligible(dev):
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    from lowlightenvironmentvideoobjectdetection_amd._lib import LlvError
+    with pytest.raises(LlvError):
+        _run_conv(dev, 1, 64, 64, 16, 16, 3, 2, 1, tile=9)      # stride 2
+    with pytest.raises(LlvError):
+        _run_conv(dev, 1, 24, 64, 16, 16, 3, 1, 1, tile=9)      # Cin not a multiple of 32

@@ -10,8 +10,13 @@ shapes = [  # name, n, cin, cout, h, w, k, stride
     ('layer1 1x1 64->256 184x320 b4', 4, 64, 256, 184, 320, 1, 1),
     ('layer3 3x3 256->256 46x80 b4', 4, 256, 256, 46, 80, 3, 1),
     ('cls 256->720 3x3 92x160 b4', 4, 256, 720, 92, 160, 3, 1),
+    ('fdvd64 3x3 368x640 b6', 6, 64, 64, 368, 640, 3, 1),
+    ('fdvd up1.2 64->128 3x3 368x640 b6', 6, 64, 128, 368, 640, 3, 1),
+    ('fdvd inc1 96->32 3x3 736x1280 b2', 2, 96, 32, 736, 1280, 3, 1),
 ]
 tiles = [int(t) for t in (sys.argv[1].split(',') if len(sys.argv) > 1 else '1,6'.split(','))]
+if len(sys.argv) > 2:                                     # optional: indices of the shapes to run
+    shapes = [shapes[int(i)] for i in sys.argv[2].split(',')]
 for name, n, cin, cout, h, w, k, st in shapes:
     g = torch.Generator().manual_seed(0)
     x = torch.randn(n, h, w, cin, generator=g).half().to(dev)
@@ -25,7 +30,7 @@ for name, n, cin, cout, h, w, k, st in shapes:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
-                ops.conv2d(x, pc, flags=ops.CONV_RELU, out=outs[t], tile=t, k_splits=1)
+                ops.conv2d(x, pc, flags=ops.CONV_RELU, out=outs[t], tile=t, k_splits=0 if t in (9, 10) else 1)
             e1.record(); torch.cuda.synchronize()
             if rnd > 0:
                 res[t].append(e0.elapsed_time(e1) / 5)
