@@ -61,6 +61,15 @@ struct EpiCtx {
     int ox, oy, n, Ho, Wo, yo;
 };
 
+// residual read through a nearest-neighbour upsample: F.interpolate(mode='nearest', size=(Ho,Wo)) is
+// src = min(floor(dst * in/out), in-1) (fpn.py:186-195)
+__device__ __forceinline__ void epi_res_ups(const ConvKArgs& a, EpiCtx& c) {
+    const float sy = (float)a.res_h / (float)c.Ho, sx = (float)a.res_w / (float)c.Wo;
+    int ry = (int)floorf((float)c.oy * sy); ry = ry < a.res_h - 1 ? ry : a.res_h - 1;
+    int rx = (int)floorf((float)c.ox * sx); rx = rx < a.res_w - 1 ? rx : a.res_w - 1;
+    c.rpix = ((long)c.n * a.res_h + ry) * a.res_w + rx;
+}
+
 __device__ __forceinline__ void epi_locate(const ConvKArgs& a, int m, EpiCtx& c) {
     int Ho = a.seg_ho[0], Wo = a.seg_wo[0], m0 = 0, yo = a.seg_yoff[0];
 #pragma unroll
@@ -79,13 +88,7 @@ __device__ __forceinline__ void epi_locate(const ConvKArgs& a, int m, EpiCtx& c)
         c.oy = t % Ho;
         c.n = t / Ho;
     }
-    if (a.flags & LLV_CONV_RES_UPS) {
-        // F.interpolate(mode='nearest', size=(Ho,Wo)): src = min(floor(dst * in/out), in-1)
-        const float sy = (float)a.res_h / (float)Ho, sx = (float)a.res_w / (float)Wo;
-        int ry = (int)floorf((float)c.oy * sy); ry = ry < a.res_h - 1 ? ry : a.res_h - 1;
-        int rx = (int)floorf((float)c.ox * sx); rx = rx < a.res_w - 1 ? rx : a.res_w - 1;
-        c.rpix = ((long)c.n * a.res_h + ry) * a.res_w + rx;
-    }
+    if (a.flags & LLV_CONV_RES_UPS) epi_res_ups(a, c);
 }
 
 __device__ __forceinline__ float act_fn(const ConvKArgs& a, float v) {
@@ -153,19 +156,17 @@ __device__ __forceinline__ void epi_store(const ConvKArgs& a, const EpiCtx& c, i
 // Phase 2 of the LDS-staged epilogue: the [BM pixels][BN couts] fp16 tile (row stride BN+8 halfs) goes to
 // global memory 16 bytes per lane, consecutive lanes = consecutive channels of a pixel. row_to_m maps a tile
 // row to the output row index m (or -1 when the row is outside the image / past the end).
-template <int BN, int BM, typename RowFn>
-__device__ __forceinline__ void staged_store(const ConvKArgs& a, const _Float16* tile, int g, int tile_n, RowFn row_to_m) {
+template <int BN, int BM, typename LocFn>
+__device__ __forceinline__ void staged_store_loc(const ConvKArgs& a, const _Float16* tile, int g, int tile_n, LocFn loc) {
     constexpr int TS = BN + 8;
     const int tid = threadIdx.x;
     if (!(a.flags & LLV_CONV_PIXSHUF)) {
         constexpr int CPR = BN / 8;  // 16-B chunks per tile row
         for (int q = tid; q < BM * CPR; q += 256) {
             const int prow = q / CPR, cc = q - prow * CPR;
-            const int m = row_to_m(prow);
             const int co = tile_n * BN + cc * 8;
-            if (m < 0 || co >= a.cout) continue;
             EpiCtx c;
-            epi_locate(a, m, c);
+            if (co >= a.cout || !loc(prow, c)) continue;
             _Float16* dst = reinterpret_cast<_Float16*>(a.y) + (a.y_gstride ? g * a.y_gstride + c.opix * a.y_ld + co : c.opix * a.y_ld + g * a.cout + co);
             const uint4 val = *reinterpret_cast<const uint4*>(tile + prow * TS + cc * 8);
             if (co + 8 <= a.cout) *reinterpret_cast<uint4*>(dst) = val;
@@ -179,11 +180,9 @@ __device__ __forceinline__ void staged_store(const ConvKArgs& a, const _Float16*
             const int o8 = q % OC8;
             const int e = (q / OC8) & 3;
             const int prow = q / (OC8 * 4);
-            const int m = row_to_m(prow);
             const int co = tile_n * BN + o8 * 32;          // first conv channel of this group
-            if (m < 0 || co >= a.cout) continue;
             EpiCtx c;
-            epi_locate(a, m, c);
+            if (co >= a.cout || !loc(prow, c)) continue;
             const int dy = e >> 1, dx = e & 1;
             if (2 * c.oy + dy >= a.ps_h || 2 * c.ox + dx >= a.ps_w) continue;
             const long p = (long)c.yo + ((long)(c.n * a.ps_h + 2 * c.oy + dy)) * a.ps_w + (2 * c.ox + dx);
@@ -207,6 +206,16 @@ __device__ __forceinline__ void staged_store(const ConvKArgs& a, const _Float16*
             *reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(a.y) + p * a.y_ld + occ) = o8v;
         }
     }
+}
+
+template <int BN, int BM, typename RowFn>
+__device__ __forceinline__ void staged_store(const ConvKArgs& a, const _Float16* tile, int g, int tile_n, RowFn row_to_m) {
+    staged_store_loc<BN, BM>(a, tile, g, tile_n, [&](int prow, EpiCtx& c) {
+        const int m = row_to_m(prow);
+        if (m < 0) return false;
+        epi_locate(a, m, c);
+        return true;
+    });
 }
 
 // split-K second pass: sum the fp32 partial slabs, then the normal epilogue. One lane per (row, 4 channels).
@@ -959,10 +968,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
     const int ty0 = (t1 % h.tiles_y[seg]) * HALO_TH;
     const int n = t1 / h.tiles_y[seg];
     const int tile_n = blockIdx.y;
-    const int g = 0;
+    const int g = blockIdx.z;                                // group: input channels [g*Cin, ..), its own weight block
     const int img_base = a.seg_xoff[seg] + n * H * W;        // pixel index of this image's (0, 0)
 
-    const __amdgpu_buffer_rsrc_t rW = make_rsrc(a.w, h.w_bytes);
+    const __amdgpu_buffer_rsrc_t rW = make_rsrc(a.w + (long)g * a.w_gstride, h.w_bytes);
     const __amdgpu_buffer_rsrc_t rX0 = make_rsrc(a.x0, h.x_bytes);
     const __amdgpu_buffer_rsrc_t rX1 = make_rsrc(a.n_src > 1 ? a.x1 : a.x0, h.x_bytes);
     const __amdgpu_buffer_rsrc_t rX2 = make_rsrc(a.n_src > 2 ? a.x2 : a.x0, h.x_bytes);
@@ -977,7 +986,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
             const int hy = px / (HALO_TW + 2), hx = px - hy * (HALO_TW + 2);
             const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
             const int c8 = (lane & 3) ^ (((hx >> 2) & 1) << 1);
-            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) hv[i] = ((img_base + gy * W + gx) * a.x_ld + c8 * 8) * 2;
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) hv[i] = ((img_base + gy * W + gx) * a.x_ld + g * a.cin + c8 * 8) * 2;
         }
     }
     const int wch = (lane & 3) ^ ((0 - (lane >> 4)) & 3);
@@ -1059,40 +1068,43 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
 #undef TAP_CHUNK
     __syncthreads();
 
-    // ---- epilogue through the LDS tile (rows = ty*32 + tx)
-    const int Wo = W;
-    auto row_to_m = [&](int prow) {
+    // ---- epilogue through the LDS tile (rows = ty*32 + tx); the tile's position is known, no row -> pixel search
+    const int ybase = a.seg_yoff[seg] + n * H * W;
+    auto loc = [&](int prow, EpiCtx& c) {
         const int oy = ty0 + (prow >> 5), ox = tx0 + (prow & 31);
-        return (oy < H && ox < Wo) ? a.seg_m0[seg] + (n * H + oy) * Wo + ox : -1;
+        if (oy >= H || ox >= W) return false;
+        c.opix = ybase + oy * W + ox;
+        c.rpix = c.opix;
+        c.ox = ox; c.oy = oy; c.n = n; c.Ho = H; c.Wo = W; c.yo = a.seg_yoff[seg];
+        if (a.flags & LLV_CONV_RES_UPS) epi_res_ups(a, c);
+        return true;
     };
     _Float16* tile = reinterpret_cast<_Float16*>(smem);
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int prow = (2 * wave + (j >> 1)) * 32 + (j & 1) * 16 + frow;
-        const int m = row_to_m(prow);
         EpiCtx ec;
-        if (m >= 0) epi_locate(a, m, ec);
+        const bool ok = loc(prow, ec);
 #pragma unroll
         for (int i = 0; i < TN; ++i) {
             const int col = i * 16 + fch * 4;
             const int co = tile_n * BN + col;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (a.stage_out) {
-                if (m >= 0 && co < a.cout) epi_compute(a, ec, g * a.cout + co, v);
+                if (ok && co < a.cout) epi_compute(a, ec, g * a.cout + co, v);
                 const f16x4 o4 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                 *reinterpret_cast<f16x4*>(tile + prow * TS + col) = o4;
-            } else if (m >= 0 && co < a.cout) {
+            } else if (ok && co < a.cout) {
                 epi_store(a, ec, g * a.cout + co, v[0], v[1], v[2], v[3]);
             }
         }
     }
     if (a.stage_out) {
         __syncthreads();
-        staged_store<BN, 256>(a, tile, g, tile_n, row_to_m);
+        staged_store_loc<BN, 256>(a, tile, g, tile_n, loc);
     }
 }
 
-// ------------------------------------------------------------------------------------------------
 // inputcv_kernel: FastDVDnet's InputCvBlock in one launch (FastDVDnet.py:22-36):
 //   Conv2d(3F, 30F, 3, groups=F) + BN + ReLU  ->  Conv2d(30F, 32, 3) + BN + ReLU        (F = 3 frames)
 // One workgroup = 8 x 32 output pixels x 32 channels. For each frame g it loads the (8+4) x (32+4) pixel patch of
@@ -1322,14 +1334,14 @@ int launch_tap(ConvKArgs& k, const llv_conv_desc* d, hipStream_t st) {
     h.x_bytes = (unsigned)tap_x_bytes(d);
     h.w_bytes = (unsigned)((size_t)d->w_rows * d->k_pad * 2);
     k.k_splits = 1;
-    dim3 grid(h.nblk, (d->cout + BN - 1) / BN, 1);
+    dim3 grid(h.nblk, (d->cout + BN - 1) / BN, d->groups);
     hipLaunchKernelGGL((conv3x3_tap_kernel<BN>), grid, dim3(256), 0, st, k, h);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
 static bool tap_eligible(const llv_conv_desc* d) {
-    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->groups != 1 || (d->cin & 31)) return false;
-    if (d->n_src > 1 && (d->src_cvec & 3)) return false;     // a 32-channel chunk must lie in one source
+    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || (d->cin & 31)) return false;
+    if (d->n_src > 1 && ((d->src_cvec & 3) || d->groups != 1)) return false;   // a 32-channel chunk must lie in one source
     for (int s = 0; s < d->n_seg; ++s)
         if (d->seg_ho[s] != d->seg_h[s] || d->seg_wo[s] != d->seg_w[s]) return false;
     // 32-bit buffer offsets, with room for the scalar k offset on top of an out-of-range marker
@@ -1423,7 +1435,7 @@ static int plan_launch(const llv_conv_desc* d, LaunchPlan& lp) {
         long blocks = 0;
         for (int s = 0; s < d->n_seg; ++s)
             blocks += (long)d->batch * ((d->seg_h[s] + HALO_TH - 1) / HALO_TH) * ((d->seg_w[s] + HALO_TW - 1) / HALO_TW);
-        blocks *= (d->cout + 63) / 64;
+        blocks *= (long)((d->cout + 63) / 64) * d->groups;
         if (blocks >= 160) {
             lp.tile = LLV_TILE_TAP64;
             lp.splits = 1;

@@ -495,3 +495,34 @@ def test_conv3x3_tap_rejects_ineligible(dev):
         _run_conv(dev, 1, 64, 64, 16, 16, 3, 2, 1, tile=9)      # stride 2
     with pytest.raises(LlvError):
         _run_conv(dev, 1, 24, 64, 16, 16, 3, 1, 1, tile=9)      # Cin not a multiple of 32
+
+
+@pytest.mark.parametrize('tile', [0, 9, 10])
+def test_conv3x3_tap_grouped_towers(dev, tile):
+    """cls and reg tower convs side by side (groups=2, 2x64 input channels) over two levels: the layout of
+    RetinaHead tower layers 1-3 (retina_head.py:93-114). tile=0 checks the planner picks a working path."""
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    g = torch.Generator().manual_seed(23)
+    levels = [(24, 40), (12, 20)]
+    w0 = (torch.randn(64, 64, 3, 3, generator=g) / 24.0).half().float()
+    w1 = (torch.randn(64, 64, 3, 3, generator=g) / 24.0).half().float()
+    b0, b1 = torch.randn(64, generator=g), torch.randn(64, generator=g)
+    pc = ops.stack_groups([ops.pack_conv(w0, b0, 1, 1), ops.pack_conv(w1, b1, 1, 1)]).to(dev)
+    xs = [torch.randn(2, 128, h, w, generator=g).half().float() for h, w in levels]
+    tot = sum(2 * h * w for h, w in levels)
+    xbuf = torch.cat([_nhwc(x).reshape(-1, 128) for x in xs]).half().to(dev)
+    ybuf = torch.zeros(tot, 128, dtype=torch.float16, device=dev)
+    segs, off = [], 0
+    for h, w in levels:
+        segs.append((h, w, h, w, off, off))
+        off += 2 * h * w
+    d = ops.make_conv_desc(pc, [xbuf], ybuf, 2, segs, 128, 128, flags=ops.CONV_RELU, tile=tile)
+    ops.launch_conv(d)
+    torch.cuda.synchronize()
+    off = 0
+    for (h, w), x in zip(levels, xs):
+        got = ybuf[off:off + 2 * h * w].float().cpu().reshape(2, h, w, 128).permute(0, 3, 1, 2)
+        ref = torch.cat([F.relu(F.conv2d(x[:, :64], w0, b0, 1, 1)), F.relu(F.conv2d(x[:, 64:], w1, b1, 1, 1))], 1)
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        assert err < 2e-3, (h, w, err)
+        off += 2 * h * w
