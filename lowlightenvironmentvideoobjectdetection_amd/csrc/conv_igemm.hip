@@ -15,6 +15,7 @@
 
 #include <hip/hip_runtime.h>
 #include <type_traits>
+#include <cstdlib>
 #include <hip/hip_fp16.h>
 #include "llv.h"
 
@@ -53,6 +54,7 @@ struct ConvKArgs {
     int k_splits;       // > 1: blockIdx.z owns k-steps [z*nk_per, ...) and writes fp32 partials to ws
     int nk_per;
     float* ws;          // [k_splits][m_total][groups*cout] fp32 partial sums
+    unsigned x_bytes, w_bytes;   // buffer-resource bounds of one source tensor / one group's weights (0: not usable)
 };
 
 // Shared epilogue: v[4] = conv sum (no bias yet) of channels gco..gco+3 of output row m.
@@ -72,10 +74,12 @@ __device__ __forceinline__ void epi_res_ups(const ConvKArgs& a, EpiCtx& c) {
 
 __device__ __forceinline__ void epi_locate(const ConvKArgs& a, int m, EpiCtx& c) {
     int Ho = a.seg_ho[0], Wo = a.seg_wo[0], m0 = 0, yo = a.seg_yoff[0];
+    if (a.n_seg > 1) {       // uniform branch: the common single-segment launch skips the search
 #pragma unroll
-    for (int s = 1; s < LLV_MAX_SEG; ++s) {
-        if (s < a.n_seg && m >= a.seg_m0[s]) {
-            Ho = a.seg_ho[s]; Wo = a.seg_wo[s]; m0 = a.seg_m0[s]; yo = a.seg_yoff[s];
+        for (int s = 1; s < LLV_MAX_SEG; ++s) {
+            if (s < a.n_seg && m >= a.seg_m0[s]) {
+                Ho = a.seg_ho[s]; Wo = a.seg_wo[s]; m0 = a.seg_m0[s]; yo = a.seg_yoff[s];
+            }
         }
     }
     const int ml = m - m0;
@@ -99,9 +103,8 @@ __device__ __forceinline__ float act_fn(const ConvKArgs& a, float v) {
 
 // bias / residual / ReLU on 4 consecutive channels. With PIXSHUF the residual and ReLU are applied at the
 // shuffled output location instead (epi_store_direct / the staged store), so only the bias is added here.
-__device__ __forceinline__ void epi_compute(const ConvKArgs& a, const EpiCtx& c, int gco, float (&v)[4]) {
+__device__ __forceinline__ void epi_compute_b(const ConvKArgs& a, const EpiCtx& c, int gco, float (&v)[4], const float4 b4) {
     const int flags = a.flags;
-    const float4 b4 = *reinterpret_cast<const float4*>(a.bias + gco);
     v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
     if (flags & LLV_CONV_PIXSHUF) return;
     if (flags & (LLV_CONV_RES_ADD | LLV_CONV_RES_RSUB)) {
@@ -118,6 +121,10 @@ __device__ __forceinline__ void epi_compute(const ConvKArgs& a, const EpiCtx& c,
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = act_fn(a, v[e]);
     }
+}
+
+__device__ __forceinline__ void epi_compute(const ConvKArgs& a, const EpiCtx& c, int gco, float (&v)[4]) {
+    epi_compute_b(a, c, gco, v, *reinterpret_cast<const float4*>(a.bias + gco));
 }
 
 __device__ __forceinline__ void epi_store(const ConvKArgs& a, const EpiCtx& c, int gco, float v0, float v1, float v2, float v3) {
@@ -161,16 +168,22 @@ __device__ __forceinline__ void staged_store_loc(const ConvKArgs& a, const _Floa
     constexpr int TS = BN + 8;
     const int tid = threadIdx.x;
     if (!(a.flags & LLV_CONV_PIXSHUF)) {
-        constexpr int CPR = BN / 8;  // 16-B chunks per tile row
-        for (int q = tid; q < BM * CPR; q += 256) {
-            const int prow = q / CPR, cc = q - prow * CPR;
-            const int co = tile_n * BN + cc * 8;
-            EpiCtx c;
-            if (co >= a.cout || !loc(prow, c)) continue;
-            _Float16* dst = reinterpret_cast<_Float16*>(a.y) + (a.y_gstride ? g * a.y_gstride + c.opix * a.y_ld + co : c.opix * a.y_ld + g * a.cout + co);
-            const uint4 val = *reinterpret_cast<const uint4*>(tile + prow * TS + cc * 8);
-            if (co + 8 <= a.cout) *reinterpret_cast<uint4*>(dst) = val;
-            else *reinterpret_cast<uint2*>(dst) = make_uint2(val.x, val.y);   // cout is a multiple of 4
+        constexpr int CPR = BN / 8;  // 16-B chunks per tile row; a lane keeps its chunk, rows advance by 256/CPR
+        static_assert(256 % CPR == 0, "lane -> chunk mapping is fixed across iterations");
+        const int cc = tid % CPR;
+        const int co = tile_n * BN + cc * 8;
+        if (co < a.cout) {
+            const long cofs = a.y_gstride ? g * a.y_gstride + co : (long)g * a.cout + co;
+            const bool full = co + 8 <= a.cout;
+#pragma unroll 4
+            for (int prow = tid / CPR; prow < BM; prow += 256 / CPR) {
+                EpiCtx c;
+                if (!loc(prow, c)) continue;
+                _Float16* dst = reinterpret_cast<_Float16*>(a.y) + c.opix * a.y_ld + cofs;
+                const uint4 val = *reinterpret_cast<const uint4*>(tile + prow * TS + cc * 8);
+                if (full) *reinterpret_cast<uint4*>(dst) = val;
+                else *reinterpret_cast<uint2*>(dst) = make_uint2(val.x, val.y);   // cout is a multiple of 4
+            }
         }
     } else if constexpr (BN >= 32) {
         // PixelShuffle(2): out pixel (2oy+dy, 2ox+dx), channel cc <- conv channel 4*cc + 2*dy + dx.
@@ -480,6 +493,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
 // ------------------------------------------------------------------------------------------------
 __device__ __attribute__((aligned(16))) const unsigned int g_zero_page[4] = {0u, 0u, 0u, 0u};
 
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+// one wave-instruction of LDS DMA: lane l's 16 bytes at base + voff + soff land at lds + 16*l; an offset at or
+// past the resource's size reads as zero (how padding taps, tile edges and tail rows are produced)
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned char* lds, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
 #ifndef GLDS_STAGES
 #define GLDS_STAGES 2
 #endif
@@ -493,7 +515,12 @@ __device__ __forceinline__ int glds_swz(int row) {
 template <int BK>
 __device__ __forceinline__ int glds_off(int row, int ch) { return row * (BK * 2) + ((ch ^ glds_swz<BK>(row)) << 4); }
 
-template <int BN, int BM, int WN, int WM, int BK>
+// UT ("uniform tap"): Cin is a multiple of BK and there is one segment, so a k-step lies inside one filter tap and one
+// source: the tap / channel part of every address is a scalar offset of a buffer load, each lane keeps ONE constant
+// byte offset per pixel piece plus a bit mask of the taps that fall inside the image, and the per-step address work
+// drops from ~18 vector instructions per piece to 3 (0 for 1x1 convolutions). The vector ALU shares its issue port
+// with the matrix core, so this is what the main loop's speed hangs on.
+template <int BN, int BM, int WN, int WM, int BK, bool UT>
 __global__ __launch_bounds__(256, (BK == 64 ? 2 : (BN * BM >= 128 * 128 ? 3 : 4))) void conv_igemm_glds_kernel(const ConvKArgs a) {
     constexpr int WAVES_N = BN / WN;
     constexpr int WAVES_M = BM / WM;
@@ -576,9 +603,77 @@ __global__ __launch_bounds__(256, (BK == 64 ? 2 : (BN * BM >= 128 * 128 ? 3 : 4)
         kq = tap - kr * a.kw;
     }
 
+    // ---- UT mode state
+    int pv[PPW];                                             // byte offset of (pixel at tap (0,0), this lane's chunk) + pad shift
+    unsigned pmask[PPW];                                     // bit t: tap t of this pixel is inside the image
+    int wv[WPW];
+    const int padb = UT ? (a.pad * a.seg_w[0] + a.pad) * a.x_ld * 2 : 0;   // resources start padb bytes early: offsets stay >= 0
+    const int oob = (int)a.x_bytes + padb;
+    __amdgpu_buffer_rsrc_t rW, rX0, rX1, rX2;
+    int u_kc = 0, u_tap = 0, u_kr = 0, u_kq = 0, u_toff = 0;
+    if constexpr (UT) {
+        rW = make_rsrc(wbase, a.w_bytes);
+        const _Float16* b0 = a.src_per_group ? (g == 0 ? a.x0 : (g == 1 ? a.x1 : a.x2)) : a.x0;
+        rX0 = make_rsrc(reinterpret_cast<const unsigned char*>(b0) - padb, (unsigned)oob);
+        rX1 = make_rsrc(reinterpret_cast<const unsigned char*>(a.n_src > 1 ? a.x1 : a.x0) - padb, (unsigned)oob);
+        rX2 = make_rsrc(reinterpret_cast<const unsigned char*>(a.n_src > 2 ? a.x2 : a.x0) - padb, (unsigned)oob);
+        const int chan0 = (a.n_src == 1 && !a.src_per_group) ? g * a.cin : 0;
+        const int ntap = a.kh * a.kw;
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int H = px_hw[i] >> 16, W = px_hw[i] & 0xffff;
+            pv[i] = ((px_base[i] + px_iy0[i] * W + px_ix0[i]) * a.x_ld + chan0 + ch * 8) * 2 + padb;
+            unsigned mk = 0;
+            for (int t = 0; t < ntap; ++t) {
+                const int r = t / a.kw, q = t - r * a.kw;
+                if ((unsigned)(px_iy0[i] + r) < (unsigned)H && (unsigned)(px_ix0[i] + q) < (unsigned)W) mk |= 1u << t;
+            }
+            pmask[i] = mk;                                   // H = W = 0 for rows past the end: no bit set
+        }
+#pragma unroll
+        for (int i = 0; i < WPW; ++i) {
+            const int grow = tile_n * BN + (wave + 4 * i) * RPP + lrow;
+            wv[i] = grow < a.w_rows ? (grow * a.k_pad + ch * 8) * 2 : (int)a.w_bytes;
+        }
+        const int k0 = ks_begin * BK;
+        u_tap = k0 / a.cin;
+        u_kc = k0 - u_tap * a.cin;
+        u_kr = u_tap / a.kw;
+        u_kq = u_tap - u_kr * a.kw;
+        u_toff = (u_kr * a.seg_w[0] + u_kq) * a.x_ld * 2;
+    }
+
     auto issue = [&](int ks, int buf) {
         unsigned char* sW = smem + buf * STAGE;
         unsigned char* sX = sW + BN * RB;
+        if constexpr (UT) {
+#pragma unroll
+            for (int i = 0; i < WPW; ++i)
+                if (wave + 4 * i < NWI) dma16(rW, sW + (wave + 4 * i) * 1024, wv[i], ks * (BK * 2));
+            int kc = u_kc, sidx = 0;
+            if (a.n_src > 1 && !a.src_per_group) {
+                sidx = kc / (a.src_cvec * 8);
+                kc -= sidx * a.src_cvec * 8;
+            }
+            const int soff = u_toff + kc * 2;
+#pragma unroll
+            for (int i = 0; i < PPW; ++i) {
+                if (wave + 4 * i < NPI) {
+                    const int voff = ((pmask[i] >> u_tap) & 1u) ? pv[i] : oob;
+                    unsigned char* dst = sX + (wave + 4 * i) * 1024;
+                    if (sidx == 0) dma16(rX0, dst, voff, soff);
+                    else if (sidx == 1) dma16(rX1, dst, voff, soff);
+                    else dma16(rX2, dst, voff, soff);
+                }
+            }
+            u_kc += BK;
+            if (u_kc >= a.cin) {
+                u_kc = 0; ++u_tap;
+                if (++u_kq == a.kw) { u_kq = 0; ++u_kr; }
+                u_toff = (u_kr * a.seg_w[0] + u_kq) * a.x_ld * 2;
+            }
+            return;
+        }
         const bool k_in = ks * BK + ch * 8 < a.k_pad;          // BK = 64 with k_pad = 32 (mod 64): the last half-step is zero
 #pragma unroll
         for (int i = 0; i < WPW; ++i) {
@@ -686,6 +781,12 @@ __global__ __launch_bounds__(256, (BK == 64 ? 2 : (BN * BM >= 128 * 128 ? 3 : 4)
     }
     if (a.stage_out) {
         _Float16* tile = reinterpret_cast<_Float16*>(smem);
+        float4 bias4[TN];                                    // this lane's 4 channels of each n-tile, loaded once
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int co = tile_n * BN + wn * WN + i * 16 + fch * 4;
+            bias4[i] = co < a.cout ? *reinterpret_cast<const float4*>(a.bias + g * a.cout + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
             const int prow = wm * WM + j * 16 + frow;
@@ -698,7 +799,7 @@ __global__ __launch_bounds__(256, (BK == 64 ? 2 : (BN * BM >= 128 * 128 ? 3 : 4)
                 const int col = wn * WN + i * 16 + fch * 4;
                 const int co = tile_n * BN + col;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (mok && co < a.cout) epi_compute(a, c, g * a.cout + co, v);
+                if (mok && co < a.cout) epi_compute_b(a, c, g * a.cout + co, v, bias4[i]);
                 const f16x4 o4 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                 *reinterpret_cast<f16x4*>(tile + prow * TS + col) = o4;
             }
@@ -920,15 +1021,6 @@ struct TapArgs {
 constexpr int TAP_HPIECES = (HALO_PX * 4 + 63) / 64;        // 1-KiB pieces per halo tile (64-B pixels): 22
 constexpr int TAP_HBYTES = TAP_HPIECES * 1024;
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
-    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
-}
-// one wave-instruction of LDS DMA: lane l's 16 bytes at base + voff + soff land at lds + 16*l; an offset at or
-// past the resource's size reads as zero (how padding taps, tile edges and tail rows are produced)
-__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned char* lds, int voff, int soff) {
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
-}
-
 // halo image: pixel (hy, hx) of the (8+2) x (32+2) tile at byte (hy*34 + hx)*64, its 16-B channel piece c8 in slot
 // c8 ^ (((hx>>2)&1)<<1). Keyed on the COLUMN only, so a tap's row shift is a pure immediate offset, and the 16
 // consecutive pixels of an MFMA fragment hit 16 distinct LDS slots at any column alignment.
@@ -1080,6 +1172,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
         return true;
     };
     _Float16* tile = reinterpret_cast<_Float16*>(smem);
+    float4 bias4[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int co = tile_n * BN + i * 16 + fch * 4;
+        bias4[i] = co < a.cout ? *reinterpret_cast<const float4*>(a.bias + g * a.cout + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int prow = (2 * wave + (j >> 1)) * 32 + (j & 1) * 16 + frow;
@@ -1091,7 +1189,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
             const int co = tile_n * BN + col;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (a.stage_out) {
-                if (ok && co < a.cout) epi_compute(a, ec, g * a.cout + co, v);
+                if (ok && co < a.cout) epi_compute_b(a, ec, g * a.cout + co, v, bias4[i]);
                 const f16x4 o4 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                 *reinterpret_cast<f16x4*>(tile + prow * TS + col) = o4;
             } else if (ok && co < a.cout) {
@@ -1368,11 +1466,13 @@ int launch(ConvKArgs& k, int groups, hipStream_t st) {
 
 template <int BN, int BM, int WN, int WM, int BK = 32>
 int launch_glds(ConvKArgs& k, int groups, hipStream_t st) {
+    const bool ut = k.x_bytes != 0 && (k.cin % BK) == 0;
     k.tiles_n = (k.cout + BN - 1) / BN;
     const int tiles_m = (k.m_total + BM - 1) / BM;
     k.nblk = k.tiles_n * tiles_m;
     dim3 grid(k.nblk, groups, k.k_splits);
-    hipLaunchKernelGGL((conv_igemm_glds_kernel<BN, BM, WN, WM, BK>), grid, dim3(256), 0, st, k);
+    if (ut) hipLaunchKernelGGL((conv_igemm_glds_kernel<BN, BM, WN, WM, BK, true>), grid, dim3(256), 0, st, k);
+    else hipLaunchKernelGGL((conv_igemm_glds_kernel<BN, BM, WN, WM, BK, false>), grid, dim3(256), 0, st, k);
     if (k.k_splits > 1) {
         const int ctot = groups * k.cout;
         long work = (long)k.m_total * (ctot >> 2);
@@ -1539,6 +1639,12 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
     k.m_total = (int)m;
     k.flags = f; k.res_h = d->res_h; k.res_w = d->res_w;
     k.w_gstride = (long)d->w_rows * d->k_pad;
+    k.x_bytes = 0; k.w_bytes = 0;
+    if (getenv("LLV_NO_UT") == nullptr && d->n_seg == 1 && d->kh * d->kw <= 32 && (d->cin & 31) == 0 &&
+        (d->n_src == 1 || d->groups == d->n_src || (d->src_cvec & 7) == 0)) {
+        const size_t xb = tap_x_bytes(d) + (size_t)(d->pad * d->seg_w[0] + d->pad) * d->x_ld * 2, wb = (size_t)d->w_rows * d->k_pad * 2;
+        if (xb < (1ull << 30) && wb < (1ull << 31)) { k.x_bytes = (unsigned)tap_x_bytes(d); k.w_bytes = (unsigned)wb; }
+    }
     k.src_per_group = (d->n_src > 1 && d->groups == d->n_src) ? 1 : 0;
     k.act_slope = d->act_slope;
     k.ps_h = 2 * d->seg_ho[0]; k.ps_w = 2 * d->seg_wo[0];
