@@ -231,6 +231,58 @@ __device__ __forceinline__ void staged_store(const ConvKArgs& a, const _Float16*
     });
 }
 
+// 4 x 4 transpose across the four 16-lane rows of a wave: lane (r, row f) holding v[e] ends up holding the old
+// v[f] of row e. Two rounds of gfx950's lane-swap instructions (v_permlane16_swap / v_permlane32_swap), no LDS.
+__device__ __forceinline__ void row_transpose4(float (&v)[4]) {
+    unsigned u0 = __float_as_uint(v[0]), u1 = __float_as_uint(v[1]), u2 = __float_as_uint(v[2]), u3 = __float_as_uint(v[3]);
+    auto s01 = __builtin_amdgcn_permlane16_swap(u0, u1, false, false);   // odd rows of [0] <-> even rows of [1]
+    auto s23 = __builtin_amdgcn_permlane16_swap(u2, u3, false, false);
+    u0 = s01[0]; u1 = s01[1]; u2 = s23[0]; u3 = s23[1];
+    auto t02 = __builtin_amdgcn_permlane32_swap(u0, u2, false, false);   // rows 2,3 of [0] <-> rows 0,1 of [2]
+    auto t13 = __builtin_amdgcn_permlane32_swap(u1, u3, false, false);
+    v[0] = __uint_as_float(t02[0]); v[2] = __uint_as_float(t02[1]);
+    v[1] = __uint_as_float(t13[0]); v[3] = __uint_as_float(t13[1]);
+}
+
+// PixelShuffle(2) store of a tile staged in SHUFFLED order: row prow*4 + e (e = 2*dy + dx) holds the BN/4 output
+// channels of output pixel (2oy+dy, 2ox+dx) contiguously (row stride BN/4 + 8 halfs), bias already added. One lane =
+// 8 channels: 16-B LDS read, 16-B skip-connection read, activation, 16-B store.
+template <int BN, int BM, typename LocFn>
+__device__ __forceinline__ void staged_store_shuffled(const ConvKArgs& a, const _Float16* tile, int g, int tile_n, LocFn loc) {
+    constexpr int OC = BN / 4, TS2 = OC + 8, CPR = OC / 8;
+    static_assert(OC % 8 == 0 && 256 % CPR == 0, "BN >= 32");
+    const int tid = threadIdx.x;
+    const int cc = tid % CPR;
+    const int co = tile_n * BN + cc * 32;                     // first conv channel behind this lane's 8 outputs
+    if (co >= a.cout) return;
+    const int occ = (g * a.cout + co) >> 2;
+    for (int row = tid / CPR; row < BM * 4; row += 256 / CPR) {
+        const int prow = row >> 2, e = row & 3;
+        EpiCtx c;
+        if (!loc(prow, c)) continue;
+        const int dy = e >> 1, dx = e & 1;
+        if (2 * c.oy + dy >= a.ps_h || 2 * c.ox + dx >= a.ps_w) continue;
+        const long p = (long)c.yo + ((long)(c.n * a.ps_h + 2 * c.oy + dy)) * a.ps_w + (2 * c.ox + dx);
+        const f16x8 t8 = *reinterpret_cast<const f16x8*>(tile + row * TS2 + cc * 8);
+        float v[8];
+#pragma unroll
+        for (int t = 0; t < 8; ++t) v[t] = (float)t8[t];
+        if (a.flags & LLV_CONV_RES_ADD) {
+            const f16x8 r8 = *reinterpret_cast<const f16x8*>(a.res + p * a.res_ld + occ);
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] += (float)r8[t];
+        }
+        if (a.flags & (LLV_CONV_RELU | LLV_CONV_LEAKY)) {
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = act_fn(a, v[t]);
+        }
+        f16x8 o8v;
+#pragma unroll
+        for (int t = 0; t < 8; ++t) o8v[t] = (_Float16)v[t];
+        *reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(a.y) + p * a.y_ld + occ) = o8v;
+    }
+}
+
 // split-K second pass: sum the fp32 partial slabs, then the normal epilogue. One lane per (row, 4 channels).
 __global__ __launch_bounds__(256) void splitk_epilogue_kernel(const ConvKArgs a, int ctot) {
     const int c4 = ctot >> 2;
@@ -1036,8 +1088,11 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
     constexpr int HPW = (TAP_HPIECES + 3) / 4;               // halo pieces per wave per chunk (<= 6)
     constexpr int TS = BN + 8;
     constexpr int RING = 2 * TAP_HBYTES + 2 * WBYTES;
-    constexpr int EPI = 256 * TS * 2;
+    constexpr int EPI0 = 256 * TS * 2;
+    constexpr int EPI1 = 256 * 4 * (BN / 4 + 8) * 2;         // PixelShuffle: rows in (pixel, sub-pixel) order
+    constexpr int EPI = EPI0 > EPI1 ? EPI0 : EPI1;
     constexpr int SMEM = RING > EPI ? RING : EPI;
+    static_assert(2 * SMEM <= 160 * 1024, "two workgroups per CU");
     constexpr int ROWB = (HALO_TW + 2) * 64;                 // bytes per halo row
     static_assert(HPW <= 8, "halo pieces are dealt one per tap step, with one step to spare");
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
@@ -1177,6 +1232,26 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
     for (int i = 0; i < TN; ++i) {
         const int co = tile_n * BN + i * 16 + fch * 4;
         bias4[i] = co < a.cout ? *reinterpret_cast<const float4*>(a.bias + g * a.cout + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    constexpr int TS2 = BN / 4 + 8;
+    constexpr bool SHUF_OK = 256 * 4 * TS2 * 2 <= SMEM;       // the shuffled tile fits (BN = 64)
+    if (SHUF_OK && a.stage_out && (a.flags & LLV_CONV_PIXSHUF)) {
+        // PixelShuffle: transpose each 4-channel group across the four fragment rows so that a lane holds 4
+        // consecutive OUTPUT channels of one sub-pixel, and stage rows in (pixel, sub-pixel) order
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int prow = (2 * wave + (j >> 1)) * 32 + (j & 1) * 16 + frow;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                float v[4] = {acc[i][j][0] + bias4[i].x, acc[i][j][1] + bias4[i].y, acc[i][j][2] + bias4[i].z, acc[i][j][3] + bias4[i].w};
+                row_transpose4(v);
+                const f16x4 o4 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                *reinterpret_cast<f16x4*>(tile + (prow * 4 + fch) * TS2 + i * 4) = o4;
+            }
+        }
+        __syncthreads();
+        staged_store_shuffled<BN, 256>(a, tile, g, tile_n, loc);
+        return;
     }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
@@ -1537,7 +1612,9 @@ static int plan_launch(const llv_conv_desc* d, LaunchPlan& lp) {
             blocks += (long)d->batch * ((d->seg_h[s] + HALO_TH - 1) / HALO_TH) * ((d->seg_w[s] + HALO_TW - 1) / HALO_TW);
         blocks *= (long)((d->cout + 63) / 64) * d->groups;
         if (blocks >= 160) {
-            lp.tile = LLV_TILE_TAP64;
+            // PixelShuffle layers take the 128-channel tile: a workgroup then owns 32 output channels of both
+            // dx sub-pixels = whole 128-byte lines of the shuffled output (and of the skip tensor it adds)
+            lp.tile = ((d->flags & LLV_CONV_PIXSHUF) && d->cout % 128 == 0) ? LLV_TILE_TAP128 : LLV_TILE_TAP64;
             lp.splits = 1;
             lp.nk_per = (d->k_pad + 31) / 32;
             return LLV_OK;
