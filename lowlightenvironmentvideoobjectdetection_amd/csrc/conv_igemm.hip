@@ -1466,6 +1466,244 @@ __global__ __launch_bounds__(256) void convpair_kernel(const ConvKArgs a, const 
     staged_store<BN2, 256>(a, tile, 0, 0, row_to_m);
 }
 
+// ------------------------------------------------------------------------------------------------
+// convpair2_kernel<CK0, BN2>: the fused conv pair re-cut for the vector/matrix issue port. Same math and the same
+// packed weights as convpair_kernel, but
+//   * every global read is an LDS DMA through a buffer resource (flat copies of the weight blocks, a gathered
+//     copy of the input patch with out-of-image pixels read as zero); group g+1's patch and first-conv weights
+//     stream in while group g's second conv runs, the second conv's weights while the first conv runs;
+//   * all LDS fragment addresses are computed once per workgroup (they do not depend on the group) and the taps
+//     are immediates, so the two MFMA phases carry almost no address arithmetic;
+//   * patch and halo use the column-keyed swizzle of the tap kernel (row shifts are immediates).
+// LDS (bytes): patch[2] | w0[2] | halo | w1     InputCvBlock 2x7168 + 2x7168 + 22528 + 19456 = 70656
+//                                               OutputCvBlock 27648 + 19456 + 22528 + 10240 = 79872   (2 per CU)
+// ------------------------------------------------------------------------------------------------
+struct Pair2Args {
+    unsigned x_bytes, w0_bytes, w1_bytes;   // buffer-resource bounds: one source tensor, ALL first-conv weights, ALL second-conv weights
+};
+
+__device__ __forceinline__ int patch_off32(int py, int px, int c8) {   // 64-B pixels, column-keyed swizzle
+    return (py * PATCH_W + px) * 64 + ((c8 ^ (((px >> 2) & 1) << 1)) << 4);
+}
+
+template <int CK0, int BN2>
+__global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, const HaloArgs h, const PreArgs pre, const Pair2Args q) {
+    constexpr int G = CK0 == 8 ? 3 : 1;                      // groups of the first conv = 32-channel chunks of the second
+    constexpr int TN2 = BN2 / 16, TM = 4;
+    constexpr int NMT = (HALO_PX + 15) / 16;                 // 22 M-tiles of 16 halo pixels
+    constexpr int MTW = (NMT + 3) / 4;                       // per wave (<= 6)
+    constexpr int NKS0 = (9 * CK0 + 31) / 32;                // k-steps of the first conv (3 or 9)
+    constexpr int WROW0 = CK0 == 8 ? 104 : 296, WROW1 = 296;
+    constexpr int PATCH_B = PATCH_PX * CK0 * 2;              // 6912 / 27648
+    constexpr int PATCH_PIECES = (PATCH_B + 1023) / 1024;    // 7 / 27
+    constexpr int W0_B = 32 * WROW0 * 2, W0_PIECES = (W0_B + 1023) / 1024;     // 6656 (7) / 18944 (19)
+    constexpr int W1_B = BN2 * WROW1 * 2, W1_PIECES = (W1_B + 1023) / 1024;    // 18944 (19) / 9472 (10)
+    constexpr int NPB = G > 1 ? 2 : 1;                       // patch / w0 buffers
+    constexpr int O_PATCH = 0, O_W0 = O_PATCH + NPB * PATCH_PIECES * 1024, O_HALO = O_W0 + NPB * W0_PIECES * 1024;
+    constexpr int O_W1 = O_HALO + TAP_HBYTES, SMEM = O_W1 + W1_PIECES * 1024;
+    constexpr int ROWB = (HALO_TW + 2) * 64, PROWB = PATCH_W * (CK0 * 2);
+    constexpr int PPW = (PATCH_PIECES + 3) / 4, W0PW = (W0_PIECES + 3) / 4, W1PW = (W1_PIECES + 3) / 4;
+    static_assert(2 * SMEM <= 160 * 1024, "two workgroups per CU");
+    static_assert(256 * (BN2 + 8) * 2 <= TAP_HBYTES, "the epilogue tile reuses the halo buffer");
+    __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    int bid = blockIdx.x;
+    {
+        const int nblk = h.nblk;
+        const int qq = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
+        bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+    }
+    const int tx0 = (bid % h.tiles_x) * HALO_TW;
+    const int t1 = bid / h.tiles_x;
+    const int ty0 = (t1 % h.tiles_y) * HALO_TH;
+    const int n = t1 / h.tiles_y;
+    const int H = h.H, W = h.W;
+    const int img_base = a.seg_xoff[0] + n * H * W;
+    const int frow = lane & 15, fch = lane >> 4;
+
+    const __amdgpu_buffer_rsrc_t rX0 = make_rsrc(a.x0, q.x_bytes);
+    const __amdgpu_buffer_rsrc_t rX1 = make_rsrc(a.x1, q.x_bytes);
+    const __amdgpu_buffer_rsrc_t rX2 = make_rsrc(a.x2, q.x_bytes);
+    const __amdgpu_buffer_rsrc_t rW0 = make_rsrc(pre.w, q.w0_bytes);
+    const __amdgpu_buffer_rsrc_t rW1 = make_rsrc(h.w, q.w1_bytes);
+
+    // ---- DMA offsets (constant over groups)
+    int pvo[PPW];                                            // patch pieces wave, wave+4, ...
+#pragma unroll
+    for (int i = 0; i < PPW; ++i) {
+        const int pc = wave + 4 * i;
+        int pp, c8;
+        if (CK0 == 8) { pp = pc * 64 + lane; c8 = 0; }
+        else { pp = pc * 16 + (lane >> 2); c8 = lane & 3; }
+        pvo[i] = (int)q.x_bytes;
+        if (pp < PATCH_PX) {
+            const int py = pp / PATCH_W, px = pp - py * PATCH_W;
+            if (CK0 == 32) c8 ^= ((px >> 2) & 1) << 1;
+            const int gy = ty0 + py - 2, gx = tx0 + px - 2;
+            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) pvo[i] = ((img_base + gy * W + gx) * a.x_ld + c8 * 8) * 2;
+        }
+    }
+    auto issue_patch = [&](int g, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            if (wave + 4 * i < PATCH_PIECES) {
+                unsigned char* dst = smem + O_PATCH + (buf * PATCH_PIECES + wave + 4 * i) * 1024;
+                if (g == 0) dma16(rX0, dst, pvo[i], 0);
+                else if (g == 1) dma16(rX1, dst, pvo[i], 0);
+                else dma16(rX2, dst, pvo[i], 0);
+            }
+        }
+    };
+    auto issue_flat = [&](__amdgpu_buffer_rsrc_t r, int npieces, int nbytes, int lds_base, int soff) __attribute__((always_inline)) {
+        for (int pc = wave; pc < npieces; pc += 4) {
+            const int o = (pc * 64 + lane) * 16;
+            dma16(r, smem + lds_base + pc * 1024, o < nbytes ? o : 0x7fffff00, soff);
+        }
+    };
+
+    // ---- fragment addresses (constant over groups)
+    // stage A: M-tile it of this wave = halo pixels 16*(wave + 4*it) + frow
+    int pa[MTW][CK0 == 8 ? NKS0 : 3];                        // patch read offsets: per k-step (CK0 = 8) / per tap column (CK0 = 32)
+    int hw[MTW];                                             // halo write offset of this lane's first 4 channels; -1: no pixel
+    unsigned inside = 0;
+#pragma unroll
+    for (int it = 0; it < MTW; ++it) {
+        const int hp = (wave + 4 * it) * 16 + frow;
+        const int hpc = hp < HALO_PX ? hp : HALO_PX - 1;
+        const int hy = hpc / (HALO_TW + 2), hx = hpc - hy * (HALO_TW + 2);
+        if (CK0 == 8) {
+#pragma unroll
+            for (int ks = 0; ks < NKS0; ++ks) {
+                int tap = ks * 4 + fch;                        // one 8-channel pixel per k chunk
+                tap = tap > 8 ? 8 : tap;                       // k >= 72: zero weights, any valid address
+                const int tr = tap / 3, tq = tap - 3 * tr;
+                pa[it][ks] = ((hy + tr) * PATCH_W + hx + tq) * 16;
+            }
+        } else {
+#pragma unroll
+            for (int tq = 0; tq < 3; ++tq) pa[it][tq] = patch_off32(hy, hx + tq, fch);
+        }
+        hw[it] = hp < HALO_PX ? tap_halo_off(hy, hx, fch >> 1) + (fch & 1) * 8 : -1;
+        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
+        if (hp < HALO_PX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) inside |= 1u << it;
+    }
+    const int wa0 = (frow * WROW0 + fch * 8) * 2;            // first-conv weights: row frow (+16: second n-tile), k chunk fch
+    const int wa1 = (frow * WROW1 + fch * 8) * 2;
+    int hb[TM][3];
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int tq = 0; tq < 3; ++tq) hb[j][tq] = tap_halo_off(2 * wave + (j >> 1), (j & 1) * 16 + frow + tq, fch);
+
+    f32x4 acc[TN2][TM];
+#pragma unroll
+    for (int i = 0; i < TN2; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    issue_flat(rW1, W1_PIECES, W1_B, O_W1, 0);
+    issue_patch(0, 0);
+    issue_flat(rW0, W0_PIECES, W0_B, O_W0, 0);
+#pragma unroll 1
+    for (int g = 0; g < G; ++g) {
+        const int pb = g & (NPB - 1);
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                     // patch/w0 of group g landed; halo and w1 are free (B of g-1 done)
+        if (g > 0) issue_flat(rW1, W1_PIECES, W1_B, O_W1, g * W1_B);
+        const float4 b0 = *reinterpret_cast<const float4*>(pre.bias + g * 32 + fch * 4);
+        const float4 b1 = *reinterpret_cast<const float4*>(pre.bias + g * 32 + 16 + fch * 4);
+        // ---- stage A: first conv on the halo tile
+        const unsigned char* sP = smem + O_PATCH + pb * PATCH_PIECES * 1024;
+        const unsigned char* sW0 = smem + O_W0 + pb * W0_PIECES * 1024;
+#pragma unroll
+        for (int it = 0; it < MTW; ++it) {
+            if (wave + 4 * it < NMT) {
+                f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+                for (int ks = 0; ks < NKS0; ++ks) {
+                    f16x8 bf;
+                    if (CK0 == 8) bf = *reinterpret_cast<const f16x8*>(sP + pa[it][ks]);
+                    else bf = *reinterpret_cast<const f16x8*>(sP + pa[it][ks % 3] + (ks / 3) * PROWB);
+                    const f16x8 a0 = *reinterpret_cast<const f16x8*>(sW0 + wa0 + ks * 64);
+                    const f16x8 a1 = *reinterpret_cast<const f16x8*>(sW0 + wa0 + 16 * WROW0 * 2 + ks * 64);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bf, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bf, c1, 0, 0, 0);
+                }
+                // bias + ReLU; zero outside the image (= the second conv's zero padding)
+                const float m = (inside >> it) & 1u ? 1.f : 0.f;
+                f16x4 o0, o1;
+                o0[0] = (_Float16)(fmaxf(c0[0] + b0.x, 0.f) * m); o0[1] = (_Float16)(fmaxf(c0[1] + b0.y, 0.f) * m);
+                o0[2] = (_Float16)(fmaxf(c0[2] + b0.z, 0.f) * m); o0[3] = (_Float16)(fmaxf(c0[3] + b0.w, 0.f) * m);
+                o1[0] = (_Float16)(fmaxf(c1[0] + b1.x, 0.f) * m); o1[1] = (_Float16)(fmaxf(c1[1] + b1.y, 0.f) * m);
+                o1[2] = (_Float16)(fmaxf(c1[2] + b1.z, 0.f) * m); o1[3] = (_Float16)(fmaxf(c1[3] + b1.w, 0.f) * m);
+                if (hw[it] >= 0) {
+                    *reinterpret_cast<f16x4*>(smem + O_HALO + hw[it]) = o0;          // channels 4*fch .. (16-B slot fch>>1)
+                    *reinterpret_cast<f16x4*>(smem + O_HALO + (hw[it] ^ 32)) = o1;   // channels 16 + 4*fch .. (slot 2 + (fch>>1))
+                }
+            }
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();                                     // halo complete, w1 of group g landed, patch/w0 buffers of g-1 free
+        if (g + 1 < G) {
+            issue_patch(g + 1, (g + 1) & (NPB - 1));
+            issue_flat(rW0, W0_PIECES, W0_B, O_W0 + ((g + 1) & (NPB - 1)) * W0_PIECES * 1024, (g + 1) * W0_B);
+        }
+        // ---- stage B: second conv, chunk g
+        const unsigned char* sH = smem + O_HALO;
+        const unsigned char* sW1 = smem + O_W1;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            f16x8 af[TN2], bf[TM];
+#pragma unroll
+            for (int j = 0; j < TM; ++j) bf[j] = *reinterpret_cast<const f16x8*>(sH + hb[j][t % 3] + (t / 3) * ROWB);
+#pragma unroll
+            for (int i = 0; i < TN2; ++i) af[i] = *reinterpret_cast<const f16x8*>(sW1 + wa1 + i * 16 * WROW1 * 2 + t * 64);
+#pragma unroll
+            for (int i = 0; i < TN2; ++i)
+#pragma unroll
+                for (int j = 0; j < TM; ++j)
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        }
+    }
+    __syncthreads();
+
+    // ---- epilogue through an LDS tile in the halo buffer
+    const int ybase = a.seg_yoff[0] + n * H * W;
+    auto loc = [&](int prow, EpiCtx& c) {
+        const int oy = ty0 + (prow >> 5), ox = tx0 + (prow & 31);
+        if (oy >= H || ox >= W) return false;
+        c.opix = ybase + oy * W + ox;
+        c.rpix = c.opix;
+        c.ox = ox; c.oy = oy; c.n = n; c.Ho = H; c.Wo = W; c.yo = a.seg_yoff[0];
+        return true;
+    };
+    constexpr int TS = BN2 + 8;
+    _Float16* tile = reinterpret_cast<_Float16*>(smem + O_HALO);
+    float4 bias4[TN2];
+#pragma unroll
+    for (int i = 0; i < TN2; ++i) {
+        const int co = i * 16 + fch * 4;
+        bias4[i] = co < a.cout ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+#pragma unroll
+    for (int j = 0; j < TM; ++j) {
+        const int prow = (2 * wave + (j >> 1)) * 32 + (j & 1) * 16 + frow;
+        EpiCtx ec;
+        const bool ok = loc(prow, ec);
+#pragma unroll
+        for (int i = 0; i < TN2; ++i) {
+            const int col = i * 16 + fch * 4;
+            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (ok && col < a.cout) epi_compute_b(a, ec, col, v, bias4[i]);
+            const f16x4 o4 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            *reinterpret_cast<f16x4*>(tile + prow * TS + col) = o4;
+        }
+    }
+    __syncthreads();
+    staged_store_loc<BN2, 256>(a, tile, 0, 0, loc);
+}
+
 template <int BN>
 int launch_halo(ConvKArgs& k, HaloArgs& h, int groups, int batch, hipStream_t st) {
     h.ntiles_n = (k.cout + BN - 1) / BN;
@@ -1847,6 +2085,16 @@ static int convpair_launch(const llv_inputcv_desc* p, void* stream, bool output_
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convpair_kernel<32, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convpair_kernel<8, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_done = true;
+    }
+    const size_t xb = (size_t)(d->seg_xoff[0] + px) * d->x_ld * 2;
+    if (getenv("LLV_CONVPAIR_V1") == nullptr && xb < (1ull << 31)) {
+        Pair2Args q;
+        q.x_bytes = (unsigned)xb;
+        q.w0_bytes = (unsigned)((output_block ? 1 : 3) * 32 * pre.wrow * 2);
+        q.w1_bytes = (unsigned)(h.n_chunks * bn2 * h.wrow * 2);
+        if (output_block) hipLaunchKernelGGL((convpair2_kernel<32, 16>), dim3(h.nblk), dim3(256), 0, (hipStream_t)stream, k, h, pre, q);
+        else hipLaunchKernelGGL((convpair2_kernel<8, 32>), dim3(h.nblk), dim3(256), 0, (hipStream_t)stream, k, h, pre, q);
+        return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
     }
     if (output_block) hipLaunchKernelGGL((convpair_kernel<32, 16>), dim3(h.nblk), dim3(256), lds, (hipStream_t)stream, k, h, pre);
     else hipLaunchKernelGGL((convpair_kernel<8, 32>), dim3(h.nblk), dim3(256), lds, (hipStream_t)stream, k, h, pre);
