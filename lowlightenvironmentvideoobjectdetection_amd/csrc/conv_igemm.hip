@@ -1496,8 +1496,10 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
     constexpr int WROW0 = CK0 == 8 ? 104 : 296, WROW1 = 296;
     constexpr int PATCH_B = PATCH_PX * CK0 * 2;              // 6912 / 27648
     constexpr int PATCH_PIECES = (PATCH_B + 1023) / 1024;    // 7 / 27
-    constexpr int W0_B = 32 * WROW0 * 2, W0_PIECES = (W0_B + 1023) / 1024;     // 6656 (7) / 18944 (19)
-    constexpr int W1_B = BN2 * WROW1 * 2, W1_PIECES = (W1_B + 1023) / 1024;    // 18944 (19) / 9472 (10)
+    constexpr int W0_B = 32 * WROW0 * 2, W1_B = BN2 * WROW1 * 2;               // bytes per group in global memory
+    // LDS images of the weights: [k-step][row][32 halfs] with lds_off's swizzle (the padded global rows are gathered
+    // into it by the DMA), so fragment reads are conflict-free under ds_read_b128's real lane grouping
+    constexpr int W0_PIECES = NKS0 * 2, W1_PIECES = 9 * BN2 / 16;              // 6 / 18 and 18 / 9 KiB
     constexpr int NPB = G > 1 ? 2 : 1;                       // patch / w0 buffers
     constexpr int O_PATCH = 0, O_W0 = O_PATCH + NPB * PATCH_PIECES * 1024, O_HALO = O_W0 + NPB * W0_PIECES * 1024;
     constexpr int O_W1 = O_HALO + TAP_HBYTES, SMEM = O_W1 + W1_PIECES * 1024;
@@ -1555,11 +1557,29 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
             }
         }
     };
-    auto issue_flat = [&](__amdgpu_buffer_rsrc_t r, int npieces, int nbytes, int lds_base, int soff) __attribute__((always_inline)) {
-        for (int pc = wave; pc < npieces; pc += 4) {
-            const int o = (pc * 64 + lane) * 16;
-            dma16(r, smem + lds_base + pc * 1024, o < nbytes ? o : 0x7fffff00, soff);
-        }
+    // weight gathers: image offset o = 1024*piece + 16*lane -> (k-step, row, physical slot) -> padded global row
+    int w0v[W0PW], w1v[W1PW];
+#pragma unroll
+    for (int i = 0; i < W0PW; ++i) {
+        const int o = (wave + 4 * i) * 1024 + lane * 16;
+        const int ks = o / 2048, row = (o % 2048) / 64, slot = (o % 64) / 16;
+        w0v[i] = (row * WROW0 + ks * 32 + ((slot ^ ((0 - (row >> 2)) & 3)) * 8)) * 2;
+    }
+#pragma unroll
+    for (int i = 0; i < W1PW; ++i) {
+        const int o = (wave + 4 * i) * 1024 + lane * 16;
+        const int t = o / (BN2 * 64), row = (o % (BN2 * 64)) / 64, slot = (o % 64) / 16;
+        w1v[i] = (row * WROW1 + t * 32 + ((slot ^ ((0 - (row >> 2)) & 3)) * 8)) * 2;
+    }
+    auto issue_w0 = [&](int g, int buf) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < W0PW; ++i)
+            if (wave + 4 * i < W0_PIECES) dma16(rW0, smem + O_W0 + (buf * W0_PIECES + wave + 4 * i) * 1024, w0v[i], g * W0_B);
+    };
+    auto issue_w1 = [&](int g) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < W1PW; ++i)
+            if (wave + 4 * i < W1_PIECES) dma16(rW1, smem + O_W1 + (wave + 4 * i) * 1024, w1v[i], g * W1_B);
     };
 
     // ---- fragment addresses (constant over groups)
@@ -1588,8 +1608,7 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
         const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
         if (hp < HALO_PX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) inside |= 1u << it;
     }
-    const int wa0 = (frow * WROW0 + fch * 8) * 2;            // first-conv weights: row frow (+16: second n-tile), k chunk fch
-    const int wa1 = (frow * WROW1 + fch * 8) * 2;
+    const int wa = lds_off(frow, fch);                       // weight fragment: row frow (+1024: next n-tile), k chunk fch
     int hb[TM][3];
 #pragma unroll
     for (int j = 0; j < TM; ++j)
@@ -1602,41 +1621,47 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-    issue_flat(rW1, W1_PIECES, W1_B, O_W1, 0);
+    issue_w1(0);
     issue_patch(0, 0);
-    issue_flat(rW0, W0_PIECES, W0_B, O_W0, 0);
+    issue_w0(0, 0);
+    const bool border = ty0 == 0 || tx0 == 0 || ty0 + HALO_TH >= H || tx0 + HALO_TW >= W;   // halo leaves the image
 #pragma unroll 1
     for (int g = 0; g < G; ++g) {
         const int pb = g & (NPB - 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                     // patch/w0 of group g landed; halo and w1 are free (B of g-1 done)
-        if (g > 0) issue_flat(rW1, W1_PIECES, W1_B, O_W1, g * W1_B);
+        if (g > 0) issue_w1(g);
         const float4 b0 = *reinterpret_cast<const float4*>(pre.bias + g * 32 + fch * 4);
         const float4 b1 = *reinterpret_cast<const float4*>(pre.bias + g * 32 + 16 + fch * 4);
-        // ---- stage A: first conv on the halo tile
+        // ---- stage A: first conv on the halo tile. The weight fragments are the same for every M-tile: registers.
         const unsigned char* sP = smem + O_PATCH + pb * PATCH_PIECES * 1024;
         const unsigned char* sW0 = smem + O_W0 + pb * W0_PIECES * 1024;
+        f16x8 a0[NKS0], a1[NKS0];
+#pragma unroll
+        for (int ks = 0; ks < NKS0; ++ks) {
+            a0[ks] = *reinterpret_cast<const f16x8*>(sW0 + ks * 2048 + wa);
+            a1[ks] = *reinterpret_cast<const f16x8*>(sW0 + ks * 2048 + 1024 + wa);
+        }
 #pragma unroll
         for (int it = 0; it < MTW; ++it) {
             if (wave + 4 * it < NMT) {
-                f32x4 c0 = {0.f, 0.f, 0.f, 0.f}, c1 = {0.f, 0.f, 0.f, 0.f};
+                f32x4 c0 = {b0.x, b0.y, b0.z, b0.w}, c1 = {b1.x, b1.y, b1.z, b1.w};   // bias rides in the accumulator
 #pragma unroll
                 for (int ks = 0; ks < NKS0; ++ks) {
                     f16x8 bf;
                     if (CK0 == 8) bf = *reinterpret_cast<const f16x8*>(sP + pa[it][ks]);
                     else bf = *reinterpret_cast<const f16x8*>(sP + pa[it][ks % 3] + (ks / 3) * PROWB);
-                    const f16x8 a0 = *reinterpret_cast<const f16x8*>(sW0 + wa0 + ks * 64);
-                    const f16x8 a1 = *reinterpret_cast<const f16x8*>(sW0 + wa0 + 16 * WROW0 * 2 + ks * 64);
-                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0, bf, c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1, bf, c1, 0, 0, 0);
+                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[ks], bf, c0, 0, 0, 0);
+                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], bf, c1, 0, 0, 0);
                 }
-                // bias + ReLU; zero outside the image (= the second conv's zero padding)
-                const float m = (inside >> it) & 1u ? 1.f : 0.f;
-                f16x4 o0, o1;
-                o0[0] = (_Float16)(fmaxf(c0[0] + b0.x, 0.f) * m); o0[1] = (_Float16)(fmaxf(c0[1] + b0.y, 0.f) * m);
-                o0[2] = (_Float16)(fmaxf(c0[2] + b0.z, 0.f) * m); o0[3] = (_Float16)(fmaxf(c0[3] + b0.w, 0.f) * m);
-                o1[0] = (_Float16)(fmaxf(c1[0] + b1.x, 0.f) * m); o1[1] = (_Float16)(fmaxf(c1[1] + b1.y, 0.f) * m);
-                o1[2] = (_Float16)(fmaxf(c1[2] + b1.z, 0.f) * m); o1[3] = (_Float16)(fmaxf(c1[3] + b1.w, 0.f) * m);
+                // ReLU on the rounded halves (max commutes with the monotone rounding); zero outside the image
+                // (= the second conv's zero padding), which only workgroups on the image border can see
+                f16x4 o0 = {(_Float16)c0[0], (_Float16)c0[1], (_Float16)c0[2], (_Float16)c0[3]};
+                f16x4 o1 = {(_Float16)c1[0], (_Float16)c1[1], (_Float16)c1[2], (_Float16)c1[3]};
+                const f16x4 z4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                o0 = __builtin_elementwise_max(o0, z4);
+                o1 = __builtin_elementwise_max(o1, z4);
+                if (border && !((inside >> it) & 1u)) { o0 = z4; o1 = z4; }
                 if (hw[it] >= 0) {
                     *reinterpret_cast<f16x4*>(smem + O_HALO + hw[it]) = o0;          // channels 4*fch .. (16-B slot fch>>1)
                     *reinterpret_cast<f16x4*>(smem + O_HALO + (hw[it] ^ 32)) = o1;   // channels 16 + 4*fch .. (slot 2 + (fch>>1))
@@ -1647,7 +1672,7 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
         __syncthreads();                                     // halo complete, w1 of group g landed, patch/w0 buffers of g-1 free
         if (g + 1 < G) {
             issue_patch(g + 1, (g + 1) & (NPB - 1));
-            issue_flat(rW0, W0_PIECES, W0_B, O_W0 + ((g + 1) & (NPB - 1)) * W0_PIECES * 1024, (g + 1) * W0_B);
+            issue_w0(g + 1, (g + 1) & (NPB - 1));
         }
         // ---- stage B: second conv, chunk g
         const unsigned char* sH = smem + O_HALO;
@@ -1658,7 +1683,7 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
 #pragma unroll
             for (int j = 0; j < TM; ++j) bf[j] = *reinterpret_cast<const f16x8*>(sH + hb[j][t % 3] + (t / 3) * ROWB);
 #pragma unroll
-            for (int i = 0; i < TN2; ++i) af[i] = *reinterpret_cast<const f16x8*>(sW1 + wa1 + i * 16 * WROW1 * 2 + t * 64);
+            for (int i = 0; i < TN2; ++i) af[i] = *reinterpret_cast<const f16x8*>(sW1 + t * (BN2 * 64) + i * 1024 + wa);
 #pragma unroll
             for (int i = 0; i < TN2; ++i)
 #pragma unroll
