@@ -85,14 +85,15 @@ def cpu_baseline(det, cleaner, clip_cpu, img_shape):
                        f'RetinaNet R-50+FPN/decode/NMS {t2 - t1:.2f} s, torch fp32, {cores} threads')
 
 
-def _profiled_traffic(frames_per_step):
-    """HBM bytes of the conv launches of one step, from the committed rocprofv3 PMC passes (profiles/*_traffic.json:
-    FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate --pmc passes), if they were taken at this frames_per_step."""
+def _profiled_traffic(frames_per_step, kernel):
+    """HBM bytes per launch of `kernel` from the committed rocprofv3 PMC passes (profiles/traffic.json, written by
+    tools/collect_profile.sh: FETCH_SIZE x2 on gfx950 + WRITE_SIZE, separate --pmc passes), if they were taken at this
+    frames_per_step; None otherwise."""
     path = os.path.join(ROOT, 'profiles', 'traffic.json')
     try:
         t = json.load(open(path))
         if int(t.get('frames_per_step', -1)) == int(frames_per_step):
-            return t['conv_hbm_bytes_per_step']
+            return t['per_kernel'][kernel]['hbm_bytes_per_launch']
     except Exception:
         pass
     return None
@@ -212,22 +213,40 @@ def main():
                 'parallelism': f'clip-sharded x{world}, no data-path collective',
             },
         }
-        # ---- roofline of the dominant kernel family (conv_igemm_kernel: every conv launch of the step)
+        # ---- roofline of the dominant kernel: the conv kernel with the largest share of the step's time. Every launch
+        # is timed with a HIP event pair on the launch stream (Plan.run_timed); flops are the algorithmic 2*MACs of
+        # the unpadded convolution. The other conv kernels are listed beside it.
         if not args.no_kernel_timing:
             timed = plan.plan.run_timed(iters=5)
-            convs = [(n, ms, fl) for (n, ms, fl, _) in timed if fl > 0]
-            conv_ms = sum(ms for _, ms, _ in convs)
+            kof = plan.plan.kernel_of
+            per = {}
+            for (n, ms, fl, _) in timed:
+                if fl <= 0:
+                    continue
+                k = kof.get(n, 'conv').split('+')[0]
+                a = per.setdefault(k, [0.0, 0.0, 0])
+                a[0] += ms; a[1] += fl; a[2] += 1
+            conv_ms = sum(a[0] for a in per.values())
+            conv_fl = sum(a[1] for a in per.values())
             all_ms = sum(ms for _, ms, _, _ in timed)
-            conv_fl = sum(fl for _, _, fl in convs)
-            top = max(convs, key=lambda c: c[1])
+            dom = max(per, key=lambda k: per[k][0])
+            dms, dfl, dn = per[dom]
             peak = 2500.0
-            ach = conv_fl / (conv_ms * 1e-3) / 1e12
+            ach = dfl / (dms * 1e-3) / 1e12
+            convs = [(n, ms, fl) for (n, ms, fl, _) in timed if fl > 0]
+            top = max(convs, key=lambda c: c[1])
             out['roofline'] = {
                 'bound': 'mfma', 'achieved': round(ach, 2), 'peak': peak, 'unit': 'TFLOP/s', 'frac': round(ach / peak, 4),
-                'traffic': _profiled_traffic(B),
-                'kernel': 'conv kernels (conv_igemm_kernel + conv3x3_halo_kernel): all %d conv launches of one step; '
-                          'algorithmic 2*MACs of the unpadded convs' % len(convs),
-                'conv_ms_per_step': round(conv_ms, 4), 'all_kernels_ms_per_step': round(all_ms, 4),
+                'traffic': _profiled_traffic(B, dom),
+                'kernel': dom, 'launches_per_step': dn, 'avg_launch_us': round(dms / dn * 1e3, 2),
+                'algorithmic_gflop_per_launch': round(dfl / dn / 1e9, 2),
+                'share_of_step_kernel_time': round(dms / all_ms, 3),
+                'all_conv_kernels': {'achieved': round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
+                                     'frac': round(conv_fl / (conv_ms * 1e-3) / 1e12 / peak, 4),
+                                     'launches_per_step': len(convs), 'ms_per_step': round(conv_ms, 4)},
+                'per_kernel': {k: {'ms_per_step': round(a[0], 4), 'tflops': round(a[1] / (a[0] * 1e-3) / 1e12, 1), 'launches': a[2]}
+                               for k, a in sorted(per.items(), key=lambda kv: -kv[1][0])},
+                'all_kernels_ms_per_step': round(all_ms, 4),
                 'top_launch': {'name': top[0], 'ms': round(top[1], 4), 'tflops': round(top[2] / (top[1] * 1e-3) / 1e12, 2)},
             }
         if lat is not None:

@@ -145,6 +145,11 @@ const char* llv_strerror(int code);
 
 int llv_conv2d_nhwc_fwd(const llv_conv_desc* desc, void* stream);
 /* bytes of workspace the launch described by desc needs (split-K partial sums); 0 when it runs unsplit */
+
+/* Which kernel llv_conv2d_nhwc_fwd will run for this descriptor: *tile = the LLV_TILE_* id the planner picks
+ * (-1: the direct halo kernel selected by w_halo), *k_splits = the split-K factor. Diagnostic / profiling aid:
+ * the reference has no counterpart (cuDNN picks its algorithm behind torch.nn.functional.conv2d). */
+int llv_conv2d_plan(const llv_conv_desc* d, int* tile, int* k_splits);
 size_t llv_conv2d_workspace_bytes(const llv_conv_desc* desc);
 /* algorithmic FLOPs (2*MACs, true channels) the launch described by desc performs */
 double llv_conv2d_flops(const llv_conv_desc* desc);

@@ -98,6 +98,7 @@ SIGNATURES = {
     'llv_conv2d_nhwc_fwd': (_I, [C.POINTER(ConvDesc), _P]),
     'llv_conv2d_flops': (C.c_double, [C.POINTER(ConvDesc)]),
     'llv_conv2d_workspace_bytes': (_Z, [C.POINTER(ConvDesc)]),
+    'llv_conv2d_plan': (_I, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
     'llv_inputcvblock_fwd': (_I, [C.POINTER(InputCvDesc), _P]),
     'llv_outputcvblock_fwd': (_I, [C.POINTER(InputCvDesc), _P]),
     'llv_maxpool3x3s2_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _P]),

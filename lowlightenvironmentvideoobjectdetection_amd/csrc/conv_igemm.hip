@@ -1893,6 +1893,16 @@ static int plan_launch(const llv_conv_desc* d, LaunchPlan& lp) {
     return LLV_OK;
 }
 
+extern "C" int llv_conv2d_plan(const llv_conv_desc* d, int* tile, int* k_splits) {
+    if (!d || d->n_seg < 1 || d->n_seg > LLV_MAX_SEG || d->cout <= 0 || d->groups < 1 || d->k_pad < 32) return LLV_E_BADARG;
+    LaunchPlan lp;
+    if (d->w_halo && !d->tile) { lp.tile = -1; lp.splits = 1; }        // conv3x3_halo_kernel
+    else if (plan_launch(d, lp) != LLV_OK) return LLV_E_BADARG;
+    if (tile) *tile = lp.tile;
+    if (k_splits) *k_splits = lp.splits;
+    return LLV_OK;
+}
+
 extern "C" size_t llv_conv2d_workspace_bytes(const llv_conv_desc* d) {
     if (!d || d->n_seg < 1 || d->n_seg > LLV_MAX_SEG || d->cout <= 0 || d->groups < 1 || d->k_pad < 32) return 0;
     if (d->w_halo && !d->tile) return 0;

@@ -95,27 +95,59 @@ __device__ __forceinline__ void wave_hist_add(unsigned* base, unsigned key, bool
 // K1: per anchor max_c sigmoid(logit) (every logit read once) + per-level score histogram.
 // A block works inside ONE level (blk0[] = first block of each level), so its histogram lives in LDS and is
 // flushed with at most one global atomic per non-empty bin.
-constexpr int kAnchorsPerBlock = 512;
-template <typename T>
+// The logits of consecutive anchors are contiguous in memory (NHWC, A*C per cell), so the block streams them as
+// 16-byte vectors, lane after lane (whole cache lines per wave); a vector lies inside one anchor (C % VEC == 0), its
+// max goes to an LDS slot, and one lane per anchor folds that anchor's C/VEC slots. The order of the max does
+// not change its value, so the result is bit-identical to the one-lane-per-anchor loop (kept as VEC = 1 for
+// layouts whose rows are not 16-byte multiples).
+constexpr int kAnchorsPerBlock = 256;
+constexpr int kMaxVecPerAnchor = 32;
+template <typename T, int VEC>
 __global__ __launch_bounds__(256) void class_max_kernel(const DecK k) {
     __shared__ unsigned lh[kBins];
+    __shared__ float part[VEC > 1 ? kAnchorsPerBlock * kMaxVecPerAnchor : 1];
     int l = 0;
 #pragma unroll
     for (int s = 1; s < LLV_MAX_SEG; ++s)
         if (s < k.n_levels && (int)blockIdx.x >= k.blk0[s]) l = s;
     IMG_SETUP(k)
     for (int i = threadIdx.x; i < kBins; i += 256) lh[i] = 0;
-    __syncthreads();
     const int n = k.a0[l + 1] - k.a0[l];
     const long cls_l = k.cls_off[l] + (long)img * k.h[l] * k.w[l];
     const int first = (blockIdx.x - k.blk0[l]) * kAnchorsPerBlock;
-    for (int loc = first + threadIdx.x; loc < first + kAnchorsPerBlock && loc < n; loc += 256) {
-        const int cell = loc / k.A, an = loc - cell * k.A;
-        const T* p = reinterpret_cast<const T*>(k.cls) + (cls_l + cell) * (long)k.cls_ld + (long)an * k.C;
-        float m = 0.f;  // sigmoid > 0
-        for (int c = 0; c < k.C; ++c) m = fmaxf(m, sigmoidf_((float)p[c]));
-        ms_i[k.a0[l] + loc] = m;
-        atomicAdd(&lh[score_bin(m)], 1u);
+    const int nb = n - first < kAnchorsPerBlock ? n - first : kAnchorsPerBlock;
+    if constexpr (VEC > 1) {
+        const int per = k.C / VEC;
+        for (int v = threadIdx.x; v < nb * per; v += 256) {
+            const int a = v / per, r = v - a * per;
+            const int loc = first + a;
+            const int cell = loc / k.A, an = loc - cell * k.A;
+            const T* p = reinterpret_cast<const T*>(k.cls) + (cls_l + cell) * (long)k.cls_ld + (long)an * k.C + r * VEC;
+            const uint4 raw = *reinterpret_cast<const uint4*>(p);
+            const T* e = reinterpret_cast<const T*>(&raw);
+            float m = 0.f;  // sigmoid > 0
+#pragma unroll
+            for (int c = 0; c < VEC; ++c) m = fmaxf(m, sigmoidf_((float)e[c]));
+            part[v] = m;
+        }
+        __syncthreads();
+        for (int a = threadIdx.x; a < nb; a += 256) {
+            float m = 0.f;
+            for (int r = 0; r < per; ++r) m = fmaxf(m, part[a * per + r]);
+            ms_i[k.a0[l] + first + a] = m;
+            atomicAdd(&lh[score_bin(m)], 1u);
+        }
+    } else {
+        __syncthreads();
+        for (int a = threadIdx.x; a < nb; a += 256) {
+            const int loc = first + a;
+            const int cell = loc / k.A, an = loc - cell * k.A;
+            const T* p = reinterpret_cast<const T*>(k.cls) + (cls_l + cell) * (long)k.cls_ld + (long)an * k.C;
+            float m = 0.f;
+            for (int c = 0; c < k.C; ++c) m = fmaxf(m, sigmoidf_((float)p[c]));
+            ms_i[k.a0[l] + loc] = m;
+            atomicAdd(&lh[score_bin(m)], 1u);
+        }
     }
     __syncthreads();
     unsigned* gh = hist_i + l * kBins;
@@ -431,8 +463,19 @@ extern "C" int llv_retina_decode_topk(const llv_decode_desc* d, void* stream) {
         k.blk0[l] = nb;
         if (l < d->n_levels) nb += (k.a0[l + 1] - k.a0[l] + kAnchorsPerBlock - 1) / kAnchorsPerBlock;
     }
-    if (k.f32) hipLaunchKernelGGL((class_max_kernel<float>), dim3(nb, batch), dim3(256), 0, st, k);
-    else hipLaunchKernelGGL((class_max_kernel<_Float16>), dim3(nb, batch), dim3(256), 0, st, k);
+    {
+        // 16-byte vector path: rows, anchors and the base pointer must be 16-byte multiples
+        const int vec = k.f32 ? 4 : 8, esz = k.f32 ? 4 : 2;
+        bool ok = (k.C % vec) == 0 && (k.cls_ld % vec) == 0 && k.C / vec <= kMaxVecPerAnchor && ((uintptr_t)k.cls & 15) == 0;
+        for (int l = 0; l < d->n_levels; ++l) ok = ok && ((k.cls_off[l] * (long)k.cls_ld * esz) & 15) == 0;
+        if (k.f32) {
+            if (ok) hipLaunchKernelGGL((class_max_kernel<float, 4>), dim3(nb, batch), dim3(256), 0, st, k);
+            else hipLaunchKernelGGL((class_max_kernel<float, 1>), dim3(nb, batch), dim3(256), 0, st, k);
+        } else {
+            if (ok) hipLaunchKernelGGL((class_max_kernel<_Float16, 8>), dim3(nb, batch), dim3(256), 0, st, k);
+            else hipLaunchKernelGGL((class_max_kernel<_Float16, 1>), dim3(nb, batch), dim3(256), 0, st, k);
+        }
+    }
     hipLaunchKernelGGL(topk_threshold_kernel, dim3(d->n_levels, batch), dim3(256), 0, st, k);
     hipLaunchKernelGGL(topk_compact_kernel, dim3(grid, batch), dim3(256), 0, st, k);
     int np2 = 1;

@@ -43,14 +43,18 @@ class Plan:
         self.device = device
         self.steps = []          # (name, fn, args, flops, bytes)
         self.keep = []           # tensors the launches point into
+        self.kernel_of = {}      # step name -> device kernel it launches (for per-kernel rooflines)
         self.graph = None
 
-    def add(self, name, fn, args, flops=0.0, nbytes=0.0):
+    def add(self, name, fn, args, flops=0.0, nbytes=0.0, kernel=None):
         self.steps.append((name, fn, args, flops, nbytes))
+        if kernel:
+            self.kernel_of[name] = kernel
 
     def extend(self, other: 'Plan'):
         self.steps += other.steps
         self.keep += other.keep
+        self.kernel_of.update(other.kernel_of)
 
     def run(self):
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
@@ -137,7 +141,7 @@ class Builder:
             d.workspace, d.workspace_bytes = self._ws.data_ptr(), wsb
             self._ws_descs.append(d)
         self.plan.keep += [pc, pc.w, pc.bias, d] + list(xs) + [y] + ([res] if res is not None else [])
-        self.plan.add(name, self._fn_conv, (C.byref(d),), flops, nbytes)
+        self.plan.add(name, self._fn_conv, (C.byref(d),), flops, nbytes, kernel=ops.conv_kernel_name(d))
         return d
 
     def conv(self, name, x, pc: ops.PackedConv, flags=0, res=None, out=None, tile=0):
@@ -448,7 +452,7 @@ def _denblock(b: Builder, sd, p, srcs, batch, tag, out):
         m = n * hh * ww
         b.plan.keep += [pc, pc2, d, x0] + list(srcs)
         b.plan.add(f'{tag}.inputcv', lib().llv_inputcvblock_fwd, (C.byref(d),), 2.0 * m * (pc.true_macs_per_pixel + pc2.true_macs_per_pixel),
-                   2.0 * m * (24 + pc2.cout))
+                   2.0 * m * (24 + pc2.cout), kernel='convpair2_kernel<8,32>')
     else:
         # each group writes its own (batch, H, W, 32) plane (full cache lines); inc1 reads the three planes as three sources
         planes = b.buf(ng, n, hh, ww, og_pad)
@@ -498,7 +502,7 @@ def _denblock(b: Builder, sd, p, srcs, batch, tag, out):
         m = n * hh * ww
         b.plan.keep += [pc0, pc1, d, x0s, out, res]
         b.plan.add(f'{tag}.outputcv', lib().llv_outputcvblock_fwd, (C.byref(d),), 2.0 * m * (pc0.true_macs_per_pixel + pc1.true_macs_per_pixel),
-                   2.0 * m * (32 + 8 + 8))
+                   2.0 * m * (32 + 8 + 8), kernel='convpair2_kernel<32,16>')
     else:
         x = b.conv(f'{tag}.out0', x0s, pc0, f)
         b.conv(f'{tag}.out1', x, pc1, CONV_RES_RSUB, res=res, out=out)

@@ -263,6 +263,22 @@ def conv2d(x, pc: PackedConv, res: Optional[torch.Tensor] = None, flags: int = 0
     return out
 
 
+_TILE_KERNEL = {
+    -1: 'conv3x3_halo_kernel', 1: 'conv_igemm_glds_kernel<128,128>', 2: 'conv_igemm_glds_kernel<64,256>',
+    3: 'conv_igemm_glds_kernel<32,256>', 4: 'conv_igemm_glds_kernel<16,256>', 5: 'conv_igemm_glds_kernel<64,64>',
+    6: 'conv_igemm_kernel<128,128>', 7: 'conv_igemm_glds_kernel<128,128,K64>', 8: 'conv_igemm_glds_kernel<64,256,K64>',
+    9: 'conv3x3_tap_kernel<128>', 10: 'conv3x3_tap_kernel<64>',
+}
+
+
+def conv_kernel_name(desc: ConvDesc) -> str:
+    """Name of the device kernel llv_conv2d_nhwc_fwd will launch for this descriptor (llv_conv2d_plan)."""
+    tile, splits = C.c_int(0), C.c_int(0)
+    check(lib().llv_conv2d_plan(C.byref(desc), C.byref(tile), C.byref(splits)), 'llv_conv2d_plan')
+    name = _TILE_KERNEL.get(tile.value, f'tile{tile.value}')
+    return name + ('+splitk' if splits.value > 1 else '')
+
+
 def conv_flops(desc: ConvDesc) -> float:
     return lib().llv_conv2d_flops(C.byref(desc))
 
