@@ -220,17 +220,17 @@ def main():
             timed = plan.plan.run_timed(iters=5)
             kof = plan.plan.kernel_of
             per = {}
-            for (n, ms, fl, _) in timed:
+            for (n, ms, fl, nb) in timed:
                 if fl <= 0:
                     continue
                 k = kof.get(n, 'conv').split('+')[0]
-                a = per.setdefault(k, [0.0, 0.0, 0])
-                a[0] += ms; a[1] += fl; a[2] += 1
+                a = per.setdefault(k, [0.0, 0.0, 0, 0.0])
+                a[0] += ms; a[1] += fl; a[2] += 1; a[3] += nb
             conv_ms = sum(a[0] for a in per.values())
             conv_fl = sum(a[1] for a in per.values())
             all_ms = sum(ms for _, ms, _, _ in timed)
             dom = max(per, key=lambda k: per[k][0])
-            dms, dfl, dn = per[dom]
+            dms, dfl, dn, dnb = per[dom]
             peak = 2500.0
             ach = dfl / (dms * 1e-3) / 1e12
             convs = [(n, ms, fl) for (n, ms, fl, _) in timed if fl > 0]
@@ -240,6 +240,7 @@ def main():
                 'traffic': _profiled_traffic(B, dom),
                 'kernel': dom, 'launches_per_step': dn, 'avg_launch_us': round(dms / dn * 1e3, 2),
                 'algorithmic_gflop_per_launch': round(dfl / dn / 1e9, 2),
+                'algorithmic_bytes_per_launch': round(dnb / dn),
                 'share_of_step_kernel_time': round(dms / all_ms, 3),
                 'all_conv_kernels': {'achieved': round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                                      'frac': round(conv_fl / (conv_ms * 1e-3) / 1e12 / peak, 4),
