@@ -295,6 +295,36 @@ int llv_iou_assign(const float* gt, int k, const float* anchors, const uint8_t* 
                    int gt_max_assign_all, int64_t* assigned_gt_inds, float* max_overlaps, void* workspace,
                    size_t workspace_bytes, void* stream);
 
+/* ---- backward pass of the convolution engine (llv_conv2d_nhwc_{dgrad,wgrad}) ----------------
+ * Replaces torch autograd's cudnn_convolution_backward_{input,weight} under mmdet's ResNet / FPN / RetinaHead
+ * (resnet.py:260-299, fpn.py:170-221, retina_head.py:93-114) in BaseDetector.train_step (base.py:220-253).
+ *
+ * wgrad: dw[g][co][tap*cin + ci] += sum over output pixels of dy[p][g*cout + co] * x[p @ tap][g*cin + ci]
+ *   d      geometry and the INPUT tensor of the forward conv (x[0], x_ld, cin (padded), cout, w_rows, k_pad, kh, kw,
+ *          stride, pad, groups, batch, segment 0: seg_h/w/ho/wo, seg_xoff = pixel offset of x, seg_yoff = of dy);
+ *          one segment and one source per call (a shared-weight conv over pyramid levels = one call per level)
+ *   dy     fp16 NHWC gradient of the conv output (before the activation), row stride dy_ld
+ *   dw     fp32, the packed weight layout [groups][w_rows][k_pad]; ACCUMULATED into (fp32 atomics): zero it first
+ * dgrad has no entry point of its own: it is llv_conv2d_nhwc_fwd on re-packed weights (flipped taps, in/out
+ * transposed; stride 2 as a 2x2 convolution + PixelShuffle), see ops.pack_dgrad in the Python host. */
+int llv_conv2d_nhwc_wgrad(const llv_conv_desc* d, const void* dy, int dy_ld, float* dw, void* stream);
+
+/* dx = (dy [+ dy2]) * (y > 0); dy2 and y may be NULL (then: plain sum / plain copy). n fp16 elements, multiple of 8.
+ * torch autograd of F.relu(x [+ identity]) (resnet.py:292-296). */
+int llv_relu_bwd(const void* dy, const void* dy2, const void* y, void* dx, int64_t n, void* stream);
+
+/* out[c] += sum_p dy[p][c]  (fp32 atomics; dy fp16 [m][ld]): the bias / BN-shift gradient of a conv */
+int llv_bias_grad(const void* dy, int64_t m, int c, int ld, float* out, void* stream);
+
+/* gradient of FPN's top-down path (fpn.py:186-195): dcoarse (n,h,w,c) (+)= sum of dfine (n,H,W,c) over the fine pixels
+ * whose F.interpolate(mode='nearest', size=(H,W)) source is that coarse pixel. fp16 NHWC, c multiple of 8. */
+int llv_upsample_add_bwd(const void* dfine, void* dcoarse, int n, int H, int W, int h, int w, int c, int accumulate, void* stream);
+
+/* torch.optim.SGD step on fp32 tensors: d = g*grad_scale + weight_decay*w; buf = first_step ? d : momentum*buf + d;
+ * w -= lr*buf  (schedule_1x.py: lr 0.01, momentum 0.9, weight_decay 1e-4; grad_scale = 1/loss_scale of fp16 training) */
+int llv_sgd_momentum(float* w, const float* g, float* mom, int64_t n, float lr, float momentum, float weight_decay,
+                     float grad_scale, int first_step, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

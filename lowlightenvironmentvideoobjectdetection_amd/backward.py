@@ -1,0 +1,144 @@
+"""Backward pass of the convolution engine: weight / data gradients on the device kernels.
+
+Replaces torch autograd's conv backward under mmdet's ResNet / FPN / RetinaHead in ``BaseDetector.train_step``
+(mmdetection/mmdet/models/detectors/base.py:220-253; resnet.py:260-299, fpn.py:170-221, retina_head.py:93-114).
+
+* wgrad  -> ``llv_conv2d_nhwc_wgrad`` (csrc/conv_bwd.hip): pixel-reduction GEMM on MFMA, fp32 accumulation into the
+  packed weight layout; :func:`unpack_wgrad` maps it back to the module's ``(Cout, Cin, kh, kw)``.
+* dgrad  -> the FORWARD kernels on re-packed weights (:func:`dgrad_weight`): a stride-1 conv's data gradient is the conv
+  of dY with the spatially flipped, in/out-transposed filter; a stride-2 conv's is a small stride-1 conv over dY that
+  produces the four output phases at once, stored through the PixelShuffle epilogue.
+* everything here works on device tensors; packing is torch indexing on a few MB of weights (plumbing).
+"""
+import ctypes as C
+from typing import Optional, Tuple
+
+import torch
+
+from . import ops
+from ._lib import lib, check, ConvDesc, CONV_PIXSHUF, CONV_RES_ADD
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+# ----------------------------------------------------------------------------------------------
+# device-side packing
+# ----------------------------------------------------------------------------------------------
+def pack_rows_device(weight: torch.Tensor, w_rows: int, cin_pad: int, k_pad: int, out: Optional[torch.Tensor] = None):
+    """(O, I, kh, kw) fp32 device tensor -> fp16 [w_rows][k_pad] with k = (r*kw + q)*cin_pad + c (ops.pack_conv's layout)."""
+    o, i, kh, kw = weight.shape
+    if out is None:
+        out = torch.zeros(w_rows, k_pad, dtype=torch.float16, device=weight.device)
+    v = out[:o, :kh * kw * cin_pad].view(o, kh, kw, cin_pad)
+    v[..., :i] = weight.permute(0, 2, 3, 1).to(torch.float16)
+    return out
+
+
+def unpack_wgrad(dw: torch.Tensor, cout: int, cin: int, kh: int, kw: int, cin_pad: int) -> torch.Tensor:
+    """fp32 [w_rows][k_pad] block of the packed gradient -> (cout, cin, kh, kw)."""
+    return dw[:cout, :kh * kw * cin_pad].view(cout, kh, kw, cin_pad)[..., :cin].permute(0, 3, 1, 2)
+
+
+def dgrad_geometry(kh: int, kw: int, stride: int, pad: int):
+    """Window of the stride-1 conv over dY that yields dX. Returns (KH', KW', pad_h, pad_w, taps) where, for stride 2,
+    taps[(py, dy)] = r (filter row feeding output phase py from window row dy), same for columns."""
+    if stride == 1:
+        return kh, kw, kh - 1 - pad, kw - 1 - pad, None
+    assert stride == 2, 'dgrad is built for stride 1 and 2 (ResNet / FPN)'
+
+    def axis(k):
+        m = {}
+        for ph in range(2):
+            for r in range(k):
+                if (ph + pad - r) % 2 == 0:
+                    m[(ph, (ph + pad - r) // 2)] = r      # forward output row = y + d
+        lo = min(d for (_, d) in m) if m else 0
+        hi = max(d for (_, d) in m) if m else 0
+        return {(ph, d - lo): r for (ph, d), r in m.items()}, hi - lo + 1, -lo
+
+    ty, KH, ph_ = axis(kh)
+    tx, KW, pw_ = axis(kw)
+    return KH, KW, ph_, pw_, (ty, tx)
+
+
+def dgrad_weight(weight: torch.Tensor, stride: int, pad: int, cin_pad: int) -> Tuple[torch.Tensor, int, int, int, int, int]:
+    """Filter of the conv that maps dY -> dX. weight: (Cout, Cin, kh, kw) fp32 (effective, BN folded).
+    Returns (w', KH', KW', pad', flags) with w' of shape (rows, Cout, KH', KW'): rows = Cin for stride 1,
+    4*cin_pad (conv channel 4*ci + 2*py + px) for stride 2 + PixelShuffle."""
+    cout, cin, kh, kw = weight.shape
+    KH, KW, ph_, pw_, taps = dgrad_geometry(kh, kw, stride, pad)
+    if stride == 1:
+        assert ph_ == pw_ and ph_ >= 0
+        return weight.flip(2, 3).permute(1, 0, 2, 3).contiguous(), KH, KW, ph_, 0
+    ty, tx = taps
+    assert ph_ == pw_, 'square geometry expected'
+    w = torch.zeros(cin_pad, 2, 2, cout, KH, KW, dtype=weight.dtype, device=weight.device)
+    # window row d of dY is forward output row y + d - pad'; window position is what the forward kernel calls (r, q)
+    for (py, dy), r in ty.items():
+        for (px, dx), q in tx.items():
+            w[:cin, py, px, :, dy, dx] = weight[:, :, r, q].t()
+    return w.view(cin_pad * 4, cout, KH, KW), KH, KW, ph_, CONV_PIXSHUF
+
+
+# ----------------------------------------------------------------------------------------------
+# launches
+# ----------------------------------------------------------------------------------------------
+def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, cin_pad: int, cout: int, w_rows: int, k_pad: int,
+               kh: int, kw: int, stride: int, pad: int, groups: int, batch: int, seg: tuple, x_ld: int, dy_ld: int):
+    """Accumulate the weight gradient of one segment into dw (fp32 [groups][w_rows][k_pad]).
+    seg = (h, w, ho, wo, x_pixel_off, dy_pixel_off)."""
+    d = ConvDesc()
+    d.x[0] = x.data_ptr()
+    d.n_src, d.n_seg = 1, 1
+    d.x_ld = x_ld
+    d.cin, d.cout, d.w_rows, d.k_pad = cin_pad, cout, w_rows, k_pad
+    d.kh, d.kw, d.stride, d.pad, d.groups, d.batch = kh, kw, stride, pad, groups, batch
+    d.seg_h[0], d.seg_w[0], d.seg_ho[0], d.seg_wo[0], d.seg_xoff[0], d.seg_yoff[0] = seg
+    check(lib().llv_conv2d_nhwc_wgrad(C.byref(d), dy.data_ptr(), dy_ld, dw.data_ptr(), _stream()), 'llv_conv2d_nhwc_wgrad')
+
+
+def relu_bwd(dy: torch.Tensor, y: Optional[torch.Tensor], dx: torch.Tensor, dy2: Optional[torch.Tensor] = None):
+    """dx = (dy [+ dy2]) * (y > 0) over contiguous fp16 buffers (in place allowed)."""
+    n = dy.numel()
+    check(lib().llv_relu_bwd(dy.data_ptr(), dy2.data_ptr() if dy2 is not None else None, y.data_ptr() if y is not None else None,
+                             dx.data_ptr(), n, _stream()), 'llv_relu_bwd')
+
+
+def bias_grad(dy: torch.Tensor, m: int, c: int, ld: int, out: torch.Tensor):
+    check(lib().llv_bias_grad(dy.data_ptr(), m, c, ld, out.data_ptr(), _stream()), 'llv_bias_grad')
+
+
+def upsample_add_bwd(dfine: torch.Tensor, dcoarse: torch.Tensor, accumulate: bool):
+    n, H, W, c = dfine.shape
+    _, h, w, c2 = dcoarse.shape
+    assert c == c2 and dfine.is_contiguous() and dcoarse.is_contiguous()
+    check(lib().llv_upsample_add_bwd(dfine.data_ptr(), dcoarse.data_ptr(), n, H, W, h, w, c, 1 if accumulate else 0, _stream()),
+          'llv_upsample_add_bwd')
+
+
+def sgd_momentum(w: torch.Tensor, g: torch.Tensor, mom: torch.Tensor, lr: float, momentum: float, weight_decay: float,
+                 grad_scale: float, first_step: bool):
+    assert w.dtype == g.dtype == mom.dtype == torch.float32 and w.is_contiguous() and g.is_contiguous() and mom.is_contiguous()
+    check(lib().llv_sgd_momentum(w.data_ptr(), g.data_ptr(), mom.data_ptr(), w.numel(), lr, momentum, weight_decay, grad_scale,
+                                 1 if first_step else 0, _stream()), 'llv_sgd_momentum')
+
+
+def conv_dgrad(dy: torch.Tensor, pcd: ops.PackedConv, dx: torch.Tensor, batch: int, segs, dy_ld: int, dx_ld: int,
+               flags: int, accumulate: bool, in_hw=None):
+    """dX (+)= dgrad conv of dY. segs: forward segments (h, w, ho, wo, x_off, y_off); the launch swaps the roles.
+    PixelShuffle (stride-2) launches crop to the forward input size."""
+    bsegs = []
+    for (h, w, ho, wo, xo, yo) in segs:
+        if flags & CONV_PIXSHUF:
+            bsegs.append((ho, wo, (h + 1) // 2, (w + 1) // 2, yo, xo))
+        else:
+            bsegs.append((ho, wo, h, w, yo, xo))
+    f = flags | (CONV_RES_ADD if accumulate else 0)
+    ps = (segs[0][0], segs[0][1]) if flags & CONV_PIXSHUF else (0, 0)
+    if flags & CONV_PIXSHUF:
+        assert len(segs) == 1, 'stride-2 data gradient is launched per level'
+    d = ops.make_conv_desc(pcd, [dy], dx, batch, bsegs, dy_ld, dx_ld, dx if accumulate else None, dx_ld if accumulate else 0, f,
+                           ps_out=ps)
+    ops.launch_conv(d)

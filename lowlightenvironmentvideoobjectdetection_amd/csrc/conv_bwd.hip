@@ -1,0 +1,378 @@
+// Backward-pass kernels of the convolution engine (gfx950 only).
+//
+//   llv_conv2d_nhwc_wgrad   dW[g][co][tap][ci] += sum_p dY[p][g*Cout + co] * X[p @ tap][g*Cin + ci]
+//   llv_relu_bwd            dx = (dy [+ dy2]) * (y > 0)
+//   llv_bias_grad           db[c] += sum_p dy[p][c]
+//   llv_upsample_add_bwd    gradient of the FPN top-down "coarse -> nearest upsample -> add" (fpn.py:186-195)
+//   llv_sgd_momentum        SGD with momentum and weight decay on fp32 master weights (torch.optim.SGD update rule)
+//
+// The data gradient needs no kernel of its own: dX of a stride-1 convolution is the forward kernel on the
+// spatially flipped, in/out-transposed weights, and dX of a stride-2 convolution is a 2x2 forward convolution over
+// dY that produces the four output phases, stored through the PixelShuffle epilogue (ops.pack_dgrad).
+//
+// Reference: torch autograd of F.conv2d / F.relu / F.interpolate as used by mmdet's ResNet / FPN / RetinaHead
+// (resnet.py:260-299, fpn.py:170-221, retina_head.py:93-114) and the optimizer of schedule_1x.py (SGD, momentum 0.9,
+// weight decay 1e-4).
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "llv.h"
+
+namespace {
+
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef __fp16 h4 __attribute__((__vector_size__(4 * sizeof(__fp16))));
+
+__device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsigned bytes) {
+    return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
+}
+__device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned char* lds, int voff, int soff) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_wgrad_kernel<BCO, BCI>: one workgroup accumulates a BCO x BCI block of dW for ONE filter tap and one group
+// over a contiguous range of output pixels (blockIdx.z = pixel split), then adds it to dW with fp32 atomics.
+// GEMM view: D[co][ci] = sum_k A[co][k] * B[k][ci] with k = output pixel. Both operands live in memory pixel-major
+// (NHWC), i.e. k-major, while the MFMA wants 8 consecutive k per lane: the tiles are copied to LDS as they are
+// ([32 pixels][channels], by LDS DMA) and read back through gfx950's transposing ds_read_b64_tr_b16, two reads
+// per 16x32 operand fragment. 16-byte chunks are XOR-swizzled by the pixel row so that the 32 lanes of a half-wave
+// (8 pixel rows x 4 column groups) hit 32 distinct 8-byte slots.
+// ------------------------------------------------------------------------------------------------
+struct WgArgs {
+    const _Float16* x;
+    const _Float16* dy;
+    float* dw;
+    int x_ld, dy_ld;
+    int cin, cout, k_pad, w_rows;
+    int kh, kw, stride, pad, groups;
+    int H, W, Ho, Wo;
+    int xoff, yoff;             // pixel offsets of image 0 in x / dy
+    int m_total, m_per_split;
+    unsigned x_bytes, dy_bytes;
+    int tiles_ci;
+};
+
+template <int BC>
+__device__ __forceinline__ int wg_swz(int row) {
+    if constexpr (BC == 128) return ((row & 3) << 1) | (((row >> 3) & 1) << 3);
+    else return (((row >> 1) & 1) << 1) | (((row >> 3) & 1) << 2);
+}
+
+template <int BCO, int BCI>
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
+    constexpr int TMO = BCO / 32, TNI = BCI / 32;            // MFMA tiles per wave (2 x 2 waves)
+    constexpr int RBA = BCO * 2, RBB = BCI * 2;              // LDS row bytes
+    constexpr int STAGE = 32 * (RBA + RBB);
+    constexpr int PA = BCO / 16, PB = BCI / 16;              // 1-KiB pieces per k-step
+    constexpr int PAW = (PA + 3) / 4, PBW = (PB + 3) / 4;
+    constexpr int RPA = 1024 / RBA, RPB = 1024 / RBB;        // pixel rows per piece
+    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int wr = wave & 1, wc = wave >> 1;
+    const int tile_ci = blockIdx.x % a.tiles_ci, tile_co = blockIdx.x / a.tiles_ci;
+    const int ntap = a.kh * a.kw;
+    const int tap = blockIdx.y % ntap, g = blockIdx.y / ntap;
+    const int tr = tap / a.kw, tq = tap - tr * a.kw;
+    const int m0 = blockIdx.z * a.m_per_split;
+    const int m1 = m0 + a.m_per_split < a.m_total ? m0 + a.m_per_split : a.m_total;
+    const int nrows = m1 - m0;
+    if (nrows <= 0) return;
+    const int nk = (nrows + 31) >> 5;
+    const int co0 = tile_co * BCO, ci0 = tile_ci * BCI;
+
+    const __amdgpu_buffer_rsrc_t rY = make_rsrc(a.dy, a.dy_bytes);
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.x, a.x_bytes);
+
+    // ---- DMA slots. dY: row m0 + 32*ks + row, a pure scalar step per k-step. X: per-lane pixel walk.
+    int yv[PAW], yrow[PAW];
+#pragma unroll
+    for (int i = 0; i < PAW; ++i) {
+        const int pc = wave + 4 * i;
+        const int row = pc * RPA + lane / (BCO / 8);
+        const int ch = (lane % (BCO / 8)) ^ wg_swz<BCO>(row);
+        const int co = co0 + ch * 8;
+        yrow[i] = row;
+        yv[i] = (pc < PA && co < a.cout) ? ((a.yoff + m0 + row) * a.dy_ld + g * a.cout + co) * 2 : (int)a.dy_bytes;
+    }
+    int xn[PBW], xoy[PBW], xox[PBW], xrow[PBW], xc[PBW];
+#pragma unroll
+    for (int i = 0; i < PBW; ++i) {
+        const int pc = wave + 4 * i;
+        const int row = pc * RPB + lane / (BCI / 8);
+        const int ch = (lane % (BCI / 8)) ^ wg_swz<BCI>(row);
+        const int ci = ci0 + ch * 8;
+        xrow[i] = row;
+        xc[i] = (pc < PB && ci < a.cin) ? (g * a.cin + ci) * 2 : -1;
+        const int m = m0 + row;
+        const int ox = m % a.Wo, t = m / a.Wo;
+        xox[i] = ox; xoy[i] = t % a.Ho; xn[i] = t / a.Ho;
+    }
+    auto issue = [&](int ks, int buf) __attribute__((always_inline)) {
+        unsigned char* sA = smem + buf * STAGE;
+        unsigned char* sB = sA + 32 * RBA;
+        const int left = nrows - ks * 32;                    // rows of this k-step that exist
+#pragma unroll
+        for (int i = 0; i < PAW; ++i) {
+            if (wave + 4 * i < PA) {
+                const int v = yrow[i] < left ? yv[i] : (int)a.dy_bytes;
+                dma16(rY, sA + (wave + 4 * i) * 1024, v, ks * 32 * a.dy_ld * 2);
+            }
+        }
+#pragma unroll
+        for (int i = 0; i < PBW; ++i) {
+            if (wave + 4 * i < PB) {
+                const int iy = xoy[i] * a.stride - a.pad + tr, ix = xox[i] * a.stride - a.pad + tq;
+                int v = (int)a.x_bytes;
+                if (xrow[i] < left && xc[i] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
+                    v = (a.xoff + (xn[i] * a.H + iy) * a.W + ix) * a.x_ld * 2 + xc[i];
+                dma16(rX, sB + (wave + 4 * i) * 1024, v, 0);
+                xox[i] += 32;
+                while (xox[i] >= a.Wo) { xox[i] -= a.Wo; ++xoy[i]; }
+                while (xoy[i] >= a.Ho) { xoy[i] -= a.Ho; ++xn[i]; }
+            }
+        }
+    };
+
+    // ---- transposed fragment reads: lane 4q+p of 16-lane group gq supplies row 8*gq + q, columns c0 + 4p ..
+    const int gq = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    const int frow = gq * 8 + q;
+    int fa[TMO], fb[TNI];
+#pragma unroll
+    for (int i = 0; i < TMO; ++i) {
+        const int col = wr * (BCO / 2) + i * 16 + 4 * p;
+        fa[i] = frow * RBA + ((((col >> 3) ^ wg_swz<BCO>(frow))) << 4) + ((col >> 2) & 1) * 8;
+    }
+#pragma unroll
+    for (int j = 0; j < TNI; ++j) {
+        const int col = wc * (BCI / 2) + j * 16 + 4 * p;
+        fb[j] = frow * RBB + ((((col >> 3) ^ wg_swz<BCI>(frow))) << 4) + ((col >> 2) & 1) * 8;
+    }
+
+    f32x4 acc[TMO][TNI];
+#pragma unroll
+    for (int i = 0; i < TMO; ++i)
+#pragma unroll
+        for (int j = 0; j < TNI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+    auto tr_read = [&](const unsigned char* base, int off) __attribute__((always_inline)) {
+        const h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(base + off));
+        return lo;
+    };
+
+    issue(0, 0);
+    for (int ks = 0; ks < nk; ++ks) {
+        const int cur = ks & 1;
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        __syncthreads();
+        if (ks + 1 < nk) issue(ks + 1, cur ^ 1);
+        const unsigned char* sA = smem + cur * STAGE;
+        const unsigned char* sB = sA + 32 * RBA;
+        f16x8 af[TMO], bf[TNI];
+#pragma unroll
+        for (int i = 0; i < TMO; ++i) {
+            const h4 lo = tr_read(sA, fa[i]), hi = tr_read(sA, fa[i] + 4 * RBA);
+            __builtin_memcpy(&af[i], &lo, 8);
+            __builtin_memcpy(reinterpret_cast<unsigned char*>(&af[i]) + 8, &hi, 8);
+        }
+#pragma unroll
+        for (int j = 0; j < TNI; ++j) {
+            const h4 lo = tr_read(sB, fb[j]), hi = tr_read(sB, fb[j] + 4 * RBB);
+            __builtin_memcpy(&bf[j], &lo, 8);
+            __builtin_memcpy(reinterpret_cast<unsigned char*>(&bf[j]) + 8, &hi, 8);
+        }
+#pragma unroll
+        for (int i = 0; i < TMO; ++i)
+#pragma unroll
+            for (int j = 0; j < TNI; ++j)
+                acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+    }
+
+    // D[m = co][n = ci]: lane holds rows 4*(lane>>4) + e, column lane&15
+    float* dwg = a.dw + (long)g * a.w_rows * a.k_pad;
+#pragma unroll
+    for (int i = 0; i < TMO; ++i) {
+#pragma unroll
+        for (int j = 0; j < TNI; ++j) {
+            const int ci = ci0 + wc * (BCI / 2) + j * 16 + (lane & 15);
+            if (ci >= a.cin) continue;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = co0 + wr * (BCO / 2) + i * 16 + 4 * (lane >> 4) + e;
+                if (co < a.cout) atomicAdd(dwg + (long)co * a.k_pad + tap * a.cin + ci, acc[i][j][e]);
+            }
+        }
+    }
+}
+
+template <int BCO, int BCI>
+int launch_wgrad(WgArgs& a, int splits, hipStream_t st) {
+    const int tiles_co = (a.cout + BCO - 1) / BCO;
+    a.tiles_ci = (a.cin + BCI - 1) / BCI;
+    dim3 grid(tiles_co * a.tiles_ci, a.kh * a.kw * a.groups, splits);
+    hipLaunchKernelGGL((conv_wgrad_kernel<BCO, BCI>), grid, dim3(256), 0, st, a);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+// ------------------------------------------------------------------------------------------------
+__global__ void relu_bwd_kernel(const _Float16* dy, const _Float16* dy2, const _Float16* y, _Float16* dx, long nvec) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        f16x8 g = reinterpret_cast<const f16x8*>(dy)[i];
+        if (dy2) {
+            const f16x8 g2 = reinterpret_cast<const f16x8*>(dy2)[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = (_Float16)((float)g[e] + (float)g2[e]);
+        }
+        if (y) {
+            const f16x8 o = reinterpret_cast<const f16x8*>(y)[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) g[e] = (float)o[e] > 0.f ? g[e] : (_Float16)0.f;
+        }
+        reinterpret_cast<f16x8*>(dx)[i] = g;
+    }
+}
+
+// column sums of a [m][c] fp16 matrix (row stride ld) into fp32: one block = 64 rows x 256 channels-of-8... simple form:
+// blockIdx.x = channel group of 64, blockIdx.y = row split; lanes = channels, rows strided; fp32 atomics at the end.
+__global__ __launch_bounds__(256) void bias_grad_kernel(const _Float16* dy, long m, int c, int ld, float* out, long rows_per) {
+    const int ch = blockIdx.x * 64 + (threadIdx.x & 63);
+    const int sub = threadIdx.x >> 6;
+    const long r0 = blockIdx.y * rows_per, r1 = r0 + rows_per < m ? r0 + rows_per : m;
+    float s = 0.f;
+    if (ch < c)
+        for (long r = r0 + sub; r < r1; r += 4) s += (float)dy[r * ld + ch];
+    __shared__ float part[256];
+    part[threadIdx.x] = s;
+    __syncthreads();
+    if (sub == 0 && ch < c) atomicAdd(out + ch, part[threadIdx.x] + part[threadIdx.x + 64] + part[threadIdx.x + 128] + part[threadIdx.x + 192]);
+}
+
+// d(coarse) += sum of the fine-grid gradients whose nearest-neighbour source is that coarse pixel
+// (F.interpolate(mode='nearest', size=(H,W)): src = min(floor(dst * h/H), h-1))
+__global__ void upsample_add_bwd_kernel(const _Float16* dfine, _Float16* dcoarse, int n, int H, int W, int h, int w, int c8, int accumulate) {
+    const long total = (long)n * h * w * c8;
+    const float sy = (float)h / (float)H, sx = (float)w / (float)W;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % c8);
+        long t = i / c8;
+        const int cx = (int)(t % w); t /= w;
+        const int cy = (int)(t % h);
+        const int im = (int)(t / h);
+        float s[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        // candidate fine rows/cols: those y with min(floor(y*sy), h-1) == cy
+        int y0 = (int)floorf((float)cy / sy) - 1, y1 = (int)ceilf((float)(cy + 1) / sy) + 1;
+        int x0 = (int)floorf((float)cx / sx) - 1, x1 = (int)ceilf((float)(cx + 1) / sx) + 1;
+        y0 = y0 < 0 ? 0 : y0; x0 = x0 < 0 ? 0 : x0; y1 = y1 > H - 1 ? H - 1 : y1; x1 = x1 > W - 1 ? W - 1 : x1;
+        for (int y = y0; y <= y1; ++y) {
+            int ry = (int)floorf((float)y * sy); ry = ry < h - 1 ? ry : h - 1;
+            if (ry != cy) continue;
+            for (int x = x0; x <= x1; ++x) {
+                int rx = (int)floorf((float)x * sx); rx = rx < w - 1 ? rx : w - 1;
+                if (rx != cx) continue;
+                const f16x8 g = reinterpret_cast<const f16x8*>(dfine)[(((long)im * H + y) * W + x) * c8 + cv];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) s[e] += (float)g[e];
+            }
+        }
+        f16x8 o;
+        if (accumulate) {
+            const f16x8 old = reinterpret_cast<const f16x8*>(dcoarse)[i];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (_Float16)((float)old[e] + s[e]);
+        } else {
+#pragma unroll
+            for (int e = 0; e < 8; ++e) o[e] = (_Float16)s[e];
+        }
+        reinterpret_cast<f16x8*>(dcoarse)[i] = o;
+    }
+}
+
+__global__ void sgd_momentum_kernel(float* w, const float* g, float* mom, long n, float lr, float momentum, float wd, float gscale, int first) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const float d = g[i] * gscale + wd * w[i];
+        const float b = first ? d : momentum * mom[i] + d;   // torch.optim.SGD: buf = d on the first step
+        mom[i] = b;
+        w[i] -= lr * b;
+    }
+}
+
+}  // namespace
+
+extern "C" int llv_conv2d_nhwc_wgrad(const llv_conv_desc* d, const void* dy, int dy_ld, float* dw, void* stream) {
+    if (!d || !dy || !dw || !d->x[0] || d->n_seg != 1 || d->n_src != 1) return LLV_E_BADARG;
+    if (d->cin <= 0 || (d->cin & 7) || d->cout <= 0 || d->groups < 1 || d->kh < 1 || d->kw < 1 || d->stride < 1 || d->pad < 0) return LLV_E_BADARG;
+    if ((d->x_ld & 7) || (dy_ld & 7) || d->x_ld < d->groups * d->cin || dy_ld < d->groups * d->cout) return LLV_E_BADARG;
+    if (d->k_pad < d->kh * d->kw * d->cin || d->w_rows < d->cout || d->batch < 1) return LLV_E_BADARG;
+    if (d->seg_h[0] < 1 || d->seg_w[0] < 1 || d->seg_ho[0] < 1 || d->seg_wo[0] < 1 || d->seg_xoff[0] < 0 || d->seg_yoff[0] < 0) return LLV_E_BADARG;
+    if (((uintptr_t)d->x[0] | (uintptr_t)dy) & 15) return LLV_E_BADARG;
+    const long m = (long)d->batch * d->seg_ho[0] * d->seg_wo[0];
+    const size_t xb = ((size_t)d->seg_xoff[0] + (size_t)d->batch * d->seg_h[0] * d->seg_w[0]) * d->x_ld * 2;
+    const size_t yb = ((size_t)d->seg_yoff[0] + (size_t)m) * dy_ld * 2;
+    if (m > 0x7fffffffL || xb >= (1ull << 31) || yb >= (1ull << 31)) return LLV_E_UNSUPPORTED;
+    WgArgs a;
+    a.x = (const _Float16*)d->x[0]; a.dy = (const _Float16*)dy; a.dw = dw;
+    a.x_ld = d->x_ld; a.dy_ld = dy_ld; a.cin = d->cin; a.cout = d->cout; a.k_pad = d->k_pad; a.w_rows = d->w_rows;
+    a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.groups = d->groups;
+    a.H = d->seg_h[0]; a.W = d->seg_w[0]; a.Ho = d->seg_ho[0]; a.Wo = d->seg_wo[0];
+    a.xoff = (int)d->seg_xoff[0]; a.yoff = (int)d->seg_yoff[0];
+    a.m_total = (int)m; a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
+    const bool big = d->cout > 64 && d->cin > 64;
+    const int bco = big ? 128 : 64, bci = big ? 128 : 64;
+    const long tiles = (long)((d->cout + bco - 1) / bco) * ((d->cin + bci - 1) / bci) * d->kh * d->kw * d->groups;
+    // enough pixel splits to put ~4 workgroups on every CU, at least 8 k-steps each
+    long splits = (1024 + tiles - 1) / tiles;
+    const long max_splits = (m + 255) / 256;
+    if (splits > max_splits) splits = max_splits;
+    if (splits < 1) splits = 1;
+    long per = (m + splits - 1) / splits;
+    per = (per + 31) & ~31L;
+    splits = (m + per - 1) / per;
+    a.m_per_split = (int)per;
+    hipStream_t st = (hipStream_t)stream;
+    return big ? launch_wgrad<128, 128>(a, (int)splits, st) : launch_wgrad<64, 64>(a, (int)splits, st);
+}
+
+extern "C" int llv_relu_bwd(const void* dy, const void* dy2, const void* y, void* dx, int64_t n, void* stream) {
+    if (!dy || !dx || n < 0 || (n & 7)) return LLV_E_BADARG;
+    if (n == 0) return LLV_OK;
+    const long nvec = n >> 3;
+    long grid = (nvec + 255) / 256;
+    grid = grid > 4096 ? 4096 : grid;
+    hipLaunchKernelGGL(relu_bwd_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)dy, (const _Float16*)dy2,
+                       (const _Float16*)y, (_Float16*)dx, nvec);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_bias_grad(const void* dy, int64_t m, int c, int ld, float* out, void* stream) {
+    if (!dy || !out || m < 0 || c < 1 || ld < c) return LLV_E_BADARG;
+    if (m == 0) return LLV_OK;
+    long splits = (m + 2047) / 2048;
+    splits = splits > 256 ? 256 : splits;
+    const long per = (m + splits - 1) / splits;
+    dim3 grid((c + 63) / 64, (int)((m + per - 1) / per));
+    hipLaunchKernelGGL(bias_grad_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const _Float16*)dy, (long)m, c, ld, out, per);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_upsample_add_bwd(const void* dfine, void* dcoarse, int n, int H, int W, int h, int w, int c, int accumulate, void* stream) {
+    if (!dfine || !dcoarse || n < 1 || H < 1 || W < 1 || h < 1 || w < 1 || c < 8 || (c & 7)) return LLV_E_BADARG;
+    const long total = (long)n * h * w * (c >> 3);
+    long grid = (total + 255) / 256;
+    grid = grid > 4096 ? 4096 : grid;
+    hipLaunchKernelGGL(upsample_add_bwd_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)dfine, (_Float16*)dcoarse,
+                       n, H, W, h, w, c >> 3, accumulate);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_sgd_momentum(float* w, const float* g, float* mom, int64_t n, float lr, float momentum, float weight_decay,
+                                float grad_scale, int first_step, void* stream) {
+    if (!w || !g || !mom || n < 0) return LLV_E_BADARG;
+    if (n == 0) return LLV_OK;
+    long grid = (n + 255) / 256;
+    grid = grid > 4096 ? 4096 : grid;
+    hipLaunchKernelGGL(sgd_momentum_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, w, g, mom, (long)n, lr, momentum, weight_decay,
+                       grad_scale, first_step);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}

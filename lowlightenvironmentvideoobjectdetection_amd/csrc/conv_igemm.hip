@@ -1972,9 +1972,10 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
         const int H = d->seg_h[ss], W = d->seg_w[ss], Ho = d->seg_ho[ss], Wo = d->seg_wo[ss];
         if (s < d->n_seg) {
             if (H < 1 || W < 1 || H > 32767 || W > 65535 || Ho < 1 || Wo < 1) return LLV_E_BADARG;
-            // geometry must agree with (k, stride, pad): every tap of every output pixel is either in
-            // range or predicated off, but the output extent must not exceed the conv formula.
-            if (Ho > (H + 2 * d->pad - d->kh) / d->stride + 1 || Wo > (W + 2 * d->pad - d->kw) / d->stride + 1) return LLV_E_BADARG;
+            // every tap of every output pixel is either in range or predicated off (reads as zero), so the output may
+            // extend past the symmetric-padding formula by up to k-1 taps (the stride-2 data gradient needs one
+            // extra zero row/column at the bottom/right); it must still touch the padded input with its first tap.
+            if (Ho > (H + 2 * d->pad - 1) / d->stride + 1 || Wo > (W + 2 * d->pad - 1) / d->stride + 1) return LLV_E_BADARG;
             const long xend = d->seg_xoff[s] + (long)d->batch * H * W;
             const long yend = d->seg_yoff[s] + (long)d->batch * Ho * Wo * ((f & LLV_CONV_PIXSHUF) ? 4 : 1);  // upper bound (cropped shuffle stores fewer)
             if (d->seg_xoff[s] < 0 || d->seg_yoff[s] < 0 || xend > 0x7fffffffL || yend > 0x7fffffffL) return LLV_E_BADARG;
