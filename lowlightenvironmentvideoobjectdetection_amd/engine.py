@@ -116,6 +116,7 @@ class Builder:
         self._fn_conv = lib().llv_conv2d_nhwc_fwd
         self._ws = None              # one split-K workspace shared by all launches of the plan (they run in order)
         self._ws_descs = []
+        self.tape = []               # every conv launch in order (training: the backward pass walks it in reverse)
 
     def buf(self, *shape, dtype=torch.float16):
         t = torch.zeros(shape, device=self.dev, dtype=dtype)
@@ -142,6 +143,8 @@ class Builder:
             self._ws_descs.append(d)
         self.plan.keep += [pc, pc.w, pc.bias, d] + list(xs) + [y] + ([res] if res is not None else [])
         self.plan.add(name, self._fn_conv, (C.byref(d),), flops, nbytes, kernel=ops.conv_kernel_name(d))
+        self.tape.append(dict(name=name, pc=pc, xs=list(xs), y=y, batch=batch, segs=list(segs), x_ld=x_ld, y_ld=y_ld, res=res,
+                              res_ld=res_ld, flags=flags, res_hw=res_hw, desc=d))
         return d
 
     def conv(self, name, x, pc: ops.PackedConv, flags=0, res=None, out=None, tile=0):
@@ -172,7 +175,14 @@ class Builder:
 # RetinaNet stages (ResNet, FPN, RetinaHead, decode + NMS)
 # ------------------------------------------------------------------------------------------------
 def _cpu_sd(sd):
-    return {k: v.detach().float().cpu() for k, v in sd.items()}
+    out = {}
+    for k, v in sd.items():
+        t = v.detach().float().cpu()
+        if t is v:
+            t = t.clone()
+        t._llv_key = k           # pack_conv records which parameters a launch was packed from (PackedConv.parts)
+        out[k] = t
+    return out
 
 
 def build_resnet(b: Builder, sd, x, depth=50, strides=(1, 2, 2, 2), style='pytorch', out_indices=(0, 1, 2, 3), p='',
@@ -289,7 +299,7 @@ def build_fpn(b: Builder, sd, feats, start_level=0, end_level=-1, num_outs=None,
     return Pyramid(pyr, level_hw, lvl_off, batch)
 
 
-def build_retina_head(b: Builder, sd, pyr: Pyramid, stacked_convs=4, logits_f32=True, p=''):
+def build_retina_head(b: Builder, sd, pyr: Pyramid, stacked_convs=4, logits_f32=True, p='', pingpong=True):
     """retina_head.py:93-114. The levels share weights -> one multi-segment launch per layer; the cls and
     reg towers run side by side (layer 0 as one 2x-wide conv on the shared input, layers 1.. as groups=2)."""
     batch, segs, tot = pyr.batch, pyr.segs(), pyr.total
@@ -312,6 +322,8 @@ def build_retina_head(b: Builder, sd, pyr: Pyramid, stacked_convs=4, logits_f32=
                 b.conv_desc('head.tower0', ops.concat_cout([pcc, pcr]), [pyr.buf], cur, batch, segs, c_f, 2 * feat_ch,
                             flags=CONV_RELU)
             else:
+                if not pingpong:
+                    nxt = b.buf(tot, 2 * feat_ch)
                 b.conv_desc(f'head.tower{i}', ops.stack_groups([pcc, pcr]), [cur], nxt, batch, segs, 2 * feat_ch,
                             2 * feat_ch, flags=CONV_RELU)
                 cur, nxt = nxt, cur

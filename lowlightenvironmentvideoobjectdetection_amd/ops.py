@@ -56,6 +56,9 @@ class PackedConv:
     true_macs_per_pixel: int = 0   # unpadded Cout*Cin/g*kh*kw, for FLOP accounting
     w_halo: Optional[torch.Tensor] = None   # second packing for the direct 3x3 kernel (add_halo_packing)
     halo_bn: int = 0
+    # which module parameters each block of rows came from (training: repack after an optimizer step, route the
+    # weight gradient back): dicts with wkey / bkey / bn (4 keys) / group / row0 / cout / cin / eps
+    parts: Optional[list] = None
 
     def to(self, device):
         self.w = self.w.to(device)
@@ -112,6 +115,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], stride=1, pad=
     eval-mode BatchNorm2d that follows the conv (norm_eval / frozen stats, resnet.py:642-651):
     w' = w * gamma / sqrt(var + eps), b' = beta + (b - mean) * gamma / sqrt(var + eps).
     """
+    weight_in, bn_in, in_map_default = weight, bn, in_map is None
     weight = weight.detach().double().cpu()
     cout, cin, kh, kw = weight.shape
     b = torch.zeros(cout, dtype=torch.float64) if bias is None else bias.detach().double().cpu()
@@ -138,10 +142,16 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], stride=1, pad=
     wfull[:, :k] = wp.reshape(w_rows, k)
     bfull = torch.zeros(cout_store, dtype=torch.float64)
     bfull[:cout] = b
-    return PackedConv(w=wfull.to(torch.float16).unsqueeze(0).contiguous(), bias=bfull.float().contiguous(),
-                      cin=cin_pad, cout=cout_store, w_rows=w_rows, k_pad=k_pad, kh=kh, kw=kw, stride=stride,
-                      pad=pad, groups=1, n_src=n_src, src_cvec=(cin_pad // 8 // n_src) if n_src > 1 else 0,
-                      true_macs_per_pixel=cout * cin * kh * kw)
+    pc = PackedConv(w=wfull.to(torch.float16).unsqueeze(0).contiguous(), bias=bfull.float().contiguous(),
+                    cin=cin_pad, cout=cout_store, w_rows=w_rows, k_pad=k_pad, kh=kh, kw=kw, stride=stride,
+                    pad=pad, groups=1, n_src=n_src, src_cvec=(cin_pad // 8 // n_src) if n_src > 1 else 0,
+                    true_macs_per_pixel=cout * cin * kh * kw)
+    wkey = getattr(weight_in, '_llv_key', None)
+    if wkey is not None and in_map_default:
+        pc.parts = [dict(wkey=wkey, bkey=getattr(bias, '_llv_key', None) if bias is not None else None,
+                         bn=tuple(getattr(t, '_llv_key', None) for t in bn_in) if bn_in is not None else None,
+                         group=0, row0=0, cout=cout, cin=cin, eps=eps)]
+    return pc
 
 
 def stack_groups(pcs: List[PackedConv]) -> PackedConv:
@@ -150,10 +160,13 @@ def stack_groups(pcs: List[PackedConv]) -> PackedConv:
     for p in pcs:
         assert (p.cin, p.cout, p.w_rows, p.k_pad, p.kh, p.kw, p.stride, p.pad, p.groups, p.n_src) == \
                (p0.cin, p0.cout, p0.w_rows, p0.k_pad, p0.kh, p0.kw, p0.stride, p0.pad, 1, 1)
-    return PackedConv(w=torch.cat([p.w for p in pcs], 0).contiguous(), bias=torch.cat([p.bias for p in pcs]).contiguous(),
-                      cin=p0.cin, cout=p0.cout, w_rows=p0.w_rows, k_pad=p0.k_pad, kh=p0.kh, kw=p0.kw,
-                      stride=p0.stride, pad=p0.pad, groups=len(pcs),
-                      true_macs_per_pixel=sum(p.true_macs_per_pixel for p in pcs))
+    out = PackedConv(w=torch.cat([p.w for p in pcs], 0).contiguous(), bias=torch.cat([p.bias for p in pcs]).contiguous(),
+                     cin=p0.cin, cout=p0.cout, w_rows=p0.w_rows, k_pad=p0.k_pad, kh=p0.kh, kw=p0.kw,
+                     stride=p0.stride, pad=p0.pad, groups=len(pcs),
+                     true_macs_per_pixel=sum(p.true_macs_per_pixel for p in pcs))
+    if all(p.parts is not None for p in pcs):
+        out.parts = [dict(q, group=g) for g, p in enumerate(pcs) for q in p.parts]
+    return out
 
 
 def concat_cout(pcs: List[PackedConv]) -> PackedConv:
@@ -169,9 +182,15 @@ def concat_cout(pcs: List[PackedConv]) -> PackedConv:
     for p in pcs:
         w[0, r:r + p.cout] = p.w[0, :p.cout].cpu()
         r += p.cout
-    return PackedConv(w=w.contiguous(), bias=torch.cat([p.bias.cpu() for p in pcs]).contiguous(), cin=p0.cin,
-                      cout=cout, w_rows=w_rows, k_pad=p0.k_pad, kh=p0.kh, kw=p0.kw, stride=p0.stride, pad=p0.pad,
-                      true_macs_per_pixel=sum(p.true_macs_per_pixel for p in pcs))
+    out = PackedConv(w=w.contiguous(), bias=torch.cat([p.bias.cpu() for p in pcs]).contiguous(), cin=p0.cin,
+                     cout=cout, w_rows=w_rows, k_pad=p0.k_pad, kh=p0.kh, kw=p0.kw, stride=p0.stride, pad=p0.pad,
+                     true_macs_per_pixel=sum(p.true_macs_per_pixel for p in pcs))
+    if all(p.parts is not None for p in pcs):
+        out.parts, r = [], 0
+        for p in pcs:
+            out.parts += [dict(q, row0=r + q['row0']) for q in p.parts]
+            r += p.cout
+    return out
 
 
 def conv_out_size(h, w, pc: PackedConv):

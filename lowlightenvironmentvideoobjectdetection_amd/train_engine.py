@@ -1,0 +1,361 @@
+"""Training step of the single-stage detector on the device kernels.
+
+  SingleStageDetector.forward_train          mmdetection/mmdet/models/detectors/single_stage.py:68-96
+  BaseDetector._parse_losses / train_step    mmdetection/mmdet/models/detectors/base.py:185-253
+  ResNet.train / _freeze_stages (norm_eval)  mmdetection/mmdet/models/backbones/resnet.py:573-590,642-651
+  SGD(lr, momentum 0.9, weight_decay 1e-4)   mmdetection/configs/_base_/schedules/schedule_1x.py
+
+Forward = the same launch list the inference plan uses (engine.build_resnet / build_fpn / build_retina_head), with
+every activation kept. Backward walks that launch tape in reverse: ReLU mask, residual / top-down-add routing, weight
+gradient (llv_conv2d_nhwc_wgrad), bias gradient, data gradient (forward kernels on re-packed weights). BatchNorm is in
+eval mode (running statistics, folded into the conv) with trainable affine parameters, exactly as norm_eval=True trains
+in the reference: d(gamma), d(beta) and d(W) are recovered from the folded conv's gradients.
+
+Gradients are fp16 with a static loss scale (the reference's fp16 mode: Fp16OptimizerHook(loss_scale=512.)), weight
+gradients accumulate in fp32. The autograd bridge (`DetectorFunction`) makes the whole thing look like one differentiable
+op to torch: `loss.backward()` fills `param.grad` of the module, so the reference's runner / OptimizerHook / DDP work
+unchanged; `TrainStep.step_fused()` is the all-device path `bench.py --mode train` measures.
+"""
+import ctypes as C
+from typing import Dict, List
+
+import torch
+import torch.distributed as dist
+
+from . import backward as B
+from . import engine, ops
+from ._lib import LlvError, CONV_RELU, CONV_RES_ADD, CONV_RES_UPS, CONV_PIXSHUF, CONV_OUT_F32
+
+
+def _sptr(t: torch.Tensor) -> int:
+    return t.untyped_storage().data_ptr()
+
+
+class TrainGraph:
+    """Forward launch list + everything the backward pass needs, for one (batch, H, W)."""
+
+    def __init__(self, det, batch: int, height: int, width: int, device, loss_scale: float = 512.0, frozen_prefixes=None):
+        head, neck, bb = det.bbox_head, det.neck, det.backbone
+        self.det, self.device, self.batch, self.loss_scale = det, device, batch, float(loss_scale)
+        self.params: Dict[str, torch.Tensor] = dict(det.named_parameters())
+        self.buffers: Dict[str, torch.Tensor] = dict(det.named_buffers())
+        for t in list(self.params.values()) + list(self.buffers.values()):
+            if t.device.type != 'cuda':
+                raise LlvError('training runs on the MI355X: move the detector to the GPU first (det.cuda()); no CPU fallback')
+        b = engine.Builder(device)
+        self.builder = b
+        sd = engine._cpu_sd(det.state_dict())
+        self.x_in = b.buf(batch, height, width, 8)
+        feats = engine.build_resnet(b, sd, self.x_in, bb.depth, bb.strides, bb.style, bb.out_indices, p='backbone.')
+        self.pyramid = engine.build_fpn(b, sd, feats, neck.start_level, -1, neck.num_outs, neck.add_extra_convs,
+                                        neck.relu_before_extra_convs, p='neck.')
+        self.cls_buf, self.reg_buf = engine.build_retina_head(b, sd, self.pyramid, head.stacked_convs, True, p='bbox_head.',
+                                                              pingpong=False)
+        self.plan = b.plan
+        self.tape = b.tape
+        # frozen part: frozen_stages of the backbone (stem + layer1 .. layerK), resnet.py:573-590
+        if frozen_prefixes is None:
+            fs = getattr(bb, 'frozen_stages', -1)
+            frozen_prefixes = (['stem.'] if fs >= 0 else []) + [f'backbone.layer{i}.' for i in range(1, fs + 1)]
+        self.frozen_prefixes = tuple(frozen_prefixes)
+        bases = {}
+        for t in b.plan.keep:
+            if isinstance(t, torch.Tensor) and t.device.type == 'cuda':
+                bases.setdefault(_sptr(t), t)
+        self.bases = bases
+        # which tensors need a gradient
+        req = set()
+        for op in self.tape:
+            op['frozen'] = op['name'].startswith(self.frozen_prefixes)
+            if op['pc'].parts is None:
+                raise LlvError(f"{op['name']}: launch has no parameter provenance (training needs PackedConv.parts)")
+            inp = any(_sptr(x) in req for x in op['xs']) or (op['res'] is not None and _sptr(op['res']) in req)
+            if not op['frozen'] or inp:
+                req.add(_sptr(op['y']))
+        self.req = req
+        # gradient buffers (fp16), one per activation buffer that needs one; fp32 logits get padded fp16 twins
+        self.grads: Dict[int, torch.Tensor] = {}
+        for op in self.tape:
+            p = _sptr(op['y'])
+            if p in req and p not in self.grads:
+                base = bases[p]
+                if base.dtype == torch.float32:
+                    c = base.shape[-1]
+                    self.grads[p] = torch.zeros(base.shape[:-1] + (ops.round_up(c, 8),), dtype=torch.float16, device=device)
+                else:
+                    self.grads[p] = torch.zeros_like(base)
+        # per-launch backward state
+        for op in self.tape:
+            pc = op['pc']
+            if not op['frozen']:
+                op['dw'] = torch.zeros(pc.groups, pc.w_rows, pc.k_pad, dtype=torch.float32, device=device)
+                op['db'] = torch.zeros(pc.groups * pc.cout, dtype=torch.float32, device=device)
+            op['need_dx'] = any(_sptr(x) in req for x in op['xs'])
+            if op['need_dx']:
+                assert len(op['xs']) == 1 and pc.n_src == 1, 'multi-source launches are not on the training path'
+                dyc = self._dy_ld(op) // pc.groups
+                KH, KW, pd, _, _ = B.dgrad_geometry(pc.kh, pc.kw, pc.stride, pc.pad)
+                rows = pc.cin * (4 if pc.stride == 2 else 1)
+                w_rows, k_pad = ops.round_up(rows, 16), ops.round_up(KH * KW * dyc, 32)
+                op['pcd'] = ops.PackedConv(w=torch.zeros(pc.groups, w_rows, k_pad, dtype=torch.float16, device=device),
+                                           bias=torch.zeros(pc.groups * rows, dtype=torch.float32, device=device), cin=dyc, cout=rows,
+                                           w_rows=w_rows, k_pad=k_pad, kh=KH, kw=KW, stride=1, pad=pd, groups=pc.groups,
+                                           true_macs_per_pixel=0)
+                op['dflags'] = CONV_PIXSHUF if pc.stride == 2 else 0
+        self.trainable = self._trainable_keys()
+
+    # ---- helpers -------------------------------------------------------------------------------
+    def _dy_ld(self, op):
+        return self.grads[_sptr(op['y'])].shape[-1] if _sptr(op['y']) in self.grads else ops.round_up(op['y'].shape[-1], 8)
+
+    def gview(self, t: torch.Tensor) -> torch.Tensor:
+        """The gradient twin of an activation tensor / view (same rows; fp32 logits map to the padded fp16 twin)."""
+        base, g = self.bases[_sptr(t)], self.grads[_sptr(t)]
+        if base.dtype == torch.float32:
+            assert t.shape == base.shape
+            return g
+        return g.as_strided(t.shape, t.stride(), t.storage_offset() - base.storage_offset())
+
+    def _trainable_keys(self) -> List[str]:
+        keys = []
+        for op in self.tape:
+            if op['frozen']:
+                continue
+            for q in op['pc'].parts:
+                ks = [q['wkey'], q['bkey']] + (list(q['bn'][:2]) if q['bn'] else [])
+                for k in ks:
+                    if k is not None and k in self.params and self.params[k].requires_grad and k not in keys:
+                        keys.append(k)
+        return keys
+
+    def _eff(self, q):
+        """Effective (BN-folded) weight and bias of one part, fp32 on device (ops.pack_conv's folding)."""
+        w = self.params[q['wkey']].detach()
+        b = self.params[q['bkey']].detach() if q['bkey'] else None
+        if q['bn']:
+            gk, bk, mk, vk = q['bn']
+            gamma, beta = self.params[gk].detach(), self.params[bk].detach()
+            mean, var = self.buffers[mk], self.buffers[vk]
+            inv = torch.rsqrt(var + q['eps'])
+            s = gamma * inv
+            we = w * s.view(-1, 1, 1, 1)
+            be = beta + ((b if b is not None else 0.0) - mean) * s
+            return we, be, (s, inv, mean)
+        return w, (b if b is not None else torch.zeros(w.shape[0], device=w.device)), None
+
+    def repack(self):
+        """Write the current parameter values into every trainable launch's packed weights (+ its dgrad filter)."""
+        for op in self.tape:
+            if op['frozen'] and not op['need_dx']:
+                continue
+            pc = op['pc']
+            per_group = {}
+            for q in pc.parts:
+                we, be, _ = self._eff(q)
+                g, r0, co = q['group'], q['row0'], q['cout']
+                if not op['frozen']:
+                    K = pc.kh * pc.kw * pc.cin
+                    tmp = torch.zeros(co, pc.kh, pc.kw, pc.cin, dtype=torch.float16, device=self.device)
+                    tmp[..., :q['cin']] = we.permute(0, 2, 3, 1).to(torch.float16)
+                    pc.w[g, r0:r0 + co, :K] = tmp.view(co, K)
+                    pc.bias[g * pc.cout + r0:g * pc.cout + r0 + co] = be
+                per_group.setdefault(g, []).append((r0, we))
+            if op['need_dx']:
+                pcd = op['pcd']
+                for g, lst in per_group.items():
+                    lst.sort(key=lambda t: t[0])
+                    wfull = torch.zeros(pc.cout, lst[0][1].shape[1], pc.kh, pc.kw, dtype=torch.float32, device=self.device)
+                    for r0, we in lst:
+                        wfull[r0:r0 + we.shape[0]] = we
+                    wd, KH, KW, pd, _ = B.dgrad_weight(wfull, pc.stride, pc.pad, pc.cin)
+                    rows, dyc = wd.shape[0], pcd.cin
+                    K = KH * KW * dyc
+                    tmp = torch.zeros(rows, KH, KW, dyc, dtype=torch.float16, device=self.device)
+                    tmp[..., :wd.shape[1]] = wd.permute(0, 2, 3, 1).to(torch.float16)
+                    pcd.w[g, :rows, :K] = tmp.view(rows, K)
+
+    # ---- forward / backward ---------------------------------------------------------------------
+    def forward(self, img: torch.Tensor):
+        """img: (N,3,H,W) fp32 normalised -> per-level fp32 NHWC logits views (cls, reg)."""
+        ops.pack_input(img.float().contiguous(), 8, out=self.x_in)
+        self.plan.run()
+        pyr = self.pyramid
+        return [pyr.level(i, self.cls_buf) for i in range(len(pyr.level_hw))], [pyr.level(i, self.reg_buf) for i in range(len(pyr.level_hw))]
+
+    def backward(self, dcls: List[torch.Tensor], dreg: List[torch.Tensor]):
+        """dcls / dreg: per-level (N,h,w,C) fp32 gradients of the loss w.r.t. the logits. Fills op['dw'] / op['db']
+        (scaled by loss_scale)."""
+        for g in self.grads.values():
+            g.zero_()
+        gc, gr = self.grads[_sptr(self.cls_buf)], self.grads[_sptr(self.reg_buf)]
+        pyr = self.pyramid
+        for i in range(len(pyr.level_hw)):
+            h, w = pyr.level_hw[i]
+            o, n = pyr.level_off[i], self.batch * h * w
+            gc[o:o + n, :dcls[i].shape[-1]] = (dcls[i].reshape(n, -1) * self.loss_scale).to(torch.float16)
+            gr[o:o + n, :dreg[i].shape[-1]] = (dreg[i].reshape(n, -1) * self.loss_scale).to(torch.float16)
+        for op in reversed(self.tape):
+            yp = _sptr(op['y'])
+            if yp not in self.req:
+                continue
+            pc, flags = op['pc'], op['flags']
+            gy_base = self.grads[yp]
+            gy = self.gview(op['y'])
+            dy_ld = gy_base.shape[-1]
+            # rows of y this launch wrote: per segment (batch*ho*wo rows at y offset)
+            if flags & CONV_RELU:
+                for (h, w, ho, wo, xo, yo) in op['segs']:
+                    n = op['batch'] * ho * wo
+                    yv, gv = self._rows(op['y'], yo, n), self._rows(gy, yo, n)
+                    B.relu_bwd(gv, yv, gv)
+            if (flags & CONV_RES_ADD) and op['res'] is not None and _sptr(op['res']) in self.req:
+                gres = self.gview(op['res'])
+                if flags & CONV_RES_UPS:
+                    B.upsample_add_bwd(gy, gres, accumulate=True)
+                else:
+                    B.relu_bwd(gres, None, gres, dy2=gy)
+            if not op['frozen']:
+                m_tot = 0
+                for (h, w, ho, wo, xo, yo) in op['segs']:
+                    B.conv_wgrad(op['xs'][0], gy, op['dw'], cin_pad=pc.cin, cout=pc.cout,
+                                 w_rows=pc.w_rows, k_pad=pc.k_pad, kh=pc.kh, kw=pc.kw, stride=pc.stride, pad=pc.pad, groups=pc.groups,
+                                 batch=op['batch'], seg=(h, w, ho, wo, xo, yo), x_ld=op['x_ld'], dy_ld=dy_ld)
+                    m_tot += op['batch'] * ho * wo
+                for (h, w, ho, wo, xo, yo) in op['segs']:
+                    n = op['batch'] * ho * wo
+                    B.bias_grad(self._rows(gy, yo, n), n, pc.groups * pc.cout, dy_ld, op['db'])
+            if op['need_dx']:
+                gx = self.gview(op['xs'][0])
+                if op['dflags'] & CONV_PIXSHUF:
+                    for seg in op['segs']:
+                        B.conv_dgrad(gy, op['pcd'], gx, op['batch'], [seg], dy_ld, op['x_ld'], op['dflags'], accumulate=True)
+                else:
+                    B.conv_dgrad(gy, op['pcd'], gx, op['batch'], op['segs'], dy_ld, op['x_ld'], 0, accumulate=True)
+
+    @staticmethod
+    def _rows(t: torch.Tensor, off: int, n: int) -> torch.Tensor:
+        """rows [off, off+n) of a pixel-major buffer, whatever its leading shape (full-buffer launches have off = 0)."""
+        c = t.shape[-1]
+        flat = t.as_strided((t.numel() // c, c), (t.stride(-2), 1), t.storage_offset()) if t.dim() > 2 else t
+        return flat[off:off + n]
+
+    def zero_param_grads(self):
+        for op in self.tape:
+            if not op['frozen']:
+                op['dw'].zero_()
+                op['db'].zero_()
+
+    def param_grads(self) -> Dict[str, torch.Tensor]:
+        """Module-parameter gradients (fp32, still multiplied by loss_scale) from the packed dW / db of every launch."""
+        out: Dict[str, torch.Tensor] = {}
+
+        def acc(k, v):
+            if k is None or k not in self.params or not self.params[k].requires_grad:
+                return
+            out[k] = out[k] + v if k in out else v
+
+        for op in self.tape:
+            if op['frozen']:
+                continue
+            pc = op['pc']
+            for q in pc.parts:
+                g, r0, co = q['group'], q['row0'], q['cout']
+                dwe = B.unpack_wgrad(op['dw'][g, r0:r0 + co], co, q['cin'], pc.kh, pc.kw, pc.cin)
+                dbe = op['db'][g * pc.cout + r0:g * pc.cout + r0 + co]
+                if q['bn']:
+                    _, _, (s, inv, mean) = self._eff(q)
+                    w = self.params[q['wkey']].detach()
+                    acc(q['wkey'], dwe * s.view(-1, 1, 1, 1))
+                    acc(q['bn'][0], (dwe * w).sum((1, 2, 3)) * inv - mean * inv * dbe)
+                    acc(q['bn'][1], dbe)
+                    if q['bkey']:
+                        acc(q['bkey'], dbe * s)
+                else:
+                    acc(q['wkey'], dwe.contiguous())
+                    acc(q['bkey'], dbe)
+        return out
+
+
+class DetectorFunction(torch.autograd.Function):
+    """The detector body (backbone + neck + head convolutions) as one differentiable op: inputs = the trainable
+    parameters, outputs = per-level logits; backward runs TrainGraph.backward and returns the parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, graph: TrainGraph, img: torch.Tensor, *params):
+        graph.repack()
+        cls, reg = graph.forward(img)
+        ctx.graph = graph
+        ctx.n_levels = len(cls)
+        return tuple(t.clone() for t in cls) + tuple(t.clone() for t in reg)
+
+    @staticmethod
+    def backward(ctx, *grads):
+        g: TrainGraph = ctx.graph
+        n = ctx.n_levels
+        g.zero_param_grads()
+        g.backward([x.contiguous() for x in grads[:n]], [x.contiguous() for x in grads[n:]])
+        pg = g.param_grads()
+        inv = 1.0 / g.loss_scale
+        return (None, None) + tuple((pg[k] * inv) if k in pg else None for k in g.trainable)
+
+
+def forward_train(det, graph: TrainGraph, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None):
+    """single_stage.py:68-96: x = extract_feat(img); losses = bbox_head.forward_train(x, ...)."""
+    from .training import anchor_head_loss
+    outs = DetectorFunction.apply(graph, img, *[graph.params[k] for k in graph.trainable])
+    n = len(outs) // 2
+    cls_scores = [t.permute(0, 3, 1, 2)[:, :det.bbox_head.num_anchors * det.bbox_head.cls_out_channels] for t in outs[:n]]
+    bbox_preds = [t.permute(0, 3, 1, 2)[:, :det.bbox_head.num_anchors * 4] for t in outs[n:]]
+    losses = anchor_head_loss(det.bbox_head, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore)
+    if losses is None:
+        raise LlvError('no valid anchors inside the image')
+    return losses
+
+
+class TrainStep:
+    """All-device training step: forward, loss, backward, gradient all-reduce over the ranks (RCCL when the process
+    group is nccl), fused SGD on one flat fp32 parameter buffer. The parameters of `det` become views of that buffer."""
+
+    def __init__(self, det, batch, height, width, device, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_scale=512.0):
+        self.det, self.device = det, device
+        self.graph = TrainGraph(det, batch, height, width, device, loss_scale)
+        self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
+        keys = self.graph.trainable
+        sizes = [self.graph.params[k].numel() for k in keys]
+        self.flat_w = torch.zeros(sum(sizes), dtype=torch.float32, device=device)
+        self.flat_g = torch.zeros_like(self.flat_w)
+        self.flat_m = torch.zeros_like(self.flat_w)
+        self.slices, o = {}, 0
+        for k, n in zip(keys, sizes):
+            p = self.graph.params[k]
+            self.flat_w[o:o + n] = p.detach().reshape(-1)
+            p.data = self.flat_w[o:o + n].view_as(p)
+            self.slices[k] = (o, n)
+            o += n
+        self.steps_done = 0
+
+    def forward_backward(self, img, img_metas, gt_bboxes, gt_labels):
+        losses = forward_train(self.det, self.graph, img, img_metas, gt_bboxes, gt_labels)
+        loss, log_vars = self.det._parse_losses(losses)
+        for k in self.graph.trainable:
+            self.graph.params[k].grad = None
+        loss.backward()
+        self.flat_g.zero_()
+        for k, (o, n) in self.slices.items():
+            gp = self.graph.params[k].grad
+            if gp is not None:
+                self.flat_g[o:o + n] = gp.reshape(-1)
+        return loss.detach(), log_vars
+
+    def all_reduce_grads(self):
+        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
+            dist.all_reduce(self.flat_g)
+            return 1.0 / dist.get_world_size()
+        return 1.0
+
+    def step_fused(self, img, img_metas, gt_bboxes, gt_labels):
+        loss, log_vars = self.forward_backward(img, img_metas, gt_bboxes, gt_labels)
+        scale = self.all_reduce_grads()
+        B.sgd_momentum(self.flat_w, self.flat_g, self.flat_m, self.lr, self.momentum, self.weight_decay, scale, self.steps_done == 0)
+        self.steps_done += 1
+        return dict(loss=loss, log_vars=log_vars, num_samples=len(img_metas))
