@@ -5,7 +5,8 @@
   heavy parts -> kernels: MaxIoUAssigner (llv_iou_assign: k x n IoU, both arg-maxes, low-quality match, no Python loop
   over gts) and the sigmoid focal loss over (N*anchors, C) logits (llv_sigmoid_focal_loss_fwd/bwd, autograd Function).
   The remaining glue touches only the positives (a few hundred rows) and stays in torch.
-Backbone/neck/head convolution backward kernels are not built yet: SingleStageDetector.forward_train raises.
+The convolution backward pass lives in train_engine.py (llv_conv2d_nhwc_wgrad + forward kernels on re-packed weights);
+SingleStageDetector.forward_train goes through it (single_stage_forward_train below).
 """
 import torch
 
@@ -97,5 +98,17 @@ def anchor_head_loss(head, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_met
 
 
 def single_stage_forward_train(det, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None):
-    raise LlvError('SingleStageDetector.forward_train: convolution backward (dgrad/wgrad) kernels are not built yet; '
-                   'the head loss itself runs (bbox_head.loss on given head outputs)')
+    """single_stage.py:68-96. The detector body runs as one autograd op on the device kernels (train_engine), so the
+    returned losses support `.backward()` and fill `param.grad` exactly as the reference's module tree does."""
+    from . import train_engine
+    if img.device.type != 'cuda':
+        raise LlvError('forward_train runs on the MI355X (conv forward/backward kernels); no CPU fallback')
+    n, _, h, w = img.shape
+    # parameters are about to change: inference plans hold packed copies of them, drop those (the training graph
+    # re-packs from the live parameters on every forward)
+    for k in [k for k in det._plans if not (isinstance(k, tuple) and k and k[0] == 'train')]:
+        del det._plans[k]
+    graph = det._plan(('train', n, h, w, str(img.device)), lambda: train_engine.TrainGraph(det, n, h, w, img.device))
+    dev = img.device
+    return train_engine.forward_train(det, graph, img, img_metas, [b.to(dev) for b in gt_bboxes], [l.to(dev) for l in gt_labels],
+                                      gt_bboxes_ignore)

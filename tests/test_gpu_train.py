@@ -181,3 +181,29 @@ def test_fused_train_steps_reduce_the_loss(dev):
     assert not torch.equal(det.bbox_head.retina_cls.weight, w0)
     o, n = ts.slices['bbox_head.retina_cls.weight']
     assert det.bbox_head.retina_cls.weight.data_ptr() == ts.flat_w[o:o + n].data_ptr()
+
+
+def test_forward_train_is_a_drop_in_for_the_reference_train_step(dev):
+    """BaseDetector.train_step (base.py:220-253) + a stock torch optimizer: losses come back as tensors, `.backward()`
+    fills param.grad through the device backward pass, optimizer.step() moves the weights, and the next simple_test
+    sees the new weights (its plan is rebuilt)."""
+    det, img, metas, gtb, gtl = _train_setup(dev, seed=5)
+    det = det.to(dev)
+    det.train()
+    opt = torch.optim.SGD([p for p in det.parameters() if p.requires_grad], lr=0.01, momentum=0.9, weight_decay=1e-4)
+    data = dict(img=img.to(dev), img_metas=metas, gt_bboxes=gtb, gt_labels=gtl)
+    first = None
+    for it in range(4):
+        out = det.train_step(data, opt)
+        assert set(out) == {'loss', 'log_vars', 'num_samples'} and out['num_samples'] == 2
+        assert {'loss_cls', 'loss_bbox', 'loss'} <= set(out['log_vars'])
+        opt.zero_grad()
+        out['loss'].backward()
+        assert det.bbox_head.retina_cls.weight.grad is not None and det.backbone.layer1[0].conv1.weight.grad is None
+        opt.step()
+        first = out['log_vars']['loss'] if first is None else first
+    assert out['log_vars']['loss'] < first
+    det.eval()
+    m = [dict(img_shape=(128, 160, 3), pad_shape=(128, 160, 3), scale_factor=np.ones(4, np.float32), ori_shape=(128, 160, 3))] * 2
+    res = det.simple_test(img.to(dev), m)
+    assert len(res) == 2 and len(res[0]) == 4
