@@ -99,6 +99,76 @@ def _profiled_traffic(frames_per_step, kernel):
     return None
 
 
+def train_bench(args, world, rank, dev):
+    """Config #3 of BASELINE.json: key frames of clips, one (or --train-batch) 1280x720 image per GPU, k = 10 ground-truth
+    boxes per image, RetinaNet R-50+FPN forward + focal/L1 loss + backward (stem and layer1 frozen, norm_eval) +
+    bucketed gradient all-reduce over the ranks + SGD(momentum 0.9, weight decay 1e-4). Synthetic data, seeded weights."""
+    import numpy as np
+    import torch.distributed as dist
+    from lowlightenvironmentvideoobjectdetection_amd import data, train_engine
+    cfg = retinanet_cfg()
+    cfg['train_cfg'] = dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0, ignore_iof_thr=-1),
+                            allowed_border=-1, pos_weight=-1, debug=False)
+    import lowlightenvironmentvideoobjectdetection_amd.models  # noqa: F401
+    from lowlightenvironmentvideoobjectdetection_amd import registry
+    from lowlightenvironmentvideoobjectdetection_amd.synthetic import seeded_weights
+    det = seeded_weights(registry.build_detector(cfg), seed=0).to(dev)
+    det.train()
+    nb = args.train_batch
+    clean = data.synth_clean_clip(nb, args.height, args.width, seed=100 + rank)
+    clip, img_shape, pad_shape = data.preprocess_clip(data.darken_and_add_noise(clean, seed=200 + rank), dev)
+    img = clip[2:2 + nb, :, :, :3].permute(0, 3, 1, 2).float().contiguous()          # (nb,3,736,1280) normalised
+    hp, wp = img.shape[2], img.shape[3]
+    rs = np.random.RandomState(rank)                                                  # _demo_mm_inputs-style boxes (test_forward.py:326-401)
+    gtb, gtl = [], []
+    for _ in range(nb):
+        cx, cy = rs.rand(10) * args.width, rs.rand(10) * args.height
+        bw, bh = rs.rand(10) * args.width * 0.4 + 16, rs.rand(10) * args.height * 0.4 + 16
+        bx = np.stack([np.clip(cx - bw / 2, 0, args.width), np.clip(cy - bh / 2, 0, args.height),
+                       np.clip(cx + bw / 2, 0, args.width), np.clip(cy + bh / 2, 0, args.height)], 1).astype(np.float32)
+        gtb.append(torch.from_numpy(bx).to(dev))
+        gtl.append(torch.from_numpy(rs.randint(0, NUM_CLASSES, 10)).long().to(dev))
+    metas = [dict(img_shape=img_shape, pad_shape=pad_shape, scale_factor=1.0)] * nb
+    ts = train_engine.TrainStep(det, nb, hp, wp, dev, lr=0.01 / 16 * nb * world)      # linear scaling from 16 images at lr 0.01
+    for _ in range(args.warmup):
+        out = ts.step_fused(img, metas, gtb, gtl)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = ts.step_fused(img, metas, gtb, gtl)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        g = ts.graph
+        fwd = sum(st[3] for st in g.plan.steps)
+        trainable_fwd = sum(2.0 * sum(op['batch'] * sg[2] * sg[3] for sg in op['segs']) * op['pc'].true_macs_per_pixel
+                            for op in g.tape if not op['frozen'])
+        dgrad_fl = sum(2.0 * sum(op['batch'] * sg[2] * sg[3] for sg in op['segs']) * op['pc'].true_macs_per_pixel
+                       for op in g.tape if op['need_dx'])
+        flops = fwd + trainable_fwd + dgrad_fl
+        print(json.dumps({
+            'metric': 'training images/sec (RetinaNet R-50+FPN forward + loss + backward + gradient all-reduce + SGD)',
+            'value': round(args.steps * nb * world / dt, 3), 'unit': 'images/s', 'n_gpus': world, 'steps': args.steps,
+            'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak',
+            'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+            'config': {'workload': f'config #3: {nb} image(s) {args.width}x{args.height} (padded {wp}x{hp}) per GPU, 10 gt boxes each, '
+                                   f'{NUM_CLASSES} classes, frozen stem+layer1, norm_eval, SGD momentum; loss scale 512',
+                       'parallelism': f'data parallel x{world}: bucketed all-reduce of {ts.flat_g.numel() * 4 / 1e6:.0f} MB fp32 gradients '
+                                      f'in {len(ts.buckets)} buckets, overlapped with backward',
+                       'algorithmic_gflop_per_image': round(flops / nb / 1e9, 1), 'last_loss': out['log_vars']['loss']},
+            'achieved_tflops': round(flops * args.steps / dt / 1e12, 2)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -112,6 +182,9 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-latency-mode', action='store_true')
+    ap.add_argument('--mode', choices=['infer', 'train'], default='infer',
+                    help="'train' = BASELINE.json config #3: RetinaNet fwd + loss + bwd + gradient all-reduce + SGD, one image per GPU")
+    ap.add_argument('--train-batch', type=int, default=1, help='images per GPU per training step')
     args = ap.parse_args()
 
     world = int(os.environ.get('WORLD_SIZE', '1'))
@@ -128,6 +201,9 @@ def main():
 
     from lowlightenvironmentvideoobjectdetection_amd import data, engine
     from lowlightenvironmentvideoobjectdetection_amd.synthetic import calibrate_head_on_device
+
+    if args.mode == 'train':
+        return train_bench(args, world, rank, dev)
 
     B, T = args.frames_per_step, args.clip_frames
     det, cleaner = build_models(seed=0)

@@ -182,9 +182,10 @@ class TrainGraph:
         pyr = self.pyramid
         return [pyr.level(i, self.cls_buf) for i in range(len(pyr.level_hw))], [pyr.level(i, self.reg_buf) for i in range(len(pyr.level_hw))]
 
-    def backward(self, dcls: List[torch.Tensor], dreg: List[torch.Tensor]):
+    def backward(self, dcls: List[torch.Tensor], dreg: List[torch.Tensor], on_op_done=None):
         """dcls / dreg: per-level (N,h,w,C) fp32 gradients of the loss w.r.t. the logits. Fills op['dw'] / op['db']
-        (scaled by loss_scale)."""
+        (scaled by loss_scale). on_op_done(op) is called as soon as a launch's weight gradient is final (launches run
+        in reverse order), which is what lets the gradient all-reduce overlap the rest of the backward pass."""
         for g in self.grads.values():
             g.zero_()
         gc, gr = self.grads[_sptr(self.cls_buf)], self.grads[_sptr(self.reg_buf)]
@@ -231,6 +232,8 @@ class TrainGraph:
                         B.conv_dgrad(gy, op['pcd'], gx, op['batch'], [seg], dy_ld, op['x_ld'], op['dflags'], accumulate=True)
                 else:
                     B.conv_dgrad(gy, op['pcd'], gx, op['batch'], op['segs'], dy_ld, op['x_ld'], 0, accumulate=True)
+            if on_op_done is not None and not op['frozen']:
+                on_op_done(op)
 
     @staticmethod
     def _rows(t: torch.Tensor, off: int, n: int) -> torch.Tensor:
@@ -245,8 +248,9 @@ class TrainGraph:
                 op['dw'].zero_()
                 op['db'].zero_()
 
-    def param_grads(self) -> Dict[str, torch.Tensor]:
-        """Module-parameter gradients (fp32, still multiplied by loss_scale) from the packed dW / db of every launch."""
+    def param_grads(self, only_op=None) -> Dict[str, torch.Tensor]:
+        """Module-parameter gradients (fp32, still multiplied by loss_scale) from the packed dW / db of every launch
+        (or of one launch)."""
         out: Dict[str, torch.Tensor] = {}
 
         def acc(k, v):
@@ -254,7 +258,7 @@ class TrainGraph:
                 return
             out[k] = out[k] + v if k in out else v
 
-        for op in self.tape:
+        for op in ([only_op] if only_op is not None else self.tape):
             if op['frozen']:
                 continue
             pc = op['pc']
@@ -274,6 +278,18 @@ class TrainGraph:
                     acc(q['wkey'], dwe.contiguous())
                     acc(q['bkey'], dbe)
         return out
+
+
+def _param_grads_keys(self, op):
+    ks = []
+    for q in op['pc'].parts:
+        for k in [q['wkey'], q['bkey']] + (list(q['bn'][:2]) if q['bn'] else []):
+            if k is not None and k in self.params and self.params[k].requires_grad and k not in ks:
+                ks.append(k)
+    return ks
+
+
+TrainGraph.param_grads_keys = _param_grads_keys
 
 
 class DetectorFunction(torch.autograd.Function):
@@ -314,48 +330,92 @@ def forward_train(det, graph: TrainGraph, img, img_metas, gt_bboxes, gt_labels, 
 
 class TrainStep:
     """All-device training step: forward, loss, backward, gradient all-reduce over the ranks (RCCL when the process
-    group is nccl), fused SGD on one flat fp32 parameter buffer. The parameters of `det` become views of that buffer."""
+    group is nccl), fused SGD on one flat fp32 parameter buffer. The parameters of `det` become views of that buffer.
 
-    def __init__(self, det, batch, height, width, device, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_scale=512.0):
+    The flat buffer is laid out in BACKWARD order (head first), so a prefix of it is final long before the backward
+    pass ends: it is cut into buckets and each bucket's all-reduce is issued asynchronously as soon as its last
+    parameter gradient has been written, overlapping the collective (xGMI) with the remaining convolution kernels."""
+
+    def __init__(self, det, batch, height, width, device, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_scale=512.0,
+                 bucket_mb=25.0):
         self.det, self.device = det, device
         self.graph = TrainGraph(det, batch, height, width, device, loss_scale)
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
-        keys = self.graph.trainable
-        sizes = [self.graph.params[k].numel() for k in keys]
+        g = self.graph
+        keys = []
+        for op in reversed(g.tape):
+            if op['frozen']:
+                continue
+            for k in g.param_grads_keys(op):
+                if k not in keys:
+                    keys.append(k)
+        assert set(keys) == set(g.trainable)
+        sizes = [g.params[k].numel() for k in keys]
         self.flat_w = torch.zeros(sum(sizes), dtype=torch.float32, device=device)
         self.flat_g = torch.zeros_like(self.flat_w)
         self.flat_m = torch.zeros_like(self.flat_w)
         self.slices, o = {}, 0
         for k, n in zip(keys, sizes):
-            p = self.graph.params[k]
+            p = g.params[k]
             self.flat_w[o:o + n] = p.detach().reshape(-1)
             p.data = self.flat_w[o:o + n].view_as(p)
             self.slices[k] = (o, n)
             o += n
+        # buckets: [start, end) ranges of the flat buffer, closed when the op owning their last key is done
+        limit = int(bucket_mb * 1024 * 1024 / 4)
+        self.buckets, start = [], 0
+        self.bucket_after_op = {}
+        done_keys = set()
+        for op in reversed(g.tape):
+            if op['frozen']:
+                continue
+            done_keys.update(g.param_grads_keys(op))
+            end = max(self.slices[k][0] + self.slices[k][1] for k in done_keys)
+            if end - start >= limit:
+                self.bucket_after_op.setdefault(id(op), []).append((start, end))
+                self.buckets.append((start, end))
+                start = end
+        if start < self.flat_w.numel():
+            last = [op for op in g.tape if not op['frozen']][0]
+            self.bucket_after_op.setdefault(id(last), []).append((start, self.flat_w.numel()))
+            self.buckets.append((start, self.flat_w.numel()))
         self.steps_done = 0
+        self._works = []
 
-    def forward_backward(self, img, img_metas, gt_bboxes, gt_labels):
-        losses = forward_train(self.det, self.graph, img, img_metas, gt_bboxes, gt_labels)
-        loss, log_vars = self.det._parse_losses(losses)
-        for k in self.graph.trainable:
-            self.graph.params[k].grad = None
-        loss.backward()
-        self.flat_g.zero_()
-        for k, (o, n) in self.slices.items():
-            gp = self.graph.params[k].grad
-            if gp is not None:
-                self.flat_g[o:o + n] = gp.reshape(-1)
-        return loss.detach(), log_vars
+    def _dist(self):
+        return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
-    def all_reduce_grads(self):
-        if dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1:
-            dist.all_reduce(self.flat_g)
-            return 1.0 / dist.get_world_size()
-        return 1.0
+    def _op_done(self, op):
+        inv = 1.0
+        for k, v in self.graph.param_grads(only_op=op).items():
+            o, n = self.slices[k]
+            self.flat_g[o:o + n].add_(v.reshape(-1), alpha=inv)
+        if self._dist():
+            for (a, b) in self.bucket_after_op.get(id(op), []):
+                self._works.append(dist.all_reduce(self.flat_g[a:b], async_op=True))
 
     def step_fused(self, img, img_metas, gt_bboxes, gt_labels):
-        loss, log_vars = self.forward_backward(img, img_metas, gt_bboxes, gt_labels)
-        scale = self.all_reduce_grads()
-        B.sgd_momentum(self.flat_w, self.flat_g, self.flat_m, self.lr, self.momentum, self.weight_decay, scale, self.steps_done == 0)
+        from .training import anchor_head_loss
+        g, head = self.graph, self.det.bbox_head
+        g.repack()
+        cls, reg = g.forward(img)
+        lc = [t.detach().requires_grad_() for t in cls]
+        lr_ = [t.detach().requires_grad_() for t in reg]
+        losses = anchor_head_loss(head, [t.permute(0, 3, 1, 2) for t in lc], [t.permute(0, 3, 1, 2) for t in lr_],
+                                  gt_bboxes, gt_labels, img_metas)
+        if losses is None:
+            raise LlvError('no valid anchors inside the image')
+        total = sum(sum(v) if isinstance(v, list) else v for k, v in losses.items() if 'loss' in k)
+        total.backward()
+        g.zero_param_grads()
+        self.flat_g.zero_()
+        self._works = []
+        g.backward([t.grad for t in lc], [t.grad for t in lr_], on_op_done=self._op_done)
+        for w in self._works:
+            w.wait()
+        world = dist.get_world_size() if self._dist() else 1
+        B.sgd_momentum(self.flat_w, self.flat_g, self.flat_m, self.lr, self.momentum, self.weight_decay,
+                       1.0 / (g.loss_scale * world), self.steps_done == 0)
         self.steps_done += 1
+        loss, log_vars = self.det._parse_losses({k: [x.detach() for x in v] if isinstance(v, list) else v.detach() for k, v in losses.items()})
         return dict(loss=loss, log_vars=log_vars, num_samples=len(img_metas))
