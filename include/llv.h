@@ -305,9 +305,30 @@ int llv_iou_assign(const float* gt, int k, const float* anchors, const uint8_t* 
  *          one segment and one source per call (a shared-weight conv over pyramid levels = one call per level)
  *   dy     fp16 NHWC gradient of the conv output (before the activation), row stride dy_ld
  *   dw     fp32, the packed weight layout [groups][w_rows][k_pad]; ACCUMULATED into (fp32 atomics): zero it first
+ *   db     optional fp32 [groups*cout]: db[g*cout + co] += sum_p dy[p][g*cout + co] (the bias / BN-shift gradient,
+ *          formed by one extra MFMA against a ones operand in the workgroups that already hold the dY tiles)
  * dgrad has no entry point of its own: it is llv_conv2d_nhwc_fwd on re-packed weights (flipped taps, in/out
  * transposed; stride 2 as a 2x2 convolution + PixelShuffle), see ops.pack_dgrad in the Python host. */
-int llv_conv2d_nhwc_wgrad(const llv_conv_desc* d, const void* dy, int dy_ld, float* dw, void* stream);
+int llv_conv2d_nhwc_wgrad(const llv_conv_desc* d, const void* dy, int dy_ld, float* dw, float* db, void* stream);
+
+/* Once per optimizer step: module parameters (fp32, torch's (Cout, Cin, kh, kw)) -> the fp16 layouts the conv kernels read,
+ * eval-mode BatchNorm folded in (s = gamma * rsqrt(var + eps); gamma = var = NULL: no BN). Replaces ops.pack_conv's host
+ * packing while training (the reference keeps cuDNN's layout = the parameter itself, resnet.py:260-299).
+ *   mode 0 forward  dst[row0+o][(r*kw+q)*cpad + i]; mode 1 data gradient of a stride-1 conv (flipped taps, in/out
+ *   transposed: dst[i][..*cpad + row0+o]); mode 2 data gradient of a stride-2 conv as a KHxKW stride-1 conv over dY that
+ *   emits the four output phases (rows 4i + 2py + px, PixelShuffle epilogue). cpad = channel pitch of dst's K axis,
+ *   rows = destination rows written (modes 1, 2), padp = padding of the KHxKW window (backward.dgrad_geometry). */
+int llv_pack_conv_weights(const float* w, const float* gamma, const float* var, float eps, void* dst, int cout, int cin,
+                          int kh, int kw, int cpad, int k_pad, int row0, int mode, int pad, int KH, int KW, int padp, int rows,
+                          void* stream);
+/* out[o] = beta + ((b ? b[o] : 0) - mean) * gamma * rsqrt(var + eps)   (gamma == NULL: out = b or 0) */
+int llv_fold_bias(const float* b, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                  float* out, int n, void* stream);
+/* packed gradient block (dw: first row of the part, db: its first channel) -> parameter gradients, any output may be NULL:
+ * gw = dw*s (Cout,Cin,kh,kw); ggamma = sum(dw*w)/sigma - mean/sigma*db; gbeta = db; gbias = db*s (norm_eval training). */
+int llv_unpack_wgrad(const float* dw, const float* db, const float* w, const float* gamma, const float* mean, const float* var,
+                     float eps, float* gw, float* ggamma, float* gbeta, float* gbias, int cout, int cin, int kh, int kw,
+                     int cpad, int k_pad, void* stream);
 
 /* dx = (dy [+ dy2]) * (y > 0); dy2 and y may be NULL (then: plain sum / plain copy). n fp16 elements, multiple of 8.
  * torch autograd of F.relu(x [+ identity]) (resnet.py:292-296). */

@@ -86,9 +86,10 @@ def dgrad_weight(weight: torch.Tensor, stride: int, pad: int, cin_pad: int) -> T
 # launches
 # ----------------------------------------------------------------------------------------------
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, cin_pad: int, cout: int, w_rows: int, k_pad: int,
-               kh: int, kw: int, stride: int, pad: int, groups: int, batch: int, seg: tuple, x_ld: int, dy_ld: int):
-    """Accumulate the weight gradient of one segment into dw (fp32 [groups][w_rows][k_pad]).
-    seg = (h, w, ho, wo, x_pixel_off, dy_pixel_off)."""
+               kh: int, kw: int, stride: int, pad: int, groups: int, batch: int, seg: tuple, x_ld: int, dy_ld: int,
+               db: Optional[torch.Tensor] = None):
+    """Accumulate the weight gradient of one segment into dw (fp32 [groups][w_rows][k_pad]) and, if given, the bias
+    gradient into db (fp32 [groups*cout]). seg = (h, w, ho, wo, x_pixel_off, dy_pixel_off)."""
     d = ConvDesc()
     d.x[0] = x.data_ptr()
     d.n_src, d.n_seg = 1, 1
@@ -96,7 +97,8 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, cin_pad: 
     d.cin, d.cout, d.w_rows, d.k_pad = cin_pad, cout, w_rows, k_pad
     d.kh, d.kw, d.stride, d.pad, d.groups, d.batch = kh, kw, stride, pad, groups, batch
     d.seg_h[0], d.seg_w[0], d.seg_ho[0], d.seg_wo[0], d.seg_xoff[0], d.seg_yoff[0] = seg
-    check(lib().llv_conv2d_nhwc_wgrad(C.byref(d), dy.data_ptr(), dy_ld, dw.data_ptr(), _stream()), 'llv_conv2d_nhwc_wgrad')
+    check(lib().llv_conv2d_nhwc_wgrad(C.byref(d), dy.data_ptr(), dy_ld, dw.data_ptr(), db.data_ptr() if db is not None else None,
+                                      _stream()), 'llv_conv2d_nhwc_wgrad')
 
 
 def relu_bwd(dy: torch.Tensor, y: Optional[torch.Tensor], dx: torch.Tensor, dy2: Optional[torch.Tensor] = None):
@@ -142,3 +144,30 @@ def conv_dgrad(dy: torch.Tensor, pcd: ops.PackedConv, dx: torch.Tensor, batch: i
     d = ops.make_conv_desc(pcd, [dy], dx, batch, bsegs, dy_ld, dx_ld, dx if accumulate else None, dx_ld if accumulate else 0, f,
                            ps_out=ps)
     ops.launch_conv(d)
+
+
+def _p(t):
+    return t.data_ptr() if t is not None else None
+
+
+def pack_weights(w: torch.Tensor, gamma, var, eps: float, dst: torch.Tensor, *, cpad: int, k_pad: int, row0: int, mode: int,
+                 pad: int = 0, KH: int = 1, KW: int = 1, padp: int = 0, rows: int = 1):
+    """llv_pack_conv_weights: (Cout,Cin,kh,kw) fp32 parameter (+ eval-mode BN scale) -> one block of a packed fp16 weight
+    tensor (dst = the group's [w_rows][k_pad] matrix). mode 0 forward, 1 / 2 data gradient of a stride-1 / stride-2 conv."""
+    cout, cin, kh, kw = w.shape
+    assert w.is_contiguous() and w.dtype == torch.float32 and dst.dtype == torch.float16
+    check(lib().llv_pack_conv_weights(w.data_ptr(), _p(gamma), _p(var), float(eps), dst.data_ptr(), cout, cin, kh, kw, cpad, k_pad,
+                                      row0, mode, pad, KH, KW, padp, rows, _stream()), 'llv_pack_conv_weights')
+
+
+def fold_bias(b, gamma, beta, mean, var, eps: float, out: torch.Tensor):
+    check(lib().llv_fold_bias(_p(b), _p(gamma), _p(beta), _p(mean), _p(var), float(eps), out.data_ptr(), out.numel(), _stream()),
+          'llv_fold_bias')
+
+
+def unpack_wgrad_device(dw: torch.Tensor, db, w: torch.Tensor, gamma, mean, var, eps: float, gw, ggamma, gbeta, gbias, *,
+                        cpad: int, k_pad: int):
+    """llv_unpack_wgrad: rows of the packed fp32 gradient (dw: first row of the part) -> parameter gradients."""
+    cout, cin, kh, kw = w.shape
+    check(lib().llv_unpack_wgrad(dw.data_ptr(), _p(db), w.data_ptr(), _p(gamma), _p(mean), _p(var), float(eps), _p(gw), _p(ggamma),
+                                 _p(gbeta), _p(gbias), cout, cin, kh, kw, cpad, k_pad, _stream()), 'llv_unpack_wgrad')

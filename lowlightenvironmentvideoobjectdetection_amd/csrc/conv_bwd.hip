@@ -44,6 +44,7 @@ struct WgArgs {
     const _Float16* x;
     const _Float16* dy;
     float* dw;
+    float* db;                  // optional: db[g*cout + co] += sum_p dy (done by the tap-0 / first-cin-tile workgroups)
     int x_ld, dy_ld;
     int cin, cout, k_pad, w_rows;
     int kh, kw, stride, pad, groups;
@@ -156,6 +157,13 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
     for (int i = 0; i < TMO; ++i)
 #pragma unroll
         for (int j = 0; j < TNI; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    // bias gradient = row sums of the dY^T operand = dY^T x ones: one extra MFMA per m-tile in the workgroups that own it
+    const bool do_bias = a.db != nullptr && tap == 0 && tile_ci == 0 && wc == 0;      // wave-uniform
+    f32x4 accb[TMO];
+#pragma unroll
+    for (int i = 0; i < TMO; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const _Float16 one = (_Float16)1.f;
+    const f16x8 ones = {one, one, one, one, one, one, one, one};
 
     auto tr_read = [&](const unsigned char* base, int off) __attribute__((always_inline)) {
         const h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(base + off));
@@ -188,6 +196,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
 #pragma unroll
             for (int j = 0; j < TNI; ++j)
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+        if (do_bias) {
+#pragma unroll
+            for (int i = 0; i < TMO; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], ones, accb[i], 0, 0, 0);
+        }
+    }
+    if (do_bias && (lane & 15) == 0) {        // every column of D holds the same row sum: take column 0
+#pragma unroll
+        for (int i = 0; i < TMO; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = co0 + wr * (BCO / 2) + i * 16 + 4 * (lane >> 4) + e;
+                if (co < a.cout) atomicAdd(a.db + g * a.cout + co, accb[i][e]);
+            }
     }
 
     // D[m = co][n = ci]: lane holds rows 4*(lane>>4) + e, column lane&15
@@ -298,9 +319,114 @@ __global__ void sgd_momentum_kernel(float* w, const float* g, float* mom, long n
     }
 }
 
+// ------------------------------------------------------------------------------------------------
+// Weight (re)packing on the device, once per optimizer step: module parameters (fp32, OIHW) -> the fp16 layouts the
+// conv kernels read, with the eval-mode BatchNorm folded in (s = gamma / sqrt(var + eps), ops.pack_conv's folding).
+//   mode 0  forward      dst[row0 + o][(r*kw + q)*cpad + i]                    = w[o][i][r][q] * s[o]
+//   mode 1  dgrad, s = 1 dst[i][((kh-1-r)*kw + (kw-1-q))*cpad + row0 + o]      = w[o][i][r][q] * s[o]
+//   mode 2  dgrad, s = 2 dst[4i + 2py + px][(dy*KW + dx)*cpad + row0 + o]      = w[o][i][r][q] * s[o]
+//           with r = py + pad - 2*(dy - padp), q likewise (backward.dgrad_geometry); taps that do not exist are 0
+// One thread per destination element of the part's block; cpad = channel pitch of the destination's K axis.
+// ------------------------------------------------------------------------------------------------
+struct PackArgs {
+    const float* w; const float* gamma; const float* var; float eps;
+    _Float16* dst;
+    int cout, cin, kh, kw, cpad, k_pad, row0, mode, pad, KH, KW, padp, rows;
+};
+
+__global__ void pack_weights_kernel(const PackArgs a) {
+    const long total = a.mode == 0 ? (long)a.cout * a.kh * a.kw * a.cpad : (long)a.rows * a.KH * a.KW * a.cout;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+        if (a.mode == 0) {
+            const int i = (int)(idx % a.cpad);
+            long t = idx / a.cpad;
+            const int q = (int)(t % a.kw); t /= a.kw;
+            const int r = (int)(t % a.kh);
+            const int o = (int)(t / a.kh);
+            float v = 0.f;
+            if (i < a.cin) {
+                v = a.w[(((long)o * a.cin + i) * a.kh + r) * a.kw + q];
+                if (a.gamma) v *= a.gamma[o] * rsqrtf(a.var[o] + a.eps);
+            }
+            a.dst[(long)(a.row0 + o) * a.k_pad + (r * a.kw + q) * a.cpad + i] = (_Float16)v;
+        } else {
+            const int o = (int)(idx % a.cout);
+            long t = idx / a.cout;
+            const int dx = (int)(t % a.KW); t /= a.KW;
+            const int dy = (int)(t % a.KH);
+            const int row = (int)(t / a.KH);
+            int i, r, q;
+            if (a.mode == 1) {
+                i = row; r = a.kh - 1 - dy; q = a.kw - 1 - dx;
+            } else {
+                i = row >> 2;
+                const int py = (row >> 1) & 1, px = row & 1;
+                r = py + a.pad - 2 * (dy - a.padp);
+                q = px + a.pad - 2 * (dx - a.padp);
+            }
+            float v = 0.f;
+            if (i < a.cin && r >= 0 && r < a.kh && q >= 0 && q < a.kw) {
+                v = a.w[(((long)o * a.cin + i) * a.kh + r) * a.kw + q];
+                if (a.gamma) v *= a.gamma[o] * rsqrtf(a.var[o] + a.eps);
+            }
+            a.dst[(long)row * a.k_pad + (dy * a.KW + dx) * a.cpad + a.row0 + o] = (_Float16)v;
+        }
+    }
+}
+
+// folded bias: out[o] = beta[o] + ((b ? b[o] : 0) - mean[o]) * s[o]   (or plain b / 0 without BN)
+__global__ void fold_bias_kernel(const float* b, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                                 float* out, int n) {
+    const int o = blockIdx.x * blockDim.x + threadIdx.x;
+    if (o >= n) return;
+    const float bv = b ? b[o] : 0.f;
+    out[o] = gamma ? beta[o] + (bv - mean[o]) * gamma[o] * rsqrtf(var[o] + eps) : bv;
+}
+
+// Packed gradient -> module parameter gradients, one workgroup per output channel:
+//   gw[o][i][r][q] = dw[row0+o][(r*kw+q)*cpad + i] * s[o]
+//   ggamma[o] = (sum_{i,r,q} dw * w) / sigma - mean / sigma * db[o],  gbeta[o] = db[o]       (eval-mode BN, affine trainable)
+//   gbias[o]  = db[o] * s[o]
+struct UnpackArgs {
+    const float* dw; const float* db; const float* w;
+    const float* gamma; const float* mean; const float* var; float eps;
+    float* gw; float* ggamma; float* gbeta; float* gbias;
+    int cin, kh, kw, cpad, k_pad;
+};
+
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const UnpackArgs a) {
+    const int o = blockIdx.x;
+    const int n = a.cin * a.kh * a.kw;
+    float inv = 1.f, s = 1.f;
+    if (a.gamma) { inv = rsqrtf(a.var[o] + a.eps); s = a.gamma[o] * inv; }
+    float part = 0.f;
+    for (int e = threadIdx.x; e < n; e += 256) {
+        const int q = e % a.kw;
+        int t = e / a.kw;
+        const int r = t % a.kh;
+        const int i = t / a.kh;
+        const float g = a.dw[(long)o * a.k_pad + (r * a.kw + q) * a.cpad + i];
+        if (a.gw) a.gw[(long)o * n + e] = g * s;
+        if (a.ggamma) part += g * a.w[(long)o * n + e];
+    }
+    __shared__ float red[256];
+    red[threadIdx.x] = part;
+    __syncthreads();
+    for (int st = 128; st > 0; st >>= 1) {
+        if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
+        __syncthreads();
+    }
+    if (threadIdx.x == 0) {
+        const float d = a.db ? a.db[o] : 0.f;
+        if (a.ggamma) a.ggamma[o] = red[0] * inv - a.mean[o] * inv * d;
+        if (a.gbeta) a.gbeta[o] = d;
+        if (a.gbias) a.gbias[o] = d * s;
+    }
+}
+
 }  // namespace
 
-extern "C" int llv_conv2d_nhwc_wgrad(const llv_conv_desc* d, const void* dy, int dy_ld, float* dw, void* stream) {
+extern "C" int llv_conv2d_nhwc_wgrad(const llv_conv_desc* d, const void* dy, int dy_ld, float* dw, float* db, void* stream) {
     if (!d || !dy || !dw || !d->x[0] || d->n_seg != 1 || d->n_src != 1) return LLV_E_BADARG;
     if (d->cin <= 0 || (d->cin & 7) || d->cout <= 0 || d->groups < 1 || d->kh < 1 || d->kw < 1 || d->stride < 1 || d->pad < 0) return LLV_E_BADARG;
     if ((d->x_ld & 7) || (dy_ld & 7) || d->x_ld < d->groups * d->cin || dy_ld < d->groups * d->cout) return LLV_E_BADARG;
@@ -312,7 +438,7 @@ extern "C" int llv_conv2d_nhwc_wgrad(const llv_conv_desc* d, const void* dy, int
     const size_t yb = ((size_t)d->seg_yoff[0] + (size_t)m) * dy_ld * 2;
     if (m > 0x7fffffffL || xb >= (1ull << 31) || yb >= (1ull << 31)) return LLV_E_UNSUPPORTED;
     WgArgs a;
-    a.x = (const _Float16*)d->x[0]; a.dy = (const _Float16*)dy; a.dw = dw;
+    a.x = (const _Float16*)d->x[0]; a.dy = (const _Float16*)dy; a.dw = dw; a.db = db;
     a.x_ld = d->x_ld; a.dy_ld = dy_ld; a.cin = d->cin; a.cout = d->cout; a.k_pad = d->k_pad; a.w_rows = d->w_rows;
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.groups = d->groups;
     a.H = d->seg_h[0]; a.W = d->seg_w[0]; a.Ho = d->seg_ho[0]; a.Wo = d->seg_wo[0];
@@ -374,5 +500,38 @@ extern "C" int llv_sgd_momentum(float* w, const float* g, float* mom, int64_t n,
     grid = grid > 4096 ? 4096 : grid;
     hipLaunchKernelGGL(sgd_momentum_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, w, g, mom, (long)n, lr, momentum, weight_decay,
                        grad_scale, first_step);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_pack_conv_weights(const float* w, const float* gamma, const float* var, float eps, void* dst, int cout, int cin,
+                                     int kh, int kw, int cpad, int k_pad, int row0, int mode, int pad, int KH, int KW, int padp,
+                                     int rows, void* stream) {
+    if (!w || !dst || cout < 1 || cin < 1 || kh < 1 || kw < 1 || cpad < 1 || k_pad < 1 || row0 < 0 || mode < 0 || mode > 2) return LLV_E_BADARG;
+    if ((gamma == nullptr) != (var == nullptr)) return LLV_E_BADARG;
+    if (mode == 0 && (cpad < cin || k_pad < kh * kw * cpad)) return LLV_E_BADARG;
+    if (mode != 0 && (KH < 1 || KW < 1 || rows < 1 || cpad < row0 + cout || k_pad < KH * KW * cpad)) return LLV_E_BADARG;
+    PackArgs a{w, gamma, var, eps, (_Float16*)dst, cout, cin, kh, kw, cpad, k_pad, row0, mode, pad, KH, KW, padp, rows};
+    const long total = mode == 0 ? (long)cout * kh * kw * cpad : (long)rows * KH * KW * cout;
+    long grid = (total + 255) / 256;
+    grid = grid > 4096 ? 4096 : grid;
+    hipLaunchKernelGGL(pack_weights_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_fold_bias(const float* b, const float* gamma, const float* beta, const float* mean, const float* var, float eps,
+                             float* out, int n, void* stream) {
+    if (!out || n < 1 || (gamma && (!beta || !mean || !var))) return LLV_E_BADARG;
+    hipLaunchKernelGGL(fold_bias_kernel, dim3((n + 255) / 256), dim3(256), 0, (hipStream_t)stream, b, gamma, beta, mean, var, eps, out, n);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_unpack_wgrad(const float* dw, const float* db, const float* w, const float* gamma, const float* mean, const float* var,
+                                float eps, float* gw, float* ggamma, float* gbeta, float* gbias, int cout, int cin, int kh, int kw,
+                                int cpad, int k_pad, void* stream) {
+    if (!dw || cout < 1 || cin < 1 || kh < 1 || kw < 1 || cpad < cin || k_pad < kh * kw * cpad) return LLV_E_BADARG;
+    if (gamma && (!mean || !var)) return LLV_E_BADARG;
+    if (ggamma && (!gamma || !w)) return LLV_E_BADARG;
+    UnpackArgs a{dw, db, w, gamma, mean, var, eps, gw, ggamma, gbeta, gbias, cin, kh, kw, cpad, k_pad};
+    hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(cout), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }

@@ -143,36 +143,31 @@ class TrainGraph:
             return we, be, (s, inv, mean)
         return w, (b if b is not None else torch.zeros(w.shape[0], device=w.device)), None
 
+    def _bn_tensors(self, q):
+        if not q['bn']:
+            return None, None, None, None
+        gk, bk, mk, vk = q['bn']
+        return self.params[gk].detach(), self.params[bk].detach(), self.buffers[mk], self.buffers[vk]
+
     def repack(self):
-        """Write the current parameter values into every trainable launch's packed weights (+ its dgrad filter)."""
+        """Write the current parameter values into every trainable launch's packed weights (+ its dgrad filter):
+        llv_pack_conv_weights / llv_fold_bias, two or three small launches per parameter tensor."""
         for op in self.tape:
             if op['frozen'] and not op['need_dx']:
                 continue
             pc = op['pc']
-            per_group = {}
             for q in pc.parts:
-                we, be, _ = self._eff(q)
+                w = self.params[q['wkey']].detach()
+                b = self.params[q['bkey']].detach() if q['bkey'] else None
+                gamma, beta, mean, var = self._bn_tensors(q)
                 g, r0, co = q['group'], q['row0'], q['cout']
                 if not op['frozen']:
-                    K = pc.kh * pc.kw * pc.cin
-                    tmp = torch.zeros(co, pc.kh, pc.kw, pc.cin, dtype=torch.float16, device=self.device)
-                    tmp[..., :q['cin']] = we.permute(0, 2, 3, 1).to(torch.float16)
-                    pc.w[g, r0:r0 + co, :K] = tmp.view(co, K)
-                    pc.bias[g * pc.cout + r0:g * pc.cout + r0 + co] = be
-                per_group.setdefault(g, []).append((r0, we))
-            if op['need_dx']:
-                pcd = op['pcd']
-                for g, lst in per_group.items():
-                    lst.sort(key=lambda t: t[0])
-                    wfull = torch.zeros(pc.cout, lst[0][1].shape[1], pc.kh, pc.kw, dtype=torch.float32, device=self.device)
-                    for r0, we in lst:
-                        wfull[r0:r0 + we.shape[0]] = we
-                    wd, KH, KW, pd, _ = B.dgrad_weight(wfull, pc.stride, pc.pad, pc.cin)
-                    rows, dyc = wd.shape[0], pcd.cin
-                    K = KH * KW * dyc
-                    tmp = torch.zeros(rows, KH, KW, dyc, dtype=torch.float16, device=self.device)
-                    tmp[..., :wd.shape[1]] = wd.permute(0, 2, 3, 1).to(torch.float16)
-                    pcd.w[g, :rows, :K] = tmp.view(rows, K)
+                    B.pack_weights(w, gamma, var, q['eps'], pc.w[g], cpad=pc.cin, k_pad=pc.k_pad, row0=r0, mode=0)
+                    B.fold_bias(b, gamma, beta, mean, var, q['eps'], pc.bias[g * pc.cout + r0:g * pc.cout + r0 + co])
+                if op['need_dx']:
+                    pcd = op['pcd']
+                    B.pack_weights(w, gamma, var, q['eps'], pcd.w[g], cpad=pcd.cin, k_pad=pcd.k_pad, row0=r0,
+                                   mode=2 if pc.stride == 2 else 1, pad=pc.pad, KH=pcd.kh, KW=pcd.kw, padp=pcd.pad, rows=pcd.cout)
 
     # ---- forward / backward ---------------------------------------------------------------------
     def forward(self, img: torch.Tensor):
@@ -220,11 +215,8 @@ class TrainGraph:
                 for (h, w, ho, wo, xo, yo) in op['segs']:
                     B.conv_wgrad(op['xs'][0], gy, op['dw'], cin_pad=pc.cin, cout=pc.cout,
                                  w_rows=pc.w_rows, k_pad=pc.k_pad, kh=pc.kh, kw=pc.kw, stride=pc.stride, pad=pc.pad, groups=pc.groups,
-                                 batch=op['batch'], seg=(h, w, ho, wo, xo, yo), x_ld=op['x_ld'], dy_ld=dy_ld)
+                                 batch=op['batch'], seg=(h, w, ho, wo, xo, yo), x_ld=op['x_ld'], dy_ld=dy_ld, db=op['db'])
                     m_tot += op['batch'] * ho * wo
-                for (h, w, ho, wo, xo, yo) in op['segs']:
-                    n = op['batch'] * ho * wo
-                    B.bias_grad(self._rows(gy, yo, n), n, pc.groups * pc.cout, dy_ld, op['db'])
             if op['need_dx']:
                 gx = self.gview(op['xs'][0])
                 if op['dflags'] & CONV_PIXSHUF:
@@ -248,15 +240,18 @@ class TrainGraph:
                 op['dw'].zero_()
                 op['db'].zero_()
 
-    def param_grads(self, only_op=None) -> Dict[str, torch.Tensor]:
+    def param_grads(self, only_op=None, dst: Dict[str, torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """Module-parameter gradients (fp32, still multiplied by loss_scale) from the packed dW / db of every launch
-        (or of one launch)."""
+        (or of one launch): llv_unpack_wgrad, one launch per parameter tensor. `dst` maps parameter names to the tensors
+        to write (TrainStep: views of its flat gradient buffer); missing ones are allocated."""
         out: Dict[str, torch.Tensor] = {}
 
-        def acc(k, v):
+        def slot(k):
             if k is None or k not in self.params or not self.params[k].requires_grad:
-                return
-            out[k] = out[k] + v if k in out else v
+                return None
+            assert k not in out, f'{k}: a parameter feeds exactly one launch on this path'
+            out[k] = dst[k] if dst is not None and k in dst else torch.empty_like(self.params[k], dtype=torch.float32)
+            return out[k]
 
         for op in ([only_op] if only_op is not None else self.tape):
             if op['frozen']:
@@ -264,19 +259,12 @@ class TrainGraph:
             pc = op['pc']
             for q in pc.parts:
                 g, r0, co = q['group'], q['row0'], q['cout']
-                dwe = B.unpack_wgrad(op['dw'][g, r0:r0 + co], co, q['cin'], pc.kh, pc.kw, pc.cin)
-                dbe = op['db'][g * pc.cout + r0:g * pc.cout + r0 + co]
-                if q['bn']:
-                    _, _, (s, inv, mean) = self._eff(q)
-                    w = self.params[q['wkey']].detach()
-                    acc(q['wkey'], dwe * s.view(-1, 1, 1, 1))
-                    acc(q['bn'][0], (dwe * w).sum((1, 2, 3)) * inv - mean * inv * dbe)
-                    acc(q['bn'][1], dbe)
-                    if q['bkey']:
-                        acc(q['bkey'], dbe * s)
-                else:
-                    acc(q['wkey'], dwe.contiguous())
-                    acc(q['bkey'], dbe)
+                w = self.params[q['wkey']].detach()
+                gamma, beta, mean, var = self._bn_tensors(q)
+                gw, gb = slot(q['wkey']), slot(q['bkey'])
+                gg, gbt = (slot(q['bn'][0]), slot(q['bn'][1])) if q['bn'] else (None, None)
+                B.unpack_wgrad_device(op['dw'][g, r0:], op['db'][g * pc.cout + r0:], w, gamma, mean, var, q['eps'], gw, gg, gbt, gb,
+                                      cpad=pc.cin, k_pad=pc.k_pad)
         return out
 
 
@@ -381,15 +369,13 @@ class TrainStep:
             self.buckets.append((start, self.flat_w.numel()))
         self.steps_done = 0
         self._works = []
+        self.gviews = {k: self.flat_g[o:o + n].view_as(g.params[k]) for k, (o, n) in self.slices.items()}
 
     def _dist(self):
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
     def _op_done(self, op):
-        inv = 1.0
-        for k, v in self.graph.param_grads(only_op=op).items():
-            o, n = self.slices[k]
-            self.flat_g[o:o + n].add_(v.reshape(-1), alpha=inv)
+        self.graph.param_grads(only_op=op, dst=self.gviews)
         if self._dist():
             for (a, b) in self.bucket_after_op.get(id(op), []):
                 self._works.append(dist.all_reduce(self.flat_g[a:b], async_op=True))
