@@ -181,8 +181,15 @@ class TrainGraph:
         """dcls / dreg: per-level (N,h,w,C) fp32 gradients of the loss w.r.t. the logits. Fills op['dw'] / op['db']
         (scaled by loss_scale). on_op_done(op) is called as soon as a launch's weight gradient is final (launches run
         in reverse order), which is what lets the gradient all-reduce overlap the rest of the backward pass."""
+        self.zero_act_grads()
+        self.set_logit_grads(dcls, dreg)
+        self.backward_ops(list(reversed(self.tape)), on_op_done)
+
+    def zero_act_grads(self):
         for g in self.grads.values():
             g.zero_()
+
+    def set_logit_grads(self, dcls, dreg):
         gc, gr = self.grads[_sptr(self.cls_buf)], self.grads[_sptr(self.reg_buf)]
         pyr = self.pyramid
         for i in range(len(pyr.level_hw)):
@@ -190,7 +197,9 @@ class TrainGraph:
             o, n = pyr.level_off[i], self.batch * h * w
             gc[o:o + n, :dcls[i].shape[-1]] = (dcls[i].reshape(n, -1) * self.loss_scale).to(torch.float16)
             gr[o:o + n, :dreg[i].shape[-1]] = (dreg[i].reshape(n, -1) * self.loss_scale).to(torch.float16)
-        for op in reversed(self.tape):
+
+    def backward_ops(self, ops_rev, on_op_done=None):
+        for op in ops_rev:
             yp = _sptr(op['y'])
             if yp not in self.req:
                 continue
@@ -211,12 +220,10 @@ class TrainGraph:
                 else:
                     B.relu_bwd(gres, None, gres, dy2=gy)
             if not op['frozen']:
-                m_tot = 0
                 for (h, w, ho, wo, xo, yo) in op['segs']:
                     B.conv_wgrad(op['xs'][0], gy, op['dw'], cin_pad=pc.cin, cout=pc.cout,
                                  w_rows=pc.w_rows, k_pad=pc.k_pad, kh=pc.kh, kw=pc.kw, stride=pc.stride, pad=pc.pad, groups=pc.groups,
                                  batch=op['batch'], seg=(h, w, ho, wo, xo, yo), x_ld=op['x_ld'], dy_ld=dy_ld, db=op['db'])
-                    m_tot += op['batch'] * ho * wo
             if op['need_dx']:
                 gx = self.gview(op['xs'][0])
                 if op['dflags'] & CONV_PIXSHUF:
@@ -325,8 +332,9 @@ class TrainStep:
     parameter gradient has been written, overlapping the collective (xGMI) with the remaining convolution kernels."""
 
     def __init__(self, det, batch, height, width, device, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_scale=512.0,
-                 bucket_mb=25.0):
+                 bucket_mb=25.0, use_graph=True):
         self.det, self.device = det, device
+        self.use_graph, self._g_fwd = use_graph, None
         self.graph = TrainGraph(det, batch, height, width, device, loss_scale)
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         g = self.graph
@@ -374,17 +382,69 @@ class TrainStep:
     def _dist(self):
         return dist.is_available() and dist.is_initialized() and dist.get_world_size() > 1
 
-    def _op_done(self, op):
-        self.graph.param_grads(only_op=op, dst=self.gviews)
-        if self._dist():
-            for (a, b) in self.bucket_after_op.get(id(op), []):
-                self._works.append(dist.all_reduce(self.flat_g[a:b], async_op=True))
+    # ---- HIP-graph capture: the launch sequences are static (same buffers every step), only the loss in the middle is
+    # dynamic (numbers of positives). Forward = one graph; backward = one graph per all-reduce bucket, so each bucket's
+    # collective can start while the next graph runs.
+    def _capture(self, img_shape):
+        g = self.graph
+        self.img_static = torch.zeros(img_shape, dtype=torch.float32, device=self.device)
+        segs, cur = [], []
+        for op in reversed(g.tape):
+            if _sptr(op['y']) not in g.req:          # frozen region: nothing to launch
+                continue
+            cur.append(op)
+            if id(op) in self.bucket_after_op:
+                segs.append((cur, self.bucket_after_op[id(op)]))
+                cur = []
+        if cur:
+            segs.append((cur, []))
+        self._segs = segs
+
+        def fwd():
+            g.repack()
+            ops.pack_input(self.img_static, 8, out=g.x_in)
+            g.plan.run()
+
+        def seg_fn(k):
+            ops_k = self._segs[k][0]
+            if k == 0:
+                g.zero_param_grads()
+            g.backward_ops(ops_k, lambda op: g.param_grads(only_op=op, dst=self.gviews))
+
+        # warm-up on a side stream (lazy initialisation, split-K workspaces), then capture
+        s = torch.cuda.Stream()
+        s.wait_stream(torch.cuda.current_stream())
+        with torch.cuda.stream(s):
+            fwd()
+            g.zero_act_grads()
+            for k in range(len(segs)):
+                seg_fn(k)
+        torch.cuda.current_stream().wait_stream(s)
+        torch.cuda.synchronize()
+        self._g_fwd = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(self._g_fwd):
+            fwd()
+        self._g_bwd = []
+        for k in range(len(segs)):
+            gk = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(gk):
+                seg_fn(k)
+            self._g_bwd.append(gk)
 
     def step_fused(self, img, img_metas, gt_bboxes, gt_labels):
         from .training import anchor_head_loss
         g, head = self.graph, self.det.bbox_head
-        g.repack()
-        cls, reg = g.forward(img)
+        if self.use_graph and self._g_fwd is None:
+            self._capture(tuple(img.shape))
+        if self.use_graph:
+            self.img_static.copy_(img)
+            self._g_fwd.replay()
+            pyr = g.pyramid
+            cls = [pyr.level(i, g.cls_buf) for i in range(len(pyr.level_hw))]
+            reg = [pyr.level(i, g.reg_buf) for i in range(len(pyr.level_hw))]
+        else:
+            g.repack()
+            cls, reg = g.forward(img)
         lc = [t.detach().requires_grad_() for t in cls]
         lr_ = [t.detach().requires_grad_() for t in reg]
         losses = anchor_head_loss(head, [t.permute(0, 3, 1, 2) for t in lc], [t.permute(0, 3, 1, 2) for t in lr_],
@@ -393,10 +453,18 @@ class TrainStep:
             raise LlvError('no valid anchors inside the image')
         total = sum(sum(v) if isinstance(v, list) else v for k, v in losses.items() if 'loss' in k)
         total.backward()
-        g.zero_param_grads()
-        self.flat_g.zero_()
         self._works = []
-        g.backward([t.grad for t in lc], [t.grad for t in lr_], on_op_done=self._op_done)
+        g.zero_act_grads()
+        g.set_logit_grads([t.grad for t in lc], [t.grad for t in lr_])
+        if self.use_graph:
+            for k, (ops_k, buckets) in enumerate(self._segs):
+                self._g_bwd[k].replay()
+                if self._dist():
+                    for (a, b) in buckets:
+                        self._works.append(dist.all_reduce(self.flat_g[a:b], async_op=True))
+        else:
+            g.zero_param_grads()
+            g.backward_ops(list(reversed(g.tape)), self._op_done)
         for w in self._works:
             w.wait()
         world = dist.get_world_size() if self._dist() else 1
@@ -405,3 +473,9 @@ class TrainStep:
         self.steps_done += 1
         loss, log_vars = self.det._parse_losses({k: [x.detach() for x in v] if isinstance(v, list) else v.detach() for k, v in losses.items()})
         return dict(loss=loss, log_vars=log_vars, num_samples=len(img_metas))
+
+    def _op_done(self, op):
+        self.graph.param_grads(only_op=op, dst=self.gviews)
+        if self._dist():
+            for (a, b) in self.bucket_after_op.get(id(op), []):
+                self._works.append(dist.all_reduce(self.flat_g[a:b], async_op=True))
