@@ -323,6 +323,25 @@ def forward_train(det, graph: TrainGraph, img, img_metas, gt_bboxes, gt_labels, 
     return losses
 
 
+def plan_buckets(keys_per_op, slices, limit):
+    """All-reduce buckets over a flat gradient buffer laid out in backward order. keys_per_op[i] = parameter names whose
+    gradients are final once the i-th launch of the backward pass is done; slices[name] = (offset, numel). Returns
+    {i: [(start, end), ...]}: the ranges that may be all-reduced right after launch i. Every element is covered exactly
+    once, a bucket is at least `limit` elements (except the last) and never contains a gradient that is not final."""
+    out, start, done = {}, 0, set()
+    total = max((o + n for o, n in slices.values()), default=0)
+    for i, ks in enumerate(keys_per_op):
+        done.update(ks)
+        end = max((slices[k][0] + slices[k][1] for k in done), default=0)
+        # the prefix [0, end) is final only if every key inside it is done (backward-ordered layout guarantees it)
+        if end - start >= limit:
+            out.setdefault(i, []).append((start, end))
+            start = end
+    if start < total:
+        out.setdefault(len(keys_per_op) - 1, []).append((start, total))
+    return out
+
+
 class TrainStep:
     """All-device training step: forward, loss, backward, gradient all-reduce over the ranks (RCCL when the process
     group is nccl), fused SGD on one flat fp32 parameter buffer. The parameters of `det` become views of that buffer.
@@ -358,23 +377,10 @@ class TrainStep:
             self.slices[k] = (o, n)
             o += n
         # buckets: [start, end) ranges of the flat buffer, closed when the op owning their last key is done
-        limit = int(bucket_mb * 1024 * 1024 / 4)
-        self.buckets, start = [], 0
-        self.bucket_after_op = {}
-        done_keys = set()
-        for op in reversed(g.tape):
-            if op['frozen']:
-                continue
-            done_keys.update(g.param_grads_keys(op))
-            end = max(self.slices[k][0] + self.slices[k][1] for k in done_keys)
-            if end - start >= limit:
-                self.bucket_after_op.setdefault(id(op), []).append((start, end))
-                self.buckets.append((start, end))
-                start = end
-        if start < self.flat_w.numel():
-            last = [op for op in g.tape if not op['frozen']][0]
-            self.bucket_after_op.setdefault(id(last), []).append((start, self.flat_w.numel()))
-            self.buckets.append((start, self.flat_w.numel()))
+        live = [op for op in reversed(g.tape) if not op['frozen']]
+        plan = plan_buckets([g.param_grads_keys(op) for op in live], self.slices, int(bucket_mb * 1024 * 1024 / 4))
+        self.bucket_after_op = {id(live[i]): rng for i, rng in plan.items()}
+        self.buckets = [r for rng in plan.values() for r in rng]
         self.steps_done = 0
         self._works = []
         self.gviews = {k: self.flat_g[o:o + n].view_as(g.params[k]) for k, (o, n) in self.slices.items()}
