@@ -70,6 +70,7 @@ extern "C" {
 #define LLV_CONV_PIXSHUF 8     /* store through nn.PixelShuffle(2): out (2Ho,2Wo,cout/4) */
 #define LLV_CONV_RES_UPS 16    /* res is (res_h,res_w), nearest-upsampled to (Ho,Wo) (fpn.py:185-191) */
 #define LLV_CONV_OUT_F32 32    /* y is fp32 instead of fp16 */
+#define LLV_CONV_ACT_FIRST 128 /* with RES_ADD: y = act(conv + bias) + res (Darknet ResBlock, darknet.py:47-53) instead of act(conv + bias + res) */
 #define LLV_CONV_LEAKY 64      /* y = y > 0 ? y : act_slope*y last (FlowNetSimple LeakyReLU(0.1), flownet_simple.py:66-68) */
 
 /*
@@ -294,6 +295,22 @@ int llv_iou_assign(const float* gt, int k, const float* anchors, const uint8_t* 
                    float pos_iou_thr, float neg_iou_thr, float min_pos_iou, int match_low_quality,
                    int gt_max_assign_all, int64_t* assigned_gt_inds, float* max_overlaps, void* workspace,
                    size_t workspace_bytes, void* stream);
+
+/* ---- YOLOv3 stand-in for config #5 ------------------------------------------------------------
+ * F.interpolate(scale_factor=2) of yolo_neck.py:123 written into a channel slice of the concat buffer (torch.cat of :124):
+ * dst[n][2y+dy][2x+dx][c] = src[n][y][x][c], fp16 NHWC, row strides src_ld / dst_ld, c multiple of 8. */
+int llv_upsample2x_nhwc(const void* src, void* dst, int n, int h, int w, int c, int src_ld, int dst_ld, void* stream);
+/* YOLOV3Head._get_bboxes per level before the top-k (yolo_head.py:262-279) + YOLOBBoxCoder.decode (yolo_bbox_coder.py:61-89)
+ * + YOLOAnchorGenerator grid (anchor_generator.py:639-665): pred fp32 [n][h][w][ld] with channel a*num_attrib + attr ->
+ * boxes [n][h*w*A][4] (xyxy), conf [n][h*w*A] = sigmoid(attr 4). anchors_wh: A (w, h) pairs (host floats). */
+int llv_yolo_decode(const float* pred, int n, int h, int w, int num_anchors, int num_attrib, int ld, int stride,
+                    const float* anchors_wh, float* boxes, float* conf, void* stream);
+/* llv_multiclass_nms_batched with multiclass_nms's score_factors (bbox_nms.py:55-62): the threshold test uses the raw score,
+ * the ranking / reported score is score * score_factors[i] (YOLOv3: objectness). score_factors [batch][n], may be NULL. */
+int llv_multiclass_nms_batched_sf(const float* boxes, const float* scores, const float* score_factors, int batch, int n,
+                                  int num_classes, int c_ld, float score_thr, float iou_thr, int max_num, float* dets,
+                                  int64_t* labels, int32_t* count, int32_t* keep_flat, void* workspace, size_t workspace_bytes,
+                                  void* stream);
 
 /* ---- backward pass of the convolution engine (llv_conv2d_nhwc_{dgrad,wgrad}) ----------------
  * Replaces torch autograd's cudnn_convolution_backward_{input,weight} under mmdet's ResNet / FPN / RetinaHead

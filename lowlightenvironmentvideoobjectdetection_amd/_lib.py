@@ -21,6 +21,7 @@ CONV_PIXSHUF = 8
 CONV_RES_UPS = 16
 CONV_OUT_F32 = 32
 CONV_LEAKY = 64
+CONV_ACT_FIRST = 128
 
 TILE_AUTO, TILE_128x128, TILE_64x256, TILE_32x256, TILE_16x256, TILE_64x64 = 0, 1, 2, 3, 4, 5
 TILE_128x128_REGSTAGE = 6
@@ -112,6 +113,9 @@ SIGNATURES = {
     'llv_multiclass_nms': (_I, [_P, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
     'llv_multiclass_nms_batched_workspace_bytes': (_Z, [_I, _I, _I, _I]),
     'llv_multiclass_nms_batched': (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    'llv_multiclass_nms_batched_sf': (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    'llv_upsample2x_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'llv_yolo_decode': (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),
     'llv_nms_workspace_bytes': (_Z, [_I]),
     'llv_nms': (_I, [_P, _P, _I, _F, _P, _P, _P, _Z, _P]),
     'llv_embed_aggregate': (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P]),

@@ -61,8 +61,10 @@ class ConvModule(nn.Module):
             raise NotImplementedError('dilated / grouped ConvModule is outside the hot path')
         self.with_norm = norm_cfg is not None
         self.with_activation = act_cfg is not None
-        if self.with_activation and act_cfg.get('type') != 'ReLU':
+        if self.with_activation and act_cfg.get('type') not in ('ReLU', 'LeakyReLU'):
             raise NotImplementedError(f'activation {act_cfg} is outside the hot path')
+        self.act_type = act_cfg.get('type') if self.with_activation else None
+        self.negative_slope = act_cfg.get('negative_slope', 0.01) if self.act_type == 'LeakyReLU' else 0.0
         if bias == 'auto':
             bias = not self.with_norm
         self.conv = nn.Conv2d(in_channels, out_channels, kernel_size, stride, padding, bias=bias)
@@ -75,7 +77,10 @@ class ConvModule(nn.Module):
         self.init_weights()
 
     def init_weights(self):
-        kaiming_init(self.conv, a=0, nonlinearity='relu')
+        if getattr(self, 'act_type', None) == 'LeakyReLU':      # mmcv ConvModule.init_weights: a = negative_slope
+            kaiming_init(self.conv, a=self.negative_slope, nonlinearity='leaky_relu')
+        else:
+            kaiming_init(self.conv, a=0, nonlinearity='relu')
         if self.with_norm:
             constant_init(self.bn, 1, bias=0)
 

@@ -107,6 +107,14 @@ __device__ __forceinline__ void epi_compute_b(const ConvKArgs& a, const EpiCtx& 
     const int flags = a.flags;
     v[0] += b4.x; v[1] += b4.y; v[2] += b4.z; v[3] += b4.w;
     if (flags & LLV_CONV_PIXSHUF) return;
+    if (flags & LLV_CONV_ACT_FIRST) {        // Darknet ResBlock: x + act(bn(conv(.))) (darknet.py:47-53)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = act_fn(a, v[e]);
+        const f16x4 r4 = *reinterpret_cast<const f16x4*>(a.res + c.rpix * a.res_ld + gco);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] += (float)r4[e];
+        return;
+    }
     if (flags & (LLV_CONV_RES_ADD | LLV_CONV_RES_RSUB)) {
         const f16x4 r4 = *reinterpret_cast<const f16x4*>(a.res + c.rpix * a.res_ld + gco);
         if (flags & LLV_CONV_RES_RSUB) {
@@ -2004,6 +2012,7 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
         k.ps_h = d->ps_out_h; k.ps_w = d->ps_out_w;
     }
     if ((f & LLV_CONV_RELU) && (f & LLV_CONV_LEAKY)) return LLV_E_BADARG;
+    if ((f & LLV_CONV_ACT_FIRST) && (!(f & LLV_CONV_RES_ADD) || (f & (LLV_CONV_RES_RSUB | LLV_CONV_RES_UPS | LLV_CONV_PIXSHUF | LLV_CONV_OUT_F32)) || d->k_splits > 1)) return LLV_E_BADARG;
     k.y_gstride = d->y_group_stride;
     if (d->y_group_stride) {
         if (d->y_group_stride < 0 || (f & (LLV_CONV_OUT_F32 | LLV_CONV_PIXSHUF)) || d->y_ld < d->cout || (d->y_group_stride & 7)) return LLV_E_BADARG;

@@ -282,6 +282,66 @@ extern "C" int llv_flow_prepare(const float* x, void* y, int n, int h, int w, in
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
+// dst[n][2y+dy][2x+dx][c] = src[n][y][x][c] (F.interpolate(scale_factor=2), nearest; yolo_neck.py:123), 16 B per lane
+__global__ void upsample2x_kernel(const _Float16* src, _Float16* dst, int n, int h, int w, int c8, int src_ld, int dst_ld) {
+    const long total = (long)n * (2 * h) * (2 * w) * c8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % c8);
+        long t = i / c8;
+        const int x = (int)(t % (2 * w)); t /= 2 * w;
+        const int y = (int)(t % (2 * h));
+        const int im = (int)(t / (2 * h));
+        const uint4 v = *reinterpret_cast<const uint4*>(src + (((long)im * h + (y >> 1)) * w + (x >> 1)) * src_ld + cv * 8);
+        *reinterpret_cast<uint4*>(dst + (((long)im * 2 * h + y) * (2 * w) + x) * dst_ld + cv * 8) = v;
+    }
+}
+
+// one lane per anchor: sigmoid(xy) -> centre, exp(wh) * anchor size -> box; objectness = sigmoid(attr 4)
+// (yolo_head.py:262-279, yolo_bbox_coder.py:61-89). The anchor of cell (cy, cx) is centred at (cx + 0.5, cy + 0.5) * stride.
+struct YoloArgs { const float* pred; float* boxes; float* conf; int n, h, w, A, na, ld, stride; float aw[8], ah[8]; };
+__global__ void yolo_decode_kernel(const YoloArgs k) {
+    const long per = (long)k.h * k.w * k.A, total = per * k.n;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int a = (int)(i % k.A);
+        long t = i / k.A;
+        const int cx = (int)(t % k.w); t /= k.w;
+        const int cy = (int)(t % k.h);
+        const int im = (int)(t / k.h);
+        const float* p = k.pred + (((long)im * k.h + cy) * k.w + cx) * k.ld + a * k.na;
+        const float sx = 1.f / (1.f + expf(-p[0])), sy = 1.f / (1.f + expf(-p[1]));
+        const float st = (float)k.stride;
+        // anchor corners as the generator makes them (base anchor + shift), then centre / size as the coder recomputes them
+        const float bx0 = 0.5f * st - 0.5f * k.aw[a] + (float)(cx * k.stride), bx1 = 0.5f * st + 0.5f * k.aw[a] + (float)(cx * k.stride);
+        const float by0 = 0.5f * st - 0.5f * k.ah[a] + (float)(cy * k.stride), by1 = 0.5f * st + 0.5f * k.ah[a] + (float)(cy * k.stride);
+        const float xc = (bx0 + bx1) * 0.5f, yc = (by0 + by1) * 0.5f, aw = bx1 - bx0, ah = by1 - by0;
+        const float px = (sx - 0.5f) * st + xc, py = (sy - 0.5f) * st + yc;
+        const float pw = expf(p[2]) * aw, ph = expf(p[3]) * ah;
+        reinterpret_cast<float4*>(k.boxes)[i] = make_float4(px - pw / 2, py - ph / 2, px + pw / 2, py + ph / 2);
+        k.conf[i] = 1.f / (1.f + expf(-p[4]));
+    }
+}
+
+extern "C" int llv_upsample2x_nhwc(const void* src, void* dst, int n, int h, int w, int c, int src_ld, int dst_ld, void* stream) {
+    if (!src || !dst || n < 1 || h < 1 || w < 1 || c < 8 || (c & 7) || (src_ld & 7) || (dst_ld & 7) || src_ld < c || dst_ld < c) return LLV_E_BADARG;
+    const long total = (long)n * 4 * h * w * (c / 8);
+    hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, (const _Float16*)src, (_Float16*)dst,
+                       n, h, w, c / 8, src_ld, dst_ld);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_yolo_decode(const float* pred, int n, int h, int w, int num_anchors, int num_attrib, int ld, int stride,
+                               const float* anchors_wh, float* boxes, float* conf, void* stream) {
+    if (!pred || !boxes || !conf || !anchors_wh || n < 1 || h < 1 || w < 1 || num_anchors < 1 || num_anchors > 8 || num_attrib < 5 ||
+        ld < num_anchors * num_attrib || stride < 1)
+        return LLV_E_BADARG;
+    YoloArgs k;
+    k.pred = pred; k.boxes = boxes; k.conf = conf; k.n = n; k.h = h; k.w = w; k.A = num_anchors; k.na = num_attrib; k.ld = ld; k.stride = stride;
+    for (int a = 0; a < 8; ++a) { k.aw[a] = a < num_anchors ? anchors_wh[2 * a] : 0.f; k.ah[a] = a < num_anchors ? anchors_wh[2 * a + 1] : 0.f; }
+    const long total = (long)n * h * w * num_anchors;
+    hipLaunchKernelGGL(yolo_decode_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, k);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
 extern "C" int llv_bilinear_resize_f32(const float* x, float* y, int nc, int h, int w, int ho, int wo, float scale_factor,
                                        float mul, void* stream) {
     if (!x || !y || nc < 1 || h < 1 || w < 1 || ho < 1 || wo < 1 || !(scale_factor > 0.f)) return LLV_E_BADARG;

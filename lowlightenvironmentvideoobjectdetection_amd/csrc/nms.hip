@@ -48,6 +48,7 @@ __device__ __forceinline__ bool iou_gt(const float4 a, const float4 b, float thr
 // the boxes that own a candidate is reduced (boxes.max() of batched_nms). Appends are unordered; the keys are
 // distinct, so the per-class sort that follows is deterministic.
 __global__ __launch_bounds__(256) void nms_scan_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                      const float* __restrict__ factors,
                                                       int n, int C, int c_ld, float thr, unsigned* maxc_u,
                                                       int* cnt_in, uint64_t* cand, long ws_stride) {
     const long total = (long)n * C;
@@ -55,6 +56,7 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const float* __restrict__
         const int img = blockIdx.y;
         boxes += (long)img * n * 4;
         scores += (long)img * n * c_ld;
+        if (factors) factors += (long)img * n;
         maxc_u = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(maxc_u) + img * ws_stride);
         cnt_in = reinterpret_cast<int*>(reinterpret_cast<char*>(cnt_in) + img * ws_stride);
         cand = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(cand) + img * ws_stride);
@@ -65,7 +67,8 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const float* __restrict__
         const float s = scores[(long)i * c_ld + c];
         if (s > thr) {
             const int slot = atomicAdd(&cnt_in[c], 1);
-            cand[(long)c * n + slot] = llv::make_key(s, (unsigned)e);
+            // score_factors multiply AFTER the threshold test (bbox_nms.py:52-62)
+            cand[(long)c * n + slot] = llv::make_key(factors ? s * factors[i] : s, (unsigned)e);
             const float4 b = reinterpret_cast<const float4*>(boxes)[i];
             const unsigned u = llv::f32_ordered(fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
             m = u > m ? u : m;
@@ -263,10 +266,10 @@ extern "C" size_t llv_multiclass_nms_workspace_bytes(int n, int num_classes, int
     return llv_multiclass_nms_batched_workspace_bytes(1, n, num_classes, max_num);
 }
 
-extern "C" int llv_multiclass_nms_batched(const float* boxes, const float* scores, int batch, int n, int num_classes, int c_ld,
-                                          float score_thr, float iou_thr, int max_num, float* dets, int64_t* labels,
-                                          int32_t* count, int32_t* keep_flat, void* workspace, size_t workspace_bytes,
-                                          void* stream) {
+extern "C" int llv_multiclass_nms_batched_sf(const float* boxes, const float* scores, const float* score_factors, int batch, int n,
+                                             int num_classes, int c_ld, float score_thr, float iou_thr, int max_num, float* dets,
+                                             int64_t* labels, int32_t* count, int32_t* keep_flat, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
     if (!dets || !labels || !count || !keep_flat || !workspace || num_classes < 1 || num_classes > 1024 || max_num < 1 ||
         n < 0 || c_ld < num_classes || batch < 1)
         return LLV_E_BADARG;
@@ -290,7 +293,7 @@ extern "C" int llv_multiclass_nms_batched(const float* boxes, const float* score
     if (n > 0) {
         long g = ((long)n * num_classes + 255) / 256;
         g = g > 1024 ? 1024 : g;
-        hipLaunchKernelGGL(nms_scan_kernel, dim3((int)g, batch), dim3(256), 0, st, boxes, scores, n, num_classes, c_ld, score_thr,
+        hipLaunchKernelGGL(nms_scan_kernel, dim3((int)g, batch), dim3(256), 0, st, boxes, scores, score_factors, n, num_classes, c_ld, score_thr,
                            maxc_u, cnt_in, cand, stride);
         int np2 = 1;
         while (np2 < n) np2 <<= 1;
@@ -311,6 +314,14 @@ extern "C" int llv_multiclass_nms(const float* boxes, const float* scores, int n
                                   void* stream) {
     return llv_multiclass_nms_batched(boxes, scores, 1, n, num_classes, c_ld, score_thr, iou_thr, max_num, dets, labels, count,
                                       keep_flat, workspace, workspace_bytes, stream);
+}
+
+extern "C" int llv_multiclass_nms_batched(const float* boxes, const float* scores, int batch, int n, int num_classes, int c_ld,
+                                          float score_thr, float iou_thr, int max_num, float* dets, int64_t* labels,
+                                          int32_t* count, int32_t* keep_flat, void* workspace, size_t workspace_bytes,
+                                          void* stream) {
+    return llv_multiclass_nms_batched_sf(boxes, scores, nullptr, batch, n, num_classes, c_ld, score_thr, iou_thr, max_num, dets, labels,
+                                         count, keep_flat, workspace, workspace_bytes, stream);
 }
 
 extern "C" size_t llv_nms_workspace_bytes(int n) {

@@ -1,0 +1,344 @@
+"""YOLOv3 stand-in for BASELINE.json config #5 with the reference's constructors, parameter names and
+test-time behaviour:
+
+  Darknet               mmdetection/mmdet/models/backbones/darknet.py:14-199
+  DetectionBlock / YOLOV3Neck   mmdetection/mmdet/models/necks/yolo_neck.py:11-136
+  YOLOV3Head            mmdetection/mmdet/models/dense_heads/yolo_head.py:20-170 (layers, forward), :172-366 (get_bboxes)
+  YOLOV3                mmdetection/mmdet/models/detectors/yolo.py
+  YOLOAnchorGenerator   mmdetection/mmdet/core/anchor/anchor_generator.py:590-665
+  YOLOBBoxCoder         mmdetection/mmdet/core/bbox/coder/yolo_bbox_coder.py
+
+All convolutions run on the HIP conv engine (conv + folded BN + LeakyReLU(0.1) epilogue; ResBlock adds after the
+activation: LLV_CONV_ACT_FIRST; the neck's upsample + concat is llv_upsample2x_nhwc into a channel slice of the buffer the
+backbone stage already wrote its half of). Box decode = llv_yolo_decode, NMS = llv_multiclass_nms_batched_sf (objectness as
+score factor). The per-level top-k on objectness and the gather of the <= 3000 selected rows are torch ops on the device
+(selection plumbing on small tensors). Training (YOLOV3Head.loss) is not built.
+"""
+import ctypes as C
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import engine, ops
+from ._lib import LlvError, lib, check, CONV_LEAKY, CONV_RES_ADD, CONV_ACT_FIRST, CONV_OUT_F32
+from .cnn import ConvModule, constant_init, kaiming_init, normal_init
+from .core.bbox import bbox2result
+from .detectors import SingleStageDetector
+from .planned import PlannedModule
+from .registry import ANCHOR_GENERATORS, BACKBONES, BBOX_CODERS, DETECTORS, HEADS, NECKS, build_anchor_generator, build_bbox_coder
+
+_CFG = dict(norm_cfg=dict(type='BN', requires_grad=True), act_cfg=dict(type='LeakyReLU', negative_slope=0.1))
+ARCH = {53: ((1, 2, 8, 8, 4), ((32, 64), (64, 128), (128, 256), (256, 512), (512, 1024)))}
+SLOPE = 0.1
+
+
+@ANCHOR_GENERATORS.register_module()
+class YOLOAnchorGenerator:
+    def __init__(self, strides, base_sizes):
+        self.strides = [(s, s) if isinstance(s, int) else tuple(s) for s in strides]
+        self.centers = [(s[0] / 2., s[1] / 2.) for s in self.strides]
+        self.base_sizes = [[(bs, bs) if isinstance(bs, (int, float)) else tuple(bs) for bs in lvl] for lvl in base_sizes]
+        assert len(self.base_sizes) == len(self.strides)
+        self.base_anchors = self.gen_base_anchors()
+
+    @property
+    def num_levels(self):
+        return len(self.base_sizes)
+
+    @property
+    def num_base_anchors(self):
+        return [b.size(0) for b in self.base_anchors]
+
+    def gen_base_anchors(self):
+        out = []
+        for sizes, (xc, yc) in zip(self.base_sizes, self.centers):
+            out.append(torch.stack([torch.Tensor([xc - 0.5 * w, yc - 0.5 * h, xc + 0.5 * w, yc + 0.5 * h]) for w, h in sizes], 0))
+        return out
+
+
+@BBOX_CODERS.register_module()
+class YOLOBBoxCoder:
+    def __init__(self, eps=1e-6):
+        self.eps = eps
+
+
+class ResBlock(nn.Module):
+    def __init__(self, in_channels, **cfg):
+        super().__init__()
+        assert in_channels % 2 == 0
+        self.conv1 = ConvModule(in_channels, in_channels // 2, 1, **cfg)
+        self.conv2 = ConvModule(in_channels // 2, in_channels, 3, padding=1, **cfg)
+
+
+@BACKBONES.register_module()
+class Darknet(PlannedModule):
+    arch_settings = ARCH
+
+    def __init__(self, depth=53, out_indices=(3, 4, 5), frozen_stages=-1, conv_cfg=None, norm_cfg=dict(type='BN', requires_grad=True),
+                 act_cfg=dict(type='LeakyReLU', negative_slope=0.1), norm_eval=True):
+        super().__init__()
+        if depth not in self.arch_settings:
+            raise KeyError(f'invalid depth {depth} for darknet')
+        if act_cfg.get('type') != 'LeakyReLU' or abs(act_cfg.get('negative_slope', 0.01) - SLOPE) > 1e-12:
+            raise NotImplementedError('Darknet on this path uses LeakyReLU(0.1)')
+        self.depth, self.out_indices, self.frozen_stages, self.norm_eval = depth, out_indices, frozen_stages, norm_eval
+        self.layers, self.channels = self.arch_settings[depth]
+        cfg = dict(conv_cfg=conv_cfg, norm_cfg=norm_cfg, act_cfg=act_cfg)
+        self.conv1 = ConvModule(3, 32, 3, padding=1, **cfg)
+        self.cr_blocks = ['conv1']
+        for i, n in enumerate(self.layers):
+            in_c, out_c = self.channels[i]
+            m = nn.Sequential()
+            m.add_module('conv', ConvModule(in_c, out_c, 3, stride=2, padding=1, **cfg))
+            for r in range(n):
+                m.add_module(f'res{r}', ResBlock(out_c, **cfg))
+            self.add_module(f'conv_res_block{i + 1}', m)
+            self.cr_blocks.append(f'conv_res_block{i + 1}')
+
+    def init_weights(self, pretrained=None):
+        if isinstance(pretrained, str):
+            from .checkpoint import load_checkpoint
+            load_checkpoint(self, pretrained, strict=False)
+        elif pretrained is None:
+            for m in self.modules():
+                if isinstance(m, nn.Conv2d):
+                    kaiming_init(m)
+                elif isinstance(m, nn.BatchNorm2d):
+                    constant_init(m, 1)
+        else:
+            raise TypeError('pretrained must be a str or None')
+        self.invalidate_plans()
+
+
+class DetectionBlock(nn.Module):
+    def __init__(self, in_channels, out_channels, **cfg):
+        super().__init__()
+        d = out_channels * 2
+        self.conv1 = ConvModule(in_channels, out_channels, 1, **cfg)
+        self.conv2 = ConvModule(out_channels, d, 3, padding=1, **cfg)
+        self.conv3 = ConvModule(d, out_channels, 1, **cfg)
+        self.conv4 = ConvModule(out_channels, d, 3, padding=1, **cfg)
+        self.conv5 = ConvModule(d, out_channels, 1, **cfg)
+
+
+@NECKS.register_module()
+class YOLOV3Neck(PlannedModule):
+    def __init__(self, num_scales, in_channels, out_channels, conv_cfg=None, norm_cfg=dict(type='BN', requires_grad=True),
+                 act_cfg=dict(type='LeakyReLU', negative_slope=0.1)):
+        super().__init__()
+        assert num_scales == len(in_channels) == len(out_channels)
+        self.num_scales, self.in_channels, self.out_channels = num_scales, in_channels, out_channels
+        cfg = dict(conv_cfg=conv_cfg, norm_cfg=norm_cfg, act_cfg=act_cfg)
+        self.detect1 = DetectionBlock(in_channels[0], out_channels[0], **cfg)
+        for i in range(1, num_scales):
+            in_c, out_c = in_channels[i], out_channels[i]
+            self.add_module(f'conv{i}', ConvModule(in_c, out_c, 1, **cfg))
+            self.add_module(f'detect{i + 1}', DetectionBlock(in_c + out_c, out_c, **cfg))
+
+    def init_weights(self):
+        pass
+
+
+@HEADS.register_module()
+class YOLOV3Head(PlannedModule):
+    def __init__(self, num_classes, in_channels, out_channels=(1024, 512, 256),
+                 anchor_generator=dict(type='YOLOAnchorGenerator',
+                                       base_sizes=[[(116, 90), (156, 198), (373, 326)], [(30, 61), (62, 45), (59, 119)],
+                                                   [(10, 13), (16, 30), (33, 23)]], strides=[32, 16, 8]),
+                 bbox_coder=dict(type='YOLOBBoxCoder'), featmap_strides=[32, 16, 8], one_hot_smoother=0., conv_cfg=None,
+                 norm_cfg=dict(type='BN', requires_grad=True), act_cfg=dict(type='LeakyReLU', negative_slope=0.1),
+                 loss_cls=None, loss_conf=None, loss_xy=None, loss_wh=None, train_cfg=None, test_cfg=None):
+        super().__init__()
+        assert len(in_channels) == len(out_channels) == len(featmap_strides)
+        self.num_classes, self.in_channels, self.out_channels = num_classes, in_channels, out_channels
+        self.featmap_strides, self.train_cfg, self.test_cfg = featmap_strides, train_cfg, test_cfg
+        self.one_hot_smoother = one_hot_smoother
+        self.bbox_coder = build_bbox_coder(bbox_coder)
+        self.anchor_generator = build_anchor_generator(anchor_generator)
+        self.num_anchors = self.anchor_generator.num_base_anchors[0]
+        assert len(self.anchor_generator.num_base_anchors) == len(featmap_strides)
+        cfg = dict(conv_cfg=conv_cfg, norm_cfg=norm_cfg, act_cfg=act_cfg)
+        self.convs_bridge, self.convs_pred = nn.ModuleList(), nn.ModuleList()
+        for i in range(self.num_levels):
+            self.convs_bridge.append(ConvModule(in_channels[i], out_channels[i], 3, padding=1, **cfg))
+            self.convs_pred.append(nn.Conv2d(out_channels[i], self.num_anchors * self.num_attrib, 1))
+
+    num_levels = property(lambda self: len(self.featmap_strides))
+    num_attrib = property(lambda self: 5 + self.num_classes)
+
+    def init_weights(self):
+        for m in self.convs_pred:
+            normal_init(m, std=0.01)
+
+    def loss(self, *a, **k):
+        raise LlvError('YOLOV3Head.loss (training) is not built on this path; the config-#5 stand-in is inference only')
+
+
+# ------------------------------------------------------------------------------------------------
+# the HIP plan
+# ------------------------------------------------------------------------------------------------
+def _cm(b, sd, name, p, x, stride=1, pad=0, res=None, out=None, y_ld=None):
+    """ConvModule = conv (no bias) + BN (folded) + LeakyReLU(0.1); with res: x + act(.) (ResBlock)."""
+    pc = ops.pack_conv(sd[p + '.conv.weight'], None, stride, pad, bn=engine._bn(sd, p + '.bn'), eps=engine.BN_EPS)
+    flags = CONV_LEAKY | ((CONV_RES_ADD | CONV_ACT_FIRST) if res is not None else 0)
+    if out is None:
+        xs = [x]
+        n, h, w, cx = x.shape
+        ho, wo = ops.conv_out_size(h, w, pc)
+        out = b.buf(n, ho, wo, pc.cout)
+        b.conv_desc(name, pc, xs, out, n, [(h, w, ho, wo, 0, 0)], x.stride(2), pc.cout, res, res.stride(2) if res is not None else 0,
+                    flags, act_slope=SLOPE)
+        return out
+    n, h, w, _ = x.shape
+    ho, wo = ops.conv_out_size(h, w, pc)
+    b.conv_desc(name, pc, [x], out, n, [(h, w, ho, wo, 0, 0)], x.stride(2), y_ld, res, res.stride(2) if res is not None else 0, flags,
+                act_slope=SLOPE)
+    return out
+
+
+class YoloPlan:
+    """Whole YOLOv3 inference plan for a fixed (batch, H, W): Darknet-53 -> neck -> head convs -> decode; results() runs
+    the selection + NMS."""
+
+    def __init__(self, det, batch, height, width, device):
+        bb, neck, head = det.backbone, det.neck, det.bbox_head
+        if height % 32 or width % 32:
+            raise LlvError('YOLOv3 input must be a multiple of 32 (Pad(size_divisor=32))')
+        b = engine.Builder(device)
+        self.builder, self.plan, self.batch, self.head, self.device = b, b.plan, batch, head, device
+        sd = engine._cpu_sd(det.state_dict())
+        self.x_in = b.buf(batch, height, width, 8)
+        layers, channels = ARCH[bb.depth]
+        ns = neck.num_scales
+        # the stages the neck concatenates with an upsampled map write straight into the concat buffer's upper channels
+        out_idx = list(bb.out_indices)
+        assert len(out_idx) == ns
+        feats = {}
+        x = _cm(b, sd, 'backbone.conv1', 'backbone.conv1', self.x_in, 1, 1)
+        for i, nres in enumerate(layers):
+            q = f'backbone.conv_res_block{i + 1}'
+            x = _cm(b, sd, q + '.conv', q + '.conv', x, 2, 1)
+            for r in range(nres):
+                y = _cm(b, sd, f'{q}.res{r}.conv1', f'{q}.res{r}.conv1', x, 1, 0)
+                last = r == nres - 1 and (i + 1) in out_idx and out_idx.index(i + 1) < ns - 1
+                if last:
+                    # concat buffer of the neck level that consumes this stage: [upsampled out_c | this stage's in_c]
+                    lvl = ns - 1 - out_idx.index(i + 1)          # feats are reversed inside the neck
+                    oc = neck.out_channels[lvl]
+                    n_, h_, w_, c_ = x.shape
+                    cat = b.buf(n_, h_, w_, oc + c_)
+                    dst = cat[..., oc:]
+                    x = _cm(b, sd, f'{q}.res{r}.conv2', f'{q}.res{r}.conv2', y, 1, 1, res=x, out=dst, y_ld=oc + c_)
+                    feats[i + 1] = (x, cat)
+                else:
+                    x = _cm(b, sd, f'{q}.res{r}.conv2', f'{q}.res{r}.conv2', y, 1, 1, res=x)
+            if (i + 1) in out_idx and (i + 1) not in feats:
+                feats[i + 1] = (x, None)
+        # neck (yolo_neck.py:110-131)
+        def detect(xin, p, tag):
+            t = _cm(b, sd, tag + '.conv1', p + 'conv1', xin, 1, 0)
+            t = _cm(b, sd, tag + '.conv2', p + 'conv2', t, 1, 1)
+            t = _cm(b, sd, tag + '.conv3', p + 'conv3', t, 1, 0)
+            t = _cm(b, sd, tag + '.conv4', p + 'conv4', t, 1, 1)
+            return _cm(b, sd, tag + '.conv5', p + 'conv5', t, 1, 0)
+        ordered = [feats[k] for k in out_idx]
+        out = detect(ordered[-1][0], 'neck.detect1.', 'neck.detect1')
+        outs = [out]
+        for i, (xf, cat) in enumerate(reversed(ordered[:-1])):
+            tmp = _cm(b, sd, f'neck.conv{i + 1}', f'neck.conv{i + 1}', out, 1, 0)
+            n_, h_, w_, c_ = tmp.shape
+            b.plan.add(f'neck.upsample{i + 1}', lib().llv_upsample2x_nhwc,
+                       (C.c_void_p(tmp.data_ptr()), C.c_void_p(cat.data_ptr()), n_, h_, w_, c_, c_, cat.shape[-1]), 0.0,
+                       2.0 * tmp.numel() * 5)
+            b.plan.keep += [tmp, cat]
+            out = detect(cat, f'neck.detect{i + 2}.', f'neck.detect{i + 2}')
+            outs.append(out)
+        # head (yolo_head.py:150-170): bridge 3x3 + 1x1 prediction (fp32 logits)
+        self.pred, self.level_hw = [], []
+        self.A, self.na = head.num_anchors, head.num_attrib
+        for i, f in enumerate(outs):
+            t = _cm(b, sd, f'head.bridge{i}', f'bbox_head.convs_bridge.{i}', f, 1, 1)
+            pc = ops.pack_conv(sd[f'bbox_head.convs_pred.{i}.weight'], sd[f'bbox_head.convs_pred.{i}.bias'], 1, 0)
+            self.pred.append(b.conv(f'head.pred{i}', t, pc, CONV_OUT_F32))
+            self.level_hw.append((t.shape[1], t.shape[2]))
+        # decode every anchor of every level (llv_yolo_decode)
+        self.boxes, self.conf, self._wh = [], [], []
+        for i, pm in enumerate(self.pred):
+            h, w = self.level_hw[i]
+            nanch = h * w * self.A
+            bx = torch.zeros(batch, nanch, 4, device=device)
+            cf = torch.zeros(batch, nanch, device=device)
+            wh = np.asarray(head.anchor_generator.base_sizes[i], dtype=np.float32).reshape(-1)
+            whc = (C.c_float * len(wh))(*wh.tolist())
+            self._wh.append(whc)
+            st = head.featmap_strides[i]
+            b.plan.add(f'decode{i}', lib().llv_yolo_decode, (C.c_void_p(pm.data_ptr()), batch, h, w, self.A, self.na, pm.shape[-1], st,
+                                                            whc, C.c_void_p(bx.data_ptr()), C.c_void_p(cf.data_ptr())), 0.0,
+                       4.0 * pm.numel())
+            self.boxes.append(bx); self.conf.append(cf)
+        self._nms = None
+
+    def results(self, img_metas=None, rescale=False):
+        """yolo_head.py:281-352 after the per-anchor decode: per-level top-k on objectness, gather, conf_thr, NMS."""
+        head, cfg = self.head, self.head.test_cfg
+        nc, bs = head.num_classes, self.batch
+        nms_pre = cfg.get('nms_pre', -1)
+        bl, sl, cl = [], [], []
+        for i, pm in enumerate(self.pred):
+            conf, box = self.conf[i], self.boxes[i]
+            pmf = pm.view(bs, -1, pm.shape[-1])[..., :self.A * self.na].reshape(bs, -1, self.na)
+            if nms_pre > 0 and conf.shape[1] > nms_pre:
+                _, ti = conf.topk(nms_pre)
+                bi = torch.arange(bs, device=conf.device).view(-1, 1).expand_as(ti)
+                box, conf, pmf = box[bi, ti, :], conf[bi, ti], pmf[bi, ti, :]
+            bl.append(box); cl.append(conf); sl.append(torch.sigmoid(pmf[..., 5:]))
+        boxes, scores, confs = torch.cat(bl, 1).contiguous(), torch.cat(sl, 1), torch.cat(cl, 1).contiguous()
+        if rescale and img_metas is not None:
+            sf = torch.tensor(np.stack([np.asarray(m['scale_factor'], dtype=np.float32).reshape(-1)[:4] * np.ones(4, np.float32)
+                                        for m in img_metas]), device=boxes.device)
+            boxes = (boxes / sf.unsqueeze(1)).contiguous()
+        thr = cfg.get('conf_thr', -1)
+        if thr > 0:       # dropping a row == making all its class scores fail the score threshold
+            scores = scores * confs.ge(thr).unsqueeze(-1)
+        scores = scores.contiguous()
+        n = boxes.shape[1]
+        nms_cfg = cfg['nms']
+        iou_thr = nms_cfg.get('iou_threshold', nms_cfg.get('iou_thr'))
+        max_num = cfg['max_per_img']
+        if self._nms is None or self._nms[0] != n:
+            wsb = int(lib().llv_multiclass_nms_batched_workspace_bytes(bs, n, nc, max_num))
+            self._nms = (n, torch.empty(wsb, dtype=torch.uint8, device=self.device),
+                         torch.zeros(bs, max_num, 5, device=self.device), torch.zeros(bs, max_num, dtype=torch.int64, device=self.device),
+                         torch.zeros(bs, dtype=torch.int32, device=self.device), torch.zeros(bs, max_num, dtype=torch.int32, device=self.device))
+        _, ws, dets, labels, count, keep = self._nms
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        check(lib().llv_multiclass_nms_batched_sf(boxes.data_ptr(), scores.data_ptr(), confs.data_ptr(), bs, n, nc, nc, cfg['score_thr'],
+                                                  iou_thr, max_num, dets.data_ptr(), labels.data_ptr(), count.data_ptr(),
+                                                  keep.data_ptr(), ws.data_ptr(), ws.numel(), stream), 'llv_multiclass_nms_batched_sf')
+        cnt = count.cpu().tolist()
+        return [(dets[i, :cnt[i]].clone(), labels[i, :cnt[i]].clone()) for i in range(bs)]
+
+
+@DETECTORS.register_module()
+class YOLOV3(SingleStageDetector):
+    """mmdetection/mmdet/models/detectors/yolo.py"""
+
+    def __init__(self, backbone, neck, bbox_head, train_cfg=None, test_cfg=None, pretrained=None):
+        super().__init__(backbone, neck, bbox_head, train_cfg, test_cfg, pretrained)
+
+    def make_plan(self, batch, height, width, device, x_in=None):
+        return YoloPlan(self, batch, height, width, device)
+
+    def simple_test(self, img, img_metas, rescale=False):
+        self._check_input(img)
+        plan = self._get_plan(img)
+        ops.pack_input(img.float().contiguous(), 8, out=plan.x_in)
+        plan.plan.run()
+        return [bbox2result(d, l, self.bbox_head.num_classes) for d, l in plan.results(img_metas, rescale)]
+
+    def extract_feat(self, img):
+        raise LlvError('YOLOV3.extract_feat: use simple_test (the plan keeps the features on the device)')
+
+    def forward_train(self, *a, **k):
+        raise LlvError('YOLOV3 training is not built on this path (config #5 is an inference stand-in)')

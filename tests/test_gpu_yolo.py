@@ -1,0 +1,94 @@
+"""YOLOv3 stand-in for config #5: HIP plan vs the fp32 CPU restatement (oracle/yolo.py).
+Parity unpinned (no reference known-answer test for this head); tolerances: feature maps 3e-2 of their scale after 75
+fp16 conv layers; post-processing on identical prediction maps: same labels, boxes rtol 1e-4, scores 1e-5."""
+import numpy as np
+import pytest
+import torch
+
+from helpers import randomize, smooth_image
+
+pytestmark = pytest.mark.gpu
+
+BASE_SIZES = [[(116, 90), (156, 198), (373, 326)], [(30, 61), (62, 45), (59, 119)], [(10, 13), (16, 30), (33, 23)]]
+TEST_CFG = dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05, conf_thr=0.005, nms=dict(type='nms', iou_threshold=0.45), max_per_img=100)
+
+
+def _cfg(nc):
+    return dict(type='YOLOV3', pretrained=None, backbone=dict(type='Darknet', depth=53, out_indices=(3, 4, 5)),
+                neck=dict(type='YOLOV3Neck', num_scales=3, in_channels=[1024, 512, 256], out_channels=[512, 256, 128]),
+                bbox_head=dict(type='YOLOV3Head', num_classes=nc, in_channels=[512, 256, 128], out_channels=[1024, 512, 256],
+                               anchor_generator=dict(type='YOLOAnchorGenerator', base_sizes=BASE_SIZES, strides=[32, 16, 8]),
+                               bbox_coder=dict(type='YOLOBBoxCoder'), featmap_strides=[32, 16, 8]),
+                test_cfg=dict(TEST_CFG))
+
+
+def _build(nc=4, seed=0):
+    import lowlightenvironmentvideoobjectdetection_amd.models as M
+    det = M.build_detector(_cfg(nc))
+    randomize(det, seed=seed)
+    with torch.no_grad():
+        for m in det.bbox_head.convs_pred:      # keep exp(tw), exp(th) and the objectness in a sane range
+            m.weight.mul_(0.2)
+            m.bias.zero_()
+    return det
+
+
+def test_yolo_feature_and_prediction_maps(dev):
+    from oracle import yolo as OY
+    det = _build()
+    img = smooth_image(2, 96, 128, seed=1)
+    sd = {k: v.detach().float() for k, v in det.state_dict().items()}
+    with torch.no_grad():
+        ref = OY.yolo_head_forward(sd, OY.yolo_neck_forward(sd, OY.darknet_forward(sd, img)))
+    det = det.to(dev).eval()
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    plan = det._get_plan(img.to(dev))
+    ops.pack_input(img.to(dev).float().contiguous(), 8, out=plan.x_in)
+    plan.plan.run()
+    torch.cuda.synchronize()
+    for pm, r in zip(plan.pred, ref):
+        got = pm.float().cpu()[..., :r.shape[1]].permute(0, 3, 1, 2)
+        err = (got - r).abs().max().item() / (r.abs().max().item() + 1e-9)
+        assert err < 3e-2, err
+
+
+def test_yolo_postprocess_matches_oracle_on_same_maps(dev):
+    """Decode + per-level top-k + conf_thr + NMS with objectness score factors on IDENTICAL prediction maps."""
+    from oracle import yolo as OY
+    det = _build(nc=6, seed=2).to(dev).eval()
+    bs, H, W = 2, 160, 224
+    img = torch.zeros(bs, 3, H, W, device=dev)
+    plan = det._get_plan(img)
+    g = torch.Generator().manual_seed(7)
+    maps = []
+    for i, pm in enumerate(plan.pred):
+        h, w = plan.level_hw[i]
+        m = torch.randn(bs, 3 * 11, h, w, generator=g)
+        m[:, 4::11] -= 1.0                     # objectness: a mix below / above conf_thr
+        m[:, 2::11] *= 0.3; m[:, 3::11] *= 0.3
+        maps.append(m)
+        pm.zero_()
+        pm[..., :33] = m.permute(0, 2, 3, 1).to(dev)
+    for name, fn, args, _, _ in plan.plan.steps:            # re-run only the decode launches on the injected maps
+        if name.startswith('decode'):
+            import ctypes as C
+            assert fn(*args, C.c_void_p(torch.cuda.current_stream().cuda_stream)) == 0
+    res = plan.results()
+    ref = OY.yolo_get_bboxes(maps, BASE_SIZES, [32, 16, 8], 6, TEST_CFG)
+    for (d, l), (rd, rl) in zip(res, ref):
+        d, l = d.cpu(), l.cpu()
+        assert len(d) == len(rd) and len(d) > 10
+        assert torch.equal(l, rl)
+        assert torch.allclose(d[:, :4], rd[:, :4], rtol=1e-4, atol=1e-3)
+        assert torch.allclose(d[:, 4], rd[:, 4], rtol=1e-5, atol=1e-6)
+
+
+def test_yolo_simple_test_end_to_end(dev):
+    det = _build(nc=4, seed=3).to(dev).eval()
+    img = smooth_image(1, 128, 160, seed=4).to(dev)
+    metas = [dict(img_shape=(128, 160, 3), pad_shape=(128, 160, 3), ori_shape=(128, 160, 3), scale_factor=np.ones(4, np.float32))]
+    out = det.simple_test(img, metas)
+    assert len(out) == 1 and len(out[0]) == 4 and all(a.shape[1] == 5 for a in out[0])
+    from lowlightenvironmentvideoobjectdetection_amd._lib import LlvError
+    with pytest.raises(LlvError):
+        det.forward_train(img, metas, [], [])
