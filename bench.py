@@ -169,6 +169,64 @@ def train_bench(args, world, rank, dev):
         dist.destroy_process_group()
 
 
+def yolo_bench(args, world, rank, dev):
+    """Config #5 of BASELINE.json: YOLO-style detector (the reference's YOLOv3-D53 stand-in) on 1920x1080
+    frames (padded 1920x1088), fp16, --frames-per-step frames per step: convs + decode as one HIP graph, then the per-level
+    top-k / NMS. Seeded random weights (no checkpoints offline), synthetic frames."""
+    import numpy as np
+    import torch.distributed as dist
+    import lowlightenvironmentvideoobjectdetection_amd.models  # noqa: F401
+    from lowlightenvironmentvideoobjectdetection_amd import data, ops, registry
+    from lowlightenvironmentvideoobjectdetection_amd.synthetic import seeded_weights
+    cfg = dict(type='YOLOV3', pretrained=None, backbone=dict(type='Darknet', depth=53, out_indices=(3, 4, 5)),
+               neck=dict(type='YOLOV3Neck', num_scales=3, in_channels=[1024, 512, 256], out_channels=[512, 256, 128]),
+               bbox_head=dict(type='YOLOV3Head', num_classes=NUM_CLASSES, in_channels=[512, 256, 128], out_channels=[1024, 512, 256]),
+               test_cfg=dict(nms_pre=1000, min_bbox_size=0, score_thr=0.05, conf_thr=0.005, nms=dict(type='nms', iou_threshold=0.45),
+                             max_per_img=100))
+    det = seeded_weights(registry.build_detector(cfg), seed=0)
+    with torch.no_grad():
+        for m in det.bbox_head.convs_pred:
+            m.weight.mul_(0.2)
+    det = det.to(dev).eval()
+    B, H, W = args.frames_per_step, 1080, 1920
+    clean = data.synth_clean_clip(B, H, W, seed=100 + rank)
+    clip, img_shape, pad_shape = data.preprocess_clip(clean.float(), dev) if False else data.preprocess_clip(data.darken_and_add_noise(clean, seed=200 + rank), dev)
+    img = clip[2:2 + B, :, :, :3].permute(0, 3, 1, 2).float().contiguous()
+    plan = det._get_plan(img)
+    ops.pack_input(img, 8, out=plan.x_in)
+    plan.plan.capture()
+    def step():
+        plan.plan.replay()
+        return plan.results()
+    for _ in range(args.warmup):
+        res = step()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        res = step()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'frames/sec (YOLOv3-D53 stand-in) on 1920x1080 video', 'value': round(args.steps * B * world / dt, 3), 'unit': 'frames/s',
+            'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+            'config': {'workload': f'config #5: YOLOv3 Darknet-53 + neck + head + decode + NMS, {W}x{H} frames (padded {img.shape[3]}x{img.shape[2]}), '
+                                   f'{NUM_CLASSES} classes', 'frames_per_step': B, 'hip_graph': True,
+                       'algorithmic_gflop_per_frame': round(plan.plan.flops / B / 1e9, 1), 'detections_last_step': int(sum(len(d) for d, _ in res))},
+            'achieved_tflops': round(plan.plan.flops * args.steps / dt / 1e12, 2)}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -182,7 +240,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-latency-mode', action='store_true')
-    ap.add_argument('--mode', choices=['infer', 'train'], default='infer',
+    ap.add_argument('--mode', choices=['infer', 'train', 'yolo'], default='infer',
                     help="'train' = BASELINE.json config #3: RetinaNet fwd + loss + bwd + gradient all-reduce + SGD, one image per GPU")
     ap.add_argument('--train-batch', type=int, default=1, help='images per GPU per training step')
     args = ap.parse_args()
@@ -204,6 +262,8 @@ def main():
 
     if args.mode == 'train':
         return train_bench(args, world, rank, dev)
+    if args.mode == 'yolo':
+        return yolo_bench(args, world, rank, dev)
 
     B, T = args.frames_per_step, args.clip_frames
     det, cleaner = build_models(seed=0)
