@@ -415,9 +415,11 @@ class DFF(BaseVideoDetector):
 @MODELS.register_module()
 class FGFA(BaseVideoDetector):
     """Flow-Guided Feature Aggregation (mmtracking/mmtrack/models/vid/fgfa.py:12-384) for a dense-head detector,
-    test-time adaptive-stride branch (`frame_stride < 1`, fgfa.py:222-231,266-283): the reference frames given with
-    frame 0 stay in the memo; every frame: backbone + FPN, FlowNetSimple on (frame, each memo frame), warp the memo
-    pyramids, EmbedAggregator(x, cat(x, warped)) per level, head."""
+    both test-time branches of extract_feats (fgfa.py:196-284). Adaptive stride (`frame_stride < 1`): the reference
+    frames given with frame 0 stay in the memo; every frame: backbone + FPN, FlowNetSimple on (frame, each memo frame),
+    warp the memo pyramids, EmbedAggregator(x, cat(x, warped)) per level, head. Fixed stride: the memo is a sliding
+    window that gains the new reference frame every `frame_stride` frames; the key frame's features come out of the
+    window (slot num_left_ref_imgs) and replace that slot of the warped stack."""
 
     def __init__(self, detector, motion, aggregator, pretrains=None, frozen_modules=None, train_cfg=None, test_cfg=None):
         super().__init__()
@@ -454,11 +456,13 @@ class FGFA(BaseVideoDetector):
     def forward_train(self, img, img_metas, **kwargs):
         raise LlvError('FGFA.forward_train: the training path is not built yet in this round')
 
-    def _agg_plan(self, st, n_ref, device):
-        """Embedding convs over the (1 + n_ref) frames of every level in one multi-segment launch + the tail per level."""
+    def _agg_plan(self, st, n_slots, key_slot, device):
+        """Embedding convs over the n_slots frames of every level in one multi-segment launch + the tail per level.
+        key_slot = which slot holds the key frame's own features (0 in the adaptive-stride branch, where the stack is
+        cat(x, warped refs); num_left_ref_imgs in the fixed-stride branch, where x replaces that warped slot)."""
         from .aggregators import embed_packed_convs
         ag = self.aggregator
-        nb = n_ref + 1
+        nb = n_slots
         hw = st.cur.level_hw
         b = engine.Builder(device)
         offs, tot = [], 0
@@ -466,7 +470,7 @@ class FGFA(BaseVideoDetector):
             offs.append(tot)
             tot += nb * hh * ww
         c = st.cur.buf.shape[-1]
-        stack = engine.Pyramid(b.buf(tot, c), hw, offs, nb)       # per level: slot 0 = x, 1.. = warped references
+        stack = engine.Pyramid(b.buf(tot, c), hw, offs, nb)
         emb = stack.buf
         for i, (pc, flags) in enumerate(embed_packed_convs(engine._cpu_sd(ag.state_dict()), ag.num_convs)):
             nxt = b.buf(tot, pc.cout)
@@ -475,7 +479,8 @@ class FGFA(BaseVideoDetector):
         for l, (hh, ww) in enumerate(hw):
             e_l, s_l = stack.level(l, emb), stack.level(l)
             b.plan.add(f'aggregate{l}', ops.lib().llv_embed_aggregate,
-                       (ops._ptr(e_l[0:1]), ops._ptr(e_l), ops._ptr(s_l), ops._ptr(st.cur.level(l)), nb, hh * ww, c, emb.shape[-1], c, c))
+                       (ops._ptr(e_l[key_slot:key_slot + 1]), ops._ptr(e_l), ops._ptr(s_l), ops._ptr(st.cur.level(l)), nb, hh * ww, c,
+                        emb.shape[-1], c, c))
         b.plan.keep += [emb]
         return b.plan, stack
 
@@ -485,25 +490,61 @@ class FGFA(BaseVideoDetector):
         n, c, h, w = img.shape
         frame_id = img_metas[0].get('frame_id', -1)
         assert frame_id >= 0
-        if img_metas[0].get('frame_stride', -1) >= 1:
-            raise LlvError('FGFA fixed-stride test mode (frame_stride >= 1) is not built; use the adaptive-stride sampler')
+        frame_stride = img_metas[0].get('frame_stride', -1)
+        num_left = img_metas[0].get('num_left_ref_imgs', -1)
+        dev = str(img.device)
+
+        def refs_of(ref_img):
+            refs = ref_img[0] if isinstance(ref_img, (list, tuple)) else ref_img
+            return (refs[0] if refs.dim() == 5 else refs).float().contiguous()
+
+        def stages(nr, batches):
+            return self._plan(('stages', h, w, nr, tuple(batches), dev), lambda: _StagePlans(self.detector, h, w, img.device, batches))
+
+        fixed = frame_stride >= 1
+        x_levels = None                   # fixed-stride branches that take x out of the memo
         if frame_id == 0 or self.memo is None:
             if ref_img is None:
-                raise LlvError('frame 0 of a video needs ref_img (fgfa.py:224-230)')
-            refs = ref_img[0] if isinstance(ref_img, (list, tuple)) else ref_img
-            refs = (refs[0] if refs.dim() == 5 else refs).float().contiguous()
+                raise LlvError('frame 0 of a video needs ref_img (fgfa.py:224-230,234-246)')
+            refs = refs_of(ref_img)
             nr = refs.shape[0]
-            st = self._plan(('stages', h, w, nr, str(img.device)), lambda: _StagePlans(self.detector, h, w, img.device, [1, nr]))
+            st = stages(nr, [1, nr])
             pyr = st.extract(refs)
             self.memo = dict(img=refs, nr=nr, feats=[pyr.level(l).clone() for l in range(len(pyr.level_hw))])
+            if fixed:                     # the key frame is one of the references (fgfa.py:243-246)
+                assert 0 <= num_left < nr
+                x_levels = [f[num_left:num_left + 1] for f in self.memo['feats']]
+        elif fixed and frame_id % frame_stride == 0:
+            # slide the window: append the new reference(s), drop the oldest (fgfa.py:247-257)
+            assert ref_img is not None
+            new = refs_of(ref_img)
+            k = new.shape[0]
+            st = stages(self.memo['nr'], [1, self.memo['nr']])
+            stn = st if k == 1 else stages(self.memo['nr'], [k])
+            pyr = stn.extract(new)
+            for l in range(len(pyr.level_hw)):
+                self.memo['feats'][l] = torch.cat((self.memo['feats'][l], pyr.level(l)), 0)[k:].contiguous()
+            self.memo['img'] = torch.cat((self.memo['img'], new), 0)[k:].contiguous()
+            x_levels = [f[num_left:num_left + 1] for f in self.memo['feats']]
+        elif fixed:
+            assert ref_img is None        # fgfa.py:258-260
         nr = self.memo['nr']
-        st = self._plan(('stages', h, w, nr, str(img.device)), lambda: _StagePlans(self.detector, h, w, img.device, [1, nr]))
-        agg_plan, stack = self._plan(('agg', h, w, nr, str(img.device)), lambda: self._agg_plan(st, nr, img.device))
-        x = st.extract(img)
-        flow_imgs = torch.cat((img.float().repeat(nr, 1, 1, 1), self.memo['img']), dim=1)      # fgfa.py:270-272
+        st = stages(nr, [1, nr])
+        n_slots, key_slot = (nr, num_left) if fixed else (nr + 1, 0)
+        agg_plan, stack = self._plan(('agg', h, w, n_slots, key_slot, dev), lambda: self._agg_plan(st, n_slots, key_slot, img.device))
+        if x_levels is None:
+            x = st.extract(img)
+            x_levels = [x.level(l) for l in range(len(x.level_hw))]
+        nl = len(x_levels)
+        flow_imgs = torch.cat((img.float().repeat(nr, 1, 1, 1), self.memo['img']), dim=1)      # fgfa.py:264-267
         flows = self.motion(flow_imgs, img_metas).contiguous()
-        for l in range(len(x.level_hw)):
-            stack.level(l)[0:1].copy_(x.level(l))
-        _warp_pyramid(self.memo['feats'], flows, [stack.level(l)[1:] for l in range(len(x.level_hw))])
+        if fixed:                         # warped references, with the key frame's slot replaced by x (fgfa.py:275-276)
+            _warp_pyramid(self.memo['feats'], flows, [stack.level(l) for l in range(nl)])
+            for l in range(nl):
+                stack.level(l)[key_slot:key_slot + 1].copy_(x_levels[l])
+        else:                             # cat(x, warped references) (fgfa.py:273-274)
+            for l in range(nl):
+                stack.level(l)[0:1].copy_(x_levels[l])
+            _warp_pyramid(self.memo['feats'], flows, [stack.level(l)[1:] for l in range(nl)])
         agg_plan.run()
         return st.detect(img_metas, rescale)
