@@ -1152,22 +1152,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
         wv[i] = grow < a.w_rows ? (grow * a.k_pad + wch * 8) * 2 : (int)h.w_bytes;
     }
 
-    const int frow = lane & 15, fch = lane >> 4;
-    // MFMA fragment read addresses: weights row i*16 + frow -> wa + i*1024; halo pixel (2*wave + (j>>1) + tr,
-    // (j&1)*16 + frow + tq) -> hb[j][tq] + tr*ROWB
-    const int wa = lds_off(frow, fch);
-    int hb[TM][3];
-#pragma unroll
-    for (int j = 0; j < TM; ++j)
-#pragma unroll
-        for (int tq = 0; tq < 3; ++tq) hb[j][tq] = tap_halo_off(2 * wave + (j >> 1), (j & 1) * 16 + frow + tq, fch);
-
-    f32x4 acc[TN][TM];
-#pragma unroll
-    for (int i = 0; i < TN; ++i)
-#pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
     unsigned char* const sHalo = smem;
     unsigned char* const sWgt = smem + 2 * TAP_HBYTES;
 
@@ -1188,6 +1172,35 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
         }
         dma16(rX0, dst, hv[i], cv * 16);
     };
+    // the first chunk's halo and the first weight slice are on their way while the rest of the set-up runs
+#pragma unroll
+    for (int i = 0; i < HPW; ++i) issue_h(0, i, 0);
+    issue_w(0, 0, 0);
+
+    const int frow = lane & 15, fch = lane >> 4;
+    // MFMA fragment read addresses: weights row i*16 + frow -> wa + i*1024; halo pixel (2*wave + (j>>1) + tr,
+    // (j&1)*16 + frow + tq) -> hb[j][tq] + tr*ROWB
+    const int wa = lds_off(frow, fch);
+    int hb[TM][3];
+#pragma unroll
+    for (int j = 0; j < TM; ++j)
+#pragma unroll
+        for (int tq = 0; tq < 3; ++tq) hb[j][tq] = tap_halo_off(2 * wave + (j >> 1), (j & 1) * 16 + frow + tq, fch);
+
+    // on the LDS-staged paths the bias rides in the accumulator (one add per output saved in the epilogue)
+    float4 bias4[TN];
+#pragma unroll
+    for (int i = 0; i < TN; ++i) {
+        const int co = tile_n * BN + i * 16 + fch * 4;
+        bias4[i] = co < a.cout ? *reinterpret_cast<const float4*>(a.bias + g * a.cout + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    const bool bias_in_acc = a.stage_out != 0;
+    f32x4 acc[TN][TM];
+#pragma unroll
+    for (int i = 0; i < TN; ++i)
+#pragma unroll
+        for (int j = 0; j < TM; ++j)
+            acc[i][j] = bias_in_acc ? (f32x4){bias4[i].x, bias4[i].y, bias4[i].z, bias4[i].w} : (f32x4){0.f, 0.f, 0.f, 0.f};
 
     // one (chunk, tap) step with static tap T, halo buffer HB and weight buffer WB. A macro, not a lambda: with the
     // accumulators captured by reference the compiler leaves the 512-byte array of the BN = 128 variant in scratch.
@@ -1212,9 +1225,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
     TAP_STEP(3, HB, W1, c, more) TAP_STEP(4, HB, W0, c, more) TAP_STEP(5, HB, W1, c, more)                    \
     TAP_STEP(6, HB, W0, c, more) TAP_STEP(7, HB, W1, c, more) TAP_STEP(8, HB, W0, c, more)
 
-#pragma unroll
-    for (int i = 0; i < HPW; ++i) issue_h(0, i, 0);
-    issue_w(0, 0, 0);
     for (int c = 0; c < h.n_chunks; c += 2) {
         { const bool more = c + 1 < h.n_chunks; TAP_CHUNK(0, 0, 1, c, more) }
         if (c + 1 < h.n_chunks) { const bool more = c + 2 < h.n_chunks; TAP_CHUNK(1, 1, 0, c + 1, more) }
@@ -1235,12 +1245,40 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
         return true;
     };
     _Float16* tile = reinterpret_cast<_Float16*>(smem);
-    float4 bias4[TN];
+    if (a.stage_out && !(a.flags & ~LLV_CONV_RELU) && a.y_gstride == 0) {
+        // the common epilogue (bias [+ ReLU] -> fp16): bias is already in the accumulator, ReLU on the rounded halves,
+        // no pixel lookup before the staging (rows of pixels outside the image are simply never stored)
+        const bool relu = (a.flags & LLV_CONV_RELU) != 0;
+        const f16x4 z4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
 #pragma unroll
-    for (int i = 0; i < TN; ++i) {
-        const int co = tile_n * BN + i * 16 + fch * 4;
-        bias4[i] = co < a.cout ? *reinterpret_cast<const float4*>(a.bias + g * a.cout + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+        for (int j = 0; j < TM; ++j) {
+            const int prow = (2 * wave + (j >> 1)) * 32 + (j & 1) * 16 + frow;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                f16x4 o4 = {(_Float16)acc[i][j][0], (_Float16)acc[i][j][1], (_Float16)acc[i][j][2], (_Float16)acc[i][j][3]};
+                if (relu) o4 = __builtin_elementwise_max(o4, z4);
+                *reinterpret_cast<f16x4*>(tile + prow * TS + i * 16 + fch * 4) = o4;
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = BN / 8;
+        const int cc = tid % CPR, co = tile_n * BN + cc * 8;
+        if (co < a.cout) {
+            const bool full = co + 8 <= a.cout;
+            _Float16* ybase_p = reinterpret_cast<_Float16*>(a.y) + (long)g * a.cout + co;
+#pragma unroll 4
+            for (int prow = tid / CPR; prow < 256; prow += 256 / CPR) {
+                const int oy = ty0 + (prow >> 5), ox = tx0 + (prow & 31);
+                if (oy >= H || ox >= W) continue;
+                const uint4 val = *reinterpret_cast<const uint4*>(tile + prow * TS + cc * 8);
+                _Float16* dst = ybase_p + (long)(ybase + oy * W + ox) * a.y_ld;
+                if (full) *reinterpret_cast<uint4*>(dst) = val;
+                else *reinterpret_cast<uint2*>(dst) = make_uint2(val.x, val.y);
+            }
+        }
+        return;
     }
+    const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
     constexpr int TS2 = BN / 4 + 8;
     constexpr bool SHUF_OK = 256 * 4 * TS2 * 2 <= SMEM;       // the shuffled tile fits (BN = 64)
     if (SHUF_OK && a.stage_out && (a.flags & LLV_CONV_PIXSHUF)) {
@@ -1251,7 +1289,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
             const int prow = (2 * wave + (j >> 1)) * 32 + (j & 1) * 16 + frow;
 #pragma unroll
             for (int i = 0; i < TN; ++i) {
-                float v[4] = {acc[i][j][0] + bias4[i].x, acc[i][j][1] + bias4[i].y, acc[i][j][2] + bias4[i].z, acc[i][j][3] + bias4[i].w};
+                float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};      // bias already inside
                 row_transpose4(v);
                 const f16x4 o4 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                 *reinterpret_cast<f16x4*>(tile + (prow * 4 + fch) * TS2 + i * 4) = o4;
@@ -1272,7 +1310,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
             const int co = tile_n * BN + col;
             float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
             if (a.stage_out) {
-                if (ok && co < a.cout) epi_compute_b(a, ec, g * a.cout + co, v, bias4[i]);
+                if (ok && co < a.cout) epi_compute_b(a, ec, g * a.cout + co, v, zero4);
                 const f16x4 o4 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                 *reinterpret_cast<f16x4*>(tile + prow * TS + col) = o4;
             } else if (ok && co < a.cout) {
