@@ -773,11 +773,16 @@ __global__ __launch_bounds__(256, (BK == 64 ? 2 : (BN * BM >= 128 * 128 ? 3 : 4)
         while (kc8 >= cvec) { kc8 -= cvec; if (++kq == a.kw) { kq = 0; ++kr; } }
     };
 
+    // staged, unsplit launches carry the bias in the accumulator (the epilogue then adds nothing)
+    const bool bias_in_acc = a.stage_out && a.k_splits <= 1;
     f32x4 acc[TN][TM];
 #pragma unroll
-    for (int i = 0; i < TN; ++i)
+    for (int i = 0; i < TN; ++i) {
+        const int co = tile_n * BN + wn * WN + i * 16 + (lane >> 4) * 4;
+        const float4 b4 = (bias_in_acc && co < a.cout) ? *reinterpret_cast<const float4*>(a.bias + g * a.cout + co) : make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){b4.x, b4.y, b4.z, b4.w};
+    }
 
     // vmcnt counts this wave's loads in issue order, so "all but the youngest stage's pieces" = stage ks has landed
     constexpr int PIECES_FULL = WPW + PPW;
@@ -841,12 +846,38 @@ __global__ __launch_bounds__(256, (BK == 64 ? 2 : (BN * BM >= 128 * 128 ? 3 : 4)
     }
     if (a.stage_out) {
         _Float16* tile = reinterpret_cast<_Float16*>(smem);
-        float4 bias4[TN];                                    // this lane's 4 channels of each n-tile, loaded once
+        if (!(a.flags & ~LLV_CONV_RELU) && a.y_gstride == 0 && a.n_seg == 1) {
+            // the common epilogue (bias [+ ReLU] -> fp16, one segment): no pixel lookup, ReLU on the rounded halves
+            const bool relu = (a.flags & LLV_CONV_RELU) != 0;
+            const f16x4 z4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
 #pragma unroll
-        for (int i = 0; i < TN; ++i) {
-            const int co = tile_n * BN + wn * WN + i * 16 + fch * 4;
-            bias4[i] = co < a.cout ? *reinterpret_cast<const float4*>(a.bias + g * a.cout + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+            for (int j = 0; j < TM; ++j) {
+                const int prow = wm * WM + j * 16 + frow;
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    f16x4 o4 = {(_Float16)acc[i][j][0], (_Float16)acc[i][j][1], (_Float16)acc[i][j][2], (_Float16)acc[i][j][3]};
+                    if (relu) o4 = __builtin_elementwise_max(o4, z4);
+                    *reinterpret_cast<f16x4*>(tile + prow * TS + wn * WN + i * 16 + fch * 4) = o4;
+                }
+            }
+            __syncthreads();
+            constexpr int CPR = BN / 8;
+            const int cc = tid % CPR, co = tile_n * BN + cc * 8;
+            if (co < a.cout) {
+                const bool full = co + 8 <= a.cout;
+                _Float16* yb = reinterpret_cast<_Float16*>(a.y) + ((long)a.seg_yoff[0] + (long)tile_m * BM) * a.y_ld + (long)g * a.cout + co;
+                const int rows = a.m_total - tile_m * BM < BM ? a.m_total - tile_m * BM : BM;
+#pragma unroll 4
+                for (int prow = tid / CPR; prow < rows; prow += 256 / CPR) {
+                    const uint4 val = *reinterpret_cast<const uint4*>(tile + prow * TS + cc * 8);
+                    _Float16* dst = yb + (long)prow * a.y_ld;
+                    if (full) *reinterpret_cast<uint4*>(dst) = val;
+                    else *reinterpret_cast<uint2*>(dst) = make_uint2(val.x, val.y);
+                }
+            }
+            return;
         }
+        const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
             const int prow = wm * WM + j * 16 + frow;
@@ -859,7 +890,7 @@ __global__ __launch_bounds__(256, (BK == 64 ? 2 : (BN * BM >= 128 * 128 ? 3 : 4)
                 const int col = wn * WN + i * 16 + fch * 4;
                 const int co = tile_n * BN + col;
                 float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-                if (mok && co < a.cout) epi_compute_b(a, c, g * a.cout + co, v, bias4[i]);
+                if (mok && co < a.cout) epi_compute_b(a, c, g * a.cout + co, v, zero4);      // bias is in the accumulator
                 const f16x4 o4 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
                 *reinterpret_cast<f16x4*>(tile + prow * TS + col) = o4;
             }
