@@ -1587,19 +1587,23 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bid = blockIdx.x;
-    {
-        const int nblk = h.nblk;
-        const int qq = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
-    }
-    const int tx0 = (bid % h.tiles_x) * HALO_TW;
-    const int t1 = bid / h.tiles_x;
-    const int ty0 = (t1 % h.tiles_y) * HALO_TH;
-    const int n = t1 / h.tiles_y;
     const int H = h.H, W = h.W;
-    const int img_base = a.seg_xoff[0] + n * H * W;
     const int frow = lane & 15, fch = lane >> 4;
+    // persistent workgroup: tiles v = blockIdx.x, blockIdx.x + gridDim.x, ... (XCD-aware order); everything that does not
+    // depend on the tile position (weight gathers, fragment addresses) is computed once
+    struct Tile { int tx0, ty0, n, img_base; };
+    auto tile_of = [&](int v) {
+        const int nblk = h.nblk;
+        const int qq = nblk >> 3, r = nblk & 7, xcd = v & 7, idx = v >> 3;
+        const int bid = (xcd < r ? xcd * (qq + 1) : r * (qq + 1) + (xcd - r) * qq) + idx;
+        Tile t;
+        t.tx0 = (bid % h.tiles_x) * HALO_TW;
+        const int t1 = bid / h.tiles_x;
+        t.ty0 = (t1 % h.tiles_y) * HALO_TH;
+        t.n = t1 / h.tiles_y;
+        t.img_base = a.seg_xoff[0] + t.n * H * W;
+        return t;
+    };
 
     const __amdgpu_buffer_rsrc_t rX0 = make_rsrc(a.x0, q.x_bytes);
     const __amdgpu_buffer_rsrc_t rX1 = make_rsrc(a.x1, q.x_bytes);
@@ -1607,22 +1611,30 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
     const __amdgpu_buffer_rsrc_t rW0 = make_rsrc(pre.w, q.w0_bytes);
     const __amdgpu_buffer_rsrc_t rW1 = make_rsrc(h.w, q.w1_bytes);
 
-    // ---- DMA offsets (constant over groups)
+    // ---- patch DMA offsets of a tile (constant over its groups)
     int pvo[PPW];                                            // patch pieces wave, wave+4, ...
+    int ppy[PPW], ppx[PPW], pc8[PPW];                        // this lane's patch pixel / channel chunk per piece (tile independent)
 #pragma unroll
     for (int i = 0; i < PPW; ++i) {
         const int pc = wave + 4 * i;
         int pp, c8;
         if (CK0 == 8) { pp = pc * 64 + lane; c8 = 0; }
         else { pp = pc * 16 + (lane >> 2); c8 = lane & 3; }
-        pvo[i] = (int)q.x_bytes;
+        ppy[i] = -1000000; ppx[i] = 0; pc8[i] = 0;
         if (pp < PATCH_PX) {
             const int py = pp / PATCH_W, px = pp - py * PATCH_W;
             if (CK0 == 32) c8 ^= ((px >> 2) & 1) << 1;
-            const int gy = ty0 + py - 2, gx = tx0 + px - 2;
-            if ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) pvo[i] = ((img_base + gy * W + gx) * a.x_ld + c8 * 8) * 2;
+            ppy[i] = py - 2; ppx[i] = px - 2; pc8[i] = c8 * 16;
         }
     }
+    auto set_pvo = [&](const Tile& t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int i = 0; i < PPW; ++i) {
+            const int gy = t.ty0 + ppy[i], gx = t.tx0 + ppx[i];
+            pvo[i] = ((unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) ? (t.img_base + gy * W + gx) * a.x_ld * 2 + pc8[i]
+                                                                                : (int)q.x_bytes;
+        }
+    };
     auto issue_patch = [&](int g, int buf) __attribute__((always_inline)) {
 #pragma unroll
         for (int i = 0; i < PPW; ++i) {
@@ -1663,7 +1675,7 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
     // stage A: M-tile it of this wave = halo pixels 16*(wave + 4*it) + frow
     int pa[MTW][CK0 == 8 ? NKS0 : 3];                        // patch read offsets: per k-step (CK0 = 8) / per tap column (CK0 = 32)
     int hw[MTW];                                             // halo write offset of this lane's first 4 channels; -1: no pixel
-    unsigned inside = 0;
+    int hyx[MTW];                                            // (hy << 8 | hx) of this lane's halo pixel per M-tile, -1: none
 #pragma unroll
     for (int it = 0; it < MTW; ++it) {
         const int hp = (wave + 4 * it) * 16 + frow;
@@ -1682,9 +1694,17 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
             for (int tq = 0; tq < 3; ++tq) pa[it][tq] = patch_off32(hy, hx + tq, fch);
         }
         hw[it] = hp < HALO_PX ? tap_halo_off(hy, hx, fch >> 1) + (fch & 1) * 8 : -1;
-        const int gy = ty0 + hy - 1, gx = tx0 + hx - 1;
-        if (hp < HALO_PX && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) inside |= 1u << it;
+        hyx[it] = hp < HALO_PX ? (hy << 8) | hx : -1;
     }
+    auto inside_of = [&](const Tile& t) __attribute__((always_inline)) {
+        unsigned m = 0;
+#pragma unroll
+        for (int it = 0; it < MTW; ++it) {
+            const int gy = t.ty0 + (hyx[it] >> 8) - 1, gx = t.tx0 + (hyx[it] & 255) - 1;
+            if (hyx[it] >= 0 && (unsigned)gy < (unsigned)H && (unsigned)gx < (unsigned)W) m |= 1u << it;
+        }
+        return m;
+    };
     const int wa = lds_off(frow, fch);                       // weight fragment: row frow (+1024: next n-tile), k chunk fch
     int hb[TM][3];
 #pragma unroll
@@ -1692,16 +1712,28 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
 #pragma unroll
         for (int tq = 0; tq < 3; ++tq) hb[j][tq] = tap_halo_off(2 * wave + (j >> 1), (j & 1) * 16 + frow + tq, fch);
 
+    float4 bias4[TN2];
+#pragma unroll
+    for (int i = 0; i < TN2; ++i) {
+        const int co = i * 16 + fch * 4;
+        bias4[i] = co < a.cout ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
+    }
+    int v = blockIdx.x;
+    Tile cur = tile_of(v);
+    set_pvo(cur);
+    issue_w1(0);
+    issue_patch(0, 0);
+    issue_w0(0, 0);
+#pragma unroll 1
+    for (;;) {
+    const int tx0 = cur.tx0, ty0 = cur.ty0, n = cur.n;
+    const unsigned inside = inside_of(cur);
+    const bool border = ty0 == 0 || tx0 == 0 || ty0 + HALO_TH >= H || tx0 + HALO_TW >= W;   // halo leaves the image
     f32x4 acc[TN2][TM];
 #pragma unroll
     for (int i = 0; i < TN2; ++i)
 #pragma unroll
         for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-
-    issue_w1(0);
-    issue_patch(0, 0);
-    issue_w0(0, 0);
-    const bool border = ty0 == 0 || tx0 == 0 || ty0 + HALO_TH >= H || tx0 + HALO_TW >= W;   // halo leaves the image
 #pragma unroll 1
     for (int g = 0; g < G; ++g) {
         const int pb = g & (NPB - 1);
@@ -1768,7 +1800,19 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
                     acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
         }
     }
-    __syncthreads();
+    __syncthreads();         // every wave is done with the patch / weight buffers and the halo
+
+    // the next tile's first loads go out now and land under this tile's epilogue
+    const int vn = v + gridDim.x;
+    const bool has_next = vn < h.nblk;
+    Tile nxt = cur;
+    if (has_next) {
+        nxt = tile_of(vn);
+        set_pvo(nxt);
+        issue_w1(0);
+        issue_patch(0, 0);
+        issue_w0(0, 0);
+    }
 
     // ---- epilogue through an LDS tile in the halo buffer
     const int ybase = a.seg_yoff[0] + n * H * W;
@@ -1782,12 +1826,6 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
     };
     constexpr int TS = BN2 + 8;
     _Float16* tile = reinterpret_cast<_Float16*>(smem + O_HALO);
-    float4 bias4[TN2];
-#pragma unroll
-    for (int i = 0; i < TN2; ++i) {
-        const int co = i * 16 + fch * 4;
-        bias4[i] = co < a.cout ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
-    }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int prow = (2 * wave + (j >> 1)) * 32 + (j & 1) * 16 + frow;
@@ -1796,14 +1834,18 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
 #pragma unroll
         for (int i = 0; i < TN2; ++i) {
             const int col = i * 16 + fch * 4;
-            float v[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (ok && col < a.cout) epi_compute_b(a, ec, col, v, bias4[i]);
-            const f16x4 o4 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+            float vv[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
+            if (ok && col < a.cout) epi_compute_b(a, ec, col, vv, bias4[i]);
+            const f16x4 o4 = {(_Float16)vv[0], (_Float16)vv[1], (_Float16)vv[2], (_Float16)vv[3]};
             *reinterpret_cast<f16x4*>(tile + prow * TS + col) = o4;
         }
     }
     __syncthreads();
     staged_store_loc<BN2, 256>(a, tile, 0, 0, loc);
+    if (!has_next) break;
+    v = vn;
+    cur = nxt;
+    }   // tile loop (the next iteration's first barrier orders this tile's staged reads before the next halo writes)
 }
 
 template <int BN>
@@ -2206,8 +2248,10 @@ static int convpair_launch(const llv_inputcv_desc* p, void* stream, bool output_
         q.x_bytes = (unsigned)xb;
         q.w0_bytes = (unsigned)((output_block ? 1 : 3) * 32 * pre.wrow * 2);
         q.w1_bytes = (unsigned)(h.n_chunks * bn2 * h.wrow * 2);
-        if (output_block) hipLaunchKernelGGL((convpair2_kernel<32, 16>), dim3(h.nblk), dim3(256), 0, (hipStream_t)stream, k, h, pre, q);
-        else hipLaunchKernelGGL((convpair2_kernel<8, 32>), dim3(h.nblk), dim3(256), 0, (hipStream_t)stream, k, h, pre, q);
+        // persistent workgroups: two per CU (the LDS footprint's limit), each walks tiles v, v + grid, ...
+        const int grid = h.nblk < 512 ? h.nblk : 512;
+        if (output_block) hipLaunchKernelGGL((convpair2_kernel<32, 16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k, h, pre, q);
+        else hipLaunchKernelGGL((convpair2_kernel<8, 32>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k, h, pre, q);
         return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
     }
     if (output_block) hipLaunchKernelGGL((convpair_kernel<32, 16>), dim3(h.nblk), dim3(256), lds, (hipStream_t)stream, k, h, pre);
