@@ -1119,14 +1119,16 @@ __device__ __forceinline__ int tap_halo_off(int hy, int hx, int c8) {
     return (hy * (HALO_TW + 2) + hx) * 64 + ((c8 ^ (((hx >> 2) & 1) << 1)) << 4);
 }
 
-template <int BN>
+// R = depth of the weight ring: the slice of step s + R - 1 is requested while step s computes (R = 2: one step ahead).
+template <int BN, int R = 2>
 __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, const TapArgs h) {
     constexpr int TN = BN / 16, TM = 4;
     constexpr int WBYTES = BN * 64;
     constexpr int WPW = BN / 64;                             // weight pieces per wave per step
     constexpr int HPW = (TAP_HPIECES + 3) / 4;               // halo pieces per wave per chunk (<= 6)
     constexpr int TS = BN + 8;
-    constexpr int RING = 2 * TAP_HBYTES + 2 * WBYTES;
+    constexpr int RING = 2 * TAP_HBYTES + R * WBYTES;
+    constexpr int D = R - 1;                                 // prefetch distance in steps
     constexpr int EPI0 = 256 * TS * 2;
     constexpr int EPI1 = 256 * 4 * (BN / 4 + 8) * 2;         // PixelShuffle: rows in (pixel, sub-pixel) order
     constexpr int EPI = EPI0 > EPI1 ? EPI0 : EPI1;
@@ -1206,7 +1208,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
     // the first chunk's halo and the first weight slice are on their way while the rest of the set-up runs
 #pragma unroll
     for (int i = 0; i < HPW; ++i) issue_h(0, i, 0);
-    issue_w(0, 0, 0);
+    const int nsteps = h.n_chunks * 9;
+#pragma unroll
+    for (int s0 = 0; s0 < D; ++s0)
+        if (s0 < nsteps) issue_w(s0 / 9, s0 % 9, s0 % R);
 
     const int frow = lane & 15, fch = lane >> 4;
     // MFMA fragment read addresses: weights row i*16 + frow -> wa + i*1024; halo pixel (2*wave + (j>>1) + tr,
@@ -1235,30 +1240,34 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
 
     // one (chunk, tap) step with static tap T, halo buffer HB and weight buffer WB. A macro, not a lambda: with the
     // accumulators captured by reference the compiler leaves the 512-byte array of the BN = 128 variant in scratch.
-#define TAP_STEP(T, HB, WB, c, more)                                                                          \
+#define TAP_STEP(T, HB, c, more)                                                                              \
     {                                                                                                         \
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                      \
-        __syncthreads(); /* this step's operands are in LDS; the other buffers are free */                    \
-        if ((T) < 8) issue_w((c), (T) + 1, (WB) ^ 1);                                                         \
-        else if (more) issue_w((c) + 1, 0, (WB) ^ 1);                                                         \
+        /* loads retire in order: all but the D-1 youngest weight groups landed = this step's operands are in */ \
+        if (D == 1 || sidx + D > nsteps) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                     \
+        else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * WPW) : "memory");                             \
+        __syncthreads(); /* this step's operands are in LDS; the buffers of step s-1 are free */              \
         if ((T) < HPW && (more)) issue_h((c) + 1, (T), (HB) ^ 1);                                             \
+        if (sidx + D < nsteps) issue_w((c) + ((T) + D) / 9, ((T) + D) % 9, (sidx + D) % R);                   \
+        const unsigned char* sWc = sWgt + (sidx % R) * WBYTES + wa;                                           \
         f16x8 af[TN], bf[TM];                                                                                 \
         _Pragma("unroll") for (int j = 0; j < TM; ++j)                                                        \
             bf[j] = *reinterpret_cast<const f16x8*>(sHalo + (HB) * TAP_HBYTES + ((T) / 3) * ROWB + hb[j][(T) % 3]); \
         _Pragma("unroll") for (int i = 0; i < TN; ++i)                                                        \
-            af[i] = *reinterpret_cast<const f16x8*>(sWgt + (WB) * WBYTES + i * 1024 + wa);                    \
+            af[i] = *reinterpret_cast<const f16x8*>(sWc + i * 1024);                                          \
         _Pragma("unroll") for (int i = 0; i < TN; ++i)                                                        \
             _Pragma("unroll") for (int j = 0; j < TM; ++j)                                                    \
                 acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);         \
+        ++sidx;                                                                                               \
     }
-#define TAP_CHUNK(HB, W0, W1, c, more)                                                                        \
-    TAP_STEP(0, HB, W0, c, more) TAP_STEP(1, HB, W1, c, more) TAP_STEP(2, HB, W0, c, more)                    \
-    TAP_STEP(3, HB, W1, c, more) TAP_STEP(4, HB, W0, c, more) TAP_STEP(5, HB, W1, c, more)                    \
-    TAP_STEP(6, HB, W0, c, more) TAP_STEP(7, HB, W1, c, more) TAP_STEP(8, HB, W0, c, more)
+#define TAP_CHUNK(HB, c, more)                                                                                \
+    TAP_STEP(0, HB, c, more) TAP_STEP(1, HB, c, more) TAP_STEP(2, HB, c, more)                                \
+    TAP_STEP(3, HB, c, more) TAP_STEP(4, HB, c, more) TAP_STEP(5, HB, c, more)                                \
+    TAP_STEP(6, HB, c, more) TAP_STEP(7, HB, c, more) TAP_STEP(8, HB, c, more)
 
+    int sidx = 0;
     for (int c = 0; c < h.n_chunks; c += 2) {
-        { const bool more = c + 1 < h.n_chunks; TAP_CHUNK(0, 0, 1, c, more) }
-        if (c + 1 < h.n_chunks) { const bool more = c + 2 < h.n_chunks; TAP_CHUNK(1, 1, 0, c + 1, more) }
+        { const bool more = c + 1 < h.n_chunks; TAP_CHUNK(0, c, more) }
+        if (c + 1 < h.n_chunks) { const bool more = c + 2 < h.n_chunks; TAP_CHUNK(1, c + 1, more) }
     }
 #undef TAP_STEP
 #undef TAP_CHUNK
@@ -1870,7 +1879,7 @@ static size_t tap_x_bytes(const llv_conv_desc* d) {
     return px * (size_t)d->x_ld * 2;
 }
 
-template <int BN>
+template <int BN, int R = 2>
 int launch_tap(ConvKArgs& k, const llv_conv_desc* d, hipStream_t st) {
     TapArgs h;
     int blk = 0;
@@ -1890,7 +1899,7 @@ int launch_tap(ConvKArgs& k, const llv_conv_desc* d, hipStream_t st) {
     h.w_bytes = (unsigned)((size_t)d->w_rows * d->k_pad * 2);
     k.k_splits = 1;
     dim3 grid(h.nblk, (d->cout + BN - 1) / BN, d->groups);
-    hipLaunchKernelGGL((conv3x3_tap_kernel<BN>), grid, dim3(256), 0, st, k, h);
+    hipLaunchKernelGGL((conv3x3_tap_kernel<BN, R>), grid, dim3(256), 0, st, k, h);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
@@ -1944,7 +1953,7 @@ void tile_dims(int tile, int& bn, int& bm) {
     switch (tile) {
         case LLV_TILE_128x128: case LLV_TILE_128x128_REGSTAGE: case LLV_TILE_128x128_K64: bn = 128; bm = 128; break;
         case LLV_TILE_TAP128: bn = 128; bm = 256; break;
-        case LLV_TILE_TAP64: bn = 64; bm = 256; break;
+        case LLV_TILE_TAP64: case LLV_TILE_TAP64_R4: bn = 64; bm = 256; break;
         case LLV_TILE_64x256: case LLV_TILE_64x256_K64: bn = 64; bm = 256; break;
         case LLV_TILE_32x256: bn = 32; bm = 256; break;
         case LLV_TILE_16x256: bn = 16; bm = 256; break;
@@ -2188,6 +2197,7 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
         case LLV_TILE_128x128_K64: return launch_glds<128, 128, 64, 64, 64>(k, d->groups, st);
         case LLV_TILE_TAP128: return tap_eligible(d) ? launch_tap<128>(k, d, st) : LLV_E_BADARG;
         case LLV_TILE_TAP64:  return tap_eligible(d) ? launch_tap<64>(k, d, st) : LLV_E_BADARG;
+        case LLV_TILE_TAP64_R4: return tap_eligible(d) ? launch_tap<64, 4>(k, d, st) : LLV_E_BADARG;
         case LLV_TILE_64x256_K64:  return launch_glds<64, 256, 64, 64, 64>(k, d->groups, st);
         default: return LLV_E_UNSUPPORTED;
     }

@@ -422,7 +422,7 @@ def test_fused_outputcvblock(dev, n, h, w):
 
 
 # ---- tap-streamed 3x3 kernel (halo resident in LDS, weights streamed per tap); tiles 9 (BN=128) and 10 (BN=64)
-@pytest.mark.parametrize('tile', [9, 10])
+@pytest.mark.parametrize('tile', [9, 10, 11])
 @pytest.mark.parametrize('cfg', [
     # n, cin, cout, h, w   (3x3 / stride 1 / pad 1)
     (1, 64, 64, 20, 33),      # ragged tile edges in both directions

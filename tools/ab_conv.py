@@ -30,7 +30,7 @@ for name, n, cin, cout, h, w, k, st in shapes:
             e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
             e0.record()
             for _ in range(5):
-                ops.conv2d(x, pc, flags=ops.CONV_RELU, out=outs[t], tile=t, k_splits=0 if t in (9, 10) else 1)
+                ops.conv2d(x, pc, flags=ops.CONV_RELU, out=outs[t], tile=t, k_splits=0 if t in (9, 10, 11) else 1)
             e1.record(); torch.cuda.synchronize()
             if rnd > 0:
                 res[t].append(e0.elapsed_time(e1) / 5)

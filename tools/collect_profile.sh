@@ -12,5 +12,5 @@ rocprofv3 --pmc FETCH_SIZE -d $O/fetch -o p --output-format csv -- python3 $R/be
 rocprofv3 --pmc WRITE_SIZE -d $O/write -o p --output-format csv -- python3 $R/bench.py --no-graph --steps 2 --warmup 1 --no-cpu-baseline --no-latency-mode --no-kernel-timing > $O/bench_write.log 2>&1 || echo "write pass failed"
 f=$(find $O/stats -name '*kernel_stats.csv' | head -1)
 cp "$f" $R/gpurun_out/${tag}_kernel_stats.csv
-python3 $R/tools/traffic_from_pmc.py $O/fetch $O/write 4 $R/gpurun_out/${tag}_traffic.json
+python3 $R/tools/traffic_from_pmc.py $O/fetch $O/write 16 $R/gpurun_out/${tag}_traffic.json
 tail -1 $O/bench_stats.log
