@@ -877,6 +877,52 @@ __global__ __launch_bounds__(256, (BK == 64 ? 2 : (BN * BM >= 128 * 128 ? 3 : 4)
             }
             return;
         }
+        if ((a.flags & ~LLV_CONV_RELU) == LLV_CONV_RES_ADD && a.y_gstride == 0 && a.n_seg == 1 && (a.cout & 7) == 0) {
+            // residual add (+ ReLU), one segment (Bottleneck conv3 + identity, resnet.py:285-296; in-place gradient
+            // accumulation): the residual tile comes in as 16 bytes per lane, whole cache lines per wave, is parked
+            // in the staging tile, and each lane then adds its own 4 channels in fp32. Gathering it 8 bytes per lane
+            // straight from memory touched sixteen 128-byte lines per wave-load for a quarter of their bytes.
+            const bool relu = (a.flags & LLV_CONV_RELU) != 0;
+            constexpr int CPR = BN / 8;
+            const int cc = tid % CPR, co8 = tile_n * BN + cc * 8;
+            const int rows = a.m_total - tile_m * BM < BM ? a.m_total - tile_m * BM : BM;
+            const bool cok = co8 < a.cout;
+            {
+                const _Float16* rb = a.res + ((long)a.seg_yoff[0] + (long)tile_m * BM) * a.res_ld + (long)g * a.cout + co8;
+#pragma unroll 4
+                for (int prow = tid / CPR; prow < BM; prow += 256 / CPR) {
+                    uint4 val = make_uint4(0, 0, 0, 0);
+                    if (cok && prow < rows) val = *reinterpret_cast<const uint4*>(rb + (long)prow * a.res_ld);
+                    *reinterpret_cast<uint4*>(tile + prow * TS + cc * 8) = val;
+                }
+            }
+            __syncthreads();
+#pragma unroll
+            for (int j = 0; j < TM; ++j) {
+                const int prow = wm * WM + j * 16 + frow;
+#pragma unroll
+                for (int i = 0; i < TN; ++i) {
+                    _Float16* tp = tile + prow * TS + wn * WN + i * 16 + fch * 4;
+                    const f16x4 r4 = *reinterpret_cast<const f16x4*>(tp);
+                    float v[4];
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) {
+                        v[e] = acc[i][j][e] + (float)r4[e];
+                        if (relu) v[e] = fmaxf(v[e], 0.f);
+                    }
+                    const f16x4 o4 = {(_Float16)v[0], (_Float16)v[1], (_Float16)v[2], (_Float16)v[3]};
+                    *reinterpret_cast<f16x4*>(tp) = o4;
+                }
+            }
+            __syncthreads();
+            if (cok) {
+                _Float16* yb = reinterpret_cast<_Float16*>(a.y) + ((long)a.seg_yoff[0] + (long)tile_m * BM) * a.y_ld + (long)g * a.cout + co8;
+#pragma unroll 4
+                for (int prow = tid / CPR; prow < rows; prow += 256 / CPR)
+                    *reinterpret_cast<uint4*>(yb + (long)prow * a.y_ld) = *reinterpret_cast<const uint4*>(tile + prow * TS + cc * 8);
+            }
+            return;
+        }
         const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
