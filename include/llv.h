@@ -70,6 +70,7 @@ extern "C" {
 #define LLV_CONV_PIXSHUF 8     /* store through nn.PixelShuffle(2): out (2Ho,2Wo,cout/4) */
 #define LLV_CONV_RES_UPS 16    /* res is (res_h,res_w), nearest-upsampled to (Ho,Wo) (fpn.py:185-191) */
 #define LLV_CONV_OUT_F32 32    /* y is fp32 instead of fp16 */
+#define LLV_CONV_PS_EMAJOR 256 /* with PIXSHUF: the conv's output channels (weight rows, bias) are packed sub-pixel-major, channel = (2*dy+dx)*(Cout/4) + cc, instead of torch's 4*cc + 2*dy + dx; 3x3/s1 launches on the tap kernel only */
 #define LLV_CONV_ACT_FIRST 128 /* with RES_ADD: y = act(conv + bias) + res (Darknet ResBlock, darknet.py:47-53) instead of act(conv + bias + res) */
 #define LLV_CONV_LEAKY 64      /* y = y > 0 ? y : act_slope*y last (FlowNetSimple LeakyReLU(0.1), flownet_simple.py:66-68) */
 

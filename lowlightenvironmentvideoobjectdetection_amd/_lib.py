@@ -22,6 +22,7 @@ CONV_RES_UPS = 16
 CONV_OUT_F32 = 32
 CONV_LEAKY = 64
 CONV_ACT_FIRST = 128
+CONV_PS_EMAJOR = 256
 
 TILE_AUTO, TILE_128x128, TILE_64x256, TILE_32x256, TILE_16x256, TILE_64x64 = 0, 1, 2, 3, 4, 5
 TILE_128x128_REGSTAGE = 6

@@ -1365,6 +1365,52 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
         return;
     }
     const float4 zero4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (a.stage_out && (a.flags & LLV_CONV_PIXSHUF) && (a.flags & LLV_CONV_PS_EMAJOR)) {
+        // PixelShuffle with the conv channels packed sub-pixel-major (channel = e*OC + cc, e = 2*dy + dx, OC = Cout/4
+        // output channels): a lane's 4 consecutive channels are 4 consecutive OUTPUT channels of one sub-pixel, so the
+        // tile is staged as it is and a row's 16-byte chunks go to the sub-pixel they belong to. A 64-channel workgroup
+        // then writes whole output pixels (OC <= 64) instead of one eighth of four of them.
+        const int OC = a.cout >> 2;
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int prow = (2 * wave + (j >> 1)) * 32 + (j & 1) * 16 + frow;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const f16x4 o4 = {(_Float16)acc[i][j][0], (_Float16)acc[i][j][1], (_Float16)acc[i][j][2], (_Float16)acc[i][j][3]};
+                *reinterpret_cast<f16x4*>(tile + prow * TS + i * 16 + fch * 4) = o4;
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = BN / 8;
+        const int cc = tid % CPR, ch = tile_n * BN + cc * 8;      // first conv channel of this lane's 8
+        if (ch < a.cout) {
+            const int e = ch / OC, oc = ch - e * OC;               // sub-pixel, first output channel
+            const int dy = e >> 1, dx = e & 1;
+            for (int prow = tid / CPR; prow < 256; prow += 256 / CPR) {
+                const int oy = ty0 + (prow >> 5), ox = tx0 + (prow & 31);
+                if (oy >= H || ox >= W || 2 * oy + dy >= a.ps_h || 2 * ox + dx >= a.ps_w) continue;
+                const long pix = (long)a.seg_yoff[seg] + ((long)(n * a.ps_h + 2 * oy + dy)) * a.ps_w + (2 * ox + dx);
+                const f16x8 t8 = *reinterpret_cast<const f16x8*>(tile + prow * TS + cc * 8);
+                float v[8];
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] = (float)t8[t];
+                if (a.flags & LLV_CONV_RES_ADD) {
+                    const f16x8 r8 = *reinterpret_cast<const f16x8*>(a.res + pix * a.res_ld + g * OC + oc);
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) v[t] += (float)r8[t];
+                }
+                if (a.flags & (LLV_CONV_RELU | LLV_CONV_LEAKY)) {
+#pragma unroll
+                    for (int t = 0; t < 8; ++t) v[t] = act_fn(a, v[t]);
+                }
+                f16x8 o8;
+#pragma unroll
+                for (int t = 0; t < 8; ++t) o8[t] = (_Float16)v[t];
+                *reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(a.y) + pix * a.y_ld + g * OC + oc) = o8;
+            }
+        }
+        return;
+    }
     constexpr int TS2 = BN / 4 + 8;
     constexpr bool SHUF_OK = 256 * 4 * TS2 * 2 <= SMEM;       // the shuffled tile fits (BN = 64)
     if (SHUF_OK && a.stage_out && (a.flags & LLV_CONV_PIXSHUF)) {
@@ -2048,10 +2094,10 @@ static int plan_launch(const llv_conv_desc* d, LaunchPlan& lp) {
         for (int s = 0; s < d->n_seg; ++s)
             blocks += (long)d->batch * ((d->seg_h[s] + HALO_TH - 1) / HALO_TH) * ((d->seg_w[s] + HALO_TW - 1) / HALO_TW);
         blocks *= (long)((d->cout + 63) / 64) * d->groups;
-        if (blocks >= 160) {
+        if (blocks >= 160 || (d->flags & LLV_CONV_PS_EMAJOR)) {      // sub-pixel-major PixelShuffle exists on the tap kernel only
             // PixelShuffle layers take the 128-channel tile: a workgroup then owns 32 output channels of both
             // dx sub-pixels = whole 128-byte lines of the shuffled output (and of the skip tensor it adds)
-            lp.tile = ((d->flags & LLV_CONV_PIXSHUF) && d->cout % 128 == 0) ? LLV_TILE_TAP128 : LLV_TILE_TAP64;
+            lp.tile = ((d->flags & LLV_CONV_PIXSHUF) && !(d->flags & LLV_CONV_PS_EMAJOR) && d->cout % 128 == 0) ? LLV_TILE_TAP128 : LLV_TILE_TAP64;
             lp.splits = 1;
             lp.nk_per = (d->k_pad + 31) / 32;
             return LLV_OK;
@@ -2178,6 +2224,7 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
         k.ps_h = d->ps_out_h; k.ps_w = d->ps_out_w;
     }
     if ((f & LLV_CONV_RELU) && (f & LLV_CONV_LEAKY)) return LLV_E_BADARG;
+    if ((f & LLV_CONV_PS_EMAJOR) && (!(f & LLV_CONV_PIXSHUF) || (d->cout & 31) || d->groups != 1)) return LLV_E_BADARG;
     if ((f & LLV_CONV_ACT_FIRST) && (!(f & LLV_CONV_RES_ADD) || (f & (LLV_CONV_RES_RSUB | LLV_CONV_RES_UPS | LLV_CONV_PIXSHUF | LLV_CONV_OUT_F32)) || d->k_splits > 1)) return LLV_E_BADARG;
     k.y_gstride = d->y_group_stride;
     if (d->y_group_stride) {
@@ -2232,6 +2279,7 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
         }
     }
     const int tile = lp.tile;
+    if ((f & LLV_CONV_PS_EMAJOR) && !(tile == LLV_TILE_TAP64 && tap_eligible(d))) return LLV_E_UNSUPPORTED;
     if ((f & LLV_CONV_PIXSHUF) && tile == LLV_TILE_16x256) k.stage_out = 0;
     switch (tile) {
         case LLV_TILE_128x128: return launch_glds<128, 128, 64, 64>(k, d->groups, st);
@@ -2242,7 +2290,7 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
         case LLV_TILE_128x128_REGSTAGE: return launch<128, 128, 64, 64>(k, d->groups, st);   // register-staged loop, kept for A/B
         case LLV_TILE_128x128_K64: return launch_glds<128, 128, 64, 64, 64>(k, d->groups, st);
         case LLV_TILE_TAP128: return tap_eligible(d) ? launch_tap<128>(k, d, st) : LLV_E_BADARG;
-        case LLV_TILE_TAP64:  return tap_eligible(d) ? launch_tap<64>(k, d, st) : LLV_E_BADARG;
+        case LLV_TILE_TAP64:  return tap_eligible(d) ? launch_tap<64>(k, d, st) : LLV_E_BADARG;      // the only kernel that reads LLV_CONV_PS_EMAJOR
         case LLV_TILE_TAP64_R4: return tap_eligible(d) ? launch_tap<64, 4>(k, d, st) : LLV_E_BADARG;
         case LLV_TILE_64x256_K64:  return launch_glds<64, 256, 64, 64, 64>(k, d->groups, st);
         default: return LLV_E_UNSUPPORTED;

@@ -25,6 +25,7 @@ BN_EPS = 1e-5
 import os as _os
 HALO = _os.environ.get('LLV_HALO', '1') != '0'
 HALO_MAX_COUT = int(_os.environ.get('LLV_HALO_MAX_COUT', '128'))
+PS_EMAJOR = _os.environ.get('LLV_PS_EMAJOR', '1') != '0'
 FUSE_INPUTCV = _os.environ.get('LLV_FUSE_INPUTCV', '1') != '0'
 FUSE_OUTPUTCV = _os.environ.get('LLV_FUSE_OUTPUTCV', '1') != '0'
 ARCH = {18: ('basic', (2, 2, 2, 2)), 34: ('basic', (3, 4, 6, 3)), 50: ('bottleneck', (3, 4, 6, 3)),
@@ -487,6 +488,9 @@ def _denblock(b: Builder, sd, p, srcs, batch, tag, out):
         x = cbr(f'{tag}.{t}.0', x, q + 'convblock.0.convblock.0', q + 'convblock.0.convblock.1')   # :111-113 is fused
         x = cbr(f'{tag}.{t}.1', x, q + 'convblock.0.convblock.3', q + 'convblock.0.convblock.4')
         pc = ops.pack_conv(sd[q + 'convblock.1.weight'], None, 1, 1)
+        if pc.cin % 32 == 0 and pc.cout % 32 == 0 and PS_EMAJOR:
+            # sub-pixel-major output channels: the 64-channel tap kernel then writes whole output pixels
+            return b.conv(f'{tag}.{t}.2', x, ops.pixshuf_emajor(pc), CONV_PIXSHUF | CONV_RES_ADD | ops.CONV_PS_EMAJOR, res=skip)
         if HALO and pc.cout <= HALO_MAX_COUT and pc.cin % 32:
             ops.add_halo_packing(pc)
         return b.conv(f'{tag}.{t}.2', x, pc, CONV_PIXSHUF | CONV_RES_ADD, res=skip)

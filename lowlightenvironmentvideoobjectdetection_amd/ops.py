@@ -11,6 +11,7 @@ import numpy as np
 import torch
 
 from . import _lib
+from ._lib import CONV_PS_EMAJOR  # noqa: F401
 from ._lib import (CONV_LEAKY, CONV_OUT_F32, CONV_PIXSHUF, CONV_RELU, CONV_RES_ADD, CONV_RES_RSUB, CONV_RES_UPS,
                    ConvDesc, DecodeDesc, LlvError, check, lib)
 
@@ -152,6 +153,20 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], stride=1, pad=
                          bn=tuple(getattr(t, '_llv_key', None) for t in bn_in) if bn_in is not None else None,
                          group=0, row0=0, cout=cout, cin=cin, eps=eps)]
     return pc
+
+
+def pixshuf_emajor(pc: PackedConv) -> PackedConv:
+    """Re-order the output channels of a conv that feeds PixelShuffle(2) from torch's 4*cc + e to e*(Cout/4) + cc (e = 2*dy + dx):
+    launched with CONV_PS_EMAJOR the tap kernel then writes whole output pixels per workgroup. Returns a new PackedConv."""
+    assert pc.groups == 1 and pc.cout % 32 == 0 and pc.w_halo is None
+    oc = pc.cout // 4
+    perm = torch.tensor([4 * (j % oc) + j // oc for j in range(pc.cout)], dtype=torch.long)
+    w = pc.w.clone()
+    w[0, :pc.cout] = pc.w[0, perm.to(pc.w.device)]
+    b = pc.bias.clone()
+    b[:pc.cout] = pc.bias[perm.to(pc.bias.device)]
+    import dataclasses
+    return dataclasses.replace(pc, w=w.contiguous(), bias=b.contiguous(), parts=None)
 
 
 def stack_groups(pcs: List[PackedConv]) -> PackedConv:

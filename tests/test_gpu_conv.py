@@ -526,3 +526,20 @@ def test_conv3x3_tap_grouped_towers(dev, tile):
         err = (got - ref).abs().max().item() / ref.abs().max().item()
         assert err < 2e-3, (h, w, err)
         off += 2 * h * w
+
+
+def test_conv3x3_tap_pixel_shuffle_subpixel_major(dev):
+    """CONV_PS_EMAJOR: the same PixelShuffle + skip-add result from weights packed sub-pixel-major (ops.pixshuf_emajor),
+    OC = 32 (two sub-pixels per 64-channel workgroup) and OC = 64 (one), with an odd crop."""
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    g = torch.Generator().manual_seed(31)
+    for cin, cout, h, w in [(64, 128, 10, 44), (128, 256, 9, 33)]:
+        x = torch.randn(2, cin, h, w, generator=g).half().float()
+        wt = (torch.randn(cout, cin, 3, 3, generator=g) / (3 * cin ** 0.5)).half().float()
+        bias = torch.randn(cout, generator=g)
+        pc = ops.pixshuf_emajor(ops.pack_conv(wt, bias, stride=1, pad=1)).to(dev)
+        res = torch.randn(2, 2 * h, 2 * w, cout // 4, generator=g).half()
+        y = ops.conv2d(_nhwc(x).half().to(dev), pc, res=res.to(dev), flags=ops.CONV_PIXSHUF | ops.CONV_RES_ADD | ops.CONV_PS_EMAJOR)
+        ref = F.pixel_shuffle(F.conv2d(x, wt, bias, 1, 1), 2) + res.float().permute(0, 3, 1, 2)
+        assert y.shape == (2, 2 * h, 2 * w, cout // 4)
+        _check(y, ref, cout // 4)
