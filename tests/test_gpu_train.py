@@ -1,4 +1,6 @@
 """GPU parity of the training-side kernels and the head loss (targets + focal/L1) against the oracle."""
+import os
+
 import numpy as np
 import pytest
 import torch
@@ -207,3 +209,47 @@ def test_forward_train_is_a_drop_in_for_the_reference_train_step(dev):
     m = [dict(img_shape=(128, 160, 3), pad_shape=(128, 160, 3), scale_factor=np.ones(4, np.float32), ori_shape=(128, 160, 3))] * 2
     res = det.simple_test(img.to(dev), m)
     assert len(res) == 2 and len(res[0]) == 4
+
+
+def _ddp_worker(rank, world, port, q):
+    import os
+    import sys
+    import torch
+    import torch.distributed as dist
+    sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+    os.environ['MASTER_ADDR'] = '127.0.0.1'
+    os.environ['MASTER_PORT'] = str(port)
+    dist.init_process_group('gloo', rank=rank, world_size=world)         # both ranks share the one GPU of the test box
+    dev = torch.device('cuda', 0)
+    from lowlightenvironmentvideoobjectdetection_amd import train_engine as TE
+    det, img, metas, gtb, gtl = _train_setup(dev, seed=3)               # same initial weights on every rank
+    det = det.to(dev)
+    img = torch.roll(img, shifts=5 * rank, dims=3)                        # different data per rank
+    ts = TE.TrainStep(det, 2, img.shape[2], img.shape[3], dev, lr=2e-5, bucket_mb=0.5)
+    out = None
+    for _ in range(2):
+        out = ts.step_fused(img.to(dev), metas, [b.to(dev) for b in gtb], [l.to(dev) for l in gtl])
+    flat = ts.flat_w.detach().clone()
+    gathered = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(gathered, flat)
+    same = all(torch.equal(gathered[0], g) for g in gathered[1:]) and bool(torch.isfinite(flat).all())
+    q.put((rank, same, len(ts.buckets), float(out['log_vars']['loss']), float(flat.abs().sum().item())))
+    dist.destroy_process_group()
+
+
+def test_data_parallel_training_two_ranks(dev):
+    """Two ranks (gloo, sharing this box's GPU), different images, the bucketed asynchronous gradient all-reduce of
+    TrainStep: after two steps every rank holds bit-identical parameters, _parse_losses reports the rank-averaged loss."""
+    import torch.multiprocessing as mp
+    ctx = mp.get_context('spawn')
+    q = ctx.Queue()
+    port = 29650 + (os.getpid() % 150)
+    ps = [ctx.Process(target=_ddp_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in ps:
+        p.start()
+    res = [q.get(timeout=600) for _ in ps]
+    for p in ps:
+        p.join(timeout=120)
+    assert all(r[1] for r in res), res
+    assert res[0][2] >= 3                       # several buckets at this bucket size
+    assert abs(res[0][3] - res[1][3]) < 1e-6    # the logged loss is the all-reduced mean
