@@ -382,13 +382,14 @@ def main():
         for s_ in range(args.warmup):
             p1.step(clip, s_ % T)
         torch.cuda.synchronize()
+        nlat = max(args.steps, 200)          # the reference's protocol (benchmark.py:83-109): batch 1, >= 200 frames
         t1 = time.perf_counter()
-        for s_ in range(args.steps):
+        for s_ in range(nlat):
             p1.step(clip, (args.warmup + s_) % T)
         torch.cuda.synchronize()
         d1 = time.perf_counter() - t1
-        lat = {'frames_per_step': 1, 'denblocks_per_frame': 4, 'value': round(args.steps / d1, 3), 'unit': 'frames/s',
-               'ms_per_frame': round(d1 / args.steps * 1e3, 4), 'algorithmic_gflop_per_frame': round(p1.plan.flops / 1e9, 1)}
+        lat = {'frames_per_step': 1, 'frames': nlat, 'denblocks_per_frame': 4, 'value': round(nlat / d1, 3), 'unit': 'frames/s',
+               'ms_per_frame': round(d1 / nlat * 1e3, 4), 'algorithmic_gflop_per_frame': round(p1.plan.flops / 1e9, 1)}
         del p1
     n_cand_thr = int((plan.det.post.dp.scores.reshape(B, -1)[0] > 0.05).sum().item())
 
