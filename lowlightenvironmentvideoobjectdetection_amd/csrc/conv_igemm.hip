@@ -1166,7 +1166,9 @@ __device__ __forceinline__ int tap_halo_off(int hy, int hx, int c8) {
 }
 
 // R = depth of the weight ring: the slice of step s + R - 1 is requested while step s computes (R = 2: one step ahead).
-template <int BN, int R = 2>
+// MSRC: the input is several tensors concatenated along C (a chunk's source is looked up per request); the common
+// single-source instantiation has no such scalar work in its step.
+template <int BN, int R = 2, bool MSRC = false>
 __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, const TapArgs h) {
     constexpr int TN = BN / 16, TM = 4;
     constexpr int WBYTES = BN * 64;
@@ -1243,7 +1245,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
         if (wave + 4 * i >= TAP_HPIECES) return;              // wave-uniform
         int cv = c * 4;
         unsigned char* dst = sHalo + buf * TAP_HBYTES + (wave + 4 * i) * 1024;
-        if (a.n_src > 1) {
+        if (MSRC) {
             const int sidx = cv / a.src_cvec;
             cv -= sidx * a.src_cvec;
             if (sidx == 1) { dma16(rX1, dst, hv[i], cv * 16); return; }
@@ -1293,8 +1295,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
         else asm volatile("s_waitcnt vmcnt(%0)" ::"n"((D - 1) * WPW) : "memory");                             \
         __syncthreads(); /* this step's operands are in LDS; the buffers of step s-1 are free */              \
         if ((T) < HPW && (more)) issue_h((c) + 1, (T), (HB) ^ 1);                                             \
-        if (sidx + D < nsteps) issue_w((c) + ((T) + D) / 9, ((T) + D) % 9, (sidx + D) % R);                   \
-        const unsigned char* sWc = sWgt + (sidx % R) * WBYTES + wa;                                           \
+        if (sidx + D < nsteps) issue_w((c) + ((T) + D) / 9, ((T) + D) % 9, (unsigned)(sidx + D) % R);         \
+        const unsigned char* sWc = sWgt + ((unsigned)sidx % R) * WBYTES + wa;                                 \
         f16x8 af[TN], bf[TM];                                                                                 \
         _Pragma("unroll") for (int j = 0; j < TM; ++j)                                                        \
             bf[j] = *reinterpret_cast<const f16x8*>(sHalo + (HB) * TAP_HBYTES + ((T) / 3) * ROWB + hb[j][(T) % 3]); \
@@ -1991,7 +1993,8 @@ int launch_tap(ConvKArgs& k, const llv_conv_desc* d, hipStream_t st) {
     h.w_bytes = (unsigned)((size_t)d->w_rows * d->k_pad * 2);
     k.k_splits = 1;
     dim3 grid(h.nblk, (d->cout + BN - 1) / BN, d->groups);
-    hipLaunchKernelGGL((conv3x3_tap_kernel<BN, R>), grid, dim3(256), 0, st, k, h);
+    if (d->n_src > 1) hipLaunchKernelGGL((conv3x3_tap_kernel<BN, R, true>), grid, dim3(256), 0, st, k, h);
+    else hipLaunchKernelGGL((conv3x3_tap_kernel<BN, R, false>), grid, dim3(256), 0, st, k, h);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
