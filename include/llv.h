@@ -298,6 +298,15 @@ int llv_iou_assign(const float* gt, int k, const float* anchors, const uint8_t* 
                    int gt_max_assign_all, int64_t* assigned_gt_inds, float* max_overlaps, void* workspace,
                    size_t workspace_bytes, void* stream);
 
+/* Test-time image pipeline of the reference in one pass:
+ * SeqBrighten (mmtracking/mmtrack/datasets/pipelines/transforms.py:376-432: one gain amp = m*h*w*3 / sum(frame0/255) for the
+ * clip, np.clip(img*amp, 0, 255).astype(uint8)), Normalize (mmdetection/mmdet/datasets/pipelines/transforms.py:547-575:
+ * BGR->RGB, (x - mean) * (1/std)) and Pad (:476-524, zeros) -> fp16 NHWC8 (3 real + 5 zero channels).
+ * frames: uint8 (t,h,w,3) on the device; out: fp16 (t,hp,wp,8); workspace: 8 bytes. The gain's denominator is summed exactly in
+ * integers (the reference sums float32 pairwise: its gain can differ in the 7th digit). */
+int llv_brighten_normalize_pad_u8(const void* frames, int t, int h, int w, int hp, int wp, float m, const float* mean3,
+                                  const float* std3, int to_rgb, void* out, void* workspace, void* stream);
+
 /* ---- YOLOv3 stand-in for config #5 ------------------------------------------------------------
  * F.interpolate(scale_factor=2) of yolo_neck.py:123 written into a channel slice of the concat buffer (torch.cat of :124):
  * dst[n][2y+dy][2x+dx][c] = src[n][y][x][c], fp16 NHWC, row strides src_ld / dst_ld, c multiple of 8. */

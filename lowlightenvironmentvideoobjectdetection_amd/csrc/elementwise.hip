@@ -321,6 +321,57 @@ __global__ void yolo_decode_kernel(const YoloArgs k) {
     }
 }
 
+// ---- test-time image pipeline fused: Brighten (one gain per clip, from frame 0) -> uint8 truncation -> BGR->RGB ->
+// (x - mean) * (1/std) -> zero pad -> NHWC8 fp16 (transforms.py:376-432 of mmtrack, Normalize / Pad of mmdet)
+__global__ void sum_u8_kernel(const unsigned char* x, long n, unsigned long long* out) {
+    unsigned long long s = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) s += x[i];
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if ((threadIdx.x & 63) == 0 && s) atomicAdd(out, s);
+}
+
+struct PrepArgs { const unsigned char* x; const unsigned long long* sum; _Float16* y; int t, h, w, hp, wp, to_rgb; double m_hw3_255; float mean[3], stdinv[3]; };
+__global__ void preprocess_kernel(const PrepArgs k) {
+    const long total = (long)k.t * k.hp * k.wp;
+    const unsigned long long s = *k.sum;
+    const double amp = k.m_hw3_255 / (double)(s ? s : 1ull);          // m*h*w*3 / sum(x/255)
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int px = (int)(i % k.wp);
+        long r = i / k.wp;
+        const int py = (int)(r % k.hp);
+        const int f = (int)(r / k.hp);
+        _Float16 o[8] = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+        if (py < k.h && px < k.w) {
+            const unsigned char* p = k.x + (((long)f * k.h + py) * k.w + px) * 3;
+#pragma unroll
+            for (int c = 0; c < 3; ++c) {
+                double v = (double)p[k.to_rgb ? 2 - c : c] * amp;        // np.clip(img * amp, 0, 255).astype(uint8): truncation
+                v = v < 0.0 ? 0.0 : (v > 255.0 ? 255.0 : v);
+                const float q = (float)(int)v;
+                o[c] = (_Float16)((q - k.mean[c]) * k.stdinv[c]);
+            }
+        }
+        *reinterpret_cast<uint4*>(k.y + i * 8) = *reinterpret_cast<const uint4*>(o);
+    }
+}
+
+extern "C" int llv_brighten_normalize_pad_u8(const void* frames, int t, int h, int w, int hp, int wp, float m, const float* mean3,
+                                             const float* std3, int to_rgb, void* out, void* workspace, void* stream) {
+    if (!frames || !out || !workspace || !mean3 || !std3 || t < 1 || h < 1 || w < 1 || hp < h || wp < w || !(m > 0.f)) return LLV_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (hipMemsetAsync(workspace, 0, 8, st) != hipSuccess) return LLV_E_LAUNCH;
+    const long n0 = (long)h * w * 3;
+    hipLaunchKernelGGL(sum_u8_kernel, dim3(grid_for(n0)), dim3(kBlock), 0, st, (const unsigned char*)frames, n0, (unsigned long long*)workspace);
+    PrepArgs k;
+    k.x = (const unsigned char*)frames; k.sum = (const unsigned long long*)workspace; k.y = (_Float16*)out;
+    k.t = t; k.h = h; k.w = w; k.hp = hp; k.wp = wp; k.to_rgb = to_rgb;
+    k.m_hw3_255 = (double)m * (double)h * (double)w * 3.0 * 255.0;
+    for (int c = 0; c < 3; ++c) { k.mean[c] = mean3[c]; k.stdinv[c] = (float)(1.0 / (double)std3[c]); }
+    hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for((long)t * hp * wp)), dim3(kBlock), 0, st, k);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
 extern "C" int llv_upsample2x_nhwc(const void* src, void* dst, int n, int h, int w, int c, int src_ld, int dst_ld, void* stream) {
     if (!src || !dst || n < 1 || h < 1 || w < 1 || c < 8 || (c & 7) || (src_ld & 7) || (dst_ld & 7) || src_ld < c || dst_ld < c) return LLV_E_BADARG;
     const long total = (long)n * 4 * h * w * (c / 8);

@@ -70,3 +70,27 @@ def preprocess_clip(frames_bgr_u8, device, m=0.25, mean=(123.675, 116.28, 103.53
         out[r] = out[replicate_ends]
         out[-1 - r] = out[replicate_ends + t - 1]
     return out, (h, w, 3), (hp, wp, 3)
+
+
+def preprocess_clip_device(frames_bgr_u8, m=0.25, mean=(123.675, 116.28, 103.53), std=(58.395, 57.12, 57.375), size_divisor=32,
+                           replicate_ends=2):
+    """preprocess_clip on the device kernel (llv_brighten_normalize_pad_u8): frames (T,H,W,3) uint8 on the GPU ->
+    (T + 2*replicate_ends, Hp, Wp, 8) fp16. One launch pair; no host arithmetic, no CPU fallback."""
+    import ctypes as C
+    from ._lib import LlvError, check, lib
+    x = frames_bgr_u8
+    if x.device.type != 'cuda' or x.dtype != torch.uint8:
+        raise LlvError('preprocess_clip_device takes uint8 frames on the GPU')
+    x = x.contiguous()
+    t, h, w, _ = x.shape
+    hp, wp = (h + size_divisor - 1) // size_divisor * size_divisor, (w + size_divisor - 1) // size_divisor * size_divisor
+    out = torch.empty((t + 2 * replicate_ends, hp, wp, 8), device=x.device, dtype=torch.float16)
+    ws = torch.zeros(1, dtype=torch.int64, device=x.device)
+    mean_c, std_c = (C.c_float * 3)(*mean), (C.c_float * 3)(*std)
+    check(lib().llv_brighten_normalize_pad_u8(x.data_ptr(), t, h, w, hp, wp, float(m), mean_c, std_c, 1, out[replicate_ends:].data_ptr(),
+                                              ws.data_ptr(), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+          'llv_brighten_normalize_pad_u8')
+    for r in range(replicate_ends):
+        out[r] = out[replicate_ends]
+        out[-1 - r] = out[replicate_ends + t - 1]
+    return out, (h, w, 3), (hp, wp, 3)

@@ -144,3 +144,23 @@ def test_decode_topk_tie_order(dev):
     ops.retina_decode_topk(plan)
     torch.cuda.synchronize()
     assert torch.equal(plan.cand_anchor.cpu().long(), torch.arange(1000))
+
+
+def test_preprocess_kernel_matches_reference_pipeline(dev):
+    """llv_brighten_normalize_pad_u8 (row a1) vs the numpy restatement of SeqBrighten -> Normalize -> Pad. The kernel sums the
+    gain's denominator exactly, the reference in float32: a pixel whose brightened value sits within 1e-6 of an integer may
+    truncate differently, so up to 1e-4 of the values may differ by one uint8 step (1/std = 0.0175); the rest match to
+    fp16 rounding."""
+    import numpy as np
+    from lowlightenvironmentvideoobjectdetection_amd import data
+    from oracle.preprocess import preprocess_clip
+    g = np.random.RandomState(3)
+    frames = (g.rand(4, 70, 90, 3) * 60).astype(np.uint8)
+    ref = preprocess_clip(frames, m=0.25, size_divisor=32)
+    out, img_shape, pad_shape = data.preprocess_clip_device(torch.from_numpy(frames).to(dev), m=0.25)
+    assert img_shape == (70, 90, 3) and pad_shape == (96, 96, 3) and out.shape == (8, 96, 96, 8)
+    got = out[2:6, :, :, :3].float().cpu().numpy()
+    diff = np.abs(got - ref)
+    assert (diff > 2e-3).mean() < 1e-4 and diff.max() < 0.02
+    assert float(out[..., 3:].abs().max()) == 0 and float(out[:, 70:].abs().max()) == 0 and float(out[:, :, 90:].abs().max()) == 0
+    assert torch.equal(out[0], out[2]) and torch.equal(out[-1], out[5])
