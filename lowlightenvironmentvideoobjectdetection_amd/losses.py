@@ -130,6 +130,156 @@ class SmoothL1Loss(nn.Module):
                                                  avg_factor=avg_factor, **kwargs)
 
 
+# ----------------------------------------------------------------------------------------------
+# IoU-family box losses (mmdetection/mmdet/models/losses/iou_loss.py:14-436). Inputs are decoded boxes
+# (reg_decoded_bbox=True, anchor_head.py:404-409); elementwise on (n, 4) tensors that live on the device.
+# ----------------------------------------------------------------------------------------------
+def _aligned_overlaps(pred, target, mode, eps):
+    """bbox_overlaps(..., is_aligned=True) (iou2d_calculator.py:115-135,151-159)"""
+    area1 = (pred[..., 2] - pred[..., 0]) * (pred[..., 3] - pred[..., 1])
+    area2 = (target[..., 2] - target[..., 0]) * (target[..., 3] - target[..., 1])
+    lt = torch.max(pred[..., :2], target[..., :2])
+    rb = torch.min(pred[..., 2:], target[..., 2:])
+    wh = (rb - lt).clamp(min=0)
+    overlap = wh[..., 0] * wh[..., 1]
+    union = area1 + area2 - overlap
+    e = union.new_tensor([eps])
+    union = torch.max(union, e)
+    ious = overlap / union
+    if mode == 'iou':
+        return ious
+    elt = torch.min(pred[..., :2], target[..., :2])
+    erb = torch.max(pred[..., 2:], target[..., 2:])
+    ewh = (erb - elt).clamp(min=0)
+    earea = torch.max(ewh[..., 0] * ewh[..., 1], e)
+    return ious - (earea - union) / earea
+
+
+@_weighted
+def iou_loss(pred, target, linear=False, eps=1e-6):
+    """iou_loss.py:14-38"""
+    ious = _aligned_overlaps(pred, target, 'iou', 1e-6).clamp(min=eps)
+    return 1 - ious if linear else -ious.log()
+
+
+@_weighted
+def bounded_iou_loss(pred, target, beta=0.2, eps=1e-3):
+    """iou_loss.py:43-83"""
+    pcx, pcy = (pred[:, 0] + pred[:, 2]) * 0.5, (pred[:, 1] + pred[:, 3]) * 0.5
+    pw, ph = pred[:, 2] - pred[:, 0], pred[:, 3] - pred[:, 1]
+    with torch.no_grad():
+        tcx, tcy = (target[:, 0] + target[:, 2]) * 0.5, (target[:, 1] + target[:, 3]) * 0.5
+        tw, th = target[:, 2] - target[:, 0], target[:, 3] - target[:, 1]
+    dx, dy = tcx - pcx, tcy - pcy
+    ldx = 1 - torch.max((tw - 2 * dx.abs()) / (tw + 2 * dx.abs() + eps), torch.zeros_like(dx))
+    ldy = 1 - torch.max((th - 2 * dy.abs()) / (th + 2 * dy.abs() + eps), torch.zeros_like(dy))
+    ldw = 1 - torch.min(tw / (pw + eps), pw / (tw + eps))
+    ldh = 1 - torch.min(th / (ph + eps), ph / (th + eps))
+    comb = torch.stack([ldx, ldy, ldw, ldh], dim=-1).view(ldx.size(0), -1)
+    return torch.where(comb < beta, 0.5 * comb * comb / beta, comb - 0.5 * beta)
+
+
+@_weighted
+def giou_loss(pred, target, eps=1e-7):
+    """iou_loss.py:88-104"""
+    return 1 - _aligned_overlaps(pred, target, 'giou', eps)
+
+
+def _diou_terms(pred, target, eps):
+    lt = torch.max(pred[:, :2], target[:, :2])
+    rb = torch.min(pred[:, 2:], target[:, 2:])
+    wh = (rb - lt).clamp(min=0)
+    overlap = wh[:, 0] * wh[:, 1]
+    ap = (pred[:, 2] - pred[:, 0]) * (pred[:, 3] - pred[:, 1])
+    ag = (target[:, 2] - target[:, 0]) * (target[:, 3] - target[:, 1])
+    ious = overlap / (ap + ag - overlap + eps)
+    ewh = (torch.max(pred[:, 2:], target[:, 2:]) - torch.min(pred[:, :2], target[:, :2])).clamp(min=0)
+    c2 = ewh[:, 0] ** 2 + ewh[:, 1] ** 2 + eps
+    rho2 = ((target[:, 0] + target[:, 2]) - (pred[:, 0] + pred[:, 2])) ** 2 / 4 + \
+        ((target[:, 1] + target[:, 3]) - (pred[:, 1] + pred[:, 3])) ** 2 / 4
+    return ious, rho2, c2
+
+
+@_weighted
+def diou_loss(pred, target, eps=1e-7):
+    """iou_loss.py:109-154"""
+    ious, rho2, c2 = _diou_terms(pred, target, eps)
+    return 1 - (ious - rho2 / c2)
+
+
+@_weighted
+def ciou_loss(pred, target, eps=1e-7):
+    """iou_loss.py:159-211"""
+    import math
+    ious, rho2, c2 = _diou_terms(pred, target, eps)
+    w1, h1 = pred[:, 2] - pred[:, 0], pred[:, 3] - pred[:, 1] + eps
+    w2, h2 = target[:, 2] - target[:, 0], target[:, 3] - target[:, 1] + eps
+    v = (4 / math.pi ** 2) * torch.pow(torch.atan(w2 / h2) - torch.atan(w1 / h1), 2)
+    return 1 - (ious - (rho2 / c2 + v ** 2 / (1 - ious + v)))
+
+
+class _BoxLoss(nn.Module):
+    """Shared forward of IoULoss / GIoULoss / DIoULoss / CIoULoss (iou_loss.py:214-436): all-zero weights short-cut,
+    (n, 4) weights averaged to (n,), reduction override."""
+    fn = None
+
+    def __init__(self, eps=1e-6, reduction='mean', loss_weight=1.0, **extra):
+        super().__init__()
+        self.eps, self.reduction, self.loss_weight, self.extra = eps, reduction, loss_weight, extra
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None, **kwargs):
+        assert reduction_override in (None, 'none', 'mean', 'sum')
+        reduction = reduction_override if reduction_override else self.reduction
+        if (weight is not None) and (not torch.any(weight > 0)) and (reduction != 'none'):
+            return (pred * weight).sum()  # 0
+        if weight is not None and weight.dim() > 1:
+            assert weight.shape == pred.shape
+            weight = weight.mean(-1)
+        return self.loss_weight * type(self).fn(pred, target, weight, eps=self.eps, reduction=reduction, avg_factor=avg_factor,
+                                                **self.extra, **kwargs)
+
+
+@LOSSES.register_module()
+class IoULoss(_BoxLoss):
+    fn = staticmethod(iou_loss)
+
+    def __init__(self, linear=False, eps=1e-6, reduction='mean', loss_weight=1.0):
+        super().__init__(eps, reduction, loss_weight, linear=linear)
+        self.linear = linear
+
+
+@LOSSES.register_module()
+class GIoULoss(_BoxLoss):
+    fn = staticmethod(giou_loss)
+
+
+@LOSSES.register_module()
+class DIoULoss(_BoxLoss):
+    fn = staticmethod(diou_loss)
+
+
+@LOSSES.register_module()
+class CIoULoss(_BoxLoss):
+    fn = staticmethod(ciou_loss)
+
+
+@LOSSES.register_module()
+class BoundedIoULoss(nn.Module):
+    """iou_loss.py:271-302"""
+
+    def __init__(self, beta=0.2, eps=1e-3, reduction='mean', loss_weight=1.0):
+        super().__init__()
+        self.beta, self.eps, self.reduction, self.loss_weight = beta, eps, reduction, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None, reduction_override=None, **kwargs):
+        if weight is not None and not torch.any(weight > 0):
+            return (pred * weight).sum()  # 0
+        assert reduction_override in (None, 'none', 'mean', 'sum')
+        reduction = reduction_override if reduction_override else self.reduction
+        return self.loss_weight * bounded_iou_loss(pred, target, weight, beta=self.beta, eps=self.eps, reduction=reduction,
+                                                   avg_factor=avg_factor, **kwargs)
+
+
 @LOSSES.register_module()
 class CrossEntropyLoss(nn.Module):
     """Constructor only (AnchorHead's default loss_cls names it, anchor_head.py:49-52); the RetinaNet path uses FocalLoss."""

@@ -30,6 +30,23 @@ def _bbox2delta(proposals, gt, means, stds):
     return deltas.sub_(deltas.new_tensor(means).unsqueeze(0)).div_(deltas.new_tensor(stds).unsqueeze(0))
 
 
+def _delta2bbox(rois, deltas, means, stds, wh_ratio_clip=16 / 1000):
+    """delta_xywh_bbox_coder.py:134-237 without max_shape (the training-time decode of anchor_head.py:404-409)"""
+    import numpy as np
+    means = deltas.new_tensor(means).view(1, -1)
+    stds = deltas.new_tensor(stds).view(1, -1)
+    d = deltas * stds + means
+    dx, dy, dw, dh = d[:, 0], d[:, 1], d[:, 2], d[:, 3]
+    max_ratio = abs(float(np.log(wh_ratio_clip)))
+    dw = dw.clamp(min=-max_ratio, max=max_ratio)
+    dh = dh.clamp(min=-max_ratio, max=max_ratio)
+    px, py = (rois[:, 0] + rois[:, 2]) * 0.5, (rois[:, 1] + rois[:, 3]) * 0.5
+    pw, ph = rois[:, 2] - rois[:, 0], rois[:, 3] - rois[:, 1]
+    gw, gh = pw * dw.exp(), ph * dh.exp()
+    gx, gy = px + pw * dx, py + ph * dy
+    return torch.stack([gx - gw * 0.5, gy - gh * 0.5, gx + gw * 0.5, gy + gh * 0.5], dim=-1)
+
+
 def get_targets_single(head, flat_anchors, valid_flags, gt_bboxes, gt_labels, img_meta):
     """anchor_head.py:175-271 with PseudoSampler; assignment over the inside anchors via a validity mask
     (identical to assigning the subset and unmapping: outside anchors neither win a gt nor get a label)."""
@@ -49,10 +66,11 @@ def get_targets_single(head, flat_anchors, valid_flags, gt_bboxes, gt_labels, im
     label_weights = flat_anchors.new_zeros(n, dtype=torch.float)
     if len(pos_inds) > 0:
         pos_gt = gt_inds[pos_inds] - 1
-        if head.reg_decoded_bbox:
-            raise LlvError('reg_decoded_bbox (IoU-family losses) is not wired yet')
-        bbox_targets[pos_inds, :] = _bbox2delta(flat_anchors[pos_inds], gt_bboxes[pos_gt, :], head.bbox_coder.means,
-                                                head.bbox_coder.stds)
+        if head.reg_decoded_bbox:                        # IoU-family losses take boxes, anchor_head.py:246-249
+            bbox_targets[pos_inds, :] = gt_bboxes[pos_gt, :].float()
+        else:
+            bbox_targets[pos_inds, :] = _bbox2delta(flat_anchors[pos_inds], gt_bboxes[pos_gt, :], head.bbox_coder.means,
+                                                    head.bbox_coder.stds)
         bbox_weights[pos_inds, :] = 1.0
         labels[pos_inds] = gt_labels[pos_gt] if gt_labels is not None else 0
         label_weights[pos_inds] = 1.0 if tc['pos_weight'] <= 0 else tc['pos_weight']
@@ -88,11 +106,14 @@ def anchor_head_loss(head, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_met
     bbox_targets_list = images_to_levels([r[2] for r in per_img], num_level_anchors)
     bbox_weights_list = images_to_levels([r[3] for r in per_img], num_level_anchors)
     losses_cls, losses_bbox = [], []
-    for cls, reg, lab, lw, bt, bw in zip(cls_scores, bbox_preds, labels_list, label_weights_list, bbox_targets_list,
-                                         bbox_weights_list):          # loss_single, anchor_head.py:375-423
+    anchors_list = images_to_levels([flat_anchors] * len(img_metas), num_level_anchors)
+    for cls, reg, anc, lab, lw, bt, bw in zip(cls_scores, bbox_preds, anchors_list, labels_list, label_weights_list,
+                                              bbox_targets_list, bbox_weights_list):          # loss_single, anchor_head.py:375-423
         cls = cls.permute(0, 2, 3, 1).reshape(-1, head.cls_out_channels)
         losses_cls.append(head.loss_cls(cls, lab.reshape(-1), lw.reshape(-1), avg_factor=num_total_samples))
         reg = reg.permute(0, 2, 3, 1).reshape(-1, 4)
+        if head.reg_decoded_bbox:
+            reg = _delta2bbox(anc.reshape(-1, 4), reg, head.bbox_coder.means, head.bbox_coder.stds)
         losses_bbox.append(head.loss_bbox(reg, bt.reshape(-1, 4), bw.reshape(-1, 4), avg_factor=num_total_samples))
     return dict(loss_cls=losses_cls, loss_bbox=losses_bbox)
 

@@ -144,7 +144,7 @@ def unmap(data, count, inds, fill=0):
 
 
 def get_targets_single(flat_anchors, valid_flags, gt_bboxes, gt_labels, img_meta, num_classes, assigner,
-                       allowed_border=-1, pos_weight=-1, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.)):
+                       allowed_border=-1, pos_weight=-1, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), reg_decoded_bbox=False):
     """anchor_head.py:175-271 with PseudoSampler (FocalLoss => no sampling)."""
     inside_flags = anchor_inside_flags(flat_anchors, valid_flags, img_meta['img_shape'][:2], allowed_border)
     if not inside_flags.any():
@@ -160,7 +160,10 @@ def get_targets_single(flat_anchors, valid_flags, gt_bboxes, gt_labels, img_meta
     label_weights = anchors.new_zeros(n, dtype=torch.float)
     if len(pos_inds) > 0:
         pos_assigned = ar.gt_inds[pos_inds] - 1
-        bbox_targets[pos_inds, :] = bbox2delta(anchors[pos_inds], gt_bboxes[pos_assigned, :], means, stds)
+        if reg_decoded_bbox:                                 # anchor_head.py:246-249
+            bbox_targets[pos_inds, :] = gt_bboxes[pos_assigned, :]
+        else:
+            bbox_targets[pos_inds, :] = bbox2delta(anchors[pos_inds], gt_bboxes[pos_assigned, :], means, stds)
         bbox_weights[pos_inds, :] = 1.0
         labels[pos_inds] = gt_labels[pos_assigned]
         label_weights[pos_inds] = 1.0 if pos_weight <= 0 else pos_weight
@@ -171,8 +174,48 @@ def get_targets_single(flat_anchors, valid_flags, gt_bboxes, gt_labels, img_meta
             unmap(bbox_targets, tot, inside_flags), unmap(bbox_weights, tot, inside_flags), pos_inds, neg_inds)
 
 
+def iou_family_loss(kind, pred, target, weight=None, avg_factor=None, eps=None, linear=False):
+    """mmdetection/mmdet/models/losses/iou_loss.py: iou_loss :14-38, giou_loss :88-104, diou_loss :109-154, ciou_loss :159-211
+    and the shared class forward (:214-436): (n,4) weights are averaged to (n,), reduction 'mean' with avg_factor."""
+    import math
+    from .bbox import bbox_overlaps
+    if weight is not None and not torch.any(weight > 0):
+        return (pred * weight).sum()
+    if weight is not None and weight.dim() > 1:
+        weight = weight.mean(-1)
+    if kind == 'iou':
+        ious = bbox_overlaps(pred, target, is_aligned=True).clamp(min=1e-6 if eps is None else eps)
+        loss = 1 - ious if linear else -ious.log()
+    elif kind == 'giou':
+        loss = 1 - bbox_overlaps(pred, target, mode='giou', is_aligned=True, eps=1e-7 if eps is None else eps)
+    else:
+        e = 1e-7 if eps is None else eps
+        lt = torch.max(pred[:, :2], target[:, :2])
+        rb = torch.min(pred[:, 2:], target[:, 2:])
+        wh = (rb - lt).clamp(min=0)
+        overlap = wh[:, 0] * wh[:, 1]
+        ap = (pred[:, 2] - pred[:, 0]) * (pred[:, 3] - pred[:, 1])
+        ag = (target[:, 2] - target[:, 0]) * (target[:, 3] - target[:, 1])
+        ious = overlap / (ap + ag - overlap + e)
+        x1y1 = torch.min(pred[:, :2], target[:, :2])
+        x2y2 = torch.max(pred[:, 2:], target[:, 2:])
+        ewh = (x2y2 - x1y1).clamp(min=0)
+        c2 = ewh[:, 0] ** 2 + ewh[:, 1] ** 2 + e
+        left = ((target[:, 0] + target[:, 2]) - (pred[:, 0] + pred[:, 2])) ** 2 / 4
+        right = ((target[:, 1] + target[:, 3]) - (pred[:, 1] + pred[:, 3])) ** 2 / 4
+        rho2 = left + right
+        if kind == 'diou':
+            loss = 1 - (ious - rho2 / c2)
+        else:
+            w1, h1 = pred[:, 2] - pred[:, 0], pred[:, 3] - pred[:, 1] + e
+            w2, h2 = target[:, 2] - target[:, 0], target[:, 3] - target[:, 1] + e
+            v = 4 / math.pi ** 2 * torch.pow(torch.atan(w2 / h2) - torch.atan(w1 / h1), 2)
+            loss = 1 - (ious - (rho2 / c2 + v ** 2 / (1 - ious + v)))
+    return weight_reduce_loss(loss, weight, 'mean', avg_factor)
+
+
 def retina_loss(cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, anchor_generator, num_classes,
-                assigner=None, gamma=2.0, alpha=0.25):
+                assigner=None, gamma=2.0, alpha=0.25, box_loss='l1'):
     """AnchorHead.loss (anchor_head.py:425-493) for RetinaHead: FocalLoss + L1Loss, avg_factor = sum max(#pos, 1)."""
     assigner = assigner or MaxIoUAssigner(0.5, 0.4, min_pos_iou=0, ignore_iof_thr=-1)
     featmap_sizes = [c.size()[-2:] for c in cls_scores]
@@ -182,7 +225,8 @@ def retina_loss(cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, anchor_
     per_img = []
     for i, meta in enumerate(img_metas):
         flags = torch.cat(anchor_generator.valid_flags(featmap_sizes, meta['pad_shape']))
-        per_img.append(get_targets_single(flat, flags, gt_bboxes[i], gt_labels[i], meta, num_classes, assigner))
+        per_img.append(get_targets_single(flat, flags, gt_bboxes[i], gt_labels[i], meta, num_classes, assigner,
+                                          reg_decoded_bbox=box_loss != 'l1'))
     num_total_pos = sum(max(r[4].numel(), 1) for r in per_img)
 
     def to_levels(k):
@@ -198,5 +242,11 @@ def retina_loss(cls_scores, bbox_preds, gt_bboxes, gt_labels, img_metas, anchor_
         cls = cls.permute(0, 2, 3, 1).reshape(-1, num_classes)
         losses_cls.append(focal_loss_labels(cls, lab.reshape(-1), lw.reshape(-1), gamma, alpha, 'mean', num_total_pos))
         reg = reg.permute(0, 2, 3, 1).reshape(-1, 4)
-        losses_bbox.append(l1_loss(reg, bt.reshape(-1, 4), bw.reshape(-1, 4), 'mean', num_total_pos))
+        if box_loss == 'l1':
+            losses_bbox.append(l1_loss(reg, bt.reshape(-1, 4), bw.reshape(-1, 4), 'mean', num_total_pos))
+        else:                                                # reg_decoded_bbox, anchor_head.py:404-409
+            from .bbox import delta2bbox
+            anc = anchors[len(losses_bbox)].repeat(cls_scores[0].shape[0], 1)
+            dec = delta2bbox(anc, reg, max_shape=None)
+            losses_bbox.append(iou_family_loss(box_loss, dec, bt.reshape(-1, 4), bw.reshape(-1, 4), num_total_pos))
     return dict(loss_cls=losses_cls, loss_bbox=losses_bbox)
