@@ -335,8 +335,8 @@ int llv_multiclass_nms_batched_sf(const float* boxes, const float* scores, const
  *   dw     fp32, the packed weight layout [groups][w_rows][k_pad]; ACCUMULATED into (fp32 atomics): zero it first
  *   db     optional fp32 [groups*cout]: db[g*cout + co] += sum_p dy[p][g*cout + co] (the bias / BN-shift gradient,
  *          formed by one extra MFMA against a ones operand in the workgroups that already hold the dY tiles)
- * dgrad has no entry point of its own: it is llv_conv2d_nhwc_fwd on re-packed weights (flipped taps, in/out
- * transposed; stride 2 as a 2x2 convolution + PixelShuffle), see ops.pack_dgrad in the Python host. */
+ * dgrad (below) is llv_conv2d_nhwc_fwd on re-packed weights (flipped taps, in/out transposed; stride 2 as a small
+ * stride-1 window + PixelShuffle). */
 int llv_conv2d_nhwc_wgrad(const llv_conv_desc* d, const void* dy, int dy_ld, float* dw, float* db, void* stream);
 
 /* Once per optimizer step: module parameters (fp32, torch's (Cout, Cin, kh, kw)) -> the fp16 layouts the conv kernels read,
@@ -357,6 +357,15 @@ int llv_fold_bias(const float* b, const float* gamma, const float* beta, const f
 int llv_unpack_wgrad(const float* dw, const float* db, const float* w, const float* gamma, const float* mean, const float* var,
                      float eps, float* gw, float* ggamma, float* gbeta, float* gbias, int cout, int cin, int kh, int kw,
                      int cpad, int k_pad, void* stream);
+
+/* dx (+)= data gradient of the convolution described by `fwd` (its x/w/y pointers are not read; geometry, groups, batch and
+ * segments are). w_dgrad: filter packed by llv_pack_conv_weights mode 1 (stride 1) or 2 (stride 2) with wd_rows x wd_k_pad,
+ * window kh x kw and padding `pad` (backward.dgrad_geometry); zero_bias: fp32 zeros, one per output row; dy / dx fp16 NHWC with
+ * row strides dy_ld / dx_ld; accumulate != 0 adds to dx in place. Stride 1 and 2, one source; stride 2 one segment per call.
+ * Workspace as for llv_conv2d_nhwc_fwd (NULL: the launch must not need split-K). */
+int llv_conv2d_nhwc_dgrad(const llv_conv_desc* fwd, const void* w_dgrad, const float* zero_bias, int wd_rows, int wd_k_pad,
+                          int kh, int kw, int pad, const void* dy, int dy_ld, void* dx, int dx_ld, int accumulate,
+                          void* workspace, size_t workspace_bytes, void* stream);
 
 /* dx = (dy [+ dy2]) * (y > 0); dy2 and y may be NULL (then: plain sum / plain copy). n fp16 elements, multiple of 8.
  * torch autograd of F.relu(x [+ identity]) (resnet.py:292-296). */

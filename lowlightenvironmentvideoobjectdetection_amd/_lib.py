@@ -131,6 +131,7 @@ SIGNATURES = {
     'llv_iou_assign_workspace_bytes': (_Z, [_I, _L]),
     'llv_iou_assign': (_I, [_P, _I, _P, _P, _L, _F, _F, _F, _I, _I, _P, _P, _P, _Z, _P]),
     'llv_conv2d_nhwc_wgrad': (_I, [C.POINTER(ConvDesc), _P, _I, _P, _P, _P]),
+    'llv_conv2d_nhwc_dgrad': (_I, [C.POINTER(ConvDesc), _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _Z, _P]),
     'llv_pack_conv_weights': (_I, [_P, _P, _P, _F, _P] + [_I] * 13 + [_P]),
     'llv_fold_bias': (_I, [_P, _P, _P, _P, _P, _F, _P, _I, _P]),
     'llv_unpack_wgrad': (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),

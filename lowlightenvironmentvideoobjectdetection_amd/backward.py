@@ -128,22 +128,28 @@ def sgd_momentum(w: torch.Tensor, g: torch.Tensor, mom: torch.Tensor, lr: float,
 
 
 def conv_dgrad(dy: torch.Tensor, pcd: ops.PackedConv, dx: torch.Tensor, batch: int, segs, dy_ld: int, dx_ld: int,
-               flags: int, accumulate: bool, in_hw=None):
-    """dX (+)= dgrad conv of dY. segs: forward segments (h, w, ho, wo, x_off, y_off); the launch swaps the roles.
-    PixelShuffle (stride-2) launches crop to the forward input size."""
-    bsegs = []
-    for (h, w, ho, wo, xo, yo) in segs:
-        if flags & CONV_PIXSHUF:
-            bsegs.append((ho, wo, (h + 1) // 2, (w + 1) // 2, yo, xo))
-        else:
-            bsegs.append((ho, wo, h, w, yo, xo))
-    f = flags | (CONV_RES_ADD if accumulate else 0)
-    ps = (segs[0][0], segs[0][1]) if flags & CONV_PIXSHUF else (0, 0)
-    if flags & CONV_PIXSHUF:
-        assert len(segs) == 1, 'stride-2 data gradient is launched per level'
-    d = ops.make_conv_desc(pcd, [dy], dx, batch, bsegs, dy_ld, dx_ld, dx if accumulate else None, dx_ld if accumulate else 0, f,
-                           ps_out=ps)
-    ops.launch_conv(d)
+               flags: int, accumulate: bool, in_hw=None, fwd_stride: int = None, fwd_cin: int = None):
+    """dX (+)= data gradient through llv_conv2d_nhwc_dgrad. segs: the FORWARD launch's segments (h, w, ho, wo, x_off, y_off);
+    pcd: the filter packed for the gradient (dgrad_weight / llv_pack_conv_weights modes 1, 2). flags: CONV_PIXSHUF for a
+    stride-2 forward conv."""
+    s2 = bool(flags & CONV_PIXSHUF)
+    f = ConvDesc()
+    f.n_src, f.n_seg = 1, len(segs)
+    f.stride = 2 if s2 else 1
+    f.cin = pcd.cout // 4 if s2 else pcd.cout
+    f.groups, f.batch = pcd.groups, batch
+    for s, (h, w, ho, wo, xo, yo) in enumerate(segs):
+        f.seg_h[s], f.seg_w[s], f.seg_ho[s], f.seg_wo[s], f.seg_xoff[s], f.seg_yoff[s] = h, w, ho, wo, xo, yo
+    # split-K workspace of the underlying forward launch, if the planner wants one
+    probe = ops.make_conv_desc(pcd, [dy], dx, batch,
+                               [((ho, wo, (h + 1) // 2, (w + 1) // 2, yo, xo) if s2 else (ho, wo, h, w, yo, xo)) for (h, w, ho, wo, xo, yo) in segs],
+                               dy_ld, dx_ld, dx if accumulate else None, dx_ld if accumulate else 0,
+                               flags | (CONV_RES_ADD if accumulate else 0), ps_out=(segs[0][0], segs[0][1]) if s2 else (0, 0))
+    wsb = ops.conv_workspace_bytes(probe)
+    ws = torch.empty((wsb,), device=dy.device, dtype=torch.uint8) if wsb else None
+    check(lib().llv_conv2d_nhwc_dgrad(C.byref(f), pcd.w.data_ptr(), pcd.bias.data_ptr(), pcd.w_rows, pcd.k_pad, pcd.kh, pcd.kw, pcd.pad,
+                                      dy.data_ptr(), dy_ld, dx.data_ptr(), dx_ld, 1 if accumulate else 0,
+                                      ws.data_ptr() if ws is not None else None, wsb, _stream()), 'llv_conv2d_nhwc_dgrad')
 
 
 def _p(t):

@@ -535,3 +535,34 @@ extern "C" int llv_unpack_wgrad(const float* dw, const float* db, const float* w
     hipLaunchKernelGGL(unpack_wgrad_kernel, dim3(cout), dim3(256), 0, (hipStream_t)stream, a);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
+
+// Data gradient of a convolution = llv_conv2d_nhwc_fwd over dY with the re-packed filter (llv_pack_conv_weights mode 1 / 2).
+// This entry point only builds that launch from the FORWARD descriptor: segments swap roles (dY is the input, dX the
+// output), a stride-2 convolution becomes the KHxKW stride-1 window + PixelShuffle cropped to the forward input size.
+extern "C" int llv_conv2d_nhwc_dgrad(const llv_conv_desc* fwd, const void* w_dgrad, const float* zero_bias, int wd_rows, int wd_k_pad,
+                                     int kh, int kw, int pad, const void* dy, int dy_ld, void* dx, int dx_ld, int accumulate,
+                                     void* workspace, size_t workspace_bytes, void* stream) {
+    if (!fwd || !w_dgrad || !zero_bias || !dy || !dx || fwd->n_src != 1 || fwd->n_seg < 1 || fwd->n_seg > LLV_MAX_SEG) return LLV_E_BADARG;
+    if (fwd->stride != 1 && fwd->stride != 2) return LLV_E_UNSUPPORTED;
+    const bool s2 = fwd->stride == 2;
+    if (s2 && fwd->n_seg != 1) return LLV_E_UNSUPPORTED;
+    llv_conv_desc d = {};
+    d.x[0] = dy; d.w = w_dgrad; d.bias = zero_bias; d.y = dx;
+    d.res = accumulate ? dx : nullptr;
+    d.n_src = 1; d.x_ld = dy_ld; d.y_ld = dx_ld; d.res_ld = accumulate ? dx_ld : 0;
+    d.cin = dy_ld / fwd->groups;                     // channel pitch of one group inside dY
+    d.cout = s2 ? 4 * fwd->cin : fwd->cin;
+    d.w_rows = wd_rows; d.k_pad = wd_k_pad;
+    d.kh = kh; d.kw = kw; d.stride = 1; d.pad = pad; d.groups = fwd->groups; d.batch = fwd->batch;
+    d.n_seg = fwd->n_seg;
+    for (int s = 0; s < fwd->n_seg; ++s) {
+        d.seg_h[s] = fwd->seg_ho[s]; d.seg_w[s] = fwd->seg_wo[s];
+        d.seg_ho[s] = s2 ? (fwd->seg_h[s] + 1) / 2 : fwd->seg_h[s];
+        d.seg_wo[s] = s2 ? (fwd->seg_w[s] + 1) / 2 : fwd->seg_w[s];
+        d.seg_xoff[s] = fwd->seg_yoff[s]; d.seg_yoff[s] = fwd->seg_xoff[s];
+    }
+    d.flags = (s2 ? LLV_CONV_PIXSHUF : 0) | (accumulate ? LLV_CONV_RES_ADD : 0);
+    if (s2) { d.ps_out_h = fwd->seg_h[0]; d.ps_out_w = fwd->seg_w[0]; }
+    d.workspace = workspace; d.workspace_bytes = workspace_bytes;
+    return llv_conv2d_nhwc_fwd(&d, stream);
+}
