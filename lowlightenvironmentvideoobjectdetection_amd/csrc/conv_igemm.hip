@@ -1912,9 +1912,9 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
     if (has_next) {
         nxt = tile_of(vn);
         set_pvo(nxt);
-        issue_w1(0);
+        if (G > 1) issue_w1(0);          // one group (OutputCvBlock): both weight images stay resident in LDS across tiles
         issue_patch(0, 0);
-        issue_w0(0, 0);
+        if (G > 1) issue_w0(0, 0);
     }
 
     // ---- epilogue through an LDS tile in the halo buffer
