@@ -1830,6 +1830,9 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
 #pragma unroll 1
     for (;;) {
     const int tx0 = cur.tx0, ty0 = cur.ty0, n = cur.n;
+    const int vn = v + gridDim.x;
+    const bool has_next = vn < h.nblk;
+    const Tile nxt = has_next ? tile_of(vn) : cur;
     const unsigned inside = inside_of(cur);
     const bool border = ty0 == 0 || tx0 == 0 || ty0 + HALO_TH >= H || tx0 + HALO_TW >= W;   // halo leaves the image
     f32x4 acc[TN2][TM];
@@ -1885,6 +1888,12 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
         if (g + 1 < G) {
             issue_patch(g + 1, (g + 1) & (NPB - 1));
             issue_w0(g + 1, (g + 1) & (NPB - 1));
+        } else if (has_next) {
+            // last group: patch / first-conv buffer 0 is free again, so the NEXT tile's first patch (and first-conv weights)
+            // stream in under this group's second conv and the epilogue
+            set_pvo(nxt);
+            issue_patch(0, 0);
+            if (G > 1) issue_w0(0, 0);
         }
         // ---- stage B: second conv, chunk g
         const unsigned char* sH = smem + O_HALO;
@@ -1905,17 +1914,9 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
     }
     __syncthreads();         // every wave is done with the patch / weight buffers and the halo
 
-    // the next tile's first loads go out now and land under this tile's epilogue
-    const int vn = v + gridDim.x;
-    const bool has_next = vn < h.nblk;
-    Tile nxt = cur;
-    if (has_next) {
-        nxt = tile_of(vn);
-        set_pvo(nxt);
-        if (G > 1) issue_w1(0);          // one group (OutputCvBlock): both weight images stay resident in LDS across tiles
-        issue_patch(0, 0);
-        if (G > 1) issue_w0(0, 0);
-    }
+    // the next tile's second-conv weights can only follow this tile's last second conv; with one group (OutputCvBlock) both
+    // weight images simply stay resident in LDS across tiles
+    if (has_next && G > 1) issue_w1(0);
 
     // ---- epilogue through an LDS tile in the halo buffer
     const int ybase = a.seg_yoff[0] + n * H * W;
