@@ -296,6 +296,9 @@ def main():
     ap.add_argument('--height', type=int, default=720)
     ap.add_argument('--width', type=int, default=1280)
     ap.add_argument('--no-graph', action='store_true')
+    ap.add_argument('--pipeline', type=int, default=1,
+                    help='1: two-stage software pipeline (FastDVDnet of step i || detector of step i-1 on two HIP streams); '
+                         '0: the two halves of a step back to back on one stream')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-latency-mode', action='store_true')
@@ -336,11 +339,10 @@ def main():
     clip, img_shape, pad_shape = data.preprocess_clip_device(dark.to(torch.uint8).to(dev))
     hp, wp = pad_shape[0], pad_shape[1]
 
-    def make_plan():
-        return engine.EnhanceDetectPlan(cleaner.state_dict(), det.state_dict(), NUM_CLASSES, B, hp, wp, dev,
-                                        detector_kwargs=dict(test_cfg=dict(det.bbox_head.test_cfg),
-                                                             img_shapes=[img_shape] * B),
-                                        use_graph=not args.no_graph)
+    def make_plan(cls=engine.EnhanceDetectPlan):
+        return cls(cleaner.state_dict(), det.state_dict(), NUM_CLASSES, B, hp, wp, dev,
+                   detector_kwargs=dict(test_cfg=dict(det.bbox_head.test_cfg), img_shapes=[img_shape] * B),
+                   use_graph=not args.no_graph)
     # one pass with the raw seeded weights, then give the head trained-detector-like statistics so that a
     # few thousand candidates pass score_thr and NMS has real work ("busy" variant)
     plan = make_plan()
@@ -349,7 +351,7 @@ def main():
     torch.cuda.synchronize()
     calibrate_head_on_device(det, plan.det, target_cls_mean=-6.0, target_cls_std=1.3)
     del plan
-    plan = make_plan()
+    plan = make_plan(engine.PipelinedEnhanceDetectPlan if args.pipeline else engine.EnhanceDetectPlan)
     plan.prepare(clip)
     n_windows = T - B + 1
 
@@ -373,7 +375,12 @@ def main():
         tt = torch.tensor([dt], device=dev, dtype=torch.float64)
         dist.all_reduce(tt, op=dist.ReduceOp.MAX)
         dt = float(tt.item())
+    # pipelined: every timed step ran one FastDVDnet pass and one detector pass (of the window before it); the detector pass
+    # of the last window follows here, outside the timed region, as the first timed step's one lay inside it
+    if args.pipeline:
+        plan.flush()
     n_det = sum(len(d) for d, _ in plan.results())
+    last = plan.p[plan._i & 1] if args.pipeline else plan
     # batch-1 latency mode (the reference's per-frame protocol: 3 temp1 + 1 temp2 DenBlocks per frame)
     lat = None
     if rank == 0 and world == 1 and B != 1 and not args.no_latency_mode:
@@ -393,7 +400,7 @@ def main():
         lat = {'frames_per_step': 1, 'frames': nlat, 'denblocks_per_frame': 4, 'value': round(nlat / d1, 3), 'unit': 'frames/s',
                'ms_per_frame': round(d1 / nlat * 1e3, 4), 'algorithmic_gflop_per_frame': round(p1.plan.flops / 1e9, 1)}
         del p1
-    n_cand_thr = int((plan.det.post.dp.scores.reshape(B, -1)[0] > 0.05).sum().item())
+    n_cand_thr = int((last.det.post.dp.scores.reshape(B, -1)[0] > 0.05).sum().item())
 
     out = None
     if rank == 0:
@@ -408,6 +415,8 @@ def main():
                             f'{args.width}x{args.height} clip (padded {wp}x{hp}), {NUM_CLASSES} classes, 1xMI355X per rank',
                 'clip_frames': T, 'frames_per_step': B, 'denblocks_per_frame': round((2 * B + 2) / B, 3),
                 'hip_graph': not args.no_graph,
+                'pipeline': ('2-stage: FastDVDnet(step i) || detector(step i-1) on two HIP streams, one graph per step'
+                             if args.pipeline else 'none'),
                 'algorithmic_gflop_per_frame': round(flops_step / B / 1e9, 1),
                 'candidates_above_score_thr': n_cand_thr, 'detections_last_step': n_det,
                 'parallelism': f'clip-sharded x{world}, no data-path collective',

@@ -581,15 +581,24 @@ class EnhanceDetectPlan:
         self.cnt_host = torch.zeros((batch,), dtype=torch.int32).pin_memory()
         self._graph = None
 
-    def _body(self, window):
+    def _enhance(self, window):
+        """FastDVDnet half of a step: the clip window -> denoised frames in the detector's input buffer."""
         self.den.frames.copy_(window)
-        self.plan.run()
+        self.den.plan.run()
+
+    def _detect(self):
+        """Detector half of a step: backbone .. NMS on the denoised frames, results into pinned host memory."""
+        self.det.plan.run()
         nb = self.det.post.nb
         self.res_dev[:, :, :5].copy_(nb.dets.reshape(self.batch, -1, 5))
         self.res_dev[:, :, 5].copy_(nb.labels.reshape(self.batch, -1))
         self.cnt_dev.copy_(nb.count)
         self.res_host.copy_(self.res_dev, non_blocking=True)
         self.cnt_host.copy_(self.cnt_dev, non_blocking=True)
+
+    def _body(self, window):
+        self._enhance(window)
+        self._detect()
 
     def prepare(self, clip):
         """Warm up once (one-time kernel attribute calls) and capture the step into a HIP graph."""
@@ -619,6 +628,75 @@ class EnhanceDetectPlan:
             r = self.res_host[n, :k]
             out.append((r[:, :5].clone(), r[:, 5].long()))
         return out
+
+
+class PipelinedEnhanceDetectPlan:
+    """EnhanceDetectPlan as a two-stage software pipeline over consecutive steps of a clip.
+
+    A step's two halves depend on each other only through the denoised frames, so step i launches
+    FastDVDnet on window i and, on a second HIP stream, the detector (backbone .. NMS .. D2H) on the frames
+    window i-1 produced. The detector's small and latency-bound launches (layer4, P6/P7, top-k select, NMS) then
+    fill the chip together with FastDVDnet's large ones instead of each draining it. Two complete plans with their
+    own buffers alternate (step i enhances into plan i%2, detects from plan (i-1)%2): no copy, no false dependence.
+    Both halves of a step are captured into one HIP graph with two branches (fork / join through stream waits).
+
+    Every frame still takes exactly the launches of EnhanceDetectPlan; results of window i are available after
+    step i+1 (`results()` returns those of the window detected by the last step)."""
+
+    def __init__(self, cleaner_sd, detector_sd, num_classes, batch, height, width, device, detector_kwargs=None,
+                 use_graph=True):
+        self.batch, self.dev, self.use_graph = batch, device, use_graph
+        self.p = [EnhanceDetectPlan(cleaner_sd, detector_sd, num_classes, batch, height, width, device,
+                                    detector_kwargs=detector_kwargs, use_graph=False) for _ in range(2)]
+        self.den, self.det, self.plan = self.p[0].den, self.p[0].det, self.p[0].plan    # launch tables (for timing / flops)
+        self.side = torch.cuda.Stream(device)
+        self._graphs = [None, None]
+        self._i = 0
+
+    def _body(self, k):
+        """enhance(window k) -> plan k on the current stream  ||  detect(plan 1-k) on the side stream."""
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            self.p[1 - k]._detect()
+        self.p[k]._enhance(self._windows[k])
+        main.wait_stream(self.side)
+
+    def prepare(self, clip):
+        b = self.batch
+        self._windows = [torch.empty_like(self.p[0].den.frames) for _ in range(2)]
+        for k in range(2):
+            self._windows[k].copy_(clip[:b + 4])
+        for k in range(2):                     # warm-up outside capture (one-time kernel attribute calls), fills both plans
+            self._body(k)
+        torch.cuda.synchronize()
+        if self.use_graph:
+            for k in range(2):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._body(k)
+                self._graphs[k] = g
+        self._i = 0
+
+    def step(self, clip, t0):
+        """Enqueue: enhance window t0 and detect the previous step's window (no host sync)."""
+        k = self._i & 1
+        self._windows[k].copy_(clip[t0:t0 + self.batch + 4])
+        if self._graphs[k] is not None:
+            self._graphs[k].replay()
+        else:
+            self._body(k)
+        self._i += 1
+
+    def flush(self):
+        """Detect the window the last step enhanced (drains the pipeline); its results are then current."""
+        k = self._i & 1
+        self.p[1 - k]._detect()
+        self._i += 1
+
+    def results(self):
+        """Detections of the window most recently detected."""
+        return self.p[self._i & 1].results()
 
 
 # ------------------------------------------------------------------------------------------------

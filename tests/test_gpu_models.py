@@ -170,3 +170,41 @@ def test_retinanet_batch_of_images_matches_single_image_runs(dev):
         assert sum(len(r) for r in res_1) > 5
         for a, b in zip(res_b[i], res_1):
             assert a.shape == b.shape and np.array_equal(a, b)
+
+
+@pytest.mark.parametrize('use_graph', [False, True])
+def test_pipelined_enhance_detect_equals_sequential(dev, use_graph):
+    """The two-stage software pipeline (FastDVDnet of step i || detector of step i-1 on two HIP streams, two branches of
+    one HIP graph) returns, window by window, bit-identical detections to the one-stream plan: same launches, same
+    buffers contents, only their placement in time differs."""
+    reg = _registry()
+    from lowlightenvironmentvideoobjectdetection_amd import engine, ops
+    from lowlightenvironmentvideoobjectdetection_amd.synthetic import seeded_weights
+    ncls, h, w, B, T = 4, 64, 96, 2, 8
+    det = seeded_weights(reg.build_detector(retinanet_cfg(num_classes=ncls)), seed=31, cls_bias=-1.0)
+    cleaner = seeded_weights(reg.build_cleaner(dict(type='FastDVDnet')), seed=32)
+    g = torch.Generator().manual_seed(33)
+    frames = smooth_image(T + 4, h, w, seed=34) + 0.2 * torch.randn(T + 4, 3, h, w, generator=g)
+    clip = ops.pack_input(frames.to(dev), 8)
+    kw = dict(detector_kwargs=dict(test_cfg=dict(det.bbox_head.test_cfg)), use_graph=use_graph)
+    seq = engine.EnhanceDetectPlan(cleaner.state_dict(), det.state_dict(), ncls, B, h, w, dev, **kw)
+    pipe = engine.PipelinedEnhanceDetectPlan(cleaner.state_dict(), det.state_dict(), ncls, B, h, w, dev, **kw)
+    seq.prepare(clip)
+    pipe.prepare(clip)
+    starts = [0, 2, 4, 6, 1, 5]
+    ref = []
+    for t0 in starts:
+        seq.step(clip, t0)
+        ref.append([(d.clone(), l.clone()) for d, l in seq.results()])
+    assert sum(len(d) for r in ref for d, _ in r) > 20
+    got = []
+    for i, t0 in enumerate(starts):
+        pipe.step(clip, t0)
+        if i > 0:
+            got.append([(d.clone(), l.clone()) for d, l in pipe.results()])
+    pipe.flush()
+    got.append([(d.clone(), l.clone()) for d, l in pipe.results()])
+    assert len(got) == len(ref)
+    for r, q in zip(ref, got):
+        for (d0, l0), (d1, l1) in zip(r, q):
+            assert torch.equal(d0, d1) and torch.equal(l0, l1)
