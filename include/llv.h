@@ -37,6 +37,8 @@
  *   llv_flow_warp            flow_warp_feats, mmtracking/mmtrack/core/motion/flow.py:4-41
  *   llv_sigmoid_focal_loss_* mmcv.ops.sigmoid_focal_loss fwd/bwd, call site
  *                            mmdetection/mmdet/models/losses/focal_loss.py:59-98
+ *   llv_eval_tpfp            tpfp_default / tpfp_imagenet of eval_map,
+ *                            mmdetection/mmdet/core/evaluation/mean_ap.py:60-244, bbox_overlaps.py:4-48
  *   llv_iou_assign           MaxIoUAssigner.assign + bbox_overlaps,
  *                            mmdetection/mmdet/core/bbox/assigners/max_iou_assigner.py:60-212,
  *                            mmdetection/mmdet/core/bbox/iou_calculators/iou2d_calculator.py:43-159
@@ -297,6 +299,17 @@ int llv_iou_assign(const float* gt, int k, const float* anchors, const uint8_t* 
                    float pos_iou_thr, float neg_iou_thr, float min_pos_iou, int match_low_quality,
                    int gt_max_assign_all, int64_t* assigned_gt_inds, float* max_overlaps, void* workspace,
                    size_t workspace_bytes, void* stream);
+
+/* True/false-positive marking of eval_map (mean_ap.py:268-400 calls tpfp_default :154-244 or, for datasets 'det'/'vid',
+ * tpfp_imagenet :60-151 once per class and image): all (class, image) cells in one launch, one wavefront per cell.
+ * dets [total_dets][5] fp32 (x1,y1,x2,y2,score); cell c owns dets[det_off[c] .. det_off[c+1]) and gts[gt_off[c] .. gt_off[c+1])
+ * (gts [total_gts][4] fp32: the cell's `bboxes` followed by its `bboxes_ignore`, gt_ignore[j] = 1 for the latter; may be NULL).
+ * area_ranges [n_ranges][2] double (min_area, max_area), n_ranges = 0: no area limits. mode 0 = default, 1 = imagenet.
+ * tp, fp: [max(n_ranges,1)][total_dets] uint8. Score ties are taken lower index first. At most 2048 detections and 4096
+ * ground-truth boxes per cell (LLV_E_UNSUPPORTED beyond; the caller passes the maxima of its offsets). */
+int llv_eval_tpfp(const float* dets, const int* det_off, const float* gts, const int* gt_off, const uint8_t* gt_ignore,
+                  int n_cells, int max_det_per_cell, int max_gt_per_cell, const double* area_ranges, int n_ranges,
+                  float iou_thr, int mode, int64_t total_dets, uint8_t* tp, uint8_t* fp, void* stream);
 
 /* Test-time image pipeline of the reference in one pass:
  * SeqBrighten (mmtracking/mmtrack/datasets/pipelines/transforms.py:376-432: one gain amp = m*h*w*3 / sum(frame0/255) for the
