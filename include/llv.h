@@ -37,6 +37,8 @@
  *   llv_flow_warp            flow_warp_feats, mmtracking/mmtrack/core/motion/flow.py:4-41
  *   llv_sigmoid_focal_loss_* mmcv.ops.sigmoid_focal_loss fwd/bwd, call site
  *                            mmdetection/mmdet/models/losses/focal_loss.py:59-98
+ *   llv_modulated_deform_im2col  column step of mmcv.ops.modulated_deform_conv2d (mmcv-full 1.3.0, un-vendored; call site
+ *                            mmtracking/mmtrack/models/aggregators/denoising_aggregator.py:103-111), SURVEY.md 8f item 3
  *   llv_eval_tpfp            tpfp_default / tpfp_imagenet of eval_map,
  *                            mmdetection/mmdet/core/evaluation/mean_ap.py:60-244, bbox_overlaps.py:4-48
  *   llv_iou_assign           MaxIoUAssigner.assign + bbox_overlaps,
@@ -299,6 +301,17 @@ int llv_iou_assign(const float* gt, int k, const float* anchors, const uint8_t* 
                    float pos_iou_thr, float neg_iou_thr, float min_pos_iou, int match_low_quality,
                    int gt_max_assign_all, int64_t* assigned_gt_inds, float* max_overlaps, void* workspace,
                    size_t workspace_bytes, void* stream);
+
+/* Modulated deformable convolution, column step (ModulatedDCNPack.forward, denoising_aggregator.py:103-111 ->
+ * mmcv.ops.modulated_deform_conv2d): x (n,h,w,x_ld) NHWC fp16 (c channels used, c % 8 == 0, (c/deform_groups) % 8 == 0);
+ * om (n,ho,wo,om_ld) fp32 = the raw conv_offset output: channels [0, 2*dg*K) offsets, (g*K + k)*2 = dy, +1 = dx; channels
+ * [2*dg*K, 3*dg*K) mask logits (sigmoid applied here), K = kh*kw, k = i*kw + j.
+ * col (n,ho,wo,col_ld) fp16, channel k*c + ch = mask * bilinear(x[ch]; y*stride - pad + i*dilation + dy, ...) with mmcv's
+ * border rule (zero outside (-1, size); corners outside the image contribute zero). The convolution itself is then
+ * llv_conv2d_nhwc_fwd as a 1x1 conv over col with the kh x kw weight packed tap-major. */
+int llv_modulated_deform_im2col(const void* x, const float* om, void* col, int n, int h, int w, int c, int x_ld, int om_ld,
+                                int col_ld, int kh, int kw, int stride, int pad, int dilation, int deform_groups, int ho,
+                                int wo, void* stream);
 
 /* True/false-positive marking of eval_map (mean_ap.py:268-400 calls tpfp_default :154-244 or, for datasets 'det'/'vid',
  * tpfp_imagenet :60-151 once per class and image): all (class, image) cells in one launch, one wavefront per cell.

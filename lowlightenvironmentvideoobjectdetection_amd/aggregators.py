@@ -1,4 +1,6 @@
-"""EmbedAggregator with the reference's constructor and parameter names
+"""Aggregators with the reference's constructors and parameter names: EmbedAggregator and the authors' DenoisingAggregator.
+
+EmbedAggregator
 (mmtracking/mmtrack/models/aggregators/embed_aggregator.py:8-81). The embedding convs run on the conv kernel over
 key + references in one launch; the tail (L2-normalise over C, cosine, softmax over frames, weighted sum) is
 llv_embed_aggregate, one read of the reference stack."""
@@ -6,7 +8,9 @@ import torch
 import torch.nn as nn
 
 from . import engine, ops
-from ._lib import CONV_RELU
+import math
+
+from ._lib import CONV_OUT_F32, CONV_RELU, CONV_RES_ADD
 from .cnn import ConvModule
 from .planned import PlannedModule
 from .registry import AGGREGATORS
@@ -65,3 +69,151 @@ class EmbedAggregator(PlannedModule):
         ops.pack_input(torch.cat([x, ref_x], 0).float().contiguous(), cp, out=feat)
         plan.run()
         return ops.unpack_output(out, c)
+
+
+# ------------------------------------------------------------------------------------------------
+# DenoisingAggregator: residual dense blocks + DCN-based temporal attention fusion
+# mmtracking/mmtrack/models/aggregators/denoising_aggregator.py
+# ------------------------------------------------------------------------------------------------
+def _conv3(cin, cout, k=3):
+    return nn.Conv2d(cin, cout, kernel_size=k, padding=k // 2)
+
+
+class DenseLayer(nn.Module):
+    """denoising_aggregator.py:10-34 (parameter container: `conv`)."""
+
+    def __init__(self, in_channels, out_channels):
+        super().__init__()
+        self.conv = _conv3(in_channels, out_channels)
+
+
+class RDB(nn.Module):
+    """denoising_aggregator.py:37-66 (`layers.{i}.conv`, `lff`)."""
+
+    def __init__(self, in_channels, channel_growth, num_layers):
+        super().__init__()
+        self.layers = nn.Sequential(*[DenseLayer(in_channels + channel_growth * i, channel_growth) for i in range(num_layers)])
+        self.lff = nn.Conv2d(in_channels + channel_growth * num_layers, in_channels, kernel_size=1)
+
+
+class ModulatedDCNPack(nn.Module):
+    """denoising_aggregator.py:69-111 over mmcv's ModulatedDeformConv2d: `weight`, `bias`, `conv_offset`. Initialisation
+    as mmcv 1.3: weight uniform(+-1/sqrt(Cin*kh*kw)), bias zero, conv_offset zero (offsets 0, mask 0.5 at the start)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride=1, padding=0, dilation=1, groups=1, deform_groups=1,
+                 bias=True):
+        super().__init__()
+        if groups != 1 or stride != 1 or dilation != 1:
+            raise NotImplementedError('ModulatedDCNPack: the temporal fusion uses groups = stride = dilation = 1')
+        k = kernel_size if isinstance(kernel_size, int) else kernel_size[0]
+        self.in_channels, self.out_channels, self.kernel_size = in_channels, out_channels, (k, k)
+        self.stride, self.padding, self.dilation, self.groups, self.deform_groups = stride, padding, dilation, groups, deform_groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, k, k))
+        self.bias = nn.Parameter(torch.zeros(out_channels)) if bias else None
+        self.conv_offset = nn.Conv2d(in_channels, deform_groups * 3 * k * k, kernel_size=k, stride=stride, padding=padding, bias=True)
+        stdv = 1.0 / math.sqrt(in_channels * k * k)
+        nn.init.uniform_(self.weight, -stdv, stdv)
+        nn.init.constant_(self.conv_offset.weight, 0)
+        nn.init.constant_(self.conv_offset.bias, 0)
+
+
+class TemporalAttentionFusion(nn.Module):
+    """denoising_aggregator.py:114-152 (`conv1`, `offset_conv`, `dcn_pack`, `emb_conv.{i}`, `conv2`)."""
+
+    def __init__(self, channels, mid_channels, emb_nums=3):
+        super().__init__()
+        self.channels, self.mid_channels, self.emb_nums = channels, mid_channels, emb_nums
+        self.conv1 = _conv3(channels, mid_channels)
+        self.offset_conv = _conv3(mid_channels * 2, mid_channels)
+        self.dcn_pack = ModulatedDCNPack(mid_channels, mid_channels, 3, padding=1, deform_groups=8)
+        self.emb_conv = nn.Sequential(*[_conv3(mid_channels, mid_channels) for _ in range(emb_nums)])
+        self.conv2 = _conv3(mid_channels, channels)
+
+
+@AGGREGATORS.register_module()
+class DenoisingAggregator(PlannedModule):
+    """The authors' denoising aggregator (denoising_aggregator.py:155-200): conv1 -> residual dense blocks -> conv2 ->
+    TemporalAttentionFusion over the N frames of the batch -> conv3, with the two inner skips and the outer identity.
+
+    forward(x): x (N, C, H, W) fp32 NCHW on the GPU = the feature maps of N frames -> same shape. Every convolution is a
+    libllv.so launch (NHWC fp16, fp32 accumulate): the dense concatenations are channel slices of one buffer, the offset /
+    mask conv writes fp32, the deformable conv is llv_modulated_deform_im2col + the implicit-GEMM kernel, and the N x N
+    (reference frame, frame) pairs of the fusion loop (denoising_aggregator.py:139-149) are one batch of N*N images.
+    The element-wise glue (x_dcn * x_ref, softmax over frames, weighted sum) is torch on the device."""
+
+    def __init__(self, in_channels=64, mid_channels=64, num_blocks=1, num_layers=6, channel_growth=64, emb_nums=3,
+                 with_rdb=True, with_taf=True):
+        super().__init__()
+        if in_channels % 8 or mid_channels % 64 or channel_growth % 8:
+            raise NotImplementedError('DenoisingAggregator: channel counts must keep 8-channel vectors whole and each of '
+                                      'the 8 deformable groups a multiple of 8 channels')
+        self.in_channels, self.mid_channels, self.num_blocks, self.num_layers = in_channels, mid_channels, num_blocks, num_layers
+        self.channel_growth, self.emb_nums, self.with_rdb, self.with_taf = channel_growth, emb_nums, with_rdb, with_taf
+        self.conv1 = _conv3(in_channels, mid_channels)
+        if with_rdb:
+            self.rdbs = nn.Sequential(*[RDB(mid_channels, channel_growth, num_layers) for _ in range(num_blocks)])
+        self.conv2 = _conv3(mid_channels, mid_channels)
+        if with_taf:
+            self.taf = TemporalAttentionFusion(mid_channels, mid_channels=mid_channels, emb_nums=emb_nums)
+        self.conv3 = _conv3(mid_channels, in_channels)
+
+    def _packed(self, device):
+        def make():
+            sd = engine._cpu_sd(self.state_dict())
+            pk = {}
+            for name, w in sd.items():
+                if not name.endswith('.weight') or name == 'taf.dcn_pack.weight':
+                    continue
+                p = name[:-len('.weight')]
+                pk[p] = ops.pack_conv(w, sd.get(p + '.bias'), 1, (w.shape[-1] - 1) // 2).to(device)
+            if self.with_taf:
+                pk['taf.dcn_pack'] = ops.pack_dcn_weight(sd['taf.dcn_pack.weight'], sd.get('taf.dcn_pack.bias')).to(device)
+            return pk
+        return self._plan(('packed', str(device)), make)
+
+    def _rdb(self, pk, p, x):
+        n, h, w, c = x.shape
+        g, L = self.channel_growth, self.num_layers
+        cat = torch.empty((n, h, w, c + g * L), device=x.device, dtype=torch.float16)
+        cat[..., :c] = x
+        for l in range(L):
+            # DenseLayer: cat([x, relu(conv(x))]) -- the conv reads the first c + g*l channels, writes the next g
+            cin = c + g * l
+            y = ops.conv2d(cat[..., :cin].contiguous(), pk[f'{p}.layers.{l}.conv'], flags=CONV_RELU)
+            cat[..., cin:cin + g] = y
+        return ops.conv2d(cat, pk[p + '.lff'], res=x, flags=CONV_RES_ADD)          # x + lff(layers(x))
+
+    def _taf(self, pk, x):
+        n, h, w, _ = x.shape
+        m = self.mid_channels
+        x = ops.conv2d(x, pk['taf.conv1'], flags=CONV_RELU)
+        # pair (i, j): reference frame i, frame j -> batch index i*n + j (the loop over i of the reference, batched)
+        xj = x.unsqueeze(0).expand(n, n, h, w, m).reshape(n * n, h, w, m)
+        xi = x.unsqueeze(1).expand(n, n, h, w, m).reshape(n * n, h, w, m)
+        x_set = ops.conv2d(torch.cat([xj, xi], dim=-1), pk['taf.offset_conv'])
+        om = ops.conv2d(x_set, pk['taf.dcn_pack.conv_offset'], flags=CONV_OUT_F32)
+        x_dcn = ops.modulated_deform_conv2d(xj.contiguous(), om, pk['taf.dcn_pack'], 3, 3, 1, 1, 1, self.taf.dcn_pack.deform_groups)
+        x_cor = x_dcn * xi
+        for e in range(self.emb_nums):
+            x_cor = ops.conv2d(x_cor, pk[f'taf.emb_conv.{e}'])
+        att = torch.softmax(x_cor.view(n, n, h, w, m).float(), dim=1)             # over the frames j
+        fused = (att * x.unsqueeze(0).float()).sum(dim=1).half().contiguous()     # (n, h, w, m): one map per reference frame i
+        return ops.conv2d(fused, pk['taf.conv2'], flags=CONV_RELU)
+
+    def forward(self, x):
+        self._check_input(x)
+        n, c, h, w = x.shape
+        assert c == self.in_channels
+        pk = self._packed(x.device)
+        x0 = ops.pack_input(x.float().contiguous(), c)
+        t = ops.conv2d(x0, pk['conv1'], flags=CONV_RELU)
+        x_f = t
+        if self.with_rdb:
+            for b in range(self.num_blocks):
+                t = self._rdb(pk, f'rdbs.{b}', t)
+        t = ops.conv2d((t.float() + x_f.float()).half(), pk['conv2'], flags=CONV_RELU)
+        x_m = t
+        if self.with_taf:
+            t = self._taf(pk, t)
+        t = ops.conv2d((t.float() + x_m.float()).half(), pk['conv3'], flags=CONV_RELU)
+        return ops.unpack_output(t, c) + x

@@ -612,3 +612,35 @@ def pack_deconv4x4s2(weight: torch.Tensor, bias: Optional[torch.Tensor] = None, 
     pc = pack_conv(w3.float(), b3.float() if b3 is not None else None, 1, 1, in_map=in_map)
     pc.true_macs_per_pixel = cout * cin * 16 // 4 * 4   # per INPUT pixel: 16 taps x Cin x Cout (4 outputs x 4 taps each)
     return pc
+
+
+# ------------------------------------------------------------------------------------------------
+# modulated deformable convolution
+# ------------------------------------------------------------------------------------------------
+def pack_dcn_weight(weight: torch.Tensor, bias: Optional[torch.Tensor]) -> PackedConv:
+    """A (Co, C, kh, kw) deformable-conv weight as the 1x1 conv over the column tensor of llv_modulated_deform_im2col
+    (channel k*Cpad + c, k = i*kw + j): the same tap-major / channel-fastest order a kh x kw conv is packed in."""
+    co, c, kh, kw = weight.shape
+    cp = round_up(c, 8)
+    w = torch.zeros(co, kh * kw, cp, dtype=torch.float32)
+    w[:, :, :c] = weight.detach().float().cpu().permute(0, 2, 3, 1).reshape(co, kh * kw, c)
+    pc = pack_conv(w.reshape(co, kh * kw * cp, 1, 1), bias, 1, 0)
+    pc.true_macs_per_pixel = co * c * kh * kw
+    return pc
+
+
+def modulated_deform_conv2d(x: torch.Tensor, om: torch.Tensor, pc: PackedConv, kh=3, kw=3, stride=1, pad=1, dilation=1,
+                            deform_groups=1, flags: int = 0, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """mmcv.ops.modulated_deform_conv2d on NHWC fp16: x (n,h,w,c); om (n,ho,wo,>=3*dg*K) fp32, the raw conv_offset output
+    (offsets then mask logits, see include/llv.h); pc from pack_dcn_weight. Column step on llv_modulated_deform_im2col,
+    the GEMM on the implicit-GEMM conv kernel as a 1x1 conv."""
+    _need_gpu(x, om, pc.w, pc.bias)
+    assert x.dtype == torch.float16 and x.is_contiguous() and om.dtype == torch.float32 and om.is_contiguous()
+    n, h, w, c = x.shape
+    ho = (h + 2 * pad - (dilation * (kh - 1) + 1)) // stride + 1
+    wo = (w + 2 * pad - (dilation * (kw - 1) + 1)) // stride + 1
+    assert om.shape[:3] == (n, ho, wo)
+    col = torch.empty((n, ho, wo, kh * kw * c), device=x.device, dtype=torch.float16)
+    check(lib().llv_modulated_deform_im2col(_ptr(x), _ptr(om), _ptr(col), n, h, w, c, c, om.shape[3], col.shape[3], kh, kw, stride,
+                                            pad, dilation, deform_groups, ho, wo, _stream()), 'llv_modulated_deform_im2col')
+    return conv2d(col, pc, flags=flags, out=out)

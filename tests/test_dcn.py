@@ -1,0 +1,178 @@
+"""Modulated deformable convolution and the authors' DenoisingAggregator.
+
+CPU: properties that pin the oracle's restatement of mmcv's modulated_deform_conv2d (oracle/dcn.py; mmcv is un-vendored and
+no reference test holds a vector for it): unit mask + zero offsets = conv2d; integer offsets = conv2d of the shifted image;
+half-pixel offsets = conv2d of the two-neighbour average, zero-filled at the border; the mask scales per (group, tap).
+GPU: llv_modulated_deform_im2col + the implicit-GEMM kernel against the oracle; DenoisingAggregator.forward against the
+oracle's restatement of denoising_aggregator.py:186-200 (fp16 storage vs fp32: tolerances at the asserts)."""
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+from helpers import randomize
+
+
+def _shift(x, dy, dx):
+    """out[..., y, x] = x[..., y + dy, x + dx], zero outside."""
+    n, c, h, w = x.shape
+    out = torch.zeros_like(x)
+    ys, xs = slice(max(0, -dy), min(h, h - dy)), slice(max(0, -dx), min(w, w - dx))
+    out[:, :, ys, xs] = x[:, :, max(0, dy):max(0, dy) + (ys.stop - ys.start), max(0, dx):max(0, dx) + (xs.stop - xs.start)]
+    return out
+
+
+def test_oracle_dcn_reduces_to_conv2d():
+    from oracle.dcn import modulated_deform_conv2d
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(2, 16, 9, 11, generator=g)
+    w = torch.randn(12, 16, 3, 3, generator=g) * 0.1
+    b = torch.randn(12, generator=g)
+    dg, K = 4, 9
+    off = torch.zeros(2, 2 * dg * K, 9, 11)
+    one = torch.ones(2, dg * K, 9, 11)
+    torch.testing.assert_close(modulated_deform_conv2d(x, off, one, w, b, 1, 1, 1, 1, dg), F.conv2d(x, w, b, padding=1), rtol=1e-5, atol=1e-5)
+    # integer offsets, the same for every tap: the conv of the shifted image. Away from the border only: a tap that lies in
+    # the zero padding of the shifted image can, with its offset, land on a real pixel of the original.
+    off[:, 0::2] = 1.0
+    off[:, 1::2] = -2.0
+    a = modulated_deform_conv2d(x, off, one, w, b, 1, 1, 1, 1, dg)
+    torch.testing.assert_close(a[..., 2:-2, 3:-3], F.conv2d(_shift(x, 1, -2), w, b, padding=1)[..., 2:-2, 3:-3], rtol=1e-5, atol=1e-5)
+    # at the border the sample rule itself: output row 0, tap row 0 samples image row 0 - 1 + 0 + 1 = 0 (a real row), while
+    # output column 0, tap column 0 samples column -3: zero. One output by hand:
+    manual = b.clone()
+    for i in range(3):
+        for j in range(3):
+            yy, xx = 0 - 1 + i + 1, 0 - 1 + j - 2
+            if 0 <= yy < 9 and 0 <= xx < 11:
+                manual += w[:, :, i, j] @ x[0, :, yy, xx]
+    torch.testing.assert_close(a[0, :, 0, 0], manual, rtol=1e-5, atol=1e-5)
+    # half a pixel to the right: average of the image and its left-shifted copy
+    off[:, 0::2] = 0.0
+    off[:, 1::2] = 0.5
+    a = modulated_deform_conv2d(x, off, one, w, b, 1, 1, 1, 1, dg)
+    torch.testing.assert_close(a[..., :, 2:-2], F.conv2d(0.5 * (x + _shift(x, 0, 1)), w, b, padding=1)[..., :, 2:-2], rtol=1e-5, atol=1e-5)
+    # position W - 0.5 lies inside (-1, W): its right corner (column W) is outside and counts zero, the left one half
+    off[:, 1::2] = 0.0
+    off[:, 2 * 4 + 1] = 10.5 - torch.arange(11.0).view(1, 1, 11)          # centre tap of group 0 samples x = 10.5 everywhere
+    a = modulated_deform_conv2d(x, off, one, w, None, 1, 1, 1, 1, dg)
+    cg = 16 // dg
+    ref = F.conv2d(x, w, None, padding=1)
+    w_c = torch.zeros_like(w); w_c[:, :cg, 1, 1] = w[:, :cg, 1, 1]
+    xe = (0.5 * x[..., 10:11]).expand(-1, -1, -1, 11)
+    ref = ref - F.conv2d(x, w_c, None, padding=1) + F.conv2d(xe, w_c[:, :, 1:2, 1:2], None)
+    torch.testing.assert_close(a, ref, rtol=1e-5, atol=1e-5)
+    # stride 2, no padding, dilation 2, two weight groups
+    w2 = torch.randn(12, 8, 3, 3, generator=g) * 0.1
+    ho, wo = (9 - 5) // 2 + 1, (11 - 5) // 2 + 1
+    torch.testing.assert_close(modulated_deform_conv2d(x, torch.zeros(2, 2 * dg * K, ho, wo), torch.ones(2, dg * K, ho, wo), w2, None, 2, 0, 2, 2, dg),
+                               F.conv2d(x, w2, None, stride=2, dilation=2, groups=2), rtol=1e-5, atol=1e-5)
+
+
+def test_oracle_dcn_mask_and_group_layout():
+    """Mask channel g*K + k scales tap k of the channels of deformable group g only; offset channel (g*2K + 2k) is dy."""
+    from oracle.dcn import modulated_deform_conv2d
+    g = torch.Generator().manual_seed(1)
+    x = torch.randn(1, 8, 6, 7, generator=g)
+    w = torch.randn(5, 8, 3, 3, generator=g)
+    dg, K = 2, 9
+    off = torch.zeros(1, 2 * dg * K, 6, 7)
+    mask = torch.ones(1, dg * K, 6, 7)
+    mask[:, 1 * K + 4] = 0.0                       # centre tap of group 1 (channels 4..7) switched off
+    w_ref = w.clone()
+    w_ref[:, 4:, 1, 1] = 0.0
+    torch.testing.assert_close(modulated_deform_conv2d(x, off, mask, w, None, 1, 1, 1, 1, dg), F.conv2d(x, w_ref, None, padding=1), rtol=1e-5, atol=1e-5)
+    off[:, 0 * 2 * K + 2 * 0] = 1.0                # tap 0 of group 0 samples one row lower
+    xs = x.clone()
+    ref = F.conv2d(x, w_ref, None, padding=1)
+    w_tap = torch.zeros_like(w); w_tap[:, :4, 0, 0] = w[:, :4, 0, 0]
+    ref = ref - F.conv2d(x, w_tap, None, padding=1) + F.conv2d(_shift(xs, 1, 0), w_tap, None, padding=1)
+    torch.testing.assert_close(modulated_deform_conv2d(x, off, mask, w, None, 1, 1, 1, 1, dg)[..., 1:-1, :], ref[..., 1:-1, :], rtol=1e-5, atol=1e-5)
+
+
+def test_denoising_aggregator_builds_from_reference_cfg_with_reference_parameter_names():
+    import lowlightenvironmentvideoobjectdetection_amd.models  # noqa: F401
+    from lowlightenvironmentvideoobjectdetection_amd import registry
+    # insert_cfg of mmtracking/configs/vid/llvod/llvod_insert_plugins_l34_i1234_vid_a7s3.py:26
+    m = registry.build_aggregator(dict(type='DenoisingAggregator', in_channels=64, mid_channels=64, num_blocks=1, num_layers=3,
+                                       channel_growth=64, emb_nums=3, with_rdb=True, with_taf=True))
+    keys = set(m.state_dict())
+    for k in ['conv1.weight', 'rdbs.0.layers.2.conv.bias', 'rdbs.0.lff.weight', 'conv2.bias', 'taf.conv1.weight', 'taf.offset_conv.weight',
+              'taf.dcn_pack.weight', 'taf.dcn_pack.bias', 'taf.dcn_pack.conv_offset.weight', 'taf.emb_conv.2.bias', 'taf.conv2.weight',
+              'conv3.bias']:
+        assert k in keys, k
+    assert m.state_dict()['taf.dcn_pack.conv_offset.weight'].shape == (8 * 3 * 9, 64, 3, 3)
+    assert float(m.state_dict()['taf.dcn_pack.conv_offset.weight'].abs().max()) == 0.0     # init_offset: zeros
+    assert m.state_dict()['rdbs.0.lff.weight'].shape == (64, 64 + 3 * 64, 1, 1)
+    m2 = registry.build_aggregator(dict(type='DenoisingAggregator', in_channels=128, with_rdb=False, with_taf=False))
+    assert not any(k.startswith('rdbs') or k.startswith('taf') for k in m2.state_dict())
+
+
+# ---------------------------------------------------------------- GPU
+@pytest.mark.gpu
+@pytest.mark.parametrize('n,c,co,h,w,dg', [(2, 64, 64, 17, 23, 8), (1, 128, 72, 12, 40, 8), (3, 32, 16, 9, 10, 4)])
+def test_device_modulated_deform_conv_vs_oracle(dev, n, c, co, h, w, dg):
+    """Random offsets (sigma 2 px, some leave the image), random mask logits. fp16 storage of x / columns / weights against
+    the fp32 oracle on the fp16-rounded inputs: 3e-3 of the output scale."""
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    from oracle.dcn import modulated_deform_conv2d
+    g = torch.Generator().manual_seed(n * 100 + c)
+    K = 9
+    x = torch.randn(n, c, h, w, generator=g).half().float()
+    wgt = (torch.randn(co, c, 3, 3, generator=g) * (2.0 / (c * 9)) ** 0.5).half().float()
+    bias = torch.randn(co, generator=g) * 0.1
+    om = torch.cat([torch.randn(n, 2 * dg * K, h, w, generator=g) * 2.0, torch.randn(n, dg * K, h, w, generator=g)], 1)
+    ref = modulated_deform_conv2d(x, om[:, :2 * dg * K], torch.sigmoid(om[:, 2 * dg * K:]), wgt, bias, 1, 1, 1, 1, dg)
+    xd = ops.pack_input(x.to(dev), c)
+    omd = om.permute(0, 2, 3, 1).contiguous().to(dev)
+    pc = ops.pack_dcn_weight(wgt, bias).to(dev)
+    out = ops.modulated_deform_conv2d(xd, omd, pc, 3, 3, 1, 1, 1, dg)
+    got = ops.unpack_output(out, co).cpu()
+    err = (got - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 3e-3, err
+
+
+@pytest.mark.gpu
+def test_device_dcn_rejects_bad_geometry(dev):
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    from lowlightenvironmentvideoobjectdetection_amd._lib import LlvError
+    x = torch.zeros(1, 4, 4, 24, device=dev, dtype=torch.float16)
+    om = torch.zeros(1, 4, 4, 3 * 2 * 9, device=dev)
+    pc = ops.pack_dcn_weight(torch.zeros(8, 24, 3, 3), None).to(dev)
+    with pytest.raises(LlvError):            # 24 channels / 2 groups = 12: a lane's 8 channels would straddle two offset groups
+        ops.modulated_deform_conv2d(x, om, pc, 3, 3, 1, 1, 1, 2)
+
+
+def _aggregator(dev, **kw):
+    import lowlightenvironmentvideoobjectdetection_amd.models  # noqa: F401
+    from lowlightenvironmentvideoobjectdetection_amd import registry
+    m = randomize(registry.build_aggregator(dict(type='DenoisingAggregator', **kw)), seed=7)
+    with torch.no_grad():
+        if hasattr(m, 'taf'):
+            m.taf.dcn_pack.conv_offset.weight.mul_(0.25)      # offsets of about a pixel, mask logits O(1)
+            g = torch.Generator().manual_seed(8)
+            m.taf.dcn_pack.bias.copy_(torch.randn(m.taf.dcn_pack.bias.shape, generator=g) * 0.05)
+    return m
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('kw,n,h,w', [
+    (dict(in_channels=64, mid_channels=64, num_blocks=1, num_layers=3, channel_growth=64, emb_nums=3), 3, 20, 28),
+    (dict(in_channels=64, mid_channels=64, num_blocks=2, num_layers=2, channel_growth=32, emb_nums=1), 2, 12, 16),
+    (dict(in_channels=128, mid_channels=64, with_rdb=False, with_taf=True), 4, 10, 12),
+    (dict(in_channels=64, mid_channels=64, num_layers=2, with_rdb=True, with_taf=False), 2, 16, 16),
+])
+def test_denoising_aggregator_vs_oracle(dev, kw, n, h, w):
+    """DenoisingAggregator.forward on the device against the oracle (fp32) with the same seeded weights: 2e-2 of the output
+    scale (fp16 feature storage through ~15 convolutions, offsets computed from fp16 features)."""
+    from oracle.dcn import denoising_aggregator_forward
+    m = _aggregator(dev, **kw)
+    x = torch.randn(n, kw['in_channels'], h, w, generator=torch.Generator().manual_seed(9))
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    ref = denoising_aggregator_forward(sd, x, num_blocks=kw.get('num_blocks', 1), num_layers=kw.get('num_layers', 6),
+                                       emb_nums=kw.get('emb_nums', 3), with_rdb=kw.get('with_rdb', True), with_taf=kw.get('with_taf', True))
+    out = m.to(dev)(x.to(dev)).cpu()
+    assert out.shape == ref.shape
+    err = (out - ref).abs().max().item() / ref.abs().max().item()
+    assert err < 2e-2, err
+    assert (ref - x).abs().max().item() > 0.1 * ref.abs().max().item()       # the block is not an identity on this input
