@@ -313,6 +313,17 @@ int llv_modulated_deform_im2col(const void* x, const float* om, void* col, int n
                                 int col_ld, int kh, int kw, int stride, int pad, int dilation, int deform_groups, int ho,
                                 int wo, void* stream);
 
+/* Element-wise steps of TemporalAttentionFusion.forward (denoising_aggregator.py:135-152) on contiguous NHWC fp16 tensors with
+ * m channels (m % 8 == 0). The reference's loop over the reference frame i is batched: pair (i, j) = image i*n + j.
+ *   llv_taf_pair_concat   x (n,h,w,m) -> y (n*n,h,w,2m): y[i*n+j] = cat(x[j], x[i])           (:141-143)
+ *   llv_taf_mul_ref       xd (n*n,h,w,m), x (n,h,w,m) -> y (n*n,h,w,m): y[i*n+j] = xd[i*n+j] * x[i]   (:146)
+ *   llv_taf_softmax_fuse  xcor (n*n,h,w,m), x (n,h,w,m) -> out (n,h,w,m): out[i] = sum_j softmax_j(xcor[i*n+j]) * x[j]   (:147-148)
+ *   llv_add_f16           y = a + b over `rows` rows of c halfs with row strides a_ld / b_ld / y_ld (all % 8 == 0)   (:193,197) */
+int llv_taf_pair_concat(const void* x, void* y, int n, int h, int w, int m, void* stream);
+int llv_taf_mul_ref(const void* xd, const void* x, void* y, int n, int h, int w, int m, void* stream);
+int llv_taf_softmax_fuse(const void* xcor, const void* x, void* out, int n, int h, int w, int m, void* stream);
+int llv_add_f16(const void* a, const void* b, void* y, int64_t rows, int c, int a_ld, int b_ld, int y_ld, void* stream);
+
 /* True/false-positive marking of eval_map (mean_ap.py:268-400 calls tpfp_default :154-244 or, for datasets 'det'/'vid',
  * tpfp_imagenet :60-151 once per class and image): all (class, image) cells in one launch, one wavefront per cell.
  * dets [total_dets][5] fp32 (x1,y1,x2,y2,score); cell c owns dets[det_off[c] .. det_off[c+1]) and gts[gt_off[c] .. gt_off[c+1])

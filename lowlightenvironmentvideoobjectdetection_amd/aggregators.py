@@ -10,7 +10,7 @@ import torch.nn as nn
 from . import engine, ops
 import math
 
-from ._lib import CONV_OUT_F32, CONV_RELU, CONV_RES_ADD
+from ._lib import CONV_RELU
 from .cnn import ConvModule
 from .planned import PlannedModule
 from .registry import AGGREGATORS
@@ -135,11 +135,9 @@ class DenoisingAggregator(PlannedModule):
     """The authors' denoising aggregator (denoising_aggregator.py:155-200): conv1 -> residual dense blocks -> conv2 ->
     TemporalAttentionFusion over the N frames of the batch -> conv3, with the two inner skips and the outer identity.
 
-    forward(x): x (N, C, H, W) fp32 NCHW on the GPU = the feature maps of N frames -> same shape. Every convolution is a
-    libllv.so launch (NHWC fp16, fp32 accumulate): the dense concatenations are channel slices of one buffer, the offset /
-    mask conv writes fp32, the deformable conv is llv_modulated_deform_im2col + the implicit-GEMM kernel, and the N x N
-    (reference frame, frame) pairs of the fusion loop (denoising_aggregator.py:139-149) are one batch of N*N images.
-    The element-wise glue (x_dcn * x_ref, softmax over frames, weighted sum) is torch on the device."""
+    forward(x): x (N, C, H, W) fp32 NCHW on the GPU = the feature maps of N frames -> same shape. The whole block is one
+    launch plan (engine.build_denoising_aggregator): every step a libllv.so launch on NHWC fp16 buffers, replayable from a
+    HIP graph, and embeddable between the stages of a backbone plan (InsertResNet)."""
 
     def __init__(self, in_channels=64, mid_channels=64, num_blocks=1, num_layers=6, channel_growth=64, emb_nums=3,
                  with_rdb=True, with_taf=True):
@@ -157,63 +155,21 @@ class DenoisingAggregator(PlannedModule):
             self.taf = TemporalAttentionFusion(mid_channels, mid_channels=mid_channels, emb_nums=emb_nums)
         self.conv3 = _conv3(mid_channels, in_channels)
 
-    def _packed(self, device):
-        def make():
-            sd = engine._cpu_sd(self.state_dict())
-            pk = {}
-            for name, w in sd.items():
-                if not name.endswith('.weight') or name == 'taf.dcn_pack.weight':
-                    continue
-                p = name[:-len('.weight')]
-                pk[p] = ops.pack_conv(w, sd.get(p + '.bias'), 1, (w.shape[-1] - 1) // 2).to(device)
-            if self.with_taf:
-                pk['taf.dcn_pack'] = ops.pack_dcn_weight(sd['taf.dcn_pack.weight'], sd.get('taf.dcn_pack.bias')).to(device)
-            return pk
-        return self._plan(('packed', str(device)), make)
+    def plan_kwargs(self):
+        return dict(num_blocks=self.num_blocks, num_layers=self.num_layers, emb_nums=self.emb_nums, with_rdb=self.with_rdb,
+                    with_taf=self.with_taf, deform_groups=self.taf.dcn_pack.deform_groups if self.with_taf else 8)
 
-    def _rdb(self, pk, p, x):
-        n, h, w, c = x.shape
-        g, L = self.channel_growth, self.num_layers
-        cat = torch.empty((n, h, w, c + g * L), device=x.device, dtype=torch.float16)
-        cat[..., :c] = x
-        for l in range(L):
-            # DenseLayer: cat([x, relu(conv(x))]) -- the conv reads the first c + g*l channels, writes the next g
-            cin = c + g * l
-            y = ops.conv2d(cat[..., :cin].contiguous(), pk[f'{p}.layers.{l}.conv'], flags=CONV_RELU)
-            cat[..., cin:cin + g] = y
-        return ops.conv2d(cat, pk[p + '.lff'], res=x, flags=CONV_RES_ADD)          # x + lff(layers(x))
-
-    def _taf(self, pk, x):
-        n, h, w, _ = x.shape
-        m = self.mid_channels
-        x = ops.conv2d(x, pk['taf.conv1'], flags=CONV_RELU)
-        # pair (i, j): reference frame i, frame j -> batch index i*n + j (the loop over i of the reference, batched)
-        xj = x.unsqueeze(0).expand(n, n, h, w, m).reshape(n * n, h, w, m)
-        xi = x.unsqueeze(1).expand(n, n, h, w, m).reshape(n * n, h, w, m)
-        x_set = ops.conv2d(torch.cat([xj, xi], dim=-1), pk['taf.offset_conv'])
-        om = ops.conv2d(x_set, pk['taf.dcn_pack.conv_offset'], flags=CONV_OUT_F32)
-        x_dcn = ops.modulated_deform_conv2d(xj.contiguous(), om, pk['taf.dcn_pack'], 3, 3, 1, 1, 1, self.taf.dcn_pack.deform_groups)
-        x_cor = x_dcn * xi
-        for e in range(self.emb_nums):
-            x_cor = ops.conv2d(x_cor, pk[f'taf.emb_conv.{e}'])
-        att = torch.softmax(x_cor.view(n, n, h, w, m).float(), dim=1)             # over the frames j
-        fused = (att * x.unsqueeze(0).float()).sum(dim=1).half().contiguous()     # (n, h, w, m): one map per reference frame i
-        return ops.conv2d(fused, pk['taf.conv2'], flags=CONV_RELU)
+    def make_plan(self, n, h, w, device):
+        b = engine.Builder(device)
+        x_in = b.buf(n, h, w, self.in_channels)
+        out = engine.build_denoising_aggregator(b, engine._cpu_sd(self.state_dict()), x_in, n, **self.plan_kwargs())
+        return b.plan, x_in, out
 
     def forward(self, x):
         self._check_input(x)
         n, c, h, w = x.shape
         assert c == self.in_channels
-        pk = self._packed(x.device)
-        x0 = ops.pack_input(x.float().contiguous(), c)
-        t = ops.conv2d(x0, pk['conv1'], flags=CONV_RELU)
-        x_f = t
-        if self.with_rdb:
-            for b in range(self.num_blocks):
-                t = self._rdb(pk, f'rdbs.{b}', t)
-        t = ops.conv2d((t.float() + x_f.float()).half(), pk['conv2'], flags=CONV_RELU)
-        x_m = t
-        if self.with_taf:
-            t = self._taf(pk, t)
-        t = ops.conv2d((t.float() + x_m.float()).half(), pk['conv3'], flags=CONV_RELU)
-        return ops.unpack_output(t, c) + x
+        plan, x_in, out = self._plan((n, h, w, str(x.device)), lambda: self.make_plan(n, h, w, x.device))
+        ops.pack_input(x.float().contiguous(), c, out=x_in)
+        plan.run()
+        return ops.unpack_output(out, c)

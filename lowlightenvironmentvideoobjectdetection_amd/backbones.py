@@ -196,3 +196,53 @@ class ResNet(PlannedModule):
         ops.pack_input(x.float().contiguous(), 8, out=x_in)
         plan.run()
         return tuple(ops.unpack_output(f, f.shape[-1]) for f in feats)
+
+
+@BACKBONES.register_module()
+class InsertResNet(ResNet):
+    """ResNet with the authors' denoising plugin appended to chosen stages
+    (mmtracking/mmtrack/models/backbones/insert_resnet.py:93-97,134-230): stage i with insert_tag[i] ends in
+    build_aggregator(insert_cfg) with in_channels = the stage's output channels, mid_channels = its planes and
+    channel_growth = 64; the plugin is module `layer{i+1}.{num_blocks}` of the stage (state_dict keys
+    `layer3.6.conv1.weight`, `layer3.6.taf.dcn_pack.weight`, ...). The batch dimension is the clip: the plugin's temporal
+    attention fuses the frames of the batch. One launch plan: stages and plugins interleaved. Dilated stages are not built."""
+
+    def __init__(self, depth, insert_tag=(False, False, False, False), insert_cfg=None, **kwargs):
+        if depth not in (50, 101):
+            raise KeyError(f'invalid depth {depth} for InsertResNet')          # insert_resnet.py:139-142
+        super().__init__(depth, **kwargs)
+        from .registry import build_aggregator
+        self.insert_tag = tuple(insert_tag)
+        assert len(self.insert_tag) == self.num_stages
+        self.insert_cfg = dict(insert_cfg) if insert_cfg is not None else None
+        self._plugins = {}
+        for i, name in enumerate(self.res_layers):
+            if not self.insert_tag[i]:
+                continue
+            planes = self.base_channels * 2 ** i
+            cfg = dict(self.insert_cfg, in_channels=planes * self.block.expansion, mid_channels=planes, channel_growth=64)
+            layer = getattr(self, name)
+            layer.add_module(str(len(layer)), build_aggregator(cfg))
+            self._plugins[i] = layer[len(layer) - 1]
+
+    def forward(self, x):
+        """x (N, 3, H, W): the N frames of a clip -> tuple of stage outputs, NCHW fp32."""
+        self._check_input(x)
+        n, c, h, w = x.shape
+
+        def make():
+            b = engine.Builder(x.device)
+            x_in = b.buf(n, h, w, 8)
+            sd = engine._cpu_sd(self.state_dict())
+
+            def after_stage(i, nb, t):
+                if i not in self._plugins:
+                    return t
+                return engine.build_denoising_aggregator(b, sd, t, n, p=f'layer{i + 1}.{nb}.', tag=f'layer{i + 1}.plugin',
+                                                         **self._plugins[i].plan_kwargs())
+            feats = engine.build_resnet(b, sd, x_in, after_stage=after_stage, **self.plan_kwargs())
+            return b.plan, x_in, feats
+        plan, x_in, feats = self._plan((n, h, w, str(x.device)), make)
+        ops.pack_input(x.float().contiguous(), 8, out=x_in)
+        plan.run()
+        return tuple(ops.unpack_output(f, f.shape[-1]) for f in feats)

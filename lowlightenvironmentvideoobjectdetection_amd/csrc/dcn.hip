@@ -66,6 +66,93 @@ __global__ __launch_bounds__(256) void mdcn_im2col_kernel(const _Float16* __rest
     }
 }
 
+
+// ---- element-wise steps of TemporalAttentionFusion.forward (denoising_aggregator.py:135-152), NHWC fp16, 8 channels per lane.
+// The reference loops over the reference frame i and works on the n frames j at once; here the n*n (i, j) pairs are one
+// batch, pair (i, j) at image index i*n + j.
+
+// y[i*n + j] = cat(x[j], x[i]) over channels (x_cat = cat([x, x_ref], dim=1), :141-143)
+__global__ __launch_bounds__(256) void taf_pair_concat_kernel(const f16x8* __restrict__ x, f16x8* __restrict__ y, int n, long hw,
+                                                             int m8) {
+    const long total = (long)n * n * hw * 2 * m8;
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(t % (2 * m8));
+        long p = t / (2 * m8);
+        const long pix = p % hw;
+        const int pair = (int)(p / hw);
+        const int i = pair / n, j = pair - i * n;
+        const int src = cv < m8 ? j : i;
+        y[t] = x[((long)src * hw + pix) * m8 + (cv < m8 ? cv : cv - m8)];
+    }
+}
+
+// y[i*n + j] = xd[i*n + j] * x[i]   (x_dcn * x_ref, :146)
+__global__ __launch_bounds__(256) void taf_mul_ref_kernel(const f16x8* __restrict__ xd, const f16x8* __restrict__ x,
+                                                         f16x8* __restrict__ y, int n, long hw, int m8) {
+    const long per = hw * m8, total = (long)n * n * per;
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int pair = (int)(t / per);
+        const long r = t - (long)pair * per;
+        const f16x8 a = xd[t], b = x[(long)(pair / n) * per + r];
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)((float)a[e] * (float)b[e]);
+        y[t] = o;
+    }
+}
+
+// out[i] = sum_j softmax_j(xcor[i*n + j]) * x[j]   (softmax over dim 0 and the weighted sum, :147-148), fp32 arithmetic
+__global__ __launch_bounds__(256) void taf_softmax_fuse_kernel(const f16x8* __restrict__ xcor, const f16x8* __restrict__ x,
+                                                              f16x8* __restrict__ out, int n, long hw, int m8) {
+    const long per = hw * m8, total = (long)n * per;
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const int i = (int)(t / per);
+        const long r = t - (long)i * per;
+        float mx[8], den[8], acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { mx[e] = -INFINITY; den[e] = 0.f; acc[e] = 0.f; }
+        for (int j = 0; j < n; ++j) {
+            const f16x8 v = xcor[((long)i * n + j) * per + r];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) mx[e] = fmaxf(mx[e], (float)v[e]);
+        }
+        for (int j = 0; j < n; ++j) {
+            const f16x8 v = xcor[((long)i * n + j) * per + r];
+            const f16x8 xv = x[(long)j * per + r];
+#pragma unroll
+            for (int e = 0; e < 8; ++e) {
+                const float w = __expf((float)v[e] - mx[e]);
+                den[e] += w;
+                acc[e] += w * (float)xv[e];
+            }
+        }
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)(acc[e] / den[e]);
+        out[t] = o;
+    }
+}
+
+// y = a + b over rows of c halfs with row strides (the two inner skips of DenoisingAggregator.forward, :193,197), fp32 add
+__global__ __launch_bounds__(256) void add_f16_kernel(const _Float16* __restrict__ a, const _Float16* __restrict__ b,
+                                                     _Float16* __restrict__ y, long rows, int c8, int a_ld, int b_ld, int y_ld) {
+    const long total = rows * c8;
+    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
+        const long r = t / c8;
+        const int cv = (int)(t - r * c8) * 8;
+        const f16x8 u = *reinterpret_cast<const f16x8*>(a + r * a_ld + cv), v = *reinterpret_cast<const f16x8*>(b + r * b_ld + cv);
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)((float)u[e] + (float)v[e]);
+        *reinterpret_cast<f16x8*>(y + r * y_ld + cv) = o;
+    }
+}
+
+inline int grid_of(long total) {
+    long b = (total + 255) / 256;
+    return (int)(b > 256 * 32 ? 256 * 32 : (b < 1 ? 1 : b));
+}
+
 }  // namespace
 
 extern "C" int llv_modulated_deform_im2col(const void* x, const float* om, void* col, int n, int h, int w, int c, int x_ld,
@@ -85,5 +172,36 @@ extern "C" int llv_modulated_deform_im2col(const void* x, const float* om, void*
     hipLaunchKernelGGL(mdcn_im2col_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, om,
                        (_Float16*)col, n, h, w, c / 8, x_ld, om_ld, col_ld, kh, kw, stride, pad, dilation, deform_groups,
                        c / deform_groups / 8, ho, wo);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_taf_pair_concat(const void* x, void* y, int n, int h, int w, int m, void* stream) {
+    if (!x || !y || n <= 0 || h <= 0 || w <= 0 || m <= 0 || (m & 7)) return LLV_E_BADARG;
+    const long total = (long)n * n * h * w * 2 * (m / 8);
+    hipLaunchKernelGGL(taf_pair_concat_kernel, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, (const f16x8*)x, (f16x8*)y, n,
+                       (long)h * w, m / 8);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_taf_mul_ref(const void* xd, const void* x, void* y, int n, int h, int w, int m, void* stream) {
+    if (!xd || !x || !y || n <= 0 || h <= 0 || w <= 0 || m <= 0 || (m & 7)) return LLV_E_BADARG;
+    const long total = (long)n * n * h * w * (m / 8);
+    hipLaunchKernelGGL(taf_mul_ref_kernel, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, (const f16x8*)xd, (const f16x8*)x,
+                       (f16x8*)y, n, (long)h * w, m / 8);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_taf_softmax_fuse(const void* xcor, const void* x, void* out, int n, int h, int w, int m, void* stream) {
+    if (!xcor || !x || !out || n <= 0 || h <= 0 || w <= 0 || m <= 0 || (m & 7)) return LLV_E_BADARG;
+    const long total = (long)n * h * w * (m / 8);
+    hipLaunchKernelGGL(taf_softmax_fuse_kernel, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, (const f16x8*)xcor,
+                       (const f16x8*)x, (f16x8*)out, n, (long)h * w, m / 8);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_add_f16(const void* a, const void* b, void* y, int64_t rows, int c, int a_ld, int b_ld, int y_ld, void* stream) {
+    if (!a || !b || !y || rows <= 0 || c <= 0 || ((c | a_ld | b_ld | y_ld) & 7) || a_ld < c || b_ld < c || y_ld < c) return LLV_E_BADARG;
+    hipLaunchKernelGGL(add_f16_kernel, dim3(grid_of(rows * (c / 8))), dim3(256), 0, (hipStream_t)stream, (const _Float16*)a,
+                       (const _Float16*)b, (_Float16*)y, (long)rows, c / 8, a_ld, b_ld, y_ld);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }

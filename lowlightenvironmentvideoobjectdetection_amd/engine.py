@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import ops
-from ._lib import (CONV_LEAKY, CONV_OUT_F32, CONV_PIXSHUF, CONV_RELU, CONV_RES_ADD, CONV_RES_RSUB, CONV_RES_UPS, LlvError, lib)
+from ._lib import (CONV_ACT_FIRST, CONV_LEAKY, CONV_OUT_F32, CONV_PIXSHUF, CONV_RELU, CONV_RES_ADD, CONV_RES_RSUB, CONV_RES_UPS, LlvError, lib)
 
 BN_EPS = 1e-5
 # direct (halo-in-LDS) 3x3 kernel for the FastDVDnet layers: on by default; LLV_HALO=0 falls back to implicit GEMM
@@ -187,7 +187,7 @@ def _cpu_sd(sd):
 
 
 def build_resnet(b: Builder, sd, x, depth=50, strides=(1, 2, 2, 2), style='pytorch', out_indices=(0, 1, 2, 3), p='',
-                 num_stages=4):
+                 num_stages=4, after_stage=None):
     """x: (N,H,W,8) fp16 NHWC normalised image (3 real channels). Returns the out_indices stage outputs.
     resnet.py:622-640 with every BatchNorm folded (norm_eval, running stats) and ReLU / identity-add fused
     into the producing conv's epilogue."""
@@ -218,8 +218,11 @@ def build_resnet(b: Builder, sd, x, depth=50, strides=(1, 2, 2, 2), style='pytor
                                                          bn=_bn(sd, q + 'bn1'), eps=BN_EPS), CONV_RELU)
                 x = b.conv(q + 'conv2', o, ops.pack_conv(sd[q + 'conv2.weight'], None, 1, 1, bn=_bn(sd, q + 'bn2'),
                                                          eps=BN_EPS), CONV_RELU | CONV_RES_ADD, res=identity)
-        if i in out_indices:
-            feats.append(x)
+        if after_stage is not None:             # InsertResNet: a plugin appended to the stage (insert_resnet.py:93-97)
+            x = after_stage(i, nb, x)
+        for j in out_indices:                   # an index may repeat (insert_resnet.py:410-415, configs use (2, 3, 3))
+            if i == j:
+                feats.append(x)
     return feats
 
 
@@ -697,6 +700,86 @@ class PipelinedEnhanceDetectPlan:
     def results(self):
         """Detections of the window most recently detected."""
         return self.p[self._i & 1].results()
+
+
+# ------------------------------------------------------------------------------------------------
+# DenoisingAggregator (SURVEY.md 8f item 3): residual dense blocks + DCN-based temporal attention fusion
+# ------------------------------------------------------------------------------------------------
+def build_denoising_aggregator(b: Builder, sd, x, n, num_blocks=1, num_layers=6, emb_nums=3, with_rdb=True, with_taf=True,
+                               deform_groups=8, p='', tag='agg'):
+    """DenoisingAggregator.forward (mmtracking/mmtrack/models/aggregators/denoising_aggregator.py:186-200) on
+    x (n, h, w, C) fp16 NHWC = the feature maps of the n frames of a clip; returns the output buffer (same shape).
+
+    Dense concatenations are channel slices of one buffer (DenseLayer :32-34 writes its growth channels behind its input),
+    x + lff(.) is the lff conv's residual epilogue (:66), relu(conv) + skip the ACT_FIRST residual epilogue (:198-199, :151),
+    the n x n (reference frame i, frame j) pairs of the fusion loop (:139-149) one batch of n*n images, the offset / mask
+    conv writes fp32 and the deformable conv is llv_modulated_deform_im2col followed by the implicit-GEMM kernel as a
+    1x1 conv over the 9*C column tensor."""
+    L = lib()
+    _, h, w, c = x.shape
+    cv = lambda q, pad=1: ops.pack_conv(sd[p + q + '.weight'], sd.get(p + q + '.bias'), 1, pad)
+    pc1 = cv('conv1')
+    m = pc1.cout
+    growth = sd[f'{p}rdbs.0.layers.0.conv.weight'].shape[0] if with_rdb else 0
+    tot = m + growth * num_layers
+
+    def add(name, a0, ld0, a1, ld1):
+        """a0 + a1 over (n*h*w, m) with row strides ld0 / ld1 -> new contiguous buffer"""
+        y = b.buf(n, h, w, m)
+        b.plan.add(name, L.llv_add_f16, (C.c_void_p(a0.data_ptr()), C.c_void_p(a1.data_ptr()), C.c_void_p(y.data_ptr()),
+                                         C.c_int64(n * h * w), m, ld0, ld1, m), 0.0, 6.0 * y.numel())
+        b.plan.keep += [a0, a1]
+        return y
+    # t / t_ld: the running feature map and its row stride (inside a dense block's concat buffer it is a channel slice)
+    t = b.buf(n, h, w, tot)
+    t_ld = tot
+    b.conv_desc(f'{tag}.conv1', pc1, [x], t, n, [(h, w, h, w, 0, 0)], c, t_ld, flags=CONV_RELU)
+    x_f, xf_ld = t, t_ld
+    if with_rdb:
+        for bi in range(num_blocks):
+            q = f'rdbs.{bi}'
+            cat = t                                     # channels [0, m) hold the block input
+            for l in range(num_layers):
+                cin = m + growth * l
+                b.conv_desc(f'{tag}.{q}.layers.{l}', cv(f'{q}.layers.{l}.conv'), [cat], cat[..., cin:], n, [(h, w, h, w, 0, 0)], tot, tot,
+                            flags=CONV_RELU)
+            last = bi == num_blocks - 1
+            t = b.buf(n, h, w, m if last else tot)      # the next block's concat buffer, or a plain map after the last block
+            t_ld = m if last else tot
+            b.conv_desc(f'{tag}.{q}.lff', cv(f'{q}.lff', 0), [cat], t, n, [(h, w, h, w, 0, 0)], tot, t_ld, res=cat, res_ld=tot,
+                        flags=CONV_RES_ADD)
+    t = b.conv(f'{tag}.conv2', add(f'{tag}.skip_f', t, t_ld, x_f, xf_ld), cv('conv2'), CONV_RELU)
+    x_m = t
+    if with_taf:
+        q = 'taf.'
+        xt = b.conv(f'{tag}.taf.conv1', t, cv(q + 'conv1'), CONV_RELU)
+        mt = xt.shape[-1]
+        pairs = b.buf(n * n, h, w, 2 * mt)
+        b.plan.add(f'{tag}.taf.pairs', L.llv_taf_pair_concat, (C.c_void_p(xt.data_ptr()), C.c_void_p(pairs.data_ptr()), n, h, w, mt),
+                   0.0, 2.0 * (xt.numel() + pairs.numel()))
+        x_set = b.conv(f'{tag}.taf.offset_conv', pairs, cv(q + 'offset_conv'))
+        om = b.conv(f'{tag}.taf.conv_offset', x_set, cv(q + 'dcn_pack.conv_offset'), CONV_OUT_F32)
+        # the deformable conv samples frame j of pair (i, j): the first mt channels of `pairs` (row stride 2*mt)
+        col = b.buf(n * n, h, w, 9 * mt)
+        b.plan.add(f'{tag}.taf.dcn_im2col', L.llv_modulated_deform_im2col,
+                   (C.c_void_p(pairs.data_ptr()), C.c_void_p(om.data_ptr()), C.c_void_p(col.data_ptr()), n * n, h, w, mt, 2 * mt,
+                    om.shape[-1], 9 * mt, 3, 3, 1, 1, 1, deform_groups, h, w), 0.0, 2.0 * col.numel() + 4.0 * om.numel())
+        x_dcn = b.conv(f'{tag}.taf.dcn_gemm', col, ops.pack_dcn_weight(sd[p + q + 'dcn_pack.weight'], sd.get(p + q + 'dcn_pack.bias')))
+        x_cor = b.buf(n * n, h, w, mt)
+        b.plan.add(f'{tag}.taf.mul_ref', L.llv_taf_mul_ref, (C.c_void_p(x_dcn.data_ptr()), C.c_void_p(xt.data_ptr()),
+                                                              C.c_void_p(x_cor.data_ptr()), n, h, w, mt), 0.0, 4.0 * x_cor.numel())
+        for e in range(emb_nums):
+            x_cor = b.conv(f'{tag}.taf.emb_conv.{e}', x_cor, cv(f'{q}emb_conv.{e}'))
+        fused = b.buf(n, h, w, mt)
+        b.plan.add(f'{tag}.taf.softmax_fuse', L.llv_taf_softmax_fuse, (C.c_void_p(x_cor.data_ptr()), C.c_void_p(xt.data_ptr()),
+                                                                        C.c_void_p(fused.data_ptr()), n, h, w, mt), 0.0, 2.0 * x_cor.numel())
+        b.plan.keep += [x_cor, x_dcn, om, x_set]
+        # relu(conv2(out)) + x_m (the skip before conv3, :197-198)
+        t = b.conv(f'{tag}.taf.conv2', fused, cv(q + 'conv2'), CONV_RELU | CONV_RES_ADD | CONV_ACT_FIRST, res=x_m)
+    else:
+        t = add(f'{tag}.skip_m', t, m, x_m, m)
+    # relu(conv3(.)) + identity (:198-199)
+    return b.conv(f'{tag}.conv3', t, cv('conv3'), CONV_RELU | CONV_RES_ADD | CONV_ACT_FIRST, res=x)
 
 
 # ------------------------------------------------------------------------------------------------

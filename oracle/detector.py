@@ -26,7 +26,10 @@ def _bn(x, sd, p, eps=1e-5):
                         False, 0.0, eps)
 
 
-def resnet_forward(sd, x, depth=50, out_indices=(0, 1, 2, 3), strides=(1, 2, 2, 2), style='pytorch', prefix='backbone.'):
+def resnet_forward(sd, x, depth=50, out_indices=(0, 1, 2, 3), strides=(1, 2, 2, 2), style='pytorch', prefix='backbone.',
+                   after_stage=None):
+    """after_stage(i, num_blocks, x) -> x: the plugin InsertResNet appends to stage i
+    (mmtracking/mmtrack/models/backbones/insert_resnet.py:93-97); an out index may repeat (:410-415)."""
     kind, blocks = ARCH[depth]
     p = prefix
     x = F.conv2d(x, sd[p + 'conv1.weight'], None, 2, 3)          # resnet.py:559-566 (7x7/s2, bias=False)
@@ -49,8 +52,11 @@ def resnet_forward(sd, x, depth=50, out_indices=(0, 1, 2, 3), strides=(1, 2, 2, 
             if (q + 'downsample.0.weight') in sd:                                # res_layer.py:36-58
                 identity = _bn(F.conv2d(x, sd[q + 'downsample.0.weight'], None, stride, 0), sd, q + 'downsample.1')
             x = F.relu(out + identity)
-        if i in out_indices:
-            outs.append(x)
+        if after_stage is not None:
+            x = after_stage(i, nb, x)
+        for j in out_indices:
+            if i == j:
+                outs.append(x)
     return tuple(outs)
 
 
