@@ -227,6 +227,83 @@ def yolo_bench(args, world, rank, dev):
         dist.destroy_process_group()
 
 
+def insert_bench(args, world, rank, dev):
+    """the authors' in-backbone denoising (InsertResNet-50, DenoisingAggregator with 8 dense layers,
+    3 embedding convs and the DCN-based temporal attention fusion after every stage, as configs/vid/llvod/
+    llvod_insert_plugins_l34_i1234_vid_a7s3.py:14-31 sets it, stride-2 stages instead of the dilated last one) on a clip of
+    --frames-per-step 1280x720 frames (default 3: key frame + 2 references). One HIP graph per step. The JSON line carries the
+    HBM roofline of the deformable-conv column kernel (llv_modulated_deform_im2col), timed per launch with HIP events."""
+    import torch.distributed as dist
+    import lowlightenvironmentvideoobjectdetection_amd.models  # noqa: F401
+    from lowlightenvironmentvideoobjectdetection_amd import data, engine, ops, registry
+    from lowlightenvironmentvideoobjectdetection_amd.synthetic import seeded_weights
+    B = args.frames_per_step if args.frames_per_step != 16 else 3
+    m = seeded_weights(registry.build_backbone(dict(
+        type='InsertResNet', depth=50, num_stages=4, out_indices=(2, 3, 3), insert_tag=[True, True, True, True],
+        insert_cfg=dict(type='DenoisingAggregator', num_blocks=1, num_layers=8, emb_nums=3, with_rdb=True, with_taf=True))), seed=0)
+    with torch.no_grad():
+        for name, mod in m.named_modules():
+            if name.endswith('dcn_pack'):
+                mod.conv_offset.weight.mul_(0.25)          # offsets of about a pixel
+    clean = data.synth_clean_clip(B, args.height, args.width, seed=100 + rank)
+    clip, img_shape, pad_shape = data.preprocess_clip_device(data.darken_and_add_noise(clean, seed=200 + rank).to(torch.uint8).to(dev))
+    hp, wp = pad_shape[:2]
+    b = engine.Builder(dev)
+    x_in = b.buf(B, hp, wp, 8)
+    sd = engine._cpu_sd(m.state_dict())
+
+    def after_stage(i, nb, t):
+        return engine.build_denoising_aggregator(b, sd, t, B, p=f'layer{i + 1}.{nb}.', tag=f'layer{i + 1}.plugin',
+                                                 **m._plugins[i].plan_kwargs())
+    engine.build_resnet(b, sd, x_in, after_stage=after_stage, **m.plan_kwargs())
+    plan = b.plan
+    x_in.copy_(clip[2:2 + B])
+    plan.capture()
+    for _ in range(args.warmup):
+        plan.replay()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        plan.replay()
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        timed = plan.run_timed(iters=5)
+        dcn = [(n, ms, nb) for (n, ms, fl, nb) in timed if n.endswith('dcn_im2col')]
+        dms, dnb = sum(x[1] for x in dcn), sum(x[2] for x in dcn)
+        plug_ms = sum(ms for (n, ms, _, _) in timed if '.plugin' in n)
+        conv_ms = sum(ms for (n, ms, fl, _) in timed if fl > 0)
+        conv_fl = sum(fl for (n, ms, fl, _) in timed if fl > 0)
+        print(json.dumps({
+            'metric': 'frames/sec (InsertResNet-50 backbone with DenoisingAggregator plugins) on 1280x720 clips',
+            'value': round(args.steps * B * world / dt, 3), 'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup,
+            'ms_per_step': round(dt / args.steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f16', 'data': 'synthetic',
+            'config': {'workload': f'SURVEY 8f.3: InsertResNet-50 (plugin after each of the 4 stages: 8 dense layers, 3 embedding convs, '
+                                   f'DCN temporal attention fusion over the {B} frames of the clip), {args.width}x{args.height} frames '
+                                   f'(padded {wp}x{hp})', 'frames_per_step': B, 'hip_graph': True,
+                       'algorithmic_gflop_per_step': round(plan.flops / 1e9, 1), 'plugin_ms_per_step': round(plug_ms, 3),
+                       'launches_per_step': len(plan.steps)},
+            'roofline': {'bound': 'hbm', 'kernel': 'mdcn_im2col_kernel', 'launches_per_step': len(dcn),
+                         'achieved': round(dnb / (dms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                         'frac': round(dnb / (dms * 1e-3) / 1e9 / 8000.0, 4), 'traffic': None,
+                         'algorithmic_bytes_per_step': round(dnb), 'ms_per_step': round(dms, 4),
+                         'all_conv_kernels': {'achieved': round(conv_fl / (conv_ms * 1e-3) / 1e12, 1), 'unit': 'TFLOP/s',
+                                              'ms_per_step': round(conv_ms, 3)}}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def fgfa_bench(args, world, rank, dev):
     """Config #4 of BASELINE.json: flow-guided feature aggregation over a 10-reference window (mmtracking FGFA with
     EmbedAggregator on the 256-channel FPN levels, RetinaNet R-50+FPN detector, FlowNetSimple), 1280x720 frames, one frame
@@ -302,7 +379,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-latency-mode', action='store_true')
-    ap.add_argument('--mode', choices=['infer', 'train', 'yolo', 'fgfa'], default='infer',
+    ap.add_argument('--mode', choices=['infer', 'train', 'yolo', 'fgfa', 'insert'], default='infer',
                     help="'train' = BASELINE.json config #3: RetinaNet fwd + loss + bwd + gradient all-reduce + SGD, one image per GPU")
     ap.add_argument('--train-batch', type=int, default=1, help='images per GPU per training step')
     args = ap.parse_args()
@@ -328,6 +405,8 @@ def main():
         return yolo_bench(args, world, rank, dev)
     if args.mode == 'fgfa':
         return fgfa_bench(args, world, rank, dev)
+    if args.mode == 'insert':
+        return insert_bench(args, world, rank, dev)
 
     B, T = args.frames_per_step, args.clip_frames
     det, cleaner = build_models(seed=0)

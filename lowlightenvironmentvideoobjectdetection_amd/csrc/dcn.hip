@@ -22,48 +22,78 @@ namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
 
+struct MdcnItem {          // one (image, pixel, tap, 8-channel vector): where to sample, what to scale with, where to write
+    const _Float16* xb;
+    _Float16* dst;
+    float py, px, m;
+};
+
+// row = img*ho + oy (blockIdx.y), t = index inside the row: ((ox*K + k)*c8 + cv). 32-bit arithmetic only: 64-bit division by
+// run-time values costs hundreds of instructions per item and made the first version of this kernel ALU-bound.
+__device__ __forceinline__ MdcnItem mdcn_locate(unsigned row, unsigned t, const _Float16* x, const float* om, _Float16* col, int h,
+                                                int w, unsigned c8, int x_ld, int om_ld, int col_ld, unsigned kw, unsigned K,
+                                                int stride, int pad, int dilation, int dg, unsigned cg8, unsigned ho, int wo) {
+    const unsigned cv = t % c8;
+    const unsigned p = t / c8;
+    const unsigned ox = p / K, k = p - ox * K;
+    const unsigned img = row / ho, oy = row - img * ho;
+    const unsigned g = cv / cg8;
+    const float* o = om + ((long)row * wo + ox) * om_ld;
+    const float2 d = *reinterpret_cast<const float2*>(o + (g * K + k) * 2);     // (dy, dx): om_ld is even, the pair 8-byte aligned
+    const float ml = o[2 * dg * K + g * K + k];
+    const unsigned ki = k / kw, kj = k - ki * kw;
+    MdcnItem it;
+    it.m = 1.f / (1.f + __expf(-ml));
+    it.py = (float)((int)oy * stride - pad + (int)ki * dilation) + d.x;
+    it.px = (float)((int)ox * stride - pad + (int)kj * dilation) + d.y;
+    it.xb = x + (long)img * h * w * x_ld + cv * 8;
+    it.dst = col + ((long)row * wo + ox) * col_ld + (k * c8 + cv) * 8;
+    return it;
+}
+
+__device__ __forceinline__ void mdcn_sample(const MdcnItem& it, int h, int w, int x_ld) {
+    float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    const float py = it.py, px = it.px;
+    if (py > -1.f && px > -1.f && py < (float)h && px < (float)w) {
+        const int y0 = (int)floorf(py), x0 = (int)floorf(px);
+        const int y1 = y0 + 1, x1 = x0 + 1;
+        const float ly = py - (float)y0, lx = px - (float)x0;
+        const float hy = 1.f - ly, hx = 1.f - lx;
+        // the four corners are requested together (a corner outside the image reads pixel (0,0) with weight zero)
+        const bool v00 = y0 >= 0 && x0 >= 0, v01 = y0 >= 0 && x1 <= w - 1, v10 = y1 <= h - 1 && x0 >= 0, v11 = y1 <= h - 1 && x1 <= w - 1;
+        const f16x8 c00 = *reinterpret_cast<const f16x8*>(it.xb + (v00 ? ((long)y0 * w + x0) * x_ld : 0));
+        const f16x8 c01 = *reinterpret_cast<const f16x8*>(it.xb + (v01 ? ((long)y0 * w + x1) * x_ld : 0));
+        const f16x8 c10 = *reinterpret_cast<const f16x8*>(it.xb + (v10 ? ((long)y1 * w + x0) * x_ld : 0));
+        const f16x8 c11 = *reinterpret_cast<const f16x8*>(it.xb + (v11 ? ((long)y1 * w + x1) * x_ld : 0));
+        const float w00 = v00 ? hy * hx : 0.f, w01 = v01 ? hy * lx : 0.f, w10 = v10 ? ly * hx : 0.f, w11 = v11 ? ly * lx : 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e)
+            acc[e] = w00 * (float)c00[e] + w01 * (float)c01[e] + w10 * (float)c10[e] + w11 * (float)c11[e];
+    }
+    f16x8 r;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) r[e] = (_Float16)(acc[e] * it.m);
+    __builtin_nontemporal_store(r, reinterpret_cast<f16x8*>(it.dst));
+}
+
 __global__ __launch_bounds__(256) void mdcn_im2col_kernel(const _Float16* __restrict__ x, const float* __restrict__ om,
-                                                         _Float16* __restrict__ col, int n, int h, int w, int c8, int x_ld,
+                                                         _Float16* __restrict__ col, int h, int w, int c8, int x_ld,
                                                          int om_ld, int col_ld, int kh, int kw, int stride, int pad,
                                                          int dilation, int dg, int cg8, int ho, int wo) {
-    const int K = kh * kw;
-    const long total = (long)n * ho * wo * K * c8;
-    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int cv = (int)(t % c8);
-        long p = t / c8;
-        const int k = (int)(p % K); p /= K;
-        const int ox = (int)(p % wo); p /= wo;
-        const int oy = (int)(p % ho);
-        const int img = (int)(p / ho);
-        const int g = cv / cg8;
-        const float* o = om + (((long)img * ho + oy) * wo + ox) * om_ld;
-        const float dy = o[(g * K + k) * 2], dx = o[(g * K + k) * 2 + 1];
-        const float ml = o[2 * dg * K + g * K + k];
-        const float m = 1.f / (1.f + __expf(-ml));
-        const int ki = k / kw, kj = k - ki * kw;
-        const float py = (float)(oy * stride - pad + ki * dilation) + dy;
-        const float px = (float)(ox * stride - pad + kj * dilation) + dx;
-        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
-        if (py > -1.f && px > -1.f && py < (float)h && px < (float)w) {
-            const int y0 = (int)floorf(py), x0 = (int)floorf(px);
-            const int y1 = y0 + 1, x1 = x0 + 1;
-            const float ly = py - (float)y0, lx = px - (float)x0;
-            const float hy = 1.f - ly, hx = 1.f - lx;
-            const _Float16* xb = x + (long)img * h * w * x_ld + cv * 8;
-            auto corner = [&](int yy, int xx, float wt) {
-                if (yy >= 0 && yy <= h - 1 && xx >= 0 && xx <= w - 1) {
-                    const f16x8 v = *reinterpret_cast<const f16x8*>(xb + ((long)yy * w + xx) * x_ld);
-#pragma unroll
-                    for (int e = 0; e < 8; ++e) acc[e] += wt * (float)v[e];
-                }
-            };
-            corner(y0, x0, hy * hx); corner(y0, x1, hy * lx); corner(y1, x0, ly * hx); corner(y1, x1, ly * lx);
-        }
-        f16x8 r;
-#pragma unroll
-        for (int e = 0; e < 8; ++e) r[e] = (_Float16)(acc[e] * m);
-        *reinterpret_cast<f16x8*>(col + (((long)img * ho + oy) * wo + ox) * col_ld + (long)k * c8 * 8 + cv * 8) = r;
+    const unsigned K = kh * kw;
+    const unsigned total = (unsigned)wo * K * c8;              // items of one output row
+    const unsigned step = gridDim.x * blockDim.x;
+    const unsigned row = blockIdx.y;
+    unsigned t = blockIdx.x * blockDim.x + threadIdx.x;
+    // two items per iteration: both offset reads, then both sets of corner reads, are in flight together
+    for (; t + step < total; t += 2 * step) {
+        const MdcnItem a = mdcn_locate(row, t, x, om, col, h, w, c8, x_ld, om_ld, col_ld, kw, K, stride, pad, dilation, dg, cg8, ho, wo);
+        const MdcnItem b = mdcn_locate(row, t + step, x, om, col, h, w, c8, x_ld, om_ld, col_ld, kw, K, stride, pad, dilation, dg, cg8, ho, wo);
+        mdcn_sample(a, h, w, x_ld);
+        mdcn_sample(b, h, w, x_ld);
     }
+    if (t < total)
+        mdcn_sample(mdcn_locate(row, t, x, om, col, h, w, c8, x_ld, om_ld, col_ld, kw, K, stride, pad, dilation, dg, cg8, ho, wo), h, w, x_ld);
 }
 
 
@@ -71,75 +101,76 @@ __global__ __launch_bounds__(256) void mdcn_im2col_kernel(const _Float16* __rest
 // The reference loops over the reference frame i and works on the n frames j at once; here the n*n (i, j) pairs are one
 // batch, pair (i, j) at image index i*n + j.
 
-// y[i*n + j] = cat(x[j], x[i]) over channels (x_cat = cat([x, x_ref], dim=1), :141-143)
-__global__ __launch_bounds__(256) void taf_pair_concat_kernel(const f16x8* __restrict__ x, f16x8* __restrict__ y, int n, long hw,
-                                                             int m8) {
-    const long total = (long)n * n * hw * 2 * m8;
-    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int cv = (int)(t % (2 * m8));
-        long p = t / (2 * m8);
-        const long pix = p % hw;
-        const int pair = (int)(p / hw);
-        const int i = pair / n, j = pair - i * n;
-        const int src = cv < m8 ? j : i;
-        y[t] = x[((long)src * hw + pix) * m8 + (cv < m8 ? cv : cv - m8)];
+// y[i*n + j] = cat(x[j], x[i]) over channels (x_cat = cat([x, x_ref], dim=1), :141-143). blockIdx.y = pair.
+__global__ __launch_bounds__(256) void taf_pair_concat_kernel(const f16x8* __restrict__ x, f16x8* __restrict__ y, unsigned n,
+                                                             unsigned hw, unsigned m8) {
+    const unsigned pair = blockIdx.y, i = pair / n, j = pair - i * n;
+    const unsigned total = hw * 2 * m8;
+    const f16x8* xj = x + (long)j * hw * m8;
+    const f16x8* xi = x + (long)i * hw * m8;
+    f16x8* yp = y + (long)pair * total;
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const unsigned pix = t / (2 * m8), cv = t - pix * 2 * m8;
+        yp[t] = cv < m8 ? xj[pix * m8 + cv] : xi[pix * m8 + cv - m8];
     }
 }
 
-// y[i*n + j] = xd[i*n + j] * x[i]   (x_dcn * x_ref, :146)
+// y[i*n + j] = xd[i*n + j] * x[i]   (x_dcn * x_ref, :146). blockIdx.y = pair.
 __global__ __launch_bounds__(256) void taf_mul_ref_kernel(const f16x8* __restrict__ xd, const f16x8* __restrict__ x,
-                                                         f16x8* __restrict__ y, int n, long hw, int m8) {
-    const long per = hw * m8, total = (long)n * n * per;
-    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int pair = (int)(t / per);
-        const long r = t - (long)pair * per;
-        const f16x8 a = xd[t], b = x[(long)(pair / n) * per + r];
+                                                         f16x8* __restrict__ y, unsigned n, unsigned per) {
+    const unsigned pair = blockIdx.y;
+    const f16x8* a = xd + (long)pair * per;
+    const f16x8* b = x + (long)(pair / n) * per;
+    f16x8* yp = y + (long)pair * per;
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < per; t += gridDim.x * blockDim.x) {
+        const f16x8 u = a[t], v = b[t];
         f16x8 o;
 #pragma unroll
-        for (int e = 0; e < 8; ++e) o[e] = (_Float16)((float)a[e] * (float)b[e]);
-        y[t] = o;
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)((float)u[e] * (float)v[e]);
+        yp[t] = o;
     }
 }
 
-// out[i] = sum_j softmax_j(xcor[i*n + j]) * x[j]   (softmax over dim 0 and the weighted sum, :147-148), fp32 arithmetic
+// out[i] = sum_j softmax_j(xcor[i*n + j]) * x[j]   (softmax over dim 0 and the weighted sum, :147-148), fp32 arithmetic.
+// blockIdx.y = reference frame i.
 __global__ __launch_bounds__(256) void taf_softmax_fuse_kernel(const f16x8* __restrict__ xcor, const f16x8* __restrict__ x,
-                                                              f16x8* __restrict__ out, int n, long hw, int m8) {
-    const long per = hw * m8, total = (long)n * per;
-    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const int i = (int)(t / per);
-        const long r = t - (long)i * per;
+                                                              f16x8* __restrict__ out, unsigned n, unsigned per) {
+    const unsigned i = blockIdx.y;
+    const f16x8* xc = xcor + (long)i * n * per;
+    for (unsigned r = blockIdx.x * blockDim.x + threadIdx.x; r < per; r += gridDim.x * blockDim.x) {
         float mx[8], den[8], acc[8];
 #pragma unroll
         for (int e = 0; e < 8; ++e) { mx[e] = -INFINITY; den[e] = 0.f; acc[e] = 0.f; }
-        for (int j = 0; j < n; ++j) {
-            const f16x8 v = xcor[((long)i * n + j) * per + r];
+        for (unsigned j = 0; j < n; ++j) {
+            const f16x8 v = xc[(long)j * per + r];
 #pragma unroll
             for (int e = 0; e < 8; ++e) mx[e] = fmaxf(mx[e], (float)v[e]);
         }
-        for (int j = 0; j < n; ++j) {
-            const f16x8 v = xcor[((long)i * n + j) * per + r];
+        for (unsigned j = 0; j < n; ++j) {
+            const f16x8 v = xc[(long)j * per + r];
             const f16x8 xv = x[(long)j * per + r];
 #pragma unroll
             for (int e = 0; e < 8; ++e) {
-                const float w = __expf((float)v[e] - mx[e]);
-                den[e] += w;
-                acc[e] += w * (float)xv[e];
+                const float wgt = __expf((float)v[e] - mx[e]);
+                den[e] += wgt;
+                acc[e] += wgt * (float)xv[e];
             }
         }
         f16x8 o;
 #pragma unroll
         for (int e = 0; e < 8; ++e) o[e] = (_Float16)(acc[e] / den[e]);
-        out[t] = o;
+        out[(long)i * per + r] = o;
     }
 }
 
 // y = a + b over rows of c halfs with row strides (the two inner skips of DenoisingAggregator.forward, :193,197), fp32 add
 __global__ __launch_bounds__(256) void add_f16_kernel(const _Float16* __restrict__ a, const _Float16* __restrict__ b,
                                                      _Float16* __restrict__ y, long rows, int c8, int a_ld, int b_ld, int y_ld) {
-    const long total = rows * c8;
-    for (long t = blockIdx.x * (long)blockDim.x + threadIdx.x; t < total; t += (long)gridDim.x * blockDim.x) {
-        const long r = t / c8;
-        const int cv = (int)(t - r * c8) * 8;
+    const unsigned total = (unsigned)(rows * c8);
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const unsigned rr = t / (unsigned)c8;
+        const long r = rr;
+        const int cv = (int)(t - rr * (unsigned)c8) * 8;
         const f16x8 u = *reinterpret_cast<const f16x8*>(a + r * a_ld + cv), v = *reinterpret_cast<const f16x8*>(b + r * b_ld + cv);
         f16x8 o;
 #pragma unroll
@@ -161,46 +192,54 @@ extern "C" int llv_modulated_deform_im2col(const void* x, const float* om, void*
     if (!x || !om || !col || n <= 0 || h <= 0 || w <= 0 || c <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || dilation <= 0 ||
         deform_groups <= 0 || ho <= 0 || wo <= 0)
         return LLV_E_BADARG;
-    if ((c & 7) || (x_ld & 7) || (col_ld & 7) || x_ld < c || col_ld < kh * kw * c || om_ld < 3 * deform_groups * kh * kw)
+    if ((c & 7) || (x_ld & 7) || (col_ld & 7) || x_ld < c || col_ld < kh * kw * c || om_ld < 3 * deform_groups * kh * kw || (om_ld & 1))
         return LLV_E_BADARG;
     if (c % deform_groups || ((c / deform_groups) & 7)) return LLV_E_UNSUPPORTED;   // a lane's 8 channels share one offset
     if (ho != (h + 2 * pad - (dilation * (kh - 1) + 1)) / stride + 1 || wo != (w + 2 * pad - (dilation * (kw - 1) + 1)) / stride + 1)
         return LLV_E_BADARG;
-    const long total = (long)n * ho * wo * kh * kw * (c / 8);
-    long blocks = (total + 255) / 256;
-    blocks = blocks > 256 * 32 ? 256 * 32 : blocks;
-    hipLaunchKernelGGL(mdcn_im2col_kernel, dim3((int)blocks), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, om,
-                       (_Float16*)col, n, h, w, c / 8, x_ld, om_ld, col_ld, kh, kw, stride, pad, dilation, deform_groups,
+    if ((long)wo * kh * kw * (c / 8) >= (1L << 30)) return LLV_E_UNSUPPORTED;
+    const long row_items = (long)wo * kh * kw * (c / 8);
+    long bx = (row_items + 511) / 512;                        // two items per thread
+    bx = bx < 1 ? 1 : bx;
+    // grid.y is limited to 65535: fold rows into y only (n*ho of a 736-row, 9-pair clip is 6624)
+    if ((long)n * ho > 65535) return LLV_E_UNSUPPORTED;
+    hipLaunchKernelGGL(mdcn_im2col_kernel, dim3((unsigned)bx, (unsigned)(n * ho)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, om,
+                       (_Float16*)col, h, w, c / 8, x_ld, om_ld, col_ld, kh, kw, stride, pad, dilation, deform_groups,
                        c / deform_groups / 8, ho, wo);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
+static bool taf_ok(int n, int h, int w, int m) {
+    return n > 0 && h > 0 && w > 0 && m > 0 && !(m & 7) && (long)n * n <= 65535 && (long)h * w * (m / 4) < (1L << 31);
+}
+
 extern "C" int llv_taf_pair_concat(const void* x, void* y, int n, int h, int w, int m, void* stream) {
-    if (!x || !y || n <= 0 || h <= 0 || w <= 0 || m <= 0 || (m & 7)) return LLV_E_BADARG;
-    const long total = (long)n * n * h * w * 2 * (m / 8);
-    hipLaunchKernelGGL(taf_pair_concat_kernel, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, (const f16x8*)x, (f16x8*)y, n,
-                       (long)h * w, m / 8);
+    if (!x || !y || !taf_ok(n, h, w, m)) return LLV_E_BADARG;
+    const long per = (long)h * w * 2 * (m / 8);
+    hipLaunchKernelGGL(taf_pair_concat_kernel, dim3(grid_of(per), n * n), dim3(256), 0, (hipStream_t)stream, (const f16x8*)x, (f16x8*)y,
+                       (unsigned)n, (unsigned)(h * w), (unsigned)(m / 8));
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
 extern "C" int llv_taf_mul_ref(const void* xd, const void* x, void* y, int n, int h, int w, int m, void* stream) {
-    if (!xd || !x || !y || n <= 0 || h <= 0 || w <= 0 || m <= 0 || (m & 7)) return LLV_E_BADARG;
-    const long total = (long)n * n * h * w * (m / 8);
-    hipLaunchKernelGGL(taf_mul_ref_kernel, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, (const f16x8*)xd, (const f16x8*)x,
-                       (f16x8*)y, n, (long)h * w, m / 8);
+    if (!xd || !x || !y || !taf_ok(n, h, w, m)) return LLV_E_BADARG;
+    const long per = (long)h * w * (m / 8);
+    hipLaunchKernelGGL(taf_mul_ref_kernel, dim3(grid_of(per), n * n), dim3(256), 0, (hipStream_t)stream, (const f16x8*)xd, (const f16x8*)x,
+                       (f16x8*)y, (unsigned)n, (unsigned)per);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
 extern "C" int llv_taf_softmax_fuse(const void* xcor, const void* x, void* out, int n, int h, int w, int m, void* stream) {
-    if (!xcor || !x || !out || n <= 0 || h <= 0 || w <= 0 || m <= 0 || (m & 7)) return LLV_E_BADARG;
-    const long total = (long)n * h * w * (m / 8);
-    hipLaunchKernelGGL(taf_softmax_fuse_kernel, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, (const f16x8*)xcor,
-                       (const f16x8*)x, (f16x8*)out, n, (long)h * w, m / 8);
+    if (!xcor || !x || !out || !taf_ok(n, h, w, m)) return LLV_E_BADARG;
+    const long per = (long)h * w * (m / 8);
+    hipLaunchKernelGGL(taf_softmax_fuse_kernel, dim3(grid_of(per), n), dim3(256), 0, (hipStream_t)stream, (const f16x8*)xcor,
+                       (const f16x8*)x, (f16x8*)out, (unsigned)n, (unsigned)per);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
 extern "C" int llv_add_f16(const void* a, const void* b, void* y, int64_t rows, int c, int a_ld, int b_ld, int y_ld, void* stream) {
     if (!a || !b || !y || rows <= 0 || c <= 0 || ((c | a_ld | b_ld | y_ld) & 7) || a_ld < c || b_ld < c || y_ld < c) return LLV_E_BADARG;
+    if (rows * (c / 8) >= (1L << 31)) return LLV_E_UNSUPPORTED;
     hipLaunchKernelGGL(add_f16_kernel, dim3(grid_of(rows * (c / 8))), dim3(256), 0, (hipStream_t)stream, (const _Float16*)a,
                        (const _Float16*)b, (_Float16*)y, (long)rows, c / 8, a_ld, b_ld, y_ld);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
