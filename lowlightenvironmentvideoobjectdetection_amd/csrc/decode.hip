@@ -72,7 +72,8 @@ __device__ __forceinline__ int level_of_anchor(const DecK& k, int g) {
 }
 
 constexpr int kBins = 4096;      // linear score histogram: bin = min(4095, int(score * 4096)), monotone in the score
-constexpr int kSortCap = 8192;   // ties-list size the final kernel sorts in LDS; longer lists take the radix path
+constexpr int kSortCap = 1024;   // ties-list size the final kernel sorts in LDS; longer lists take the radix-select path
+                                 // (a bitonic sort of 8192 keys by one workgroup took 0.4 ms: 91 LDS passes)
 
 __device__ __forceinline__ int score_bin(float m) {
     int b = (int)(m * (float)kBins);
@@ -252,8 +253,7 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const DecK k) {
     uint64_t* fin = lds;             // [np2k]
     uint64_t* tbuf = lds + np2k;     // [kSortCap]
     __shared__ unsigned hist[256];
-    __shared__ uint64_t sh_prefix;
-    __shared__ unsigned sh_need, sh_cnt;
+    __shared__ uint64_t sh_sel[2];
     const int* meta = meta_i + l * 4;
     const int nA = meta[2], nT = meta[3];
     const int m = kk - nA;           // keys still needed, all from T (nT >= m by construction)
@@ -269,48 +269,9 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const DecK k) {
         for (int i = tid; i < m; i += blockDim.x) fin[nA + i] = tbuf[i];
         __syncthreads();
     } else {
-        // long tie list (e.g. a blank frame: every score equal): 8 x 8-bit radix select on the distinct 64-bit keys
-        uint64_t prefix = 0;
-        unsigned need = (unsigned)m;
-        for (int pass = 0; pass < 8; ++pass) {
-            const int shift = 56 - 8 * pass;
-            for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
-            __syncthreads();
-            for (int i0 = 0; i0 < nT; i0 += blockDim.x) {
-                const int i = i0 + tid;
-                bool ok = false;
-                unsigned d = 0;
-                if (i < nT) {
-                    const uint64_t key = Tl[i];
-                    ok = pass == 0 ? true : ((key >> (shift + 8)) == prefix);
-                    d = (unsigned)((key >> shift) & 255ull);
-                }
-                wave_hist_add(hist, d, ok);
-            }
-            __syncthreads();
-            if (tid == 0) {
-                unsigned cum = 0;
-                int b = 255;
-                for (; b > 0; --b) {
-                    if (cum + hist[b] >= need) break;
-                    cum += hist[b];
-                }
-                sh_need = need - cum;
-                sh_prefix = (prefix << 8) | (uint64_t)b;
-            }
-            __syncthreads();
-            prefix = sh_prefix;
-            need = sh_need;
-            __syncthreads();
-        }
-        // prefix is now the m-th largest key; keys are distinct, so exactly m keys are >= it
-        if (tid == 0) sh_cnt = 0;
-        __syncthreads();
-        for (int i = tid; i < nT; i += blockDim.x) {
-            const uint64_t key = Tl[i];
-            if (key >= prefix) fin[nA + atomicAdd(&sh_cnt, 1u)] = key;
-        }
-        __syncthreads();
+        // long list (a crowded histogram bin, or a blank frame where every score is equal): radix select of the m largest
+        // of the distinct 64-bit keys straight from the global list, no sort of T at all
+        if (m > 0) llv::block_select_top(Tl, nT, m, fin + nA, hist, sh_sel);
     }
     llv::bitonic_sort_desc(fin, np2k);
     for (int i = tid; i < kk; i += blockDim.x) sel[i] = k.a0[l] + (int)llv::key_index(fin[i]);

@@ -62,24 +62,34 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const float* __restrict__
         cand = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(cand) + img * ws_stride);
     }
     unsigned m = 0;
-    for (long e = blockIdx.x * (long)blockDim.x + threadIdx.x; e < total; e += (long)gridDim.x * blockDim.x) {
-        const int i = (int)(e / C), c = (int)(e - (long)i * C);
+    const unsigned utotal = (unsigned)total, uC = (unsigned)C;        // n * C < 2^31 (checked by the caller)
+    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < utotal; e += gridDim.x * blockDim.x) {
+        const unsigned i = e / uC, c = e - i * uC;
         const float s = scores[(long)i * c_ld + c];
         if (s > thr) {
             const int slot = atomicAdd(&cnt_in[c], 1);
             // score_factors multiply AFTER the threshold test (bbox_nms.py:52-62)
-            cand[(long)c * n + slot] = llv::make_key(factors ? s * factors[i] : s, (unsigned)e);
+            cand[(long)c * n + slot] = llv::make_key(factors ? s * factors[i] : s, e);
             const float4 b = reinterpret_cast<const float4*>(boxes)[i];
             const unsigned u = llv::f32_ordered(fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
             m = u > m ? u : m;
         }
     }
+    // boxes.max(): wave -> block -> ONE atomic per block (thousands of waves hitting one address serialise in L2:
+    // that was most of this kernel's 138 us on a single image)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) {
         const unsigned t = __shfl_xor(m, o);
         m = t > m ? t : m;
     }
-    if ((threadIdx.x & 63) == 0 && m) atomicMax(maxc_u, m);
+    __shared__ unsigned wmax[4];
+    if ((threadIdx.x & 63) == 0) wmax[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        const unsigned a = wmax[0] > wmax[1] ? wmax[0] : wmax[1], b = wmax[2] > wmax[3] ? wmax[2] : wmax[3];
+        const unsigned mm = a > b ? a : b;
+        if (mm) atomicMax(maxc_u, mm);
+    }
 }
 
 // Greedy scan over `cnt` sorted keys (LDS) by wave 0. box_of(idx) gives the (offset) box of
@@ -180,22 +190,42 @@ __global__ __launch_bounds__(1024) void nms_merge_kernel(const float* __restrict
     extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
     uint64_t* keys = reinterpret_cast<uint64_t*>(sm);
     __shared__ int s_off[1025];
-    if (threadIdx.x == 0) {
-        int s = 0;
-        for (int c = 0; c < C; ++c) { s_off[c] = s; s += cls_cnt[c]; }
-        s_off[C] = s;
+    __shared__ int s_scr[17];
+    __shared__ unsigned s_hist[256];
+    __shared__ uint64_t s_sel[2];
+    // offsets of the per-class lists: block-wide exclusive scan of cls_cnt (C <= 1024 = blockDim)
+    const int mine = (int)threadIdx.x < C ? cls_cnt[threadIdx.x] : 0;
+    int total = 0;
+    const int excl = llv::block_exclusive_scan(mine, s_scr, &total);
+    if ((int)threadIdx.x < C) s_off[threadIdx.x] = excl;
+    if (threadIdx.x == 0) s_off[C] = total;
+    __syncthreads();
+    // gather the kept lists: entry e of the concatenation belongs to the class c with s_off[c] <= e < s_off[c+1]
+    for (int e = threadIdx.x; e < total; e += blockDim.x) {
+        int lo = 0, hi = C;                                  // invariant: s_off[lo] <= e < s_off[hi]
+        while (hi - lo > 1) {
+            const int mid = (lo + hi) >> 1;
+            if (s_off[mid] <= e) lo = mid; else hi = mid;
+        }
+        keys[e] = cls_keys[(long)lo * max_num + (e - s_off[lo])];
     }
     __syncthreads();
-    const int total = s_off[C];
-    const int np2 = llv::next_pow2(total > 1 ? total : 1);
-    for (int c = 0; c < C; ++c) {
-        const int cc = cls_cnt[c];
-        for (int j = threadIdx.x; j < cc; j += blockDim.x) keys[s_off[c] + j] = cls_keys[(long)c * max_num + j];
-    }
-    for (int i = total + threadIdx.x; i < np2; i += blockDim.x) keys[i] = 0;
-    __syncthreads();
-    llv::bitonic_sort_desc(keys, np2);
     const int k = total < max_num ? total : max_num;
+    const int kp2 = llv::next_pow2(k > 1 ? k : 1);
+    if (total > 2 * kp2 && total > 1024) {
+        // only the k best of `total` kept boxes are wanted: radix-select them, then sort k keys instead of `total`
+        uint64_t* top = keys + llv::next_pow2(total);
+        llv::block_select_top(keys, total, k, top, s_hist, s_sel);
+        for (int i = k + threadIdx.x; i < kp2; i += blockDim.x) top[i] = 0;
+        __syncthreads();
+        llv::bitonic_sort_desc(top, kp2);
+        keys = top;
+    } else {
+        const int np2 = llv::next_pow2(total > 1 ? total : 1);
+        for (int i = total + threadIdx.x; i < np2; i += blockDim.x) keys[i] = 0;
+        __syncthreads();
+        llv::bitonic_sort_desc(keys, np2);
+    }
     for (int i = threadIdx.x; i < k; i += blockDim.x) {
         const uint64_t key = keys[i];
         const unsigned flat = llv::key_index(key);
@@ -292,7 +322,7 @@ extern "C" int llv_multiclass_nms_batched_sf(const float* boxes, const float* sc
         if (hipMemsetAsync(ws + (size_t)b * stride, 0, o_keys, st) != hipSuccess) return LLV_E_LAUNCH;
     if (n > 0) {
         long g = ((long)n * num_classes + 255) / 256;
-        g = g > 1024 ? 1024 : g;
+        g = g > 256 ? 256 : g;
         hipLaunchKernelGGL(nms_scan_kernel, dim3((int)g, batch), dim3(256), 0, st, boxes, scores, score_factors, n, num_classes, c_ld, score_thr,
                            maxc_u, cnt_in, cand, stride);
         int np2 = 1;
@@ -303,7 +333,9 @@ extern "C" int llv_multiclass_nms_batched_sf(const float* boxes, const float* sc
     }
     int mp2 = 1;
     while (mp2 < num_classes * max_num) mp2 <<= 1;
-    hipLaunchKernelGGL(nms_merge_kernel, dim3(1, batch), dim3(1024), (size_t)mp2 * 8, st, boxes, n, num_classes, max_num,
+    int kp2 = 1;
+    while (kp2 < max_num) kp2 <<= 1;
+    hipLaunchKernelGGL(nms_merge_kernel, dim3(1, batch), dim3(1024), (size_t)(mp2 + kp2) * 8, st, boxes, n, num_classes, max_num,
                        cls_cnt, cls_keys, dets, labels, count, keep_flat, stride);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }

@@ -70,4 +70,59 @@ __device__ inline int block_exclusive_scan(int v, int* scratch, int* total) {
     return base + incl - v;
 }
 
+
+// The m largest of n DISTINCT 64-bit keys src[0..n) (global or LDS) -> dst[0..m) in LDS, unordered; 1 <= m <= n.
+// 8 x 8-bit radix select, most significant digit first: per pass an LDS histogram of the digit over the keys that still
+// match the prefix, then wave 0 walks the 256 bins from the top (4 bins per lane, suffix sums by shuffles) to the bin that
+// holds the m-th largest key. All threads of the block call; hist = 256 unsigned and sh = 2 uint64 of LDS.
+// Cost is O(8 * n / blockDim) instead of the O(n log^2 n / blockDim) of a bitonic sort: the caller sorts only dst.
+__device__ inline void block_select_top(const uint64_t* src, int n, int m, uint64_t* dst, unsigned* hist, uint64_t* sh) {
+    const int tid = threadIdx.x, lane = tid & 63;
+    uint64_t prefix = 0;
+    unsigned need = (unsigned)m;
+    for (int pass = 0; pass < 8; ++pass) {
+        const int shift = 56 - 8 * pass;
+        for (int i = tid; i < 256; i += blockDim.x) hist[i] = 0;
+        __syncthreads();
+        for (int i = tid; i < n; i += blockDim.x) {
+            const uint64_t key = src[i];
+            if (pass == 0 || (key >> (shift + 8)) == prefix) atomicAdd(&hist[(unsigned)((key >> shift) & 255ull)], 1u);
+        }
+        __syncthreads();
+        if (tid < 64) {
+            const int b0 = 255 - 4 * lane;                       // this lane's bins b0, b0-1, b0-2, b0-3 (descending)
+            const unsigned h0 = hist[b0], h1 = hist[b0 - 1], h2 = hist[b0 - 2], h3 = hist[b0 - 3];
+            const unsigned s = h0 + h1 + h2 + h3;
+            unsigned incl = s;
+#pragma unroll
+            for (int o = 1; o < 64; o <<= 1) {
+                const unsigned t = __shfl_up(incl, o);
+                if (lane >= o) incl += t;
+            }
+            unsigned cum = incl - s;                             // keys in bins above this lane's
+            if (cum < need && need <= incl) {                    // exactly one lane: the matching keys number >= need
+                int b = b0;
+                if (cum + h0 < need) { cum += h0; b = b0 - 1;
+                    if (cum + h1 < need) { cum += h1; b = b0 - 2;
+                        if (cum + h2 < need) { cum += h2; b = b0 - 3; } } }
+                sh[0] = (prefix << 8) | (uint64_t)b;
+                sh[1] = (uint64_t)(need - cum);
+            }
+        }
+        __syncthreads();
+        prefix = sh[0];
+        need = (unsigned)sh[1];
+        __syncthreads();
+    }
+    // prefix is the m-th largest key; the keys are distinct, so exactly m of them are >= it
+    unsigned* cnt = hist;
+    if (tid == 0) *cnt = 0;
+    __syncthreads();
+    for (int i = tid; i < n; i += blockDim.x) {
+        const uint64_t key = src[i];
+        if (key >= prefix) dst[atomicAdd(cnt, 1u)] = key;
+    }
+    __syncthreads();
+}
+
 }  // namespace llv
