@@ -21,9 +21,9 @@ inline int grid_for(long work) {
 __global__ void maxpool3x3s2_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y, int batch,
                                     int h, int w, int c8, int ho, int wo) {
     const long total = (long)batch * ho * wo * c8;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {   // total < 2^31 (host check): 32-bit divisions
         const int cv = (int)(i % c8);
-        long p = i / c8;
+        unsigned p = i / c8;
         const int ox = (int)(p % wo); p /= wo;
         const int oy = (int)(p % ho);
         const int n = (int)(p / ho);
@@ -46,7 +46,7 @@ __global__ void maxpool3x3s2_kernel(const _Float16* __restrict__ x, _Float16* __
             }
         }
         (void)any;
-        *reinterpret_cast<f16x8*>(y + i * 8) = m;
+        *reinterpret_cast<f16x8*>(y + (long)i * 8) = m;
     }
 }
 
@@ -54,8 +54,8 @@ __global__ void maxpool3x3s2_kernel(const _Float16* __restrict__ x, _Float16* __
 __global__ void pack_kernel(const float* __restrict__ x, _Float16* __restrict__ y, int batch, int c, long hw,
                             int c_pad, const float* __restrict__ scale, const float* __restrict__ shift) {
     const long total = (long)batch * hw;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long n = i / hw, p = i - n * hw;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {   // total < 2^31 (host check): 32-bit divisions
+        const unsigned n = i / (unsigned)hw, p = i - n * (unsigned)hw;
         for (int cb = 0; cb < c_pad; cb += 8) {
             f16x8 o;
 #pragma unroll
@@ -68,7 +68,7 @@ __global__ void pack_kernel(const float* __restrict__ x, _Float16* __restrict__ 
                 }
                 o[e] = (_Float16)v;
             }
-            *reinterpret_cast<f16x8*>(y + i * c_pad + cb) = o;
+            *reinterpret_cast<f16x8*>(y + (long)i * c_pad + cb) = o;
         }
     }
 }
@@ -76,11 +76,11 @@ __global__ void pack_kernel(const float* __restrict__ x, _Float16* __restrict__ 
 template <typename T>
 __global__ void unpack_kernel(const T* __restrict__ x, float* __restrict__ y, int batch, int c, long hw, int ld) {
     const long total = (long)batch * c * hw;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const long p = i % hw;
-        const long t = i / hw;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {   // total < 2^31 (host check): 32-bit divisions
+        const unsigned p = i % (unsigned)hw;
+        const unsigned t = i / (unsigned)hw;
         const int ch = (int)(t % c);
-        const long n = t / c;
+        const unsigned n = t / c;
         y[i] = (float)x[(n * hw + p) * ld + ch];
     }
 }
@@ -170,9 +170,9 @@ __global__ void flow_warp_kernel(const _Float16* __restrict__ x, const float* __
                                  _Float16* __restrict__ y, int nb, int h, int w, int c8, int ld, int hf, int wf,
                                  float rscale_h, float rscale_w, float mul) {
     const long total = (long)nb * h * w * c8;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {   // total < 2^31 (host check): 32-bit divisions
         const int cv = (int)(i % c8);
-        long p = i / c8;
+        unsigned p = i / c8;
         const int ox = (int)(p % w); p /= w;
         const int oy = (int)(p % h);
         const int n = (int)(p / h);
@@ -226,13 +226,13 @@ __device__ __forceinline__ float bilerp_plane(const float* f, int h, int w, floa
 __global__ void bilinear_resize_kernel(const float* __restrict__ x, float* __restrict__ y, int nc, int h, int w, int ho,
                                        int wo, float rscale, float mul) {
     const long total = (long)nc * ho * wo;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {   // total < 2^31 (host check): 32-bit divisions
         const int ox = (int)(i % wo);
-        const long t = i / wo;
+        const unsigned t = i / wo;
         const int oy = (int)(t % ho);
-        const long p = t / ho;
+        const unsigned p = t / ho;
         const float sy = ((float)oy + 0.5f) * rscale - 0.5f, sx = ((float)ox + 0.5f) * rscale - 0.5f;
-        y[i] = bilerp_plane(x + p * h * w, h, w, sy, sx) * mul;
+        y[i] = bilerp_plane(x + (long)p * h * w, h, w, sy, sx) * mul;
     }
 }
 
@@ -241,11 +241,11 @@ __global__ void flow_prepare_kernel(const float* __restrict__ x, _Float16* __res
                                     int wo, int img_h, int img_w, const float* __restrict__ scale,
                                     const float* __restrict__ shift, float rscale) {
     const long total = (long)n * ho * wo;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {   // total < 2^31 (host check): 32-bit divisions
         const int ox = (int)(i % wo);
-        const long t = i / wo;
+        const unsigned t = i / wo;
         const int oy = (int)(t % ho);
-        const long b = t / ho;
+        const unsigned b = t / ho;
         float sy = ((float)oy + 0.5f) * rscale - 0.5f, sx = ((float)ox + 0.5f) * rscale - 0.5f;
         sy = sy < 0.f ? 0.f : sy;
         sx = sx < 0.f ? 0.f : sx;
@@ -266,7 +266,7 @@ __global__ void flow_prepare_kernel(const float* __restrict__ x, _Float16* __res
             }
             o[c] = (_Float16)v;
         }
-        *reinterpret_cast<f16x8*>(y + i * 8) = o;
+        *reinterpret_cast<f16x8*>(y + (long)i * 8) = o;
     }
 }
 
@@ -277,6 +277,7 @@ extern "C" int llv_flow_prepare(const float* x, void* y, int n, int h, int w, in
     if (!x || !y || !scale || !shift || n < 1 || h < 1 || w < 1 || ho < 1 || wo < 1 || !(resize_scale > 0.f)) return LLV_E_BADARG;
     if ((int)floor((double)h * (double)resize_scale) != ho || (int)floor((double)w * (double)resize_scale) != wo) return LLV_E_BADARG;
     const long total = (long)n * ho * wo;
+    if (total >= (1L << 31)) return LLV_E_UNSUPPORTED;   // the kernel indexes with 32-bit arithmetic
     hipLaunchKernelGGL(flow_prepare_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, x, (_Float16*)y, n, h, w,
                        ho, wo, img_h, img_w, scale, shift, 1.f / resize_scale);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
@@ -285,9 +286,9 @@ extern "C" int llv_flow_prepare(const float* x, void* y, int n, int h, int w, in
 // dst[n][2y+dy][2x+dx][c] = src[n][y][x][c] (F.interpolate(scale_factor=2), nearest; yolo_neck.py:123), 16 B per lane
 __global__ void upsample2x_kernel(const _Float16* src, _Float16* dst, int n, int h, int w, int c8, int src_ld, int dst_ld) {
     const long total = (long)n * (2 * h) * (2 * w) * c8;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {   // total < 2^31 (host check): 32-bit divisions
         const int cv = (int)(i % c8);
-        long t = i / c8;
+        unsigned t = i / c8;
         const int x = (int)(t % (2 * w)); t /= 2 * w;
         const int y = (int)(t % (2 * h));
         const int im = (int)(t / (2 * h));
@@ -301,9 +302,9 @@ __global__ void upsample2x_kernel(const _Float16* src, _Float16* dst, int n, int
 struct YoloArgs { const float* pred; float* boxes; float* conf; int n, h, w, A, na, ld, stride; float aw[8], ah[8]; };
 __global__ void yolo_decode_kernel(const YoloArgs k) {
     const long per = (long)k.h * k.w * k.A, total = per * k.n;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {   // total < 2^31 (host check): 32-bit divisions
         const int a = (int)(i % k.A);
-        long t = i / k.A;
+        unsigned t = i / k.A;
         const int cx = (int)(t % k.w); t /= k.w;
         const int cy = (int)(t % k.h);
         const int im = (int)(t / k.h);
@@ -336,9 +337,9 @@ __global__ void preprocess_kernel(const PrepArgs k) {
     const long total = (long)k.t * k.hp * k.wp;
     const unsigned long long s = *k.sum;
     const double amp = k.m_hw3_255 / (double)(s ? s : 1ull);          // m*h*w*3 / sum(x/255)
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {   // total < 2^31 (host check): 32-bit divisions
         const int px = (int)(i % k.wp);
-        long r = i / k.wp;
+        unsigned r = i / k.wp;
         const int py = (int)(r % k.hp);
         const int f = (int)(r / k.hp);
         _Float16 o[8] = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
@@ -352,7 +353,7 @@ __global__ void preprocess_kernel(const PrepArgs k) {
                 o[c] = (_Float16)((q - k.mean[c]) * k.stdinv[c]);
             }
         }
-        *reinterpret_cast<uint4*>(k.y + i * 8) = *reinterpret_cast<const uint4*>(o);
+        *reinterpret_cast<uint4*>(k.y + (long)i * 8) = *reinterpret_cast<const uint4*>(o);
     }
 }
 
@@ -368,6 +369,7 @@ extern "C" int llv_brighten_normalize_pad_u8(const void* frames, int t, int h, i
     k.t = t; k.h = h; k.w = w; k.hp = hp; k.wp = wp; k.to_rgb = to_rgb;
     k.m_hw3_255 = (double)m * (double)h * (double)w * 3.0 * 255.0;
     for (int c = 0; c < 3; ++c) { k.mean[c] = mean3[c]; k.stdinv[c] = (float)(1.0 / (double)std3[c]); }
+    if ((long)t * hp * wp >= (1L << 31)) return LLV_E_UNSUPPORTED;
     hipLaunchKernelGGL(preprocess_kernel, dim3(grid_for((long)t * hp * wp)), dim3(kBlock), 0, st, k);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
@@ -375,6 +377,7 @@ extern "C" int llv_brighten_normalize_pad_u8(const void* frames, int t, int h, i
 extern "C" int llv_upsample2x_nhwc(const void* src, void* dst, int n, int h, int w, int c, int src_ld, int dst_ld, void* stream) {
     if (!src || !dst || n < 1 || h < 1 || w < 1 || c < 8 || (c & 7) || (src_ld & 7) || (dst_ld & 7) || src_ld < c || dst_ld < c) return LLV_E_BADARG;
     const long total = (long)n * 4 * h * w * (c / 8);
+    if (total >= (1L << 31)) return LLV_E_UNSUPPORTED;   // the kernel indexes with 32-bit arithmetic
     hipLaunchKernelGGL(upsample2x_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, (const _Float16*)src, (_Float16*)dst,
                        n, h, w, c / 8, src_ld, dst_ld);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
@@ -389,6 +392,7 @@ extern "C" int llv_yolo_decode(const float* pred, int n, int h, int w, int num_a
     k.pred = pred; k.boxes = boxes; k.conf = conf; k.n = n; k.h = h; k.w = w; k.A = num_anchors; k.na = num_attrib; k.ld = ld; k.stride = stride;
     for (int a = 0; a < 8; ++a) { k.aw[a] = a < num_anchors ? anchors_wh[2 * a] : 0.f; k.ah[a] = a < num_anchors ? anchors_wh[2 * a + 1] : 0.f; }
     const long total = (long)n * h * w * num_anchors;
+    if (total >= (1L << 31)) return LLV_E_UNSUPPORTED;   // the kernel indexes with 32-bit arithmetic
     hipLaunchKernelGGL(yolo_decode_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, k);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
@@ -398,6 +402,7 @@ extern "C" int llv_bilinear_resize_f32(const float* x, float* y, int nc, int h, 
     if (!x || !y || nc < 1 || h < 1 || w < 1 || ho < 1 || wo < 1 || !(scale_factor > 0.f)) return LLV_E_BADARG;
     if ((int)floor((double)h * (double)scale_factor) != ho || (int)floor((double)w * (double)scale_factor) != wo) return LLV_E_BADARG;
     const long total = (long)nc * ho * wo;
+    if (total >= (1L << 31)) return LLV_E_UNSUPPORTED;   // the kernel indexes with 32-bit arithmetic
     hipLaunchKernelGGL(bilinear_resize_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, x, y, nc, h, w, ho, wo,
                        1.f / scale_factor, mul);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
@@ -407,6 +412,7 @@ extern "C" int llv_maxpool3x3s2_nhwc(const void* x, void* y, int batch, int h, i
     if (!x || !y || batch < 1 || h < 1 || w < 1 || c < 8 || (c & 7)) return LLV_E_BADARG;
     const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
     const long total = (long)batch * ho * wo * (c / 8);
+    if (total >= (1L << 31)) return LLV_E_UNSUPPORTED;   // the kernel indexes with 32-bit arithmetic
     hipLaunchKernelGGL(maxpool3x3s2_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream,
                        (const _Float16*)x, (_Float16*)y, batch, h, w, c / 8, ho, wo);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
@@ -417,6 +423,7 @@ extern "C" int llv_pack_nchw_f32_to_nhwc_f16(const float* x, void* y, int batch,
     if (!x || !y || batch < 1 || c < 1 || h < 1 || w < 1 || c_pad < c || (c_pad & 7)) return LLV_E_BADARG;
     if ((scale == nullptr) != (shift == nullptr)) return LLV_E_BADARG;
     const long total = (long)batch * h * w;
+    if (total >= (1L << 31)) return LLV_E_UNSUPPORTED;   // the kernel indexes with 32-bit arithmetic
     hipLaunchKernelGGL(pack_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, x, (_Float16*)y,
                        batch, c, (long)h * w, c_pad, scale, shift);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
@@ -426,6 +433,7 @@ extern "C" int llv_unpack_nhwc_f16_to_nchw_f32(const void* x, float* y, int batc
                                                void* stream) {
     if (!x || !y || batch < 1 || c < 1 || h < 1 || w < 1 || ld < c) return LLV_E_BADARG;
     const long total = (long)batch * c * h * w;
+    if (total >= (1L << 31)) return LLV_E_UNSUPPORTED;   // the kernel indexes with 32-bit arithmetic
     hipLaunchKernelGGL((unpack_kernel<_Float16>), dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream,
                        (const _Float16*)x, y, batch, c, (long)h * w, ld);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
@@ -435,6 +443,7 @@ extern "C" int llv_unpack_nhwc_f32_to_nchw_f32(const float* x, float* y, int bat
                                                void* stream) {
     if (!x || !y || batch < 1 || c < 1 || h < 1 || w < 1 || ld < c) return LLV_E_BADARG;
     const long total = (long)batch * c * h * w;
+    if (total >= (1L << 31)) return LLV_E_UNSUPPORTED;   // the kernel indexes with 32-bit arithmetic
     hipLaunchKernelGGL((unpack_kernel<float>), dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, x, y,
                        batch, c, (long)h * w, ld);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
@@ -479,6 +488,7 @@ extern "C" int llv_flow_warp(const void* x, const float* flow, void* y, int n, i
     if ((int)floor((double)hf * (double)s) != h || (int)floor((double)wf * (double)s) != w) return LLV_E_BADARG;
     const float rs = 1.f / s;
     const long total = (long)n * h * w * (c / 8);
+    if (total >= (1L << 31)) return LLV_E_UNSUPPORTED;   // the kernel indexes with 32-bit arithmetic
     hipLaunchKernelGGL(flow_warp_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream,
                        (const _Float16*)x, flow, (_Float16*)y, n, h, w, c / 8, ld, hf, wf, rs, rs, s);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
