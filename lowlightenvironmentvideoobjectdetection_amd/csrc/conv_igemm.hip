@@ -1382,34 +1382,61 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
                 *reinterpret_cast<f16x4*>(tile + prow * TS + i * 16 + fch * 4) = o4;
             }
         }
-        __syncthreads();
-        constexpr int CPR = BN / 8;
+        // destination pixels and the skip values of this lane's CPR rows: requested BEFORE the barrier, so the global reads
+        // are in flight while the tile is being staged (one exposed latency per tile instead of one per row)
+        constexpr int CPR = BN / 8, RPI = 256 / CPR;
         const int cc = tid % CPR, ch = tile_n * BN + cc * 8;      // first conv channel of this lane's 8
-        if (ch < a.cout) {
-            const int e = ch / OC, oc = ch - e * OC;               // sub-pixel, first output channel
-            const int dy = e >> 1, dx = e & 1;
-            for (int prow = tid / CPR; prow < 256; prow += 256 / CPR) {
+        const bool chok = ch < a.cout;
+        const int e = chok ? ch / OC : 0, oc = ch - e * OC;       // sub-pixel, first output channel
+        const int dy = e >> 1, dx = e & 1;
+        const bool has_res = (a.flags & LLV_CONV_RES_ADD) != 0;
+        // BN = 64 (8 rows per lane): pixel indices and skip values are requested BEFORE the barrier; the 128-channel
+        // variant (16 rows per lane) would spill and keeps the row-at-a-time loop
+        constexpr bool PRE = BN <= 64;
+        long pixs[PRE ? CPR : 1];
+        f16x8 r8s[PRE ? CPR : 1];
+        if (PRE) {
+#pragma unroll
+            for (int it = 0; it < CPR; ++it) {
+                const int prow = tid / CPR + it * RPI;
                 const int oy = ty0 + (prow >> 5), ox = tx0 + (prow & 31);
-                if (oy >= H || ox >= W || 2 * oy + dy >= a.ps_h || 2 * ox + dx >= a.ps_w) continue;
-                const long pix = (long)a.seg_yoff[seg] + ((long)(n * a.ps_h + 2 * oy + dy)) * a.ps_w + (2 * ox + dx);
-                const f16x8 t8 = *reinterpret_cast<const f16x8*>(tile + prow * TS + cc * 8);
-                float v[8];
-#pragma unroll
-                for (int t = 0; t < 8; ++t) v[t] = (float)t8[t];
-                if (a.flags & LLV_CONV_RES_ADD) {
-                    const f16x8 r8 = *reinterpret_cast<const f16x8*>(a.res + pix * a.res_ld + g * OC + oc);
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) v[t] += (float)r8[t];
-                }
-                if (a.flags & (LLV_CONV_RELU | LLV_CONV_LEAKY)) {
-#pragma unroll
-                    for (int t = 0; t < 8; ++t) v[t] = act_fn(a, v[t]);
-                }
-                f16x8 o8;
-#pragma unroll
-                for (int t = 0; t < 8; ++t) o8[t] = (_Float16)v[t];
-                *reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(a.y) + pix * a.y_ld + g * OC + oc) = o8;
+                const bool ok = chok && oy < H && ox < W && 2 * oy + dy < a.ps_h && 2 * ox + dx < a.ps_w;
+                pixs[it] = ok ? (long)a.seg_yoff[seg] + ((long)(n * a.ps_h + 2 * oy + dy)) * a.ps_w + (2 * ox + dx) : -1;
+                if (ok && has_res) r8s[it] = *reinterpret_cast<const f16x8*>(a.res + pixs[it] * a.res_ld + g * OC + oc);
             }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int it = 0; it < CPR; ++it) {
+            const int prow = tid / CPR + it * RPI;
+            long pix;
+            f16x8 r8;
+            if (PRE) {
+                pix = pixs[it];
+                r8 = r8s[it];
+            } else {
+                const int oy = ty0 + (prow >> 5), ox = tx0 + (prow & 31);
+                const bool ok = chok && oy < H && ox < W && 2 * oy + dy < a.ps_h && 2 * ox + dx < a.ps_w;
+                pix = ok ? (long)a.seg_yoff[seg] + ((long)(n * a.ps_h + 2 * oy + dy)) * a.ps_w + (2 * ox + dx) : -1;
+                if (ok && has_res) r8 = *reinterpret_cast<const f16x8*>(a.res + pix * a.res_ld + g * OC + oc);
+            }
+            if (pix < 0) continue;
+            const f16x8 t8 = *reinterpret_cast<const f16x8*>(tile + prow * TS + cc * 8);
+            float v[8];
+#pragma unroll
+            for (int t = 0; t < 8; ++t) v[t] = (float)t8[t];
+            if (has_res) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] += (float)r8[t];
+            }
+            if (a.flags & (LLV_CONV_RELU | LLV_CONV_LEAKY)) {
+#pragma unroll
+                for (int t = 0; t < 8; ++t) v[t] = act_fn(a, v[t]);
+            }
+            f16x8 o8;
+#pragma unroll
+            for (int t = 0; t < 8; ++t) o8[t] = (_Float16)v[t];
+            *reinterpret_cast<f16x8*>(reinterpret_cast<_Float16*>(a.y) + pix * a.y_ld + g * OC + oc) = o8;
         }
         return;
     }
