@@ -1848,6 +1848,9 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
         const int co = i * 16 + fch * 4;
         bias4[i] = co < a.cout ? *reinterpret_cast<const float4*>(a.bias + co) : make_float4(0.f, 0.f, 0.f, 0.f);
     }
+    // bias (+ ReLU) only, as the InputCvBlock's second conv is: the bias rides in the accumulator, ReLU is applied to the rounded
+    // halves, and no pixel is located before the staging (the tap kernel's lean epilogue)
+    const bool lean = CK0 == 8 && !(a.flags & ~LLV_CONV_RELU) && a.y_gstride == 0;   // compiled out of the OutputCvBlock instantiation (residual subtract)
     int v = blockIdx.x;
     Tile cur = tile_of(v);
     set_pvo(cur);
@@ -1866,7 +1869,8 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
 #pragma unroll
     for (int i = 0; i < TN2; ++i)
 #pragma unroll
-        for (int j = 0; j < TM; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+        for (int j = 0; j < TM; ++j)
+            acc[i][j] = lean ? (f32x4){bias4[i].x, bias4[i].y, bias4[i].z, bias4[i].w} : (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll 1
     for (int g = 0; g < G; ++g) {
         const int pb = g & (NPB - 1);
@@ -1957,6 +1961,40 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, co
     };
     constexpr int TS = BN2 + 8;
     _Float16* tile = reinterpret_cast<_Float16*>(smem + O_HALO);
+    if (lean) {
+        const bool relu = (a.flags & LLV_CONV_RELU) != 0;
+        const f16x4 z4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int prow = (2 * wave + (j >> 1)) * 32 + (j & 1) * 16 + frow;
+#pragma unroll
+            for (int i = 0; i < TN2; ++i) {
+                f16x4 o4 = {(_Float16)acc[i][j][0], (_Float16)acc[i][j][1], (_Float16)acc[i][j][2], (_Float16)acc[i][j][3]};
+                if (relu) o4 = __builtin_elementwise_max(o4, z4);
+                *reinterpret_cast<f16x4*>(tile + prow * TS + i * 16 + fch * 4) = o4;
+            }
+        }
+        __syncthreads();
+        constexpr int CPR = BN2 / 8;
+        const int cc = tid % CPR, co = cc * 8;
+        if (co < a.cout) {
+            const bool full = co + 8 <= a.cout;
+            _Float16* yb = reinterpret_cast<_Float16*>(a.y) + co;
+#pragma unroll
+            for (int prow = tid / CPR; prow < 256; prow += 256 / CPR) {
+                const int oy = ty0 + (prow >> 5), ox = tx0 + (prow & 31);
+                if (oy >= H || ox >= W) continue;
+                const uint4 val = *reinterpret_cast<const uint4*>(tile + prow * TS + cc * 8);
+                _Float16* dst = yb + (long)(ybase + oy * W + ox) * a.y_ld;
+                if (full) *reinterpret_cast<uint4*>(dst) = val;
+                else *reinterpret_cast<uint2*>(dst) = make_uint2(val.x, val.y);
+            }
+        }
+        if (!has_next) break;
+        v = vn;
+        cur = nxt;
+        continue;
+    }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int prow = (2 * wave + (j >> 1)) * 32 + (j & 1) * 16 + frow;
