@@ -392,6 +392,13 @@ def main():
         raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
+    if world > 1:
+        # set-up (synthetic clip, weight packing) runs on the host in every rank: share the cores instead of oversubscribing them
+        try:
+            ncpu = len(os.sched_getaffinity(0))
+        except AttributeError:
+            ncpu = os.cpu_count() or 8
+        torch.set_num_threads(max(1, min(16, ncpu // world)))
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
