@@ -390,6 +390,11 @@ def main():
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
         raise SystemExit('bench.py needs an MI355X: the product path has no CPU fallback')
+    # rehearsal of the multi-rank path on a one-GPU box: LLV_BENCH_ONE_GPU=1 puts every rank on device 0 and uses gloo
+    # (RCCL refuses two ranks on one device); never set by the driver
+    one_gpu = os.environ.get('LLV_BENCH_ONE_GPU', '0') == '1'
+    if one_gpu:
+        local_rank = 0
     torch.cuda.set_device(local_rank)
     dev = torch.device('cuda', local_rank)
     if world > 1:
@@ -402,7 +407,10 @@ def main():
     import torch.distributed as dist
     if world > 1:
         os.environ.setdefault('MASTER_ADDR', '127.0.0.1')
-        dist.init_process_group('nccl', device_id=dev)
+        if one_gpu:
+            dist.init_process_group('gloo')
+        else:
+            dist.init_process_group('nccl', device_id=dev)
 
     from lowlightenvironmentvideoobjectdetection_amd import data, engine
     from lowlightenvironmentvideoobjectdetection_amd.synthetic import calibrate_head_on_device
