@@ -41,6 +41,7 @@
  *                            mmtracking/mmtrack/models/aggregators/denoising_aggregator.py:103-111), SURVEY.md 8f item 3
  *   llv_eval_tpfp            tpfp_default / tpfp_imagenet of eval_map,
  *                            mmdetection/mmdet/core/evaluation/mean_ap.py:60-244, bbox_overlaps.py:4-48
+ *   llv_coco_match           COCOeval.evaluateImg (pycocotools, un-vendored; call site coco_video_dataset.py:374-461)
  *   llv_iou_assign           MaxIoUAssigner.assign + bbox_overlaps,
  *                            mmdetection/mmdet/core/bbox/assigners/max_iou_assigner.py:60-212,
  *                            mmdetection/mmdet/core/bbox/iou_calculators/iou2d_calculator.py:43-159
@@ -334,6 +335,18 @@ int llv_add_f16(const void* a, const void* b, void* y, int64_t rows, int c, int 
 int llv_eval_tpfp(const float* dets, const int* det_off, const float* gts, const int* gt_off, const uint8_t* gt_ignore,
                   int n_cells, int max_det_per_cell, int max_gt_per_cell, const double* area_ranges, int n_ranges,
                   float iou_thr, int mode, int64_t total_dets, uint8_t* tp, uint8_t* fp, void* stream);
+
+/* COCO-protocol matching (CocoVideoDataset.evaluate, mmtracking/mmtrack/datasets/coco_video_dataset.py:374-461 ->
+ * mmdet CocoDataset.evaluate -> pycocotools COCOeval.evaluateImg; pycocotools is un-vendored): one wavefront per (category, image)
+ * cell, one lane per (area range, IoU threshold) pair (n_ranges * n_thrs <= 64). dets [total_dets][4] double (x, y, w, h), per cell
+ * already in score-descending order and truncated to the largest maxDets; gts [total_gts][4] double with gt_area (the annotation's
+ * `area`), gt_crowd (`iscrowd`) and gt_ignore flags; area_ranges [n_ranges][2], iou_thrs [n_thrs] double.
+ * Out: dt_matched, dt_ignore [n_ranges][n_thrs][total_dets] uint8; gt_valid [n_ranges][n_cells] int32 = ground truths of the cell
+ * that count for the range. At most 256 ground truths per cell. */
+int llv_coco_match(const double* dets, const int* det_off, const double* gts, const double* gt_area, const uint8_t* gt_crowd,
+                   const uint8_t* gt_ignore, const int* gt_off, int n_cells, int max_gt_per_cell, const double* area_ranges,
+                   int n_ranges, const double* iou_thrs, int n_thrs, int64_t total_dets, uint8_t* dt_matched, uint8_t* dt_ignore,
+                   int32_t* gt_valid, void* stream);
 
 /* Test-time image pipeline of the reference in one pass:
  * SeqBrighten (mmtracking/mmtrack/datasets/pipelines/transforms.py:376-432: one gain amp = m*h*w*3 / sum(frame0/255) for the

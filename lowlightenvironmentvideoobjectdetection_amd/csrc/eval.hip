@@ -171,3 +171,103 @@ extern "C" int llv_eval_tpfp(const float* dets, const int* det_off, const float*
                            area_ranges, n_ranges, iou_thr, (long)total_dets, tp, fp);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
+
+// ------------------------------------------------------------------------------------------------
+// COCO-protocol matching (what CocoVideoDataset.evaluate / CocoDataset.evaluate run through pycocotools' COCOeval.evaluateImg;
+// pycocotools is un-vendored, its published algorithm is restated in oracle/coco_eval.py):
+// one wavefront per (category, image) cell, one LANE per (area range, IoU threshold) pair (4 x 10 = 40 of the 64 lanes for the
+// standard parameters): every lane runs the sequential greedy matching of its own pair over the cell's detections (already in
+// score-descending order, truncated to the largest maxDets) and ground truths, IoUs in double precision as maskUtils.iou
+// computes them (crowd: intersection over the detection's area).
+//   gt order: evaluateImg stably sorts the gts by their ignore flag for the area range; walking the non-ignored ones first and
+//   the ignored ones second, each in the original order, is the same order.
+//   outputs: dt_matched / dt_ignore [A][T][total_dets] uint8, gt_valid [A][n_cells] int32 (ground truths not ignored).
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+constexpr int kCocoMaxGt = 256;
+
+__device__ __forceinline__ double coco_iou(const double* d, const double* g, bool crowd) {   // boxes are (x, y, w, h)
+    const double w = fmin(d[0] + d[2], g[0] + g[2]) - fmax(d[0], g[0]);
+    const double h = fmin(d[1] + d[3], g[1] + g[3]) - fmax(d[1], g[1]);
+    if (w <= 0.0 || h <= 0.0) return 0.0;
+    const double inter = w * h;
+    const double uni = crowd ? d[2] * d[3] : d[2] * d[3] + g[2] * g[3] - inter;
+    return inter / uni;
+}
+
+__global__ __launch_bounds__(64) void coco_match_kernel(const double* __restrict__ dets, const int* __restrict__ det_off,
+                                                       const double* __restrict__ gts, const double* __restrict__ gt_area,
+                                                       const uint8_t* __restrict__ gt_crowd, const uint8_t* __restrict__ gt_ign,
+                                                       const int* __restrict__ gt_off, const double* __restrict__ area_rng, int A,
+                                                       const double* __restrict__ iou_thrs, int T, long total_dets, int n_cells,
+                                                       uint8_t* __restrict__ dt_matched, uint8_t* __restrict__ dt_ignore,
+                                                       int* __restrict__ gt_valid) {
+    __shared__ uint8_t gtm[64][kCocoMaxGt];          // per lane: gt already matched at this (area range, threshold)
+    const int cell = blockIdx.x, lane = threadIdx.x;
+    const int d0 = det_off[cell], m = det_off[cell + 1] - d0;
+    const int g0 = gt_off[cell], n = gt_off[cell + 1] - g0;
+    if (lane >= A * T) return;
+    const int a = lane / T, t = lane - a * T;
+    const double lo = area_rng[2 * a], hi = area_rng[2 * a + 1];
+    const double thr = fmin(iou_thrs[t], 1.0 - 1e-10);
+    for (int j = 0; j < n; ++j) gtm[lane][j] = 0;
+    if (t == 0) {
+        int valid = 0;
+        for (int j = 0; j < n; ++j) {
+            const double ar = gt_area[g0 + j];
+            if (!(gt_ign[g0 + j] || ar < lo || ar > hi)) ++valid;
+        }
+        gt_valid[(long)a * n_cells + cell] = valid;
+    }
+    uint8_t* om = dt_matched + ((long)a * T + t) * total_dets + d0;
+    uint8_t* oi = dt_ignore + ((long)a * T + t) * total_dets + d0;
+    for (int i = 0; i < m; ++i) {
+        const double* db = dets + (long)(d0 + i) * 4;
+        double best = thr;
+        int mj = -1;
+        bool m_ign = false;
+        for (int pass = 0; pass < 2; ++pass) {           // non-ignored gts first, then the ignored ones
+            if (pass == 1 && mj >= 0) break;             // matched a non-ignored gt: the ignored section is not entered
+            for (int j = 0; j < n; ++j) {
+                const double ar = gt_area[g0 + j];
+                const bool ig = gt_ign[g0 + j] || ar < lo || ar > hi;
+                if ((int)ig != pass) continue;
+                const bool crowd = gt_crowd[g0 + j] != 0;
+                if (gtm[lane][j] && !crowd) continue;
+                const double v = coco_iou(db, gts + (long)(g0 + j) * 4, crowd);
+                if (v < best) continue;
+                best = v;
+                mj = j;
+                m_ign = ig;
+            }
+        }
+        uint8_t matched = 0, ignore = 0;
+        if (mj >= 0) {
+            matched = 1;
+            ignore = m_ign ? 1 : 0;
+            gtm[lane][mj] = 1;
+        } else {
+            const double ar = db[2] * db[3];
+            ignore = (ar < lo || ar > hi) ? 1 : 0;       // unmatched detections outside the area range are ignored
+        }
+        om[i] = matched;
+        oi[i] = ignore;
+    }
+}
+
+}  // namespace
+
+extern "C" int llv_coco_match(const double* dets, const int* det_off, const double* gts, const double* gt_area,
+                              const uint8_t* gt_crowd, const uint8_t* gt_ignore, const int* gt_off, int n_cells,
+                              int max_gt_per_cell, const double* area_ranges, int n_ranges, const double* iou_thrs, int n_thrs,
+                              int64_t total_dets, uint8_t* dt_matched, uint8_t* dt_ignore, int32_t* gt_valid, void* stream) {
+    if (n_cells < 0 || !det_off || !gt_off || !area_ranges || !iou_thrs || n_ranges < 1 || n_thrs < 1 || !gt_valid) return LLV_E_BADARG;
+    if (n_ranges * n_thrs > 64 || max_gt_per_cell > kCocoMaxGt) return LLV_E_UNSUPPORTED;
+    if (n_cells == 0) return LLV_OK;
+    if (total_dets > 0 && (!dets || !dt_matched || !dt_ignore)) return LLV_E_BADARG;
+    hipLaunchKernelGGL(coco_match_kernel, dim3(n_cells), dim3(64), 0, (hipStream_t)stream, dets, det_off, gts, gt_area, gt_crowd,
+                       gt_ignore, gt_off, area_ranges, n_ranges, iou_thrs, n_thrs, (long)total_dets, n_cells, dt_matched, dt_ignore,
+                       gt_valid);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
