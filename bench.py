@@ -478,6 +478,7 @@ def main():
     last = plan.p[plan._i & 1] if args.pipeline else plan
     # batch-1 latency mode (the reference's per-frame protocol: 3 temp1 + 1 temp2 DenBlocks per frame)
     lat = None
+    stream = None
     if rank == 0 and world == 1 and B != 1 and not args.no_latency_mode:
         p1 = engine.EnhanceDetectPlan(cleaner.state_dict(), det.state_dict(), NUM_CLASSES, 1, hp, wp, dev,
                                       detector_kwargs=dict(test_cfg=dict(det.bbox_head.test_cfg), img_shapes=[img_shape]),
@@ -494,6 +495,24 @@ def main():
         d1 = time.perf_counter() - t1
         lat = {'frames_per_step': 1, 'frames': nlat, 'denblocks_per_frame': 4, 'value': round(nlat / d1, 3), 'unit': 'frames/s',
                'ms_per_frame': round(d1 / nlat * 1e3, 4), 'algorithmic_gflop_per_frame': round(p1.plan.flops / 1e9, 1)}
+        # streaming mode: consecutive frames of one video, the two first-stage DenBlock results a frame shares with its
+        # predecessor carried over instead of recomputed (2 DenBlocks per frame; the first frame of each pass over the clip is a
+        # full 3+1 step). Same kernels, bit-identical output (tests/test_gpu_models.py::test_streaming_steps_equal_full_steps).
+        p1.prepare_stream()
+        for s_ in range(args.warmup):
+            p1.step(clip, s_ % T, carry=(s_ % T) != 0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        full_steps = 0
+        for s_ in range(nlat):
+            t0_ = (args.warmup + s_) % T
+            full_steps += t0_ == 0
+            p1.step(clip, t0_, carry=t0_ != 0)
+        torch.cuda.synchronize()
+        d1 = time.perf_counter() - t1
+        stream = {'frames_per_step': 1, 'frames': nlat, 'denblocks_per_frame': round((4 * full_steps + 2 * (nlat - full_steps)) / nlat, 3),
+                  'value': round(nlat / d1, 3), 'unit': 'frames/s', 'ms_per_frame': round(d1 / nlat * 1e3, 4),
+                  'note': 'consecutive frames of one video; first-stage DenBlock results shared with the previous frame are carried over'}
         del p1
     n_cand_thr = int((last.det.post.dp.scores.reshape(B, -1)[0] > 0.05).sum().item())
 
@@ -556,6 +575,8 @@ def main():
             }
         if lat is not None:
             out['latency_mode'] = lat
+        if stream is not None:
+            out['streaming_mode'] = stream
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(det, cleaner, clip.cpu(), img_shape)
         print(json.dumps(out), flush=True)

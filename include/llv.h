@@ -348,6 +348,10 @@ int llv_coco_match(const double* dets, const int* det_off, const double* gts, co
                    int n_ranges, const double* iou_thrs, int n_thrs, int64_t total_dets, uint8_t* dt_matched, uint8_t* dt_ignore,
                    int32_t* gt_valid, void* stream);
 
+/* Stream-ordered device-to-device copy (a launch-plan step: the streaming FastDVDnet plan carries the last two first-stage
+ * DenBlock outputs of a step to the front of the next step's buffer). Regions must not overlap. */
+int llv_copy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+
 /* Test-time image pipeline of the reference in one pass:
  * SeqBrighten (mmtracking/mmtrack/datasets/pipelines/transforms.py:376-432: one gain amp = m*h*w*3 / sum(frame0/255) for the
  * clip, np.clip(img*amp, 0, 255).astype(uint8)), Normalize (mmdetection/mmdet/datasets/pipelines/transforms.py:547-575:

@@ -494,6 +494,12 @@ extern "C" int llv_flow_warp(const void* x, const float* flow, void* y, int n, i
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
+extern "C" int llv_copy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
+    if (!dst || !src) return LLV_E_BADARG;
+    if (bytes == 0) return LLV_OK;
+    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
 extern "C" int llv_abi_version(void) { return LLV_ABI_VERSION; }
 
 extern "C" const char* llv_strerror(int code) {

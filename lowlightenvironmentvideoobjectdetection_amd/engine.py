@@ -552,6 +552,39 @@ class FastDVDnetPlan:
         _denblock(b, sd, p1, srcs, n1, 'temp1', self.mid)
         srcs2 = [self.mid[s:s + batch] for s in range(3)]
         _denblock(b, sd, p2, srcs2, batch, 'temp2', self.out)
+        self._sd, self._p1, self.plan_stream = sd, p1, None
+
+    def enable_stream(self):
+        """Build `plan_stream`, the step for a window that directly FOLLOWS the previous step's window in the same video
+        (frames t0 .. t0+batch-1 after t0-batch .. t0-1): the first-stage outputs centred on frames t0-1 and t0 were the last two
+        the previous step computed, so they are moved to the front of `mid` and only the `batch` new first-stage DenBlocks run
+        (2 DenBlocks per frame instead of 2 + 2/batch; batch = 1: 2 instead of the reference's 4). Same kernels on the same
+        pixels: the output is bit-identical to `plan`'s. The first step of a video must use `plan`."""
+        if self.plan_stream is not None:
+            return self.plan_stream
+        batch, dev = self.batch, self.plan.device
+        bs = Builder(dev)
+        srcs = [self.frames[s + 2:s + 2 + batch] for s in range(3)]
+        _denblock(bs, self._sd, self._p1, srcs, batch, 'temp1', self.mid[2:2 + batch])
+        ps = Plan(dev)
+        img_bytes = self.mid[0].numel() * 2
+        if batch >= 2:
+            ps.add('temp1.carry', lib().llv_copy_d2d, (C.c_void_p(self.mid.data_ptr()), C.c_void_p(self.mid[batch:].data_ptr()),
+                                                      C.c_size_t(2 * img_bytes)), 0.0, 4.0 * img_bytes)
+        else:   # batch 1: mid = [c-1, c, c+1]; the two carried images overlap their destination, so they move one at a time
+            ps.add('temp1.carry0', lib().llv_copy_d2d, (C.c_void_p(self.mid[0].data_ptr()), C.c_void_p(self.mid[1].data_ptr()),
+                                                       C.c_size_t(img_bytes)), 0.0, 2.0 * img_bytes)
+            ps.add('temp1.carry1', lib().llv_copy_d2d, (C.c_void_p(self.mid[1].data_ptr()), C.c_void_p(self.mid[2].data_ptr()),
+                                                       C.c_size_t(img_bytes)), 0.0, 2.0 * img_bytes)
+        ps.extend(bs.plan)
+        for st in self.plan.steps:
+            if st[0].startswith('temp2.'):
+                ps.steps.append(st)
+                if st[0] in self.plan.kernel_of:
+                    ps.kernel_of[st[0]] = self.plan.kernel_of[st[0]]
+        ps.keep += self.plan.keep
+        self.plan_stream = ps
+        return ps
 
 
 # ------------------------------------------------------------------------------------------------
@@ -584,10 +617,11 @@ class EnhanceDetectPlan:
         self.cnt_host = torch.zeros((batch,), dtype=torch.int32).pin_memory()
         self._graph = None
 
-    def _enhance(self, window):
-        """FastDVDnet half of a step: the clip window -> denoised frames in the detector's input buffer."""
+    def _enhance(self, window, carry=False):
+        """FastDVDnet half of a step: the clip window -> denoised frames in the detector's input buffer. carry=True: the window
+        directly follows the previous step's (FastDVDnetPlan.enable_stream)."""
         self.den.frames.copy_(window)
-        self.den.plan.run()
+        (self.den.plan_stream if carry else self.den.plan).run()
 
     def _detect(self):
         """Detector half of a step: backbone .. NMS on the denoised frames, results into pinned host memory."""
@@ -599,8 +633,8 @@ class EnhanceDetectPlan:
         self.res_host.copy_(self.res_dev, non_blocking=True)
         self.cnt_host.copy_(self.cnt_dev, non_blocking=True)
 
-    def _body(self, window):
-        self._enhance(window)
+    def _body(self, window, carry=False):
+        self._enhance(window, carry)
         self._detect()
 
     def prepare(self, clip):
@@ -615,10 +649,28 @@ class EnhanceDetectPlan:
                 self._body(self._window)
             self._graph = g
 
-    def step(self, clip, t0):
+    def prepare_stream(self):
+        """Add the streaming step (consecutive windows of one video carry their two shared first-stage results): call after
+        prepare(); then step(clip, t0, carry=True) for every window that directly follows the previous one."""
+        self.den.enable_stream()
+        self._body(self._window, carry=True)
+        torch.cuda.synchronize()
+        self._graph_stream = None
+        if self.use_graph:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                self._body(self._window, carry=True)
+            self._graph_stream = g
+
+    def step(self, clip, t0, carry=False):
         """Enqueue one step (no host sync). Results land in res_host/cnt_host after the stream drains."""
         self._window.copy_(clip[t0:t0 + self.batch + 4])
-        if self._graph is not None:
+        if carry:
+            if self._graph_stream is not None:
+                self._graph_stream.replay()
+            else:
+                self._body(self._window, carry=True)
+        elif self._graph is not None:
             self._graph.replay()
         else:
             self._body(self._window)
