@@ -243,3 +243,55 @@ def test_fgfa_fixed_stride_vs_oracle(dev):
     out = model(img=[frames[2].to(dev)], img_metas=[[meta]], ref_img=[new.unsqueeze(0).to(dev)], return_loss=False)
     frac, tot = match_detections(out['bbox_results'], ref)
     assert tot > 10 and frac >= 0.8, f'frame 2: {frac:.3f} of {tot}'
+
+
+def test_fastdvdnet_detect_model_api_vs_oracle(dev):
+    """FastDVDnetDetect through the reference's test-time call (selsa_fastdvd_darkfarm.py:262-319): every frame with its own four
+    reference frames (a sliding window: consecutive frames take the streaming step), then the reference's memo behaviour (no
+    ref_img after frame 0: the cached references are reused). Each result against the oracle on the same window."""
+    import lowlightenvironmentvideoobjectdetection_amd.models as M
+    from lowlightenvironmentvideoobjectdetection_amd.synthetic import seeded_weights
+    from helpers import calibrate_cls, img_meta, match_detections, retinanet_cfg, smooth_image
+    from oracle.cleaner import fastdvdnet_forward
+    from oracle.detector import retinanet_simple_test
+    ncls, h, w, T = 4, 64, 96, 6
+    model = M.build_model(dict(type='FastDVDnetDetect', pretrains=None, detector=retinanet_cfg(num_classes=ncls),
+                               cleaner=dict(type='FastDVDnet'), frozen_modules='cleaner'))
+    seeded_weights(model.detector, seed=51, cls_bias=-1.5)
+    seeded_weights(model.cleaner, seed=52)
+    g = torch.Generator().manual_seed(53)
+    clean = smooth_image(1, h, w, seed=54)
+    frames = torch.cat([clean + 0.3 * torch.randn(1, 3, h, w, generator=g) for _ in range(T)], 0)
+    sd_c = {k: v.detach().float().cpu() for k, v in model.cleaner.state_dict().items()}
+    with torch.no_grad():
+        calibrate_cls(model.detector, fastdvdnet_forward(sd_c, frames[[0, 0, 0, 1, 2]].reshape(1, 15, h, w)))
+    sd_d = {k: v.detach().float().cpu() for k, v in model.detector.state_dict().items()}
+    model = model.to(dev).eval()
+
+    def window_of(t):                      # reference sampler: frames t-2 .. t+2 clamped to the video
+        idx = [min(max(t + o, 0), T - 1) for o in (-2, -1, 0, 1, 2)]
+        return idx
+
+    def oracle(idx):
+        with torch.no_grad():
+            den = fastdvdnet_forward(sd_c, frames[idx].reshape(1, 15, h, w))
+            return retinanet_simple_test(sd_d, den, img_meta(h, w), num_classes=ncls)
+    tot = 0
+    for t in range(T):
+        idx = window_of(t)
+        refs = frames[[idx[0], idx[1], idx[3], idx[4]]].unsqueeze(0).to(dev)
+        meta = dict(img_meta(h, w), frame_id=t)
+        res = model(return_loss=False, img=[frames[t:t + 1].to(dev)], img_metas=[[meta]], ref_img=[refs], rescale=False)['bbox_results']
+        frac, n = match_detections(res, oracle(idx))
+        assert n > 5 and frac >= 0.8, f'frame {t}: {frac:.2f} of {n}'
+        tot += n
+    plan = next(iter(model._plans.values()))
+    assert plan.den.plan_stream is not None           # frames 1.. took the streaming step
+    # memo behaviour: frame 0 caches its references, later frames arrive without ref_img and reuse them
+    idx0 = window_of(0)
+    refs0 = frames[[idx0[0], idx0[1], idx0[3], idx0[4]]].unsqueeze(0).to(dev)
+    model(return_loss=False, img=[frames[0:1].to(dev)], img_metas=[[dict(img_meta(h, w), frame_id=0)]], ref_img=[refs0])
+    res = model(return_loss=False, img=[frames[3:4].to(dev)], img_metas=[[dict(img_meta(h, w), frame_id=1)]])['bbox_results']
+    frac, n = match_detections(res, oracle([idx0[0], idx0[1], 3, idx0[3], idx0[4]]))
+    assert n > 5 and frac >= 0.8
+    assert tot > 40
