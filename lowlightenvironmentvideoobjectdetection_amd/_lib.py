@@ -160,6 +160,10 @@ def lib():
             raise LlvError(
                 f'{LIB_PATH} not found: build it with `python -c "import __graft_entry__ as g; g.build()"` '
                 f'or `make -C {os.path.join(_HERE, "csrc")}`. There is no CPU fallback.')
+        # torch first: its wheel bundles its own libamdhip64.so, and libllv.so must bind to THAT runtime (the one whose streams
+        # and allocations it is handed). Loaded before torch, libllv.so pulls in /opt/rocm's copy and the process ends up with two
+        # HIP runtimes: every launch then fails (seen as `kernel launch failed` in build(); smoke() run in one process).
+        import torch  # noqa: F401
         handle = C.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the ABI lost a symbol
