@@ -39,6 +39,7 @@
  *                            mmdetection/mmdet/models/losses/focal_loss.py:59-98
  *   llv_modulated_deform_im2col  column step of mmcv.ops.modulated_deform_conv2d (mmcv-full 1.3.0, un-vendored; call site
  *                            mmtracking/mmtrack/models/aggregators/denoising_aggregator.py:103-111), SURVEY.md 8f item 3
+ *   llv_roi_align            mmcv.ops.roi_align behind SingleRoIExtractor (first piece)
  *   llv_eval_tpfp            tpfp_default / tpfp_imagenet of eval_map,
  *                            mmdetection/mmdet/core/evaluation/mean_ap.py:60-244, bbox_overlaps.py:4-48
  *   llv_coco_match           COCOeval.evaluateImg (pycocotools, un-vendored; call site coco_video_dataset.py:374-461)
@@ -324,6 +325,13 @@ int llv_taf_pair_concat(const void* x, void* y, int n, int h, int w, int m, void
 int llv_taf_mul_ref(const void* xd, const void* x, void* y, int n, int h, int w, int m, void* stream);
 int llv_taf_softmax_fuse(const void* xcor, const void* x, void* out, int n, int h, int w, int m, void* stream);
 int llv_add_f16(const void* a, const void* b, void* y, int64_t rows, int c, int a_ld, int b_ld, int y_ld, void* stream);
+
+/* RoIAlign (mmcv.ops.roi_align, pool_mode 'avg'; mmcv-full 1.3.0 un-vendored; call site: the `roi_layer=dict(type='RoIAlign',
+ * output_size=7, sampling_ratio=2)` of mmtracking/configs/vid/llvod/*.py through mmdet's SingleRoIExtractor) -- the first piece of the
+ * two-stage path of SURVEY.md section 8f item 4. feat (n,h,w,ld) NHWC fp16 (c channels, c % 8 == 0); rois [k][5] fp32 = (batch index,
+ * x1, y1, x2, y2); out (k,ph,pw,c) NHWC fp16, or fp32 with out_f32. sampling_ratio 0 = adaptive (ceil(bin size)). */
+int llv_roi_align(const void* feat, const float* rois, void* out, int n, int h, int w, int c, int ld, int k, int ph, int pw,
+                  float spatial_scale, int sampling_ratio, int aligned, int out_f32, void* stream);
 
 /* True/false-positive marking of eval_map (mean_ap.py:268-400 calls tpfp_default :154-244 or, for datasets 'det'/'vid',
  * tpfp_imagenet :60-151 once per class and image): all (class, image) cells in one launch, one wavefront per cell.

@@ -244,3 +244,83 @@ extern "C" int llv_add_f16(const void* a, const void* b, void* y, int64_t rows, 
                        (const _Float16*)b, (_Float16*)y, (long)rows, c / 8, a_ld, b_ld, y_ld);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
+
+// ------------------------------------------------------------------------------------------------
+// RoIAlign (first piece of SURVEY.md section 8f item 4, the authors' two-stage SELSA path:
+// mmtracking/configs/vid/llvod/*.py `roi_layer=dict(type='RoIAlign', output_size=7, sampling_ratio=2)` ->
+// mmdet SingleRoIExtractor -> mmcv.ops.roi_align (mmcv-full 1.3.0, un-vendored), pool_mode 'avg', aligned=True).
+//   feat (n, h, w, ld) NHWC fp16; rois [k][5] fp32 = (batch index, x1, y1, x2, y2) in image coordinates;
+//   out (k, ph, pw, c) NHWC fp16 (or fp32). One lane = 8 channels of one output bin: grid x grid bilinear samples averaged.
+// mmcv's rules: start = coord * spatial_scale - 0.5 (aligned), bin = roi size / pooled size (no minimum size when aligned),
+// sample (iy + 0.5) * bin / grid inside the bin; a sample outside [-1, H] x [-1, W] contributes zero, coordinates are clamped
+// to >= 0, and the upper neighbour is clamped to the last row / column.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+template <typename OutT>
+__global__ __launch_bounds__(256) void roi_align_kernel(const _Float16* __restrict__ feat, const float* __restrict__ rois,
+                                                       OutT* __restrict__ out, int n, int h, int w, int c8, int ld, int ph, int pw,
+                                                       float scale, int grid, int aligned, unsigned total) {
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const unsigned cv = t % (unsigned)c8;
+        unsigned p = t / (unsigned)c8;
+        const unsigned ox = p % (unsigned)pw; p /= (unsigned)pw;
+        const unsigned oy = p % (unsigned)ph;
+        const unsigned r = p / (unsigned)ph;
+        const float* roi = rois + (long)r * 5;
+        const int b = (int)roi[0];
+        const float off = aligned ? 0.5f : 0.f;
+        const float x1 = roi[1] * scale - off, y1 = roi[2] * scale - off, x2 = roi[3] * scale - off, y2 = roi[4] * scale - off;
+        float rw = x2 - x1, rh = y2 - y1;
+        if (!aligned) { rw = fmaxf(rw, 1.f); rh = fmaxf(rh, 1.f); }
+        const float bw = rw / (float)pw, bh = rh / (float)ph;
+        const int gh = grid > 0 ? grid : (int)ceilf(rh / (float)ph), gw = grid > 0 ? grid : (int)ceilf(rw / (float)pw);
+        const float cnt = fmaxf((float)(gh * gw), 1.f);
+        float acc[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+        if (b >= 0 && b < n) {
+            const _Float16* fb = feat + (long)b * h * w * ld + cv * 8;
+            for (int iy = 0; iy < gh; ++iy) {
+                float y = y1 + (float)oy * bh + ((float)iy + 0.5f) * bh / (float)gh;
+                for (int ix = 0; ix < gw; ++ix) {
+                    float x = x1 + (float)ox * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                    if (y < -1.f || y > (float)h || x < -1.f || x > (float)w) continue;
+                    float yy = y <= 0.f ? 0.f : y, xx = x <= 0.f ? 0.f : x;
+                    int yl = (int)yy, xl = (int)xx, yh, xh;
+                    if (yl >= h - 1) { yh = yl = h - 1; yy = (float)yl; } else yh = yl + 1;
+                    if (xl >= w - 1) { xh = xl = w - 1; xx = (float)xl; } else xh = xl + 1;
+                    const float ly = yy - (float)yl, lx = xx - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+                    const f16x8 v1 = *reinterpret_cast<const f16x8*>(fb + ((long)yl * w + xl) * ld);
+                    const f16x8 v2 = *reinterpret_cast<const f16x8*>(fb + ((long)yl * w + xh) * ld);
+                    const f16x8 v3 = *reinterpret_cast<const f16x8*>(fb + ((long)yh * w + xl) * ld);
+                    const f16x8 v4 = *reinterpret_cast<const f16x8*>(fb + ((long)yh * w + xh) * ld);
+#pragma unroll
+                    for (int e = 0; e < 8; ++e)
+                        acc[e] += hy * hx * (float)v1[e] + hy * lx * (float)v2[e] + ly * hx * (float)v3[e] + ly * lx * (float)v4[e];
+                }
+            }
+        }
+        OutT* o = out + (((long)r * ph + oy) * pw + ox) * (c8 * 8) + cv * 8;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (OutT)(acc[e] / cnt);
+    }
+}
+
+}  // namespace
+
+extern "C" int llv_roi_align(const void* feat, const float* rois, void* out, int n, int h, int w, int c, int ld, int k, int ph, int pw,
+                             float spatial_scale, int sampling_ratio, int aligned, int out_f32, void* stream) {
+    if (!feat || !out || n <= 0 || h <= 0 || w <= 0 || c <= 0 || (c & 7) || (ld & 7) || ld < c || k < 0 || ph <= 0 || pw <= 0 ||
+        !(spatial_scale > 0.f) || sampling_ratio < 0)
+        return LLV_E_BADARG;
+    if (k == 0) return LLV_OK;
+    if (!rois) return LLV_E_BADARG;
+    const long total = (long)k * ph * pw * (c / 8);
+    if (total >= (1L << 31)) return LLV_E_UNSUPPORTED;
+    if (out_f32)
+        hipLaunchKernelGGL(roi_align_kernel<float>, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)feat, rois,
+                           (float*)out, n, h, w, c / 8, ld, ph, pw, spatial_scale, sampling_ratio, aligned, (unsigned)total);
+    else
+        hipLaunchKernelGGL(roi_align_kernel<_Float16>, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)feat,
+                           rois, (_Float16*)out, n, h, w, c / 8, ld, ph, pw, spatial_scale, sampling_ratio, aligned, (unsigned)total);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}

@@ -644,3 +644,22 @@ def modulated_deform_conv2d(x: torch.Tensor, om: torch.Tensor, pc: PackedConv, k
     check(lib().llv_modulated_deform_im2col(_ptr(x), _ptr(om), _ptr(col), n, h, w, c, c, om.shape[3], col.shape[3], kh, kw, stride,
                                             pad, dilation, deform_groups, ho, wo, _stream()), 'llv_modulated_deform_im2col')
     return conv2d(col, pc, flags=flags, out=out)
+
+
+# ------------------------------------------------------------------------------------------------
+# RoIAlign (first piece)
+# ------------------------------------------------------------------------------------------------
+def roi_align(feat: torch.Tensor, rois: torch.Tensor, output_size, spatial_scale: float = 1.0, sampling_ratio: int = 0,
+              aligned: bool = True, out_f32: bool = False) -> torch.Tensor:
+    """mmcv.ops.roi_align (avg) on NHWC fp16: feat (n,h,w,c), rois (k,5) fp32 = (batch index, x1, y1, x2, y2) ->
+    (k, ph, pw, c) fp16 (fp32 with out_f32)."""
+    _need_gpu(feat, rois)
+    assert feat.dtype == torch.float16 and feat.is_contiguous() and rois.dtype == torch.float32 and rois.shape[1] == 5
+    ph, pw = (output_size, output_size) if isinstance(output_size, int) else output_size
+    n, h, w, c = feat.shape
+    k = rois.shape[0]
+    rois = rois.contiguous()
+    out = torch.empty((k, ph, pw, c), device=feat.device, dtype=torch.float32 if out_f32 else torch.float16)
+    check(lib().llv_roi_align(_ptr(feat), _ptr(rois), _ptr(out), n, h, w, c, c, k, ph, pw, float(spatial_scale), int(sampling_ratio),
+                              1 if aligned else 0, 1 if out_f32 else 0, _stream()), 'llv_roi_align')
+    return out
