@@ -387,7 +387,7 @@ extern "C" int llv_retina_decode_topk(const llv_decode_desc* d, void* stream) {
     if (!d->cls || !d->reg || !d->base_anchors || !d->boxes || !d->scores || !d->cand_anchor || !d->workspace) return LLV_E_BADARG;
     if (d->workspace_bytes < llv_retina_decode_workspace_bytes(d)) return LLV_E_WORKSPACE;
     if (d->cls_ld < k.A * k.C || d->reg_ld < k.A * 4) return LLV_E_BADARG;
-    if (d->nms_pre > 4096) return LLV_E_UNSUPPORTED;
+    if (d->nms_pre > 8192) return LLV_E_UNSUPPORTED;   // top-k list sorted in LDS: (8192 + kSortCap) keys = 72 KiB (RPN: nms_pre 6000)
     if (d->n_cand != k.c0[d->n_levels]) return LLV_E_BADARG;
     k.cls_ld = d->cls_ld; k.reg_ld = d->reg_ld; k.f32 = d->logits_f32;
     k.cls = d->cls; k.reg = d->reg; k.base = d->base_anchors;
