@@ -384,6 +384,12 @@ int llv_multiclass_nms_batched_sf(const float* boxes, const float* scores, const
                                   int num_classes, int c_ld, float score_thr, float iou_thr, int max_num, float* dets,
                                   int64_t* labels, int32_t* count, int32_t* keep_flat, void* workspace, size_t workspace_bytes,
                                   void* stream);
+/* The same with class-specific boxes (multiclass_nms with multi_bboxes of shape (n, #class*4), bbox_nms.py:31-35: the two-stage bbox
+ * heads with reg_class_agnostic=False): class_specific != 0 reads boxes as [batch][n][num_classes][4]. */
+int llv_multiclass_nms_batched_ex(const float* boxes, const float* scores, const float* score_factors, int class_specific, int batch,
+                                  int n, int num_classes, int c_ld, float score_thr, float iou_thr, int max_num, float* dets,
+                                  int64_t* labels, int32_t* count, int32_t* keep_flat, void* workspace, size_t workspace_bytes,
+                                  void* stream);
 
 /* ---- backward pass of the convolution engine (llv_conv2d_nhwc_{dgrad,wgrad}) ----------------
  * Replaces torch autograd's cudnn_convolution_backward_{input,weight} under mmdet's ResNet / FPN / RetinaHead

@@ -116,6 +116,7 @@ SIGNATURES = {
     'llv_multiclass_nms_batched_workspace_bytes': (_Z, [_I, _I, _I, _I]),
     'llv_multiclass_nms_batched': (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
     'llv_multiclass_nms_batched_sf': (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
+    'llv_multiclass_nms_batched_ex': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
     'llv_brighten_normalize_pad_u8': (_I, [_P, _I, _I, _I, _I, _I, _F, C.POINTER(C.c_float), C.POINTER(C.c_float), _I, _P, _P, _P]),
     'llv_upsample2x_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'llv_yolo_decode': (_I, [_P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _P, _P]),

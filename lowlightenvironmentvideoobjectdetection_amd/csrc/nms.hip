@@ -50,11 +50,11 @@ __device__ __forceinline__ bool iou_gt(const float4 a, const float4 b, float thr
 __global__ __launch_bounds__(256) void nms_scan_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                       const float* __restrict__ factors,
                                                       int n, int C, int c_ld, float thr, unsigned* maxc_u,
-                                                      int* cnt_in, uint64_t* cand, long ws_stride) {
+                                                      int* cnt_in, uint64_t* cand, long ws_stride, int cs) {
     const long total = (long)n * C;
     {   // image = blockIdx.y: inputs are [batch][n][...], the workspace repeats every ws_stride bytes
         const int img = blockIdx.y;
-        boxes += (long)img * n * 4;
+        boxes += (long)img * n * 4 * (cs ? C : 1);      // cs: class-specific boxes [n][C][4] (bbox_nms.py:31-35)
         scores += (long)img * n * c_ld;
         if (factors) factors += (long)img * n;
         maxc_u = reinterpret_cast<unsigned*>(reinterpret_cast<char*>(maxc_u) + img * ws_stride);
@@ -70,7 +70,7 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const float* __restrict__
             const int slot = atomicAdd(&cnt_in[c], 1);
             // score_factors multiply AFTER the threshold test (bbox_nms.py:52-62)
             cand[(long)c * n + slot] = llv::make_key(factors ? s * factors[i] : s, e);
-            const float4 b = reinterpret_cast<const float4*>(boxes)[i];
+            const float4 b = reinterpret_cast<const float4*>(boxes)[cs ? e : i];
             const unsigned u = llv::f32_ordered(fmaxf(fmaxf(b.x, b.y), fmaxf(b.z, b.w)));
             m = u > m ? u : m;
         }
@@ -135,11 +135,11 @@ __device__ inline int greedy_scan(const uint64_t* keys, int cnt, float thr, int 
 // one workgroup per class: sort its candidate list in LDS, greedy scan by wave 0
 __global__ __launch_bounds__(256) void nms_class_kernel(const float* __restrict__ boxes, int n, int C, float iou_thr,
                                                         int max_num, const unsigned* maxc_u, const int* cnt_in,
-                                                        const uint64_t* cand, int* cls_cnt, uint64_t* cls_keys, long ws_stride) {
+                                                        const uint64_t* cand, int* cls_cnt, uint64_t* cls_keys, long ws_stride, int cs) {
     const int c = blockIdx.x;
     {
         const int img = blockIdx.y;
-        boxes += (long)img * n * 4;
+        boxes += (long)img * n * 4 * (cs ? C : 1);
         maxc_u = reinterpret_cast<const unsigned*>(reinterpret_cast<const char*>(maxc_u) + img * ws_stride);
         cnt_in = reinterpret_cast<const int*>(reinterpret_cast<const char*>(cnt_in) + img * ws_stride);
         cand = reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(cand) + img * ws_stride);
@@ -163,7 +163,7 @@ __global__ __launch_bounds__(256) void nms_class_kernel(const float* __restrict_
         // boxes_for_nms = boxes + idxs.to(boxes) * (max_coordinate + 1)   (mmcv batched_nms)
         const float off = (float)c * (llv::f32_unordered(*maxc_u) + 1.0f);
         auto box_of = [&](unsigned flat) {
-            float4 b = reinterpret_cast<const float4*>(boxes)[flat / (unsigned)C];
+            float4 b = reinterpret_cast<const float4*>(boxes)[cs ? flat : flat / (unsigned)C];
             b.x += off; b.y += off; b.z += off; b.w += off;
             return b;
         };
@@ -176,10 +176,10 @@ __global__ __launch_bounds__(256) void nms_class_kernel(const float* __restrict_
 __global__ __launch_bounds__(1024) void nms_merge_kernel(const float* __restrict__ boxes, int n, int C, int max_num,
                                                          const int* cls_cnt,
                                                          const uint64_t* cls_keys, float* dets, int64_t* labels,
-                                                         int* count, int* keep_flat, long ws_stride) {
+                                                         int* count, int* keep_flat, long ws_stride, int cs) {
     {
         const int img = blockIdx.y;
-        boxes += (long)img * n * 4;
+        boxes += (long)img * n * 4 * (cs ? C : 1);
         cls_cnt = reinterpret_cast<const int*>(reinterpret_cast<const char*>(cls_cnt) + img * ws_stride);
         cls_keys = reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(cls_keys) + img * ws_stride);
         dets += (long)img * max_num * 5;
@@ -230,7 +230,7 @@ __global__ __launch_bounds__(1024) void nms_merge_kernel(const float* __restrict
         const uint64_t key = keys[i];
         const unsigned flat = llv::key_index(key);
         const unsigned bi = flat / (unsigned)C, c = flat - bi * (unsigned)C;
-        const float4 b = reinterpret_cast<const float4*>(boxes)[bi];
+        const float4 b = reinterpret_cast<const float4*>(boxes)[cs ? flat : bi];
         dets[i * 5 + 0] = b.x; dets[i * 5 + 1] = b.y; dets[i * 5 + 2] = b.z; dets[i * 5 + 3] = b.w;
         dets[i * 5 + 4] = llv::key_score(key);
         labels[i] = (int64_t)c;
@@ -300,6 +300,15 @@ extern "C" int llv_multiclass_nms_batched_sf(const float* boxes, const float* sc
                                              int num_classes, int c_ld, float score_thr, float iou_thr, int max_num, float* dets,
                                              int64_t* labels, int32_t* count, int32_t* keep_flat, void* workspace,
                                              size_t workspace_bytes, void* stream) {
+    return llv_multiclass_nms_batched_ex(boxes, scores, score_factors, 0, batch, n, num_classes, c_ld, score_thr, iou_thr, max_num, dets,
+                                         labels, count, keep_flat, workspace, workspace_bytes, stream);
+}
+
+extern "C" int llv_multiclass_nms_batched_ex(const float* boxes, const float* scores, const float* score_factors, int class_specific,
+                                             int batch, int n, int num_classes, int c_ld, float score_thr, float iou_thr, int max_num,
+                                             float* dets, int64_t* labels, int32_t* count, int32_t* keep_flat, void* workspace,
+                                             size_t workspace_bytes, void* stream) {
+    const int cs = class_specific ? 1 : 0;
     if (!dets || !labels || !count || !keep_flat || !workspace || num_classes < 1 || num_classes > 1024 || max_num < 1 ||
         n < 0 || c_ld < num_classes || batch < 1)
         return LLV_E_BADARG;
@@ -324,19 +333,19 @@ extern "C" int llv_multiclass_nms_batched_sf(const float* boxes, const float* sc
         long g = ((long)n * num_classes + 255) / 256;
         g = g > 256 ? 256 : g;
         hipLaunchKernelGGL(nms_scan_kernel, dim3((int)g, batch), dim3(256), 0, st, boxes, scores, score_factors, n, num_classes, c_ld, score_thr,
-                           maxc_u, cnt_in, cand, stride);
+                           maxc_u, cnt_in, cand, stride, cs);
         int np2 = 1;
         while (np2 < n) np2 <<= 1;
         const size_t lds = (size_t)np2 * 8 + (size_t)max_num * 16;
         hipLaunchKernelGGL(nms_class_kernel, dim3(num_classes, batch), dim3(256), lds, st, boxes, n, num_classes, iou_thr, max_num,
-                           maxc_u, cnt_in, cand, cls_cnt, cls_keys, stride);
+                           maxc_u, cnt_in, cand, cls_cnt, cls_keys, stride, cs);
     }
     int mp2 = 1;
     while (mp2 < num_classes * max_num) mp2 <<= 1;
     int kp2 = 1;
     while (kp2 < max_num) kp2 <<= 1;
     hipLaunchKernelGGL(nms_merge_kernel, dim3(1, batch), dim3(1024), (size_t)(mp2 + kp2) * 8, st, boxes, n, num_classes, max_num,
-                       cls_cnt, cls_keys, dets, labels, count, keep_flat, stride);
+                       cls_cnt, cls_keys, dets, labels, count, keep_flat, stride, cs);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 

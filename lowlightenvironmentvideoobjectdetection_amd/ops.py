@@ -482,17 +482,25 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, r
     multi_scores carries the background column last, which is ignored, as in the reference.
     """
     _need_gpu(multi_bboxes, multi_scores)
-    if multi_bboxes.shape[1] > 4:
-        raise LlvError('class-specific boxes (n, #class*4) are not on the dense-head path')
     num_classes = multi_scores.shape[1] - 1
     n = multi_bboxes.shape[0]
+    class_specific = multi_bboxes.shape[1] > 4        # (n, #class*4): the two-stage bbox heads with reg_class_agnostic=False
+    if class_specific and multi_bboxes.shape[1] != 4 * num_classes:
+        raise LlvError(f'multiclass_nms: boxes of shape (n, {multi_bboxes.shape[1]}) with {num_classes} classes')
     iou_thr = nms_cfg.get('iou_threshold', nms_cfg.get('iou_thr'))
     if nms_cfg.get('type', 'nms') != 'nms':
         raise LlvError(f"nms type {nms_cfg.get('type')} not supported")
     cap = max_num if max_num > 0 else n * num_classes
     bufs = NmsBuffers(max(n, 1), num_classes, max(cap, 1), multi_bboxes.device)
-    multiclass_nms_into(multi_bboxes.float().contiguous(), multi_scores.float().contiguous(), score_thr, iou_thr, bufs,
-                        num_classes)
+    if class_specific:
+        bx, sc = multi_bboxes.float().contiguous(), multi_scores.float().contiguous()
+        check(lib().llv_multiclass_nms_batched_ex(_ptr(bx), _ptr(sc), None, 1, 1, n, num_classes, sc.shape[-1], float(score_thr),
+                                                  float(iou_thr), bufs.max_num, _ptr(bufs.dets), _ptr(bufs.labels), _ptr(bufs.count),
+                                                  _ptr(bufs.keep_flat), _ptr(bufs.ws), bufs.ws_bytes, _stream()),
+              'llv_multiclass_nms_batched_ex')
+    else:
+        multiclass_nms_into(multi_bboxes.float().contiguous(), multi_scores.float().contiguous(), score_thr, iou_thr, bufs,
+                            num_classes)
     k = int(bufs.count.item())
     dets, labels = bufs.dets[:k].clone(), bufs.labels[:k].clone()
     if return_inds:

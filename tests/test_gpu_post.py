@@ -164,3 +164,24 @@ def test_preprocess_kernel_matches_reference_pipeline(dev):
     assert (diff > 2e-3).mean() < 1e-4 and diff.max() < 0.02
     assert float(out[..., 3:].abs().max()) == 0 and float(out[:, 70:].abs().max()) == 0 and float(out[:, :, 90:].abs().max()) == 0
     assert torch.equal(out[0], out[2]) and torch.equal(out[-1], out[5])
+
+
+@pytest.mark.parametrize('n,C', [(300, 30), (64, 5), (1000, 8)])
+def test_multiclass_nms_class_specific_boxes_index_exact(dev, n, C):
+    """multi_bboxes of shape (n, #class*4) (bbox_nms.py:31-35; the two-stage bbox heads with reg_class_agnostic=False): every class
+    has its own regressed box per proposal. Index-exact against the oracle."""
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    from oracle.nms import multiclass_nms
+    g = torch.Generator().manual_seed(n + C)
+    base = _clustered_boxes(n, g)
+    jit = torch.randn(n, C, 4, generator=g) * 6
+    boxes = (base[:, None, :] + jit)
+    boxes[..., 2:] = torch.maximum(boxes[..., 2:], boxes[..., :2] + 1)
+    boxes = boxes.reshape(n, C * 4).contiguous()
+    scores = torch.cat([torch.rand(n, C, generator=g) ** 4, torch.zeros(n, 1)], 1)
+    cfg = dict(type='nms', iou_threshold=0.5)
+    d_ref, l_ref, i_ref = multiclass_nms(boxes, scores, 0.05, cfg, 100, return_inds=True)
+    d, l, i = ops.multiclass_nms(boxes.to(dev), scores.to(dev), 0.05, cfg, 100, return_inds=True)
+    assert len(d_ref) > 20
+    assert torch.equal(i.cpu(), i_ref) and torch.equal(l.cpu(), l_ref)
+    torch.testing.assert_close(d.cpu(), d_ref, rtol=0, atol=0)
