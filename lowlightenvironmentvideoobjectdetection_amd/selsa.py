@@ -1,0 +1,183 @@
+"""RoI side of the SELSA two-stage video detector at test time (third piece), with the reference's
+constructors and parameter names:
+  SelsaAggregator   mmtracking/mmtrack/models/aggregators/selsa_aggregator.py:8-73
+  SelsaBBoxHead     mmtracking/mmtrack/models/roi_heads/bbox_heads/selsa_bbox_head.py:8-84 (over mmdet ConvFCBBoxHead / BBoxHead.get_bboxes,
+                    mmdetection/mmdet/models/roi_heads/bbox_heads/bbox_head.py:270-371)
+  SelsaRoIHead      mmtracking/mmtrack/models/roi_heads/selsa_roi_head.py:61-78,113-187 (simple_test)
+
+What is native here: RoI features through `llv_roi_align`, detections through `llv_multiclass_nms_batched_ex` with class-specific
+boxes. The fully connected layers and the attention of the aggregator are plain GEMMs and run as torch (rocBLAS / hipBLASLt) calls on
+the device; the element-wise decode is torch on the device. No CPU path: CPU inputs raise. Training (`forward_train`, sampling,
+losses), `TemporalRoIAlign` and the `SELSA` detector class that drives RPN + RoI head over key and reference frames are not built."""
+import numpy as np
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from . import ops
+from ._lib import LlvError
+from .core.bbox import bbox2result
+from .registry import AGGREGATORS, HEADS, ROI_EXTRACTORS, build, build_aggregator
+
+
+def _gpu(*ts):
+    for t in ts:
+        if t is not None and not t.is_cuda:
+            raise LlvError('the SELSA RoI head runs on an MI355X only (RoIAlign / NMS kernels, device GEMMs); no CPU path')
+
+
+@AGGREGATORS.register_module()
+class SelsaAggregator(nn.Module):
+    def __init__(self, in_channels, num_attention_blocks=16):
+        super().__init__()
+        self.fc_embed = nn.Linear(in_channels, in_channels)
+        self.ref_fc_embed = nn.Linear(in_channels, in_channels)
+        self.fc = nn.Linear(in_channels, in_channels)
+        self.ref_fc = nn.Linear(in_channels, in_channels)
+        self.num_attention_blocks = num_attention_blocks
+
+    def forward(self, x, ref_x):
+        """x [N, C] key-frame proposal features, ref_x [M, C] reference ones -> [N, C] (selsa_aggregator.py:29-73)."""
+        _gpu(x, ref_x)
+        n, m, nb = x.shape[0], ref_x.shape[0], self.num_attention_blocks
+        x_embed = self.fc_embed(x).view(n, nb, -1).permute(1, 0, 2)
+        ref_embed = self.ref_fc_embed(ref_x).view(m, nb, -1).permute(1, 2, 0)
+        weights = (torch.bmm(x_embed, ref_embed) / (x_embed.shape[-1] ** 0.5)).softmax(dim=2)
+        ref_new = self.ref_fc(ref_x).view(m, nb, -1).permute(1, 0, 2)
+        x_new = torch.bmm(weights, ref_new).permute(1, 0, 2).contiguous()
+        return self.fc(x_new.view(n, -1))
+
+
+@HEADS.register_module()
+class SelsaBBoxHead(nn.Module):
+    """ConvFCBBoxHead restricted to what the SELSA configs use: `num_shared_fcs` fully connected layers (no convs), one
+    SelsaAggregator after each, fc_cls (num_classes + 1) and fc_reg (4 or 4 * num_classes)."""
+
+    def __init__(self, aggregator, num_shared_convs=0, num_shared_fcs=2, num_cls_convs=0, num_cls_fcs=0, num_reg_convs=0, num_reg_fcs=0,
+                 conv_out_channels=256, fc_out_channels=1024, with_avg_pool=False, with_cls=True, with_reg=True, roi_feat_size=7,
+                 in_channels=256, num_classes=80, bbox_coder=dict(type='DeltaXYWHBBoxCoder', clip_border=True, target_means=[0., 0., 0., 0.],
+                                                                  target_stds=[0.1, 0.1, 0.2, 0.2]),
+                 reg_class_agnostic=False, reg_decoded_bbox=False, loss_cls=None, loss_bbox=None, **kwargs):
+        super().__init__()
+        if num_shared_convs or num_cls_convs or num_cls_fcs or num_reg_convs or num_reg_fcs or with_avg_pool or not (with_cls and with_reg):
+            raise NotImplementedError('SelsaBBoxHead: only the shared-fc form of the SELSA configs is built')
+        from .registry import build_bbox_coder
+        self.num_shared_fcs, self.num_classes, self.reg_class_agnostic = num_shared_fcs, num_classes, reg_class_agnostic
+        self.in_channels, self.fc_out_channels = in_channels, fc_out_channels
+        self.roi_feat_size = (roi_feat_size, roi_feat_size) if isinstance(roi_feat_size, int) else tuple(roi_feat_size)
+        self.bbox_coder = build_bbox_coder(bbox_coder)
+        last = in_channels * self.roi_feat_size[0] * self.roi_feat_size[1]
+        self.shared_fcs = nn.ModuleList()
+        for i in range(num_shared_fcs):
+            self.shared_fcs.append(nn.Linear(last if i == 0 else fc_out_channels, fc_out_channels))
+        self.fc_cls = nn.Linear(fc_out_channels, num_classes + 1)
+        self.fc_reg = nn.Linear(fc_out_channels, 4 if reg_class_agnostic else 4 * num_classes)
+        self.aggregator = nn.ModuleList([build_aggregator(aggregator) for _ in range(num_shared_fcs)])
+
+    def init_weights(self):                      # bbox_head.py:93-101, convfc_bbox_head.py:119-127
+        nn.init.normal_(self.fc_cls.weight, 0, 0.01); nn.init.constant_(self.fc_cls.bias, 0)
+        nn.init.normal_(self.fc_reg.weight, 0, 0.001); nn.init.constant_(self.fc_reg.bias, 0)
+        for m in self.shared_fcs:
+            nn.init.xavier_uniform_(m.weight); nn.init.constant_(m.bias, 0)
+
+    def forward(self, x, ref_x):
+        """x [N, C, H, W] key-frame RoI features, ref_x [M, C, H, W] -> (cls_score [N, classes+1], bbox_pred [N, 4*classes])."""
+        _gpu(x, ref_x)
+        x, ref_x = x.flatten(1), ref_x.flatten(1)
+        for i, fc in enumerate(self.shared_fcs):
+            x, ref_x = fc(x), fc(ref_x)
+            x = x + self.aggregator[i](x, ref_x)
+            ref_x, x = F.relu(ref_x), F.relu(x)
+        return self.fc_cls(x), self.fc_reg(x)
+
+    def _decode(self, rois, deltas, max_shape):
+        """delta_xywh_bbox_coder.py:134-237 for (n, 4) rois and (n, 4k) deltas, on the device."""
+        k4 = deltas.size(-1) // 4
+        means = deltas.new_tensor(self.bbox_coder.means).repeat(k4)
+        stds = deltas.new_tensor(self.bbox_coder.stds).repeat(k4)
+        d = deltas * stds + means
+        dx, dy, dw, dh = d[:, 0::4], d[:, 1::4], d[:, 2::4], d[:, 3::4]
+        max_ratio = float(np.abs(np.log(16 / 1000)))
+        dw, dh = dw.clamp(min=-max_ratio, max=max_ratio), dh.clamp(min=-max_ratio, max=max_ratio)
+        px, py = ((rois[:, 0] + rois[:, 2]) * 0.5).unsqueeze(-1), ((rois[:, 1] + rois[:, 3]) * 0.5).unsqueeze(-1)
+        pw, ph = (rois[:, 2] - rois[:, 0]).unsqueeze(-1), (rois[:, 3] - rois[:, 1]).unsqueeze(-1)
+        gw, gh = pw * dw.exp(), ph * dh.exp()
+        gx, gy = px + pw * dx, py + ph * dy
+        b = torch.stack([gx - gw * 0.5, gy - gh * 0.5, gx + gw * 0.5, gy + gh * 0.5], dim=-1)
+        if self.bbox_coder.clip_border and max_shape is not None:
+            lim = b.new_tensor([max_shape[1], max_shape[0], max_shape[1], max_shape[0]])
+            b = torch.minimum(b.clamp(min=0), lim)
+        return b.view(deltas.size())
+
+    def get_bboxes(self, rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=False, cfg=None):
+        """bbox_head.py:270-371 (one image): softmax, per-class delta2bbox clipped to the image, optional rescale, multiclass NMS."""
+        _gpu(rois, cls_score, bbox_pred)
+        scores = F.softmax(cls_score.float(), dim=-1)
+        bboxes = self._decode(rois[:, 1:].float(), bbox_pred.float(), img_shape)
+        if rescale and bboxes.size(0) > 0:
+            sf = bboxes.new_tensor(np.asarray(scale_factor, dtype=np.float32).reshape(-1)[:4]).repeat(bboxes.size(-1) // 4)
+            bboxes = bboxes / sf
+        if cfg is None:
+            return bboxes, scores
+        if bboxes.size(0) == 0:
+            return bboxes.new_zeros((0, 5)), bboxes.new_zeros((0,), dtype=torch.long)
+        return ops.multiclass_nms(bboxes.contiguous(), scores.contiguous(), cfg['score_thr'], cfg['nms'], cfg['max_per_img'])
+
+
+def bbox2roi(bbox_list):
+    """mmdetection/mmdet/core/bbox/transforms.py:72-96."""
+    rois_list = []
+    for img_id, bboxes in enumerate(bbox_list):
+        if bboxes.size(0) > 0:
+            rois_list.append(torch.cat([bboxes.new_full((bboxes.size(0), 1), img_id), bboxes[:, :4]], dim=-1))
+        else:
+            rois_list.append(bboxes.new_zeros((0, 5)))
+    return torch.cat(rois_list, 0)
+
+
+@HEADS.register_module()
+class SelsaRoIHead(nn.Module):
+    def __init__(self, bbox_roi_extractor=None, bbox_head=None, mask_roi_extractor=None, mask_head=None, shared_head=None, train_cfg=None,
+                 test_cfg=None):
+        super().__init__()
+        if mask_head is not None or shared_head is not None:
+            raise NotImplementedError('SelsaRoIHead: mask / shared heads are not on this path')
+        if bbox_roi_extractor.get('type') != 'SingleRoIExtractor':
+            raise NotImplementedError(f"bbox_roi_extractor {bbox_roi_extractor.get('type')}: only SingleRoIExtractor is built")
+        self.bbox_roi_extractor = build(bbox_roi_extractor, ROI_EXTRACTORS)
+        self.bbox_head = build(bbox_head, HEADS)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+
+    with_bbox, with_mask = True, False
+
+    def init_weights(self):
+        self.bbox_head.init_weights()
+
+    def _bbox_forward(self, x, ref_x, rois, ref_rois):
+        """selsa_roi_head.py:61-78."""
+        n_in = self.bbox_roi_extractor.num_inputs
+        bbox_feats = self.bbox_roi_extractor(x[:n_in], rois)
+        ref_bbox_feats = self.bbox_roi_extractor(ref_x[:n_in], ref_rois)
+        cls_score, bbox_pred = self.bbox_head(bbox_feats, ref_bbox_feats)
+        return dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=bbox_feats)
+
+    def forward_train(self, *a, **k):
+        raise LlvError('SelsaRoIHead.forward_train: the two-stage training path is not built')
+
+    def simple_test_bboxes(self, x, ref_x, proposals, ref_proposals, img_metas, rcnn_test_cfg, rescale=False):
+        """selsa_roi_head.py:134-187."""
+        rois, ref_rois = bbox2roi(proposals), bbox2roi(ref_proposals)
+        res = self._bbox_forward(x, ref_x, rois, ref_rois)
+        counts = tuple(len(p) for p in proposals)
+        rois_s, cls_s, reg_s = rois.split(counts, 0), res['cls_score'].split(counts, 0), res['bbox_pred'].split(counts, 0)
+        det_bboxes, det_labels = [], []
+        for i in range(len(proposals)):
+            d, l = self.bbox_head.get_bboxes(rois_s[i], cls_s[i], reg_s[i], img_metas[i]['img_shape'], img_metas[i]['scale_factor'],
+                                             rescale=rescale, cfg=rcnn_test_cfg)
+            det_bboxes.append(d); det_labels.append(l)
+        return det_bboxes, det_labels
+
+    def simple_test(self, x, ref_x, proposals_list, ref_proposals_list, img_metas, proposals=None, rescale=False):
+        """selsa_roi_head.py:113-132: list per image of list[num_classes] of (k, 5) arrays."""
+        det_bboxes, det_labels = self.simple_test_bboxes(x, ref_x, proposals_list, ref_proposals_list, img_metas, self.test_cfg, rescale)
+        return [bbox2result(det_bboxes[i], det_labels[i], self.bbox_head.num_classes) for i in range(len(det_bboxes))]
