@@ -181,3 +181,134 @@ class SelsaRoIHead(nn.Module):
         """selsa_roi_head.py:113-132: list per image of list[num_classes] of (k, 5) arrays."""
         det_bboxes, det_labels = self.simple_test_bboxes(x, ref_x, proposals_list, ref_proposals_list, img_metas, self.test_cfg, rescale)
         return [bbox2result(det_bboxes[i], det_labels[i], self.bbox_head.num_classes) for i in range(len(det_bboxes))]
+
+
+# ------------------------------------------------------------------------------------------------
+# two-stage detector container and the SELSA video detector (test time)
+# ------------------------------------------------------------------------------------------------
+from .detectors import BaseDetector  # noqa: E402
+from .registry import DETECTORS, MODELS, build_backbone, build_detector, build_head, build_neck  # noqa: E402
+from .vid import BaseVideoDetector  # noqa: E402
+
+
+@DETECTORS.register_module()
+class TwoStageDetector(BaseDetector):
+    """mmdetection/mmdet/models/detectors/two_stage.py:10-70 as far as the SELSA test path needs it: backbone, neck, rpn_head, roi_head
+    built from the config (train_cfg / test_cfg split into the `rpn` / `rcnn` parts), `extract_feat` = backbone + neck."""
+
+    def __init__(self, backbone, neck=None, rpn_head=None, roi_head=None, train_cfg=None, test_cfg=None, pretrained=None):
+        super().__init__()
+        self.backbone = build_backbone(backbone)
+        self.neck = build_neck(neck) if neck is not None else None
+        if rpn_head is not None:
+            rh = dict(rpn_head)
+            rh.update(train_cfg=train_cfg['rpn'] if train_cfg is not None else None, test_cfg=test_cfg['rpn'] if test_cfg is not None else None)
+            self.rpn_head = build_head(rh)
+        if roi_head is not None:
+            rr = dict(roi_head)
+            rr.update(train_cfg=train_cfg['rcnn'] if train_cfg is not None else None, test_cfg=test_cfg['rcnn'] if test_cfg is not None else None)
+            self.roi_head = build_head(rr)
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+
+    with_rpn = property(lambda self: hasattr(self, 'rpn_head') and self.rpn_head is not None)
+    with_roi_head = property(lambda self: hasattr(self, 'roi_head') and self.roi_head is not None)
+
+    def init_weights(self, pretrained=None):
+        self.backbone.init_weights(pretrained)
+        for m in (self.neck, getattr(self, 'rpn_head', None), getattr(self, 'roi_head', None)):
+            if m is not None:
+                m.init_weights()
+
+    def extract_feat(self, img):
+        x = self.backbone(img)
+        return self.neck(x) if self.neck is not None else x
+
+    def forward_train(self, *a, **k):
+        raise LlvError('two-stage training is not built')
+
+    def simple_test(self, img, img_metas, proposals=None, rescale=False):
+        raise LlvError('the two-stage detector is driven by the SELSA video detector here (key + reference frames)')
+
+
+@DETECTORS.register_module()
+class FasterRCNN(TwoStageDetector):
+    """mmdetection/mmdet/models/detectors/faster_rcnn.py"""
+
+
+@MODELS.register_module()
+class SELSA(BaseVideoDetector):
+    """Sequence-level semantics aggregation at test time (mmtracking/mmtrack/models/vid/selsa.py:14-56,172-330): the RoI features of the
+    key frame's proposals attend to those of the reference frames' proposals. `extract_feats` keeps the reference-frame feature maps of
+    a video in `self.memo` (both of the reference's modes: all references given with frame 0 when frame_stride < 1, or a sliding window
+    refreshed every frame_stride frames), proposals come from the RPN on key and reference features, detections from SelsaRoIHead."""
+
+    def __init__(self, detector, pretrains=None, frozen_modules=None, train_cfg=None, test_cfg=None):
+        super().__init__()
+        self.detector = build_detector(detector)
+        assert hasattr(self.detector, 'roi_head'), 'selsa video detector only supports two stage detector'
+        self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.memo = None
+        self.init_weights(pretrains)
+        if frozen_modules is not None:
+            self.freeze_module(frozen_modules)
+
+    def init_weights(self, pretrain):
+        if pretrain is None:
+            pretrain = dict()
+        assert isinstance(pretrain, dict), '`pretrain` must be a dict.'
+        if self.with_detector and pretrain.get('detector', False):
+            self.init_module('detector', pretrain['detector'])
+
+    def forward_train(self, *a, **k):
+        raise LlvError('SELSA.forward_train: the two-stage training path is not built')
+
+    def extract_feats(self, img, img_metas, ref_img, ref_img_metas):
+        """selsa.py:172-258."""
+        frame_id = img_metas[0].get('frame_id', -1)
+        assert frame_id >= 0
+        num_left_ref_imgs = img_metas[0].get('num_left_ref_imgs', -1)
+        frame_stride = img_metas[0].get('frame_stride', -1)
+        if frame_stride < 1:
+            if frame_id == 0:
+                self.memo = dict(img_metas=list(ref_img_metas[0]), feats=list(self.detector.extract_feat(ref_img[0])))
+            x = self.detector.extract_feat(img)
+            ref_x = [torch.cat((r, xi), dim=0) for r, xi in zip(self.memo['feats'], x)]
+            ref_metas = list(self.memo['img_metas']) + list(img_metas)
+        else:
+            if frame_id == 0:
+                ref = self.detector.extract_feat(ref_img[0])
+                self.memo = dict(img_metas=list(ref_img_metas[0]), feats=list(ref))
+                x = [r[[num_left_ref_imgs]] for r in ref]
+            elif frame_id % frame_stride == 0:
+                assert ref_img is not None
+                ref = self.detector.extract_feat(ref_img[0])
+                x = []
+                for i in range(len(ref)):
+                    self.memo['feats'][i] = torch.cat((self.memo['feats'][i], ref[i]), dim=0)[1:]
+                    x.append(self.memo['feats'][i][[num_left_ref_imgs]])
+                self.memo['img_metas'] = (self.memo['img_metas'] + list(ref_img_metas[0]))[1:]
+            else:
+                assert ref_img is None
+                x = self.detector.extract_feat(img)
+            ref_x = [f.clone() for f in self.memo['feats']]
+            for i in range(len(x)):
+                ref_x[i][num_left_ref_imgs] = x[i][0]
+            ref_metas = list(self.memo['img_metas'])
+            ref_metas[num_left_ref_imgs] = img_metas[0]
+        return tuple(x), img_metas, tuple(ref_x), ref_metas
+
+    def simple_test(self, img, img_metas, ref_img=None, ref_img_metas=None, proposals=None, ref_proposals=None, rescale=False):
+        """selsa.py:260-330. Returns {'bbox_results': list[num_classes] of (k, 5) arrays}."""
+        self._check_input(img)
+        if ref_img is not None:
+            ref_img = ref_img[0]
+        if ref_img_metas is not None:
+            ref_img_metas = ref_img_metas[0]
+        x, img_metas, ref_x, ref_img_metas = self.extract_feats(img, img_metas, ref_img, ref_img_metas)
+        if proposals is None:
+            proposal_list = self.detector.rpn_head.simple_test_rpn(x, img_metas)
+            ref_proposals_list = self.detector.rpn_head.simple_test_rpn(ref_x, ref_img_metas)
+        else:
+            proposal_list, ref_proposals_list = proposals, ref_proposals
+        outs = self.detector.roi_head.simple_test(x, ref_x, proposal_list, ref_proposals_list, img_metas, rescale=rescale)
+        return dict(bbox_results=outs[0])
