@@ -134,6 +134,9 @@ typedef struct llv_conv_desc {
     float act_slope;               /* negative slope for LLV_CONV_LEAKY */
     int32_t ps_out_h, ps_out_w;    /* LLV_CONV_PIXSHUF: stored extent (<= 2Ho x 2Wo; 0 = full). A 4x4/stride-2/pad-1 transposed conv is
                                       a 3x3 conv to 4*Cout channels + this shuffle; the crop is FlowNetSimple.crop_like (flownet_simple.py:246-251) */
+    int32_t dilation;              /* 0 or 1: none; d > 1: tap (r, q) reads input (y*stride - pad + r*d, x*stride - pad + q*d) -- the dilated
+                                      last stage of the DC5 backbones of the SELSA configs (resnet.py `dilations=(1, 1, 1, 2)`); forward only,
+                                      on the implicit-GEMM kernels */
 } llv_conv_desc;
 
 #define LLV_TILE_AUTO 0

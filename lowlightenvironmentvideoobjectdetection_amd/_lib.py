@@ -62,6 +62,7 @@ class ConvDesc(C.Structure):
         ('y_group_stride', C.c_int64),
         ('act_slope', C.c_float),
         ('ps_out_h', C.c_int32), ('ps_out_w', C.c_int32),
+        ('dilation', C.c_int32),
     ]
 
 

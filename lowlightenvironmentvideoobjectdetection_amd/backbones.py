@@ -106,8 +106,8 @@ class ResNet(PlannedModule):
         super().__init__()
         if depth not in self.arch_settings:
             raise KeyError(f'invalid depth {depth} for resnet')
-        if deep_stem or avg_down or dcn is not None or plugins is not None or any(d != 1 for d in dilations) or in_channels != 3:
-            raise NotImplementedError('deep_stem / avg_down / dcn / plugins / dilation are outside the hot path')
+        if deep_stem or avg_down or dcn is not None or plugins is not None or in_channels != 3:
+            raise NotImplementedError('deep_stem / avg_down / dcn / plugins are outside the hot path')
         self.depth = depth
         stem_channels = stem_channels or base_channels
         self.stem_channels, self.base_channels, self.num_stages = stem_channels, base_channels, num_stages
@@ -180,7 +180,7 @@ class ResNet(PlannedModule):
 
     def plan_kwargs(self):
         return dict(depth=self.depth, strides=self.strides, style=self.style, out_indices=self.out_indices,
-                    num_stages=self.num_stages)
+                    num_stages=self.num_stages, dilations=tuple(self.dilations))
 
     def forward(self, x):
         """NCHW fp32 image on the GPU -> tuple of NCHW fp32 stage outputs (BN uses running statistics)."""

@@ -37,6 +37,7 @@ struct ConvKArgs {
     int x_ld, y_ld, res_ld;
     int cin, cout, w_rows, k_pad;
     int kh, kw, stride, pad;
+    int dil;            // dilation (>= 1): tap (r, q) reads input (y*stride - pad + r*dil, x*stride - pad + q*dil)
     int n_seg;
     int seg_h[LLV_MAX_SEG], seg_w[LLV_MAX_SEG], seg_ho[LLV_MAX_SEG], seg_wo[LLV_MAX_SEG];
     int seg_m0[LLV_MAX_SEG + 1];
@@ -427,7 +428,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
 #pragma unroll
         for (int i = 0; i < XVEC; ++i) {
             const int H = px_hw[i] >> 16, W = px_hw[i] & 0xffff;
-            const int y = px_iy0[i] + kr, x = px_ix0[i] + kq;
+            const int y = px_iy0[i] + kr * a.dil, x = px_ix0[i] + kq * a.dil;
             uint4 v = make_uint4(0, 0, 0, 0);
             if (tap_ok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
                 v = *reinterpret_cast<const uint4*>(xb + (long)(px_base[i] + y * W + x) * a.x_ld + cofs);
@@ -686,7 +687,7 @@ __global__ __launch_bounds__(256, (BK == 64 ? 2 : (BN * BM >= 128 * 128 ? 3 : 4)
             unsigned mk = 0;
             for (int t = 0; t < ntap; ++t) {
                 const int r = t / a.kw, q = t - r * a.kw;
-                if ((unsigned)(px_iy0[i] + r) < (unsigned)H && (unsigned)(px_ix0[i] + q) < (unsigned)W) mk |= 1u << t;
+                if ((unsigned)(px_iy0[i] + r * a.dil) < (unsigned)H && (unsigned)(px_ix0[i] + q * a.dil) < (unsigned)W) mk |= 1u << t;
             }
             pmask[i] = mk;                                   // H = W = 0 for rows past the end: no bit set
         }
@@ -700,7 +701,7 @@ __global__ __launch_bounds__(256, (BK == 64 ? 2 : (BN * BM >= 128 * 128 ? 3 : 4)
         u_kc = k0 - u_tap * a.cin;
         u_kr = u_tap / a.kw;
         u_kq = u_tap - u_kr * a.kw;
-        u_toff = (u_kr * a.seg_w[0] + u_kq) * a.x_ld * 2;
+        u_toff = (u_kr * a.seg_w[0] + u_kq) * a.dil * a.x_ld * 2;
     }
 
     auto issue = [&](int ks, int buf) {
@@ -730,7 +731,7 @@ __global__ __launch_bounds__(256, (BK == 64 ? 2 : (BN * BM >= 128 * 128 ? 3 : 4)
             if (u_kc >= a.cin) {
                 u_kc = 0; ++u_tap;
                 if (++u_kq == a.kw) { u_kq = 0; ++u_kr; }
-                u_toff = (u_kr * a.seg_w[0] + u_kq) * a.x_ld * 2;
+                u_toff = (u_kr * a.seg_w[0] + u_kq) * a.dil * a.x_ld * 2;
             }
             return;
         }
@@ -761,7 +762,7 @@ __global__ __launch_bounds__(256, (BK == 64 ? 2 : (BN * BM >= 128 * 128 ? 3 : 4)
         for (int i = 0; i < PPW; ++i) {
             if (wave + 4 * i < NPI) {
                 const int H = px_hw[i] >> 16, W = px_hw[i] & 0xffff;
-                const int y = px_iy0[i] + kr, x = px_ix0[i] + kq;
+                const int y = px_iy0[i] + kr * a.dil, x = px_ix0[i] + kq * a.dil;
                 const _Float16* src = zero;
                 if (tap_ok && (unsigned)y < (unsigned)H && (unsigned)x < (unsigned)W)
                     src = xb + (long)(px_base[i] + y * W + x) * a.x_ld + cofs;
@@ -2065,7 +2066,7 @@ int launch_tap(ConvKArgs& k, const llv_conv_desc* d, hipStream_t st) {
 }
 
 static bool tap_eligible(const llv_conv_desc* d) {
-    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || (d->cin & 31)) return false;
+    if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->dilation > 1 || (d->cin & 31)) return false;
     if (d->n_src > 1 && ((d->src_cvec & 3) || d->groups != 1)) return false;   // a 32-channel chunk must lie in one source
     for (int s = 0; s < d->n_seg; ++s)
         if (d->seg_ho[s] != d->seg_h[s] || d->seg_wo[s] != d->seg_w[s]) return false;
@@ -2225,6 +2226,8 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
     if ((d->w_rows & 15) || d->w_rows < d->cout) return LLV_E_BADARG;
     if ((d->k_pad & 31) || d->k_pad < d->kh * d->kw * d->cin) return LLV_E_BADARG;
     if (d->kh < 1 || d->kw < 1 || d->stride < 1 || d->pad < 0 || d->groups < 1 || d->batch < 1) return LLV_E_BADARG;
+    if (d->dilation < 0) return LLV_E_BADARG;
+    if (d->dilation > 1 && (d->flags & LLV_CONV_PIXSHUF)) return LLV_E_UNSUPPORTED;
     if ((d->x_ld & 7) || (d->y_ld & 3)) return LLV_E_BADARG;
     if (d->n_src > 1 && d->groups == d->n_src) {
         if (d->src_cvec * 8 != d->cin || d->x_ld < d->cin) return LLV_E_BADARG;   // group g reads source g
@@ -2263,6 +2266,7 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
     k.x_ld = d->x_ld; k.y_ld = d->y_ld; k.res_ld = d->res_ld;
     k.cin = d->cin; k.cout = d->cout; k.w_rows = d->w_rows; k.k_pad = d->k_pad;
     k.kh = d->kh; k.kw = d->kw; k.stride = d->stride; k.pad = d->pad;
+    k.dil = d->dilation > 1 ? d->dilation : 1;
     k.n_seg = d->n_seg;
     long m = 0;
     for (int s = 0; s < LLV_MAX_SEG; ++s) {
@@ -2331,7 +2335,7 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
     hipStream_t st = (hipStream_t)stream;
     if (d->w_halo && !d->tile) {
         // direct (halo-in-LDS) path: 3x3 / stride 1 / pad 1, one segment, Cin in {8,16,24} or a multiple of 32
-        if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->n_seg != 1) return LLV_E_BADARG;
+        if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->dilation > 1 || d->n_seg != 1) return LLV_E_BADARG;
         if (!(d->cin == 8 || d->cin == 16 || d->cin == 24 || (d->cin & 31) == 0)) return LLV_E_BADARG;
         if (d->n_src > 1 && d->groups != d->n_src && (d->groups != 1 || (d->src_cvec * 8) % (d->cin < 32 ? d->cin : 32) != 0)) return LLV_E_BADARG;
         if (d->halo_bn != 16 && d->halo_bn != 32 && d->halo_bn != 64) return LLV_E_BADARG;
@@ -2398,7 +2402,7 @@ static int convpair_launch(const llv_inputcv_desc* p, void* stream, bool output_
     k.x2 = (const _Float16*)(output_block ? d->x[0] : d->x[2]);
     k.bias = d->bias; k.y = d->y; k.res = (const _Float16*)d->res;
     k.n_src = d->n_src; k.src_cvec = 1; k.x_ld = d->x_ld; k.y_ld = d->y_ld; k.res_ld = d->res_ld;
-    k.cin = d->cin; k.cout = d->cout; k.kh = 3; k.kw = 3; k.stride = 1; k.pad = 1; k.n_seg = 1;
+    k.cin = d->cin; k.cout = d->cout; k.kh = 3; k.kw = 3; k.stride = 1; k.pad = 1; k.dil = 1; k.n_seg = 1;
     for (int s = 0; s < LLV_MAX_SEG; ++s) {
         k.seg_h[s] = d->seg_h[0]; k.seg_w[s] = d->seg_w[0]; k.seg_ho[s] = d->seg_h[0]; k.seg_wo[s] = d->seg_w[0];
         k.seg_xoff[s] = (int)d->seg_xoff[0]; k.seg_yoff[s] = (int)d->seg_yoff[0]; k.seg_m0[s] = 0;

@@ -187,7 +187,7 @@ def _cpu_sd(sd):
 
 
 def build_resnet(b: Builder, sd, x, depth=50, strides=(1, 2, 2, 2), style='pytorch', out_indices=(0, 1, 2, 3), p='',
-                 num_stages=4, after_stage=None):
+                 num_stages=4, after_stage=None, dilations=(1, 1, 1, 1)):
     """x: (N,H,W,8) fp16 NHWC normalised image (3 real channels). Returns the out_indices stage outputs.
     resnet.py:622-640 with every BatchNorm folded (norm_eval, running stats) and ReLU / identity-add fused
     into the producing conv's epilogue."""
@@ -201,6 +201,7 @@ def build_resnet(b: Builder, sd, x, depth=50, strides=(1, 2, 2, 2), style='pytor
         for j in range(nb):
             q = f'{p}layer{i + 1}.{j}.'
             stride = strides[i] if j == 0 else 1
+            dil = dilations[i]                               # resnet.py:151-167: conv2 padding = dilation (DC5 stages)
             identity = x
             if (q + 'downsample.0.weight') in sd:          # res_layer.py:36-58: conv1x1(stride) + BN
                 identity = b.conv(q + 'downsample', x, ops.pack_conv(sd[q + 'downsample.0.weight'], None, stride, 0,
@@ -209,13 +210,13 @@ def build_resnet(b: Builder, sd, x, depth=50, strides=(1, 2, 2, 2), style='pytor
                 s1, s2 = (1, stride) if style == 'pytorch' else (stride, 1)          # resnet.py:151-156
                 o = b.conv(q + 'conv1', x, ops.pack_conv(sd[q + 'conv1.weight'], None, s1, 0, bn=_bn(sd, q + 'bn1'),
                                                          eps=BN_EPS), CONV_RELU)
-                o = b.conv(q + 'conv2', o, ops.pack_conv(sd[q + 'conv2.weight'], None, s2, 1, bn=_bn(sd, q + 'bn2'),
-                                                         eps=BN_EPS), CONV_RELU)
+                o = b.conv(q + 'conv2', o, ops.pack_conv(sd[q + 'conv2.weight'], None, s2, dil, bn=_bn(sd, q + 'bn2'),
+                                                         eps=BN_EPS, dilation=dil), CONV_RELU)
                 x = b.conv(q + 'conv3', o, ops.pack_conv(sd[q + 'conv3.weight'], None, 1, 0, bn=_bn(sd, q + 'bn3'),
                                                          eps=BN_EPS), CONV_RELU | CONV_RES_ADD, res=identity)
             else:
-                o = b.conv(q + 'conv1', x, ops.pack_conv(sd[q + 'conv1.weight'], None, stride, 1,
-                                                         bn=_bn(sd, q + 'bn1'), eps=BN_EPS), CONV_RELU)
+                o = b.conv(q + 'conv1', x, ops.pack_conv(sd[q + 'conv1.weight'], None, stride, dil,
+                                                         bn=_bn(sd, q + 'bn1'), eps=BN_EPS, dilation=dil), CONV_RELU)
                 x = b.conv(q + 'conv2', o, ops.pack_conv(sd[q + 'conv2.weight'], None, 1, 1, bn=_bn(sd, q + 'bn2'),
                                                          eps=BN_EPS), CONV_RELU | CONV_RES_ADD, res=identity)
         if after_stage is not None:             # InsertResNet: a plugin appended to the stage (insert_resnet.py:93-97)

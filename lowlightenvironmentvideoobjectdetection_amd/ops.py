@@ -57,6 +57,7 @@ class PackedConv:
     true_macs_per_pixel: int = 0   # unpadded Cout*Cin/g*kh*kw, for FLOP accounting
     w_halo: Optional[torch.Tensor] = None   # second packing for the direct 3x3 kernel (add_halo_packing)
     halo_bn: int = 0
+    dilation: int = 1        # > 1: dilated taps (forward only, implicit-GEMM kernels)
     # which module parameters each block of rows came from (training: repack after an optimizer step, route the
     # weight gradient back): dicts with wkey / bkey / bn (4 keys) / group / row0 / cout / cin / eps
     parts: Optional[list] = None
@@ -108,7 +109,7 @@ def add_halo_packing(pc: 'PackedConv') -> 'PackedConv':
 
 def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], stride=1, pad=0,
               in_map: Optional[Sequence[int]] = None, cout_store: Optional[int] = None,
-              n_src: int = 1, bn=None, eps: float = 1e-5) -> PackedConv:
+              n_src: int = 1, bn=None, eps: float = 1e-5, dilation: int = 1) -> PackedConv:
     """Pack a dense conv weight [Cout, Cin, kh, kw] (fp32) for the implicit-GEMM kernel.
 
     in_map[j] = original input channel feeding padded channel j, or -1 for a zero channel; default is
@@ -146,7 +147,7 @@ def pack_conv(weight: torch.Tensor, bias: Optional[torch.Tensor], stride=1, pad=
     pc = PackedConv(w=wfull.to(torch.float16).unsqueeze(0).contiguous(), bias=bfull.float().contiguous(),
                     cin=cin_pad, cout=cout_store, w_rows=w_rows, k_pad=k_pad, kh=kh, kw=kw, stride=stride,
                     pad=pad, groups=1, n_src=n_src, src_cvec=(cin_pad // 8 // n_src) if n_src > 1 else 0,
-                    true_macs_per_pixel=cout * cin * kh * kw)
+                    true_macs_per_pixel=cout * cin * kh * kw, dilation=int(dilation))
     wkey = getattr(weight_in, '_llv_key', None)
     if wkey is not None and in_map_default:
         pc.parts = [dict(wkey=wkey, bkey=getattr(bias, '_llv_key', None) if bias is not None else None,
@@ -209,7 +210,8 @@ def concat_cout(pcs: List[PackedConv]) -> PackedConv:
 
 
 def conv_out_size(h, w, pc: PackedConv):
-    return (h + 2 * pc.pad - pc.kh) // pc.stride + 1, (w + 2 * pc.pad - pc.kw) // pc.stride + 1
+    d = max(int(getattr(pc, 'dilation', 1)), 1)
+    return (h + 2 * pc.pad - d * (pc.kh - 1) - 1) // pc.stride + 1, (w + 2 * pc.pad - d * (pc.kw - 1) - 1) // pc.stride + 1
 
 
 def make_conv_desc(pc: PackedConv, xs: Sequence[torch.Tensor], y: torch.Tensor, batch: int,
@@ -241,7 +243,8 @@ def make_conv_desc(pc: PackedConv, xs: Sequence[torch.Tensor], y: torch.Tensor, 
     d.y_group_stride = y_group_stride
     d.act_slope = act_slope
     d.ps_out_h, d.ps_out_w = ps_out
-    if pc.w_halo is not None and len(segs) == 1 and tile == 0 and segs[0][0] == segs[0][2] and segs[0][1] == segs[0][3]:
+    d.dilation = max(int(getattr(pc, 'dilation', 1)), 1)
+    if pc.w_halo is not None and d.dilation == 1 and len(segs) == 1 and tile == 0 and segs[0][0] == segs[0][2] and segs[0][1] == segs[0][3]:
         d.w_halo, d.halo_bn = pc.w_halo.data_ptr(), pc.halo_bn
     else:
         d.w_halo, d.halo_bn = 0, 0

@@ -27,7 +27,7 @@ def _bn(x, sd, p, eps=1e-5):
 
 
 def resnet_forward(sd, x, depth=50, out_indices=(0, 1, 2, 3), strides=(1, 2, 2, 2), style='pytorch', prefix='backbone.',
-                   after_stage=None):
+                   after_stage=None, dilations=(1, 1, 1, 1)):
     """after_stage(i, num_blocks, x) -> x: the plugin InsertResNet appends to stage i
     (mmtracking/mmtrack/models/backbones/insert_resnet.py:93-97); an out index may repeat (:410-415)."""
     kind, blocks = ARCH[depth]
@@ -40,14 +40,15 @@ def resnet_forward(sd, x, depth=50, out_indices=(0, 1, 2, 3), strides=(1, 2, 2, 
         for b in range(nb):
             q = f'{p}layer{i + 1}.{b}.'
             stride = strides[i] if b == 0 else 1
+            dil = dilations[i]                         # resnet.py:151-167: conv2 (Bottleneck) / conv1 (BasicBlock) padding = dilation
             identity = x
             if kind == 'bottleneck':
                 s1, s2 = (1, stride) if style == 'pytorch' else (stride, 1)    # resnet.py:151-156
                 out = F.relu(_bn(F.conv2d(x, sd[q + 'conv1.weight'], None, s1, 0), sd, q + 'bn1'))
-                out = F.relu(_bn(F.conv2d(out, sd[q + 'conv2.weight'], None, s2, 1), sd, q + 'bn2'))
+                out = F.relu(_bn(F.conv2d(out, sd[q + 'conv2.weight'], None, s2, dil, dil), sd, q + 'bn2'))
                 out = _bn(F.conv2d(out, sd[q + 'conv3.weight'], None, 1, 0), sd, q + 'bn3')
             else:
-                out = F.relu(_bn(F.conv2d(x, sd[q + 'conv1.weight'], None, stride, 1), sd, q + 'bn1'))
+                out = F.relu(_bn(F.conv2d(x, sd[q + 'conv1.weight'], None, stride, dil, dil), sd, q + 'bn1'))
                 out = _bn(F.conv2d(out, sd[q + 'conv2.weight'], None, 1, 1), sd, q + 'bn2')
             if (q + 'downsample.0.weight') in sd:                                # res_layer.py:36-58
                 identity = _bn(F.conv2d(x, sd[q + 'downsample.0.weight'], None, stride, 0), sd, q + 'downsample.1')

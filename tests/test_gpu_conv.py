@@ -543,3 +543,30 @@ def test_conv3x3_tap_pixel_shuffle_subpixel_major(dev):
         ref = F.pixel_shuffle(F.conv2d(x, wt, bias, 1, 1), 2) + res.float().permute(0, 3, 1, 2)
         assert y.shape == (2, 2 * h, 2 * w, cout // 4)
         _check(y, ref, cout // 4)
+
+
+@pytest.mark.parametrize('tile', [0, 1, 2, 5, 6, 7])
+@pytest.mark.parametrize('cfg', [
+    # n, cin, cout, h, w, k, stride, pad, dilation
+    (1, 64, 64, 20, 33, 3, 1, 2, 2),        # the dilated 3x3 of a DC5 stage (pad = dilation: same size); UT mode (cin % 32 == 0)
+    (2, 96, 40, 13, 17, 3, 1, 2, 2),
+    (1, 24, 32, 16, 24, 3, 1, 3, 3),        # general mode (cin not a multiple of 32)
+    (1, 32, 48, 19, 21, 3, 2, 2, 2),        # dilation with stride 2
+    (1, 64, 16, 9, 40, 3, 1, 0, 2),         # no padding: the output shrinks by 2*dilation
+])
+def test_conv_dilation_matches_torch(dev, cfg, tile):
+    """Dilated taps (`llv_conv_desc.dilation`, resnet.py `dilations=(1, 1, 1, 2)` of the SELSA DC5 backbones) on the implicit-GEMM
+    kernels, auto selection included (the tap-streamed kernel must not take a dilated layer)."""
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    n, cin, cout, h, w, k, s, p, d = cfg
+    g = torch.Generator().manual_seed(91)
+    x = torch.randn(n, cin, h, w, generator=g).half().float()
+    wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).half().float()
+    b = torch.randn(cout, generator=g)
+    pc = ops.pack_conv(wt, b, stride=s, pad=p, dilation=d).to(dev)
+    xp = torch.zeros(n, h, w, pc.cin, dtype=torch.float16)
+    xp[..., :cin] = _nhwc(x).half()
+    y = ops.conv2d(xp.to(dev), pc, flags=ops.CONV_RELU, tile=tile)
+    ref = F.relu(F.conv2d(x, wt, b, s, p, d))
+    assert tuple(y.shape[1:3]) == tuple(ref.shape[2:])
+    _check(y, ref, cout)

@@ -242,3 +242,19 @@ def test_streaming_steps_equal_full_steps(dev, B, use_graph):
             n_det += len(d0)
     assert n_det > 20
     assert len(strm.den.plan_stream.steps) < len(strm.den.plan.steps) + 3
+
+
+def test_resnet_dc5_dilated_stage_vs_oracle(dev):
+    """The backbone of the reference's SELSA configs (mmtracking/configs/vid/llvod/*.py: strides (1, 2, 2, 1), dilations (1, 1, 1, 2),
+    out_indices (3,)): the last stage keeps stride 16 with dilated 3x3 convs (`llv_conv_desc.dilation`)."""
+    reg = _registry()
+    from oracle.detector import resnet_forward
+    m = randomize(reg.build_backbone(dict(type='ResNet', depth=50, num_stages=4, out_indices=(3,), strides=(1, 2, 2, 1),
+                                          dilations=(1, 1, 1, 2), frozen_stages=-1, norm_eval=True, style='pytorch')), seed=93)
+    x = smooth_image(2, 96, 128, seed=94)
+    sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
+    with torch.no_grad():
+        ref = resnet_forward(sd, x, depth=50, out_indices=(3,), strides=(1, 2, 2, 1), dilations=(1, 1, 1, 2), prefix='')[0]
+    out = m.to(dev).eval()(x.to(dev))[0].cpu()
+    assert out.shape == ref.shape == (2, 2048, 6, 8)
+    assert _rel(out, ref) < 1.5e-2
