@@ -20,6 +20,7 @@ import os
 import sys
 import time
 
+import numpy as np
 import torch
 
 ROOT = os.path.dirname(os.path.abspath(__file__))
@@ -304,6 +305,88 @@ def insert_bench(args, world, rank, dev):
         dist.destroy_process_group()
 
 
+def selsa_bench(args, world, rank, dev):
+    """the authors' two-stage SELSA video detector at test time (FasterRCNN with a DC5 ResNet-50
+    (strides (1,2,2,1), dilations (1,1,1,2)), ChannelMapper 2048 -> 512, RPNHead (12 anchors, nms_pre 6000, 300 proposals),
+    SelsaRoIHead with two 1024-wide shared fcs and SelsaAggregators, 30 classes: detector of mmtracking/configs/vid/llvod/
+    llvod_insert_plugins_l34_i1234_vid_a7s3.py:12-86,129-139 without the backbone plugins and with SingleRoIExtractor), one 1280x720
+    frame per step, 2 reference frames given with frame 0 and kept in the memo. Module-level calls (NCHW at every module boundary, no
+    launch plan yet): a first number for this row, not a tuned path."""
+    import torch.distributed as dist
+    import lowlightenvironmentvideoobjectdetection_amd.models as M
+    from lowlightenvironmentvideoobjectdetection_amd import data
+    from lowlightenvironmentvideoobjectdetection_amd.synthetic import seeded_weights
+    NC = 30
+    cfg = dict(type='SELSA', pretrains=None, detector=dict(
+        type='FasterRCNN', pretrained=None,
+        backbone=dict(type='ResNet', depth=50, num_stages=4, out_indices=(3,), strides=(1, 2, 2, 1), dilations=(1, 1, 1, 2), frozen_stages=-1,
+                      norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, style='pytorch'),
+        neck=dict(type='ChannelMapper', in_channels=[2048], out_channels=512, kernel_size=3),
+        rpn_head=dict(type='RPNHead', in_channels=512, feat_channels=512,
+                      anchor_generator=dict(type='AnchorGenerator', scales=[4, 8, 16, 32], ratios=[0.5, 1.0, 2.0], strides=[16]),
+                      bbox_coder=dict(type='DeltaXYWHBBoxCoder', target_means=[.0, .0, .0, .0], target_stds=[1.0, 1.0, 1.0, 1.0]),
+                      loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0),
+                      loss_bbox=dict(type='SmoothL1Loss', beta=1.0 / 9.0, loss_weight=1.0)),
+        roi_head=dict(type='SelsaRoIHead',
+                      bbox_roi_extractor=dict(type='SingleRoIExtractor', roi_layer=dict(type='RoIAlign', output_size=7, sampling_ratio=2),
+                                              out_channels=512, featmap_strides=[16]),
+                      bbox_head=dict(type='SelsaBBoxHead', num_shared_fcs=2, aggregator=dict(type='SelsaAggregator', in_channels=1024, num_attention_blocks=16),
+                                     in_channels=512, fc_out_channels=1024, roi_feat_size=7, num_classes=NC,
+                                     bbox_coder=dict(type='DeltaXYWHBBoxCoder', target_means=[0., 0., 0., 0.], target_stds=[0.2, 0.2, 0.2, 0.2]),
+                                     reg_class_agnostic=False)),
+        test_cfg=dict(rpn=dict(nms_across_levels=False, nms_pre=6000, nms_post=300, max_num=300, nms_thr=0.7, min_bbox_size=0),
+                      rcnn=dict(score_thr=0.0001, nms=dict(type='nms', iou_threshold=0.5), max_per_img=100))))
+    model = M.build_model(cfg)
+    seeded_weights(model.detector.backbone, seed=0)
+    seeded_weights(model.detector.neck, seed=1)
+    seeded_weights(model.detector.rpn_head, seed=2)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        model.detector.rpn_head.rpn_cls.bias.add_(-2.0)
+        model.detector.rpn_head.rpn_reg.weight.mul_(0.3)
+        for p in model.detector.roi_head.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * ((1.0 / p.shape[1]) ** 0.5 if p.dim() == 2 else 0.05))
+    model = model.to(dev).eval()
+    T = 8
+    clean = data.synth_clean_clip(T, args.height, args.width, seed=100 + rank)
+    clip, img_shape, pad_shape = data.preprocess_clip_device(data.darken_and_add_noise(clean, seed=200 + rank).to(torch.uint8).to(dev))
+    frames = clip[2:2 + T, :, :, :3].permute(0, 3, 1, 2).float().contiguous()
+    meta0 = dict(img_shape=img_shape, pad_shape=pad_shape, ori_shape=img_shape, scale_factor=np.ones(4, np.float32), flip=False)
+
+    def step(i, first=False):
+        meta = dict(meta0, frame_id=0 if first else 1 + i, num_left_ref_imgs=-1, frame_stride=-1)
+        kw = dict(ref_img=[frames[:2].unsqueeze(0)], ref_img_metas=[[[meta0, meta0]]]) if first else {}
+        with torch.no_grad():
+            return model(return_loss=False, img=[frames[2 + i % (T - 2):3 + i % (T - 2)]], img_metas=[[meta]], **kw)['bbox_results']
+    res = step(0, first=True)
+    for i in range(args.warmup):
+        res = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for i in range(args.steps):
+        res = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    if rank == 0:
+        print(json.dumps({
+            'metric': 'frames/sec (SELSA two-stage video detector, test time) on 1280x720 video', 'value': round(args.steps * world / dt, 3),
+            'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
+            'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
+            'config': {'workload': f'SURVEY 8f.4: SELSA (FasterRCNN R-50 DC5 + ChannelMapper + RPN 300 proposals + SelsaRoIHead, {NC} classes), '
+                                   f'{args.width}x{args.height} frames, 2 reference frames in the memo, module-level eager calls',
+                       'frames_per_step': 1, 'hip_graph': False, 'detections_last_step': int(sum(len(r) for r in res))}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def fgfa_bench(args, world, rank, dev):
     """Config #4 of BASELINE.json: flow-guided feature aggregation over a 10-reference window (mmtracking FGFA with
     EmbedAggregator on the 256-channel FPN levels, RetinaNet R-50+FPN detector, FlowNetSimple), 1280x720 frames, one frame
@@ -380,7 +463,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-latency-mode', action='store_true')
-    ap.add_argument('--mode', choices=['infer', 'train', 'yolo', 'fgfa', 'insert'], default='infer',
+    ap.add_argument('--mode', choices=['infer', 'train', 'yolo', 'fgfa', 'insert', 'selsa'], default='infer',
                     help="'train' = BASELINE.json config #3: RetinaNet fwd + loss + bwd + gradient all-reduce + SGD, one image per GPU")
     ap.add_argument('--train-batch', type=int, default=1, help='images per GPU per training step')
     args = ap.parse_args()
@@ -423,6 +506,8 @@ def main():
         return fgfa_bench(args, world, rank, dev)
     if args.mode == 'insert':
         return insert_bench(args, world, rank, dev)
+    if args.mode == 'selsa':
+        return selsa_bench(args, world, rank, dev)
 
     B, T = args.frames_per_step, args.clip_frames
     det, cleaner = build_models(seed=0)
