@@ -62,12 +62,31 @@ extern "C" {
 #define LLV_E_LAUNCH (-2)
 #define LLV_E_UNSUPPORTED (-3)
 #define LLV_E_WORKSPACE (-4)
+#define LLV_E_EXTENT (-5) /* the launch would touch memory outside a declared buffer extent (llv_extents) */
 
-#define LLV_ABI_VERSION 1
+#define LLV_ABI_VERSION 2
 
 #define LLV_MAX_SEG 5 /* pyramid levels batched into one conv launch */
 #define LLV_MAX_SRC 3 /* input tensors concatenated along C by one conv launch */
 #define LLV_MAX_BATCH 16 /* images decoded / suppressed by one batched post-processing launch */
+
+/*
+ * Buffer extents: bytes addressable from each pointer of a descriptor to the end of the allocation it points into
+ * (0 = not declared, not checked). The reference never needed this (ATen owns its tensors' sizes); a C ABI that takes
+ * raw pointers does: several kernels fetch through hardware buffer resources whose scalar offsets are outside the
+ * range check, read residuals / skips as whole 16-byte lines and start resources before the tensor (padding rows).
+ * llv_conv2d_extents / llv_convpair_extents replay, on the host and in the kernels' own 32-bit arithmetic, every address
+ * the selected kernel variant forms for its operands (all workgroups, waves, lanes and k-steps; the buffer rule "voffset
+ * >= num_records reads zero, soffset is not checked" included) and report 1 + the highest byte touched per pointer, and
+ * whether any access falls below a pointer. When a descriptor carries `extents` and the environment variable
+ * LLV_CHECK_EXTENTS=1 is set (or the library was built with -DLLV_DEBUG_EXTENTS), llv_conv2d_nhwc_fwd /
+ * llv_inputcvblock_fwd / llv_outputcvblock_fwd run that replay before launching and return LLV_E_EXTENT on a violation.
+ */
+typedef struct llv_extents {
+    uint64_t x[LLV_MAX_SRC];
+    uint64_t w, bias, res, y, workspace, w_halo, w_pre, bias_pre;
+    int32_t below; /* out (llv_*_extents): bit i set = an access below pointer i (order of the fields above, x[0] = bit 0) */
+} llv_extents;
 
 /* llv_conv_desc.flags */
 #define LLV_CONV_RELU 1        /* y = max(y, 0) last */
@@ -137,6 +156,7 @@ typedef struct llv_conv_desc {
     int32_t dilation;              /* 0 or 1: none; d > 1: tap (r, q) reads input (y*stride - pad + r*d, x*stride - pad + q*d) -- the dilated
                                       last stage of the DC5 backbones of the SELSA configs (resnet.py `dilations=(1, 1, 1, 2)`); forward only,
                                       on the implicit-GEMM kernels */
+    const llv_extents* extents;    /* optional declared sizes of the buffers behind the pointers above (NULL: none) */
 } llv_conv_desc;
 
 #define LLV_TILE_AUTO 0
@@ -166,6 +186,12 @@ size_t llv_conv2d_workspace_bytes(const llv_conv_desc* desc);
 /* algorithmic FLOPs (2*MACs, true channels) the launch described by desc performs */
 double llv_conv2d_flops(const llv_conv_desc* desc);
 
+/* need = 1 + highest byte offset the launch llv_conv2d_nhwc_fwd(d) would touch through each pointer (0: pointer unused);
+ * pure host arithmetic, no launch. Returns LLV_OK, or the error llv_conv2d_nhwc_fwd would return for d. */
+int llv_conv2d_extents(const llv_conv_desc* d, llv_extents* need);
+/* LLV_OK when need fits have for every declared (non-zero) field of have and need->below == 0, else LLV_E_EXTENT */
+int llv_extents_fit(const llv_extents* need, const llv_extents* have);
+
 /*
  * FastDVDnet InputCvBlock in one launch (mmtracking/mmtrack/models/cleaners/FastDVDnet.py:22-36):
  *   Conv2d(9, 90, 3, groups=3) + BN + ReLU -> Conv2d(90, 32, 3) + BN + ReLU; the 90-channel intermediate stays in LDS.
@@ -186,6 +212,8 @@ int llv_inputcvblock_fwd(const llv_inputcv_desc* desc, void* stream);
  * input tensor, cin = 32, cout <= 16 multiple of 8, w_halo [16 rows][296], res = in1); w_pre = first conv, halo packing
  * [32 rows][296]; bias_pre fp32 [32]. */
 int llv_outputcvblock_fwd(const llv_inputcv_desc* desc, void* stream);
+/* llv_conv2d_extents for the two fused blocks (output_block = 0: InputCvBlock, 1: OutputCvBlock); conv.extents declares w_pre / bias_pre too */
+int llv_convpair_extents(const llv_inputcv_desc* desc, int output_block, llv_extents* need);
 
 /* 3x3 stride-2 pad-1 max pooling, NHWC fp16, c multiple of 8. */
 int llv_maxpool3x3s2_nhwc(const void* x, void* y, int batch, int h, int w, int c, void* stream);
@@ -330,7 +358,7 @@ int llv_taf_softmax_fuse(const void* xcor, const void* x, void* out, int n, int 
 int llv_add_f16(const void* a, const void* b, void* y, int64_t rows, int c, int a_ld, int b_ld, int y_ld, void* stream);
 
 /* RoIAlign (mmcv.ops.roi_align, pool_mode 'avg'; mmcv-full 1.3.0 un-vendored; call site: the `roi_layer=dict(type='RoIAlign',
- * output_size=7, sampling_ratio=2)` of mmtracking/configs/vid/llvod/*.py through mmdet's SingleRoIExtractor) -- the first piece of the
+ * output_size=7, sampling_ratio=2)` of mmtracking/configs/vid/llvod/ (every .py there) through mmdet's SingleRoIExtractor) -- the first piece of the
  * two-stage path of SURVEY.md section 8f item 4. feat (n,h,w,ld) NHWC fp16 (c channels, c % 8 == 0); rois [k][5] fp32 = (batch index,
  * x1, y1, x2, y2); out (k,ph,pw,c) NHWC fp16, or fp32 with out_f32. sampling_ratio 0 = adaptive (ceil(bin size)). */
 int llv_roi_align(const void* feat, const float* rois, void* out, int n, int h, int w, int c, int ld, int k, int ph, int pw,

@@ -35,6 +35,18 @@ class LlvError(RuntimeError):
     pass
 
 
+class Extents(C.Structure):
+    """llv_extents: bytes addressable from each pointer of a descriptor (0 = not declared); `below` is an output bit mask."""
+    _fields_ = [('x', C.c_uint64 * LLV_MAX_SRC), ('w', C.c_uint64), ('bias', C.c_uint64), ('res', C.c_uint64), ('y', C.c_uint64),
+                ('workspace', C.c_uint64), ('w_halo', C.c_uint64), ('w_pre', C.c_uint64), ('bias_pre', C.c_uint64), ('below', C.c_int32)]
+    NAMES = ('x0', 'x1', 'x2', 'w', 'bias', 'res', 'y', 'workspace', 'w_halo', 'w_pre', 'bias_pre')
+
+    def as_dict(self):
+        d = {f'x{i}': int(self.x[i]) for i in range(LLV_MAX_SRC)}
+        d.update({n: int(getattr(self, n)) for n in self.NAMES[3:]})
+        return d
+
+
 class ConvDesc(C.Structure):
     _fields_ = [
         ('x', C.c_void_p * LLV_MAX_SRC),
@@ -63,6 +75,7 @@ class ConvDesc(C.Structure):
         ('act_slope', C.c_float),
         ('ps_out_h', C.c_int32), ('ps_out_w', C.c_int32),
         ('dilation', C.c_int32),
+        ('extents', C.POINTER(Extents)),
     ]
 
 
@@ -103,6 +116,9 @@ SIGNATURES = {
     'llv_conv2d_flops': (C.c_double, [C.POINTER(ConvDesc)]),
     'llv_conv2d_workspace_bytes': (_Z, [C.POINTER(ConvDesc)]),
     'llv_conv2d_plan': (_I, [C.POINTER(ConvDesc), C.POINTER(C.c_int), C.POINTER(C.c_int)]),
+    'llv_conv2d_extents': (_I, [C.POINTER(ConvDesc), C.POINTER(Extents)]),
+    'llv_convpair_extents': (_I, [C.POINTER(InputCvDesc), _I, C.POINTER(Extents)]),
+    'llv_extents_fit': (_I, [C.POINTER(Extents), C.POINTER(Extents)]),
     'llv_inputcvblock_fwd': (_I, [C.POINTER(InputCvDesc), _P]),
     'llv_outputcvblock_fwd': (_I, [C.POINTER(InputCvDesc), _P]),
     'llv_maxpool3x3s2_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _P]),
@@ -172,7 +188,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.llv_abi_version() != 1:
+        if handle.llv_abi_version() != 2:
             raise LlvError('libllv.so ABI version mismatch')
         _lib = handle
     return _lib

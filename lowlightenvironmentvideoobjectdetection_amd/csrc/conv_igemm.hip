@@ -58,6 +58,14 @@ struct ConvKArgs {
     unsigned x_bytes, w_bytes;   // buffer-resource bounds of one source tensor / one group's weights (0: not usable)
 };
 
+// source tensor s (0..2) of a multi-source launch, without a pointer table (see conv_igemm_glds_kernel)
+__device__ __forceinline__ const _Float16* src_sel(const ConvKArgs& a, int s) {
+    const long d1 = reinterpret_cast<const char*>(a.x1) - reinterpret_cast<const char*>(a.x0);
+    const long d2 = reinterpret_cast<const char*>(a.x2) - reinterpret_cast<const char*>(a.x0);
+    const long off = (d1 & -(long)(s == 1)) | (d2 & -(long)(s == 2));
+    return reinterpret_cast<const _Float16*>(reinterpret_cast<const char*>(a.x0) + off);
+}
+
 // Shared epilogue: v[4] = conv sum (no bias yet) of channels gco..gco+3 of output row m.
 struct EpiCtx {
     long opix, rpix;
@@ -411,14 +419,17 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(const ConvKArgs a) {
                 v = *reinterpret_cast<const uint4*>(wbase + (long)grow * a.k_pad + ks * 32 + ch * 8);
             wreg[i] = v;
         }
+        // the source tensor of this lane's chunk, selected with integer masks on the distance from x0: a ternary chain over
+        // (x0, x1, x2) with a per-lane index is compiled into a 24-byte table in scratch memory (private segment 32 B per lane,
+        // a scratch_load per k-step), which is how every launch of this kernel came to need a scratch allocation
         const _Float16* xb;
         int cofs;
         if (a.src_per_group) {
-            xb = g == 0 ? a.x0 : (g == 1 ? a.x1 : a.x2);
+            xb = src_sel(a, g);
             cofs = kc8 * 8;
         } else if (a.n_src > 1) {
             const int s = kc8 / a.src_cvec;
-            xb = s == 0 ? a.x0 : (s == 1 ? a.x1 : a.x2);
+            xb = src_sel(a, s);
             cofs = (kc8 - s * a.src_cvec) * 8;
         } else {
             xb = a.x0;
@@ -744,14 +755,17 @@ __global__ __launch_bounds__(256, (BK == 64 ? 2 : (BN * BM >= 128 * 128 ? 3 : 4)
                                                  (__attribute__((address_space(3))) void*)(sW + (wave + 4 * i) * 1024), 16, 0, 0);
             }
         }
+        // the source tensor of this lane's chunk, selected with integer masks on the distance from x0: a ternary chain over
+        // (x0, x1, x2) with a per-lane index is compiled into a 24-byte table in scratch memory (private segment 32 B per lane,
+        // a scratch_load per k-step), which is how every launch of this kernel came to need a scratch allocation
         const _Float16* xb;
         int cofs;
         if (a.src_per_group) {
-            xb = g == 0 ? a.x0 : (g == 1 ? a.x1 : a.x2);
+            xb = src_sel(a, g);
             cofs = kc8 * 8;
         } else if (a.n_src > 1) {
             const int s = kc8 / a.src_cvec;
-            xb = s == 0 ? a.x0 : (s == 1 ? a.x1 : a.x2);
+            xb = src_sel(a, s);
             cofs = (kc8 - s * a.src_cvec) * 8;
         } else {
             xb = a.x0;
@@ -1210,8 +1224,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
 
     const __amdgpu_buffer_rsrc_t rW = make_rsrc(a.w + (long)g * a.w_gstride, h.w_bytes);
     const __amdgpu_buffer_rsrc_t rX0 = make_rsrc(a.x0, h.x_bytes);
-    const __amdgpu_buffer_rsrc_t rX1 = make_rsrc(a.n_src > 1 ? a.x1 : a.x0, h.x_bytes);
-    const __amdgpu_buffer_rsrc_t rX2 = make_rsrc(a.n_src > 2 ? a.x2 : a.x0, h.x_bytes);
 
     // ---- per-lane DMA offsets, fixed for the whole k loop (the chunk / tap part is a scalar offset)
     int hv[HPW];
@@ -1247,10 +1259,12 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
         int cv = c * 4;
         unsigned char* dst = sHalo + buf * TAP_HBYTES + (wave + 4 * i) * 1024;
         if (MSRC) {
+            // the chunk's source tensor: a resource built from a masked pointer sum (scalar), not a choice among three
+            // resources (which the compiler turned into a table in scratch memory: 512 / 1040 B of private segment)
             const int sidx = cv / a.src_cvec;
             cv -= sidx * a.src_cvec;
-            if (sidx == 1) { dma16(rX1, dst, hv[i], cv * 16); return; }
-            if (sidx == 2) { dma16(rX2, dst, hv[i], cv * 16); return; }
+            dma16(make_rsrc(src_sel(a, sidx), h.x_bytes), dst, hv[i], cv * 16);
+            return;
         }
         dma16(rX0, dst, hv[i], cv * 16);
     };
@@ -2040,9 +2054,7 @@ static size_t tap_x_bytes(const llv_conv_desc* d) {
     return px * (size_t)d->x_ld * 2;
 }
 
-template <int BN, int R = 2>
-int launch_tap(ConvKArgs& k, const llv_conv_desc* d, hipStream_t st) {
-    TapArgs h;
+static void fill_tap(const llv_conv_desc* d, TapArgs& h) {
     int blk = 0;
     for (int s = 0; s < LLV_MAX_SEG; ++s) {
         h.tiles_x[s] = h.tiles_y[s] = 0;
@@ -2058,6 +2070,12 @@ int launch_tap(ConvKArgs& k, const llv_conv_desc* d, hipStream_t st) {
     h.n_chunks = d->cin / 32;
     h.x_bytes = (unsigned)tap_x_bytes(d);
     h.w_bytes = (unsigned)((size_t)d->w_rows * d->k_pad * 2);
+}
+
+template <int BN, int R = 2>
+int launch_tap(ConvKArgs& k, const llv_conv_desc* d, hipStream_t st) {
+    TapArgs h;
+    fill_tap(d, h);
     k.k_splits = 1;
     dim3 grid(h.nblk, (d->cout + BN - 1) / BN, d->groups);
     if (d->n_src > 1) hipLaunchKernelGGL((conv3x3_tap_kernel<BN, R, true>), grid, dim3(256), 0, st, k, h);
@@ -2218,7 +2236,19 @@ extern "C" double llv_conv2d_flops(const llv_conv_desc* d) {
     return 2.0 * m * (double)d->groups * d->cout * d->kh * d->kw * d->cin;
 }
 
-extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
+// everything llv_conv2d_nhwc_fwd decides on the host: validated kernel arguments, the kernel variant and its split
+struct ConvPrepared {
+    ConvKArgs k;
+    LaunchPlan lp;
+    bool halo;        // conv3x3_halo_kernel (w_halo given, no forced tile)
+    HaloArgs h;
+    int halo_bn;
+};
+
+static int conv_prepare(const llv_conv_desc* d, ConvPrepared& P) {
+    ConvKArgs& k = P.k;
+    LaunchPlan& lp = P.lp;
+    P.halo = false;
     if (!d || !d->x[0] || !d->w || !d->bias || !d->y) return LLV_E_BADARG;
     if (d->n_seg < 1 || d->n_seg > LLV_MAX_SEG) return LLV_E_BADARG;
     if (d->n_src < 1 || d->n_src > LLV_MAX_SRC) return LLV_E_BADARG;
@@ -2254,7 +2284,6 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
         return LLV_E_BADARG;
     }
 
-    ConvKArgs k;
     k.x0 = (const _Float16*)d->x[0];
     k.x1 = (const _Float16*)(d->n_src > 1 ? d->x[1] : d->x[0]);
     k.x2 = (const _Float16*)(d->n_src > 2 ? d->x[2] : d->x[0]);
@@ -2322,7 +2351,6 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
             k.stage_out = 1;
         }
     }
-    LaunchPlan lp;
     plan_launch(d, lp);
     k.k_splits = lp.splits;
     k.nk_per = lp.nk_per;
@@ -2332,14 +2360,13 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
         if (!d->workspace || d->workspace_bytes < llv_conv2d_workspace_bytes(d)) return LLV_E_WORKSPACE;
     }
 
-    hipStream_t st = (hipStream_t)stream;
     if (d->w_halo && !d->tile) {
         // direct (halo-in-LDS) path: 3x3 / stride 1 / pad 1, one segment, Cin in {8,16,24} or a multiple of 32
         if (d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1 || d->dilation > 1 || d->n_seg != 1) return LLV_E_BADARG;
         if (!(d->cin == 8 || d->cin == 16 || d->cin == 24 || (d->cin & 31) == 0)) return LLV_E_BADARG;
         if (d->n_src > 1 && d->groups != d->n_src && (d->groups != 1 || (d->src_cvec * 8) % (d->cin < 32 ? d->cin : 32) != 0)) return LLV_E_BADARG;
         if (d->halo_bn != 16 && d->halo_bn != 32 && d->halo_bn != 64) return LLV_E_BADARG;
-        HaloArgs h;
+        HaloArgs& h = P.h;
         h.w = (const _Float16*)d->w_halo;
         h.H = d->seg_h[0]; h.W = d->seg_w[0];
         if (d->seg_ho[0] != h.H || d->seg_wo[0] != h.W) return LLV_E_BADARG;
@@ -2354,15 +2381,47 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
         h.w_gstride = (long)h.n_chunks * nt * bn * h.wrow;
         if ((f & LLV_CONV_PIXSHUF) && bn < 32) k.stage_out = 0;
         k.k_splits = 1;
-        switch (bn) {
-            case 16: return launch_halo<16>(k, h, d->groups, d->batch, st);
-            case 32: return launch_halo<32>(k, h, d->groups, d->batch, st);
-            default: return launch_halo<64>(k, h, d->groups, d->batch, st);
-        }
+        P.halo = true;
+        P.halo_bn = bn;
+        return LLV_OK;
     }
     const int tile = lp.tile;
     if ((f & LLV_CONV_PS_EMAJOR) && !(tile == LLV_TILE_TAP64 && tap_eligible(d))) return LLV_E_UNSUPPORTED;
     if ((f & LLV_CONV_PIXSHUF) && tile == LLV_TILE_16x256) k.stage_out = 0;
+    if ((tile == LLV_TILE_TAP128 || tile == LLV_TILE_TAP64 || tile == LLV_TILE_TAP64_R4) && !tap_eligible(d)) return LLV_E_BADARG;
+    if (tile < LLV_TILE_128x128 || tile > LLV_TILE_TAP64_R4) return LLV_E_UNSUPPORTED;
+    return LLV_OK;
+}
+
+static bool extents_enabled() {
+#ifdef LLV_DEBUG_EXTENTS
+    return true;
+#else
+    static const bool on = getenv("LLV_CHECK_EXTENTS") != nullptr && atoi(getenv("LLV_CHECK_EXTENTS")) != 0;
+    return on;
+#endif
+}
+
+extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
+    ConvPrepared P;
+    const int rc = conv_prepare(d, P);
+    if (rc != LLV_OK) return rc;
+    if (d->extents && extents_enabled()) {
+        llv_extents need;
+        const int rce = llv_conv2d_extents(d, &need);
+        if (rce != LLV_OK) return rce;
+        if (llv_extents_fit(&need, d->extents) != LLV_OK) return LLV_E_EXTENT;
+    }
+    ConvKArgs& k = P.k;
+    hipStream_t st = (hipStream_t)stream;
+    if (P.halo) {
+        switch (P.halo_bn) {
+            case 16: return launch_halo<16>(k, P.h, d->groups, d->batch, st);
+            case 32: return launch_halo<32>(k, P.h, d->groups, d->batch, st);
+            default: return launch_halo<64>(k, P.h, d->groups, d->batch, st);
+        }
+    }
+    const int tile = P.lp.tile;
     switch (tile) {
         case LLV_TILE_128x128: return launch_glds<128, 128, 64, 64>(k, d->groups, st);
         case LLV_TILE_64x256:  return launch_glds<64, 256, 64, 64>(k, d->groups, st);
@@ -2380,7 +2439,17 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
 }
 
 
-static int convpair_launch(const llv_inputcv_desc* p, void* stream, bool output_block) {
+struct PairPrepared {
+    ConvKArgs k;
+    HaloArgs h;
+    PreArgs pre;
+    Pair2Args q;
+    bool v2;          // convpair2_kernel (DMA staging, persistent workgroups); false: the register-staged convpair_kernel
+    size_t lds;
+    int grid2;
+};
+
+static int convpair_prepare(const llv_inputcv_desc* p, bool output_block, PairPrepared& P) {
     if (!p || !p->w_pre || !p->bias_pre) return LLV_E_BADARG;
     const llv_conv_desc* d = &p->conv;
     if (!d->w_halo || !d->bias || !d->y || d->n_seg != 1 || d->kh != 3 || d->kw != 3 || d->stride != 1 || d->pad != 1) return LLV_E_BADARG;
@@ -2388,7 +2457,8 @@ static int convpair_launch(const llv_inputcv_desc* p, void* stream, bool output_
     if (d->seg_h[0] < 1 || d->seg_w[0] < 1 || d->seg_ho[0] != d->seg_h[0] || d->seg_wo[0] != d->seg_w[0] || d->batch < 1) return LLV_E_BADARG;
     const long px = (long)d->batch * d->seg_h[0] * d->seg_w[0];
     if (d->seg_xoff[0] < 0 || d->seg_yoff[0] < 0 || d->seg_xoff[0] + px > 0x7fffffffL || d->seg_yoff[0] + px > 0x7fffffffL) return LLV_E_BADARG;
-    ConvKArgs k = {};
+    ConvKArgs& k = P.k;
+    k = ConvKArgs{};
     if (!output_block) {
         if (d->n_src != 3 || !d->x[0] || !d->x[1] || !d->x[2] || d->x_ld < 8 || (d->x_ld & 7)) return LLV_E_BADARG;
         if (d->cin != 96 || d->cout != 32 || (d->flags & ~(LLV_CONV_RELU))) return LLV_E_BADARG;
@@ -2410,40 +2480,59 @@ static int convpair_launch(const llv_inputcv_desc* p, void* stream, bool output_
     k.seg_m0[LLV_MAX_SEG] = (int)px; k.m_total = (int)px;
     k.flags = d->flags; k.stage_out = 1; k.k_splits = 1; k.y_gstride = 0; k.src_per_group = 0;
     k.act_slope = 0.f; k.ps_h = 0; k.ps_w = 0;
-    HaloArgs h;
+    HaloArgs& h = P.h;
     h.w = (const _Float16*)d->w_halo;
     h.H = d->seg_h[0]; h.W = d->seg_w[0];
     h.tiles_x = (h.W + HALO_TW - 1) / HALO_TW; h.tiles_y = (h.H + HALO_TH - 1) / HALO_TH;
     h.ck = 32; h.n_chunks = output_block ? 1 : 3; h.kc_pad = 288; h.wrow = 296; h.ntiles_n = 1;
     h.nblk = h.tiles_x * h.tiles_y * d->batch; h.w_gstride = 0;
-    PreArgs pre;
+    PreArgs& pre = P.pre;
     pre.w = (const _Float16*)p->w_pre; pre.bias = p->bias_pre; pre.wrow = output_block ? 296 : 104;
     const int ck0 = output_block ? 32 : 8, bn2 = output_block ? 16 : 32;
     size_t lds = (size_t)HALO_PX * 64 + (size_t)bn2 * h.wrow * 2 + (size_t)PATCH_PX * ck0 * 2 + (size_t)32 * pre.wrow * 2;
     const size_t epi = (size_t)256 * (bn2 + 8) * 2;
     if (lds < epi) lds = epi;
+    P.lds = lds;
+    const size_t xb = (size_t)(d->seg_xoff[0] + px) * d->x_ld * 2;
+    P.v2 = getenv("LLV_CONVPAIR_V1") == nullptr && xb < (1ull << 31);
+    Pair2Args& q = P.q;
+    q.x_bytes = (unsigned)xb;
+    q.w0_bytes = (unsigned)((output_block ? 1 : 3) * 32 * pre.wrow * 2);
+    q.w1_bytes = (unsigned)(h.n_chunks * bn2 * h.wrow * 2);
+    // persistent workgroups: two per CU (the LDS footprint's limit), each walks tiles v, v + grid, ...
+    P.grid2 = h.nblk < 512 ? h.nblk : 512;
+    return LLV_OK;
+}
+
+static int convpair_launch(const llv_inputcv_desc* p, void* stream, bool output_block) {
+    PairPrepared P;
+    const int rc = convpair_prepare(p, output_block, P);
+    if (rc != LLV_OK) return rc;
+    if (p->conv.extents && extents_enabled()) {
+        llv_extents need;
+        const int rce = llv_convpair_extents(p, output_block ? 1 : 0, &need);
+        if (rce != LLV_OK) return rce;
+        if (llv_extents_fit(&need, p->conv.extents) != LLV_OK) return LLV_E_EXTENT;
+    }
     static bool attr_done = false;
     if (!attr_done) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convpair_kernel<32, 16>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(convpair_kernel<8, 32>), hipFuncAttributeMaxDynamicSharedMemorySize, 96 * 1024);
         attr_done = true;
     }
-    const size_t xb = (size_t)(d->seg_xoff[0] + px) * d->x_ld * 2;
-    if (getenv("LLV_CONVPAIR_V1") == nullptr && xb < (1ull << 31)) {
-        Pair2Args q;
-        q.x_bytes = (unsigned)xb;
-        q.w0_bytes = (unsigned)((output_block ? 1 : 3) * 32 * pre.wrow * 2);
-        q.w1_bytes = (unsigned)(h.n_chunks * bn2 * h.wrow * 2);
-        // persistent workgroups: two per CU (the LDS footprint's limit), each walks tiles v, v + grid, ...
-        const int grid = h.nblk < 512 ? h.nblk : 512;
-        if (output_block) hipLaunchKernelGGL((convpair2_kernel<32, 16>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k, h, pre, q);
-        else hipLaunchKernelGGL((convpair2_kernel<8, 32>), dim3(grid), dim3(256), 0, (hipStream_t)stream, k, h, pre, q);
+    ConvKArgs& k = P.k;
+    HaloArgs& h = P.h;
+    if (P.v2) {
+        if (output_block) hipLaunchKernelGGL((convpair2_kernel<32, 16>), dim3(P.grid2), dim3(256), 0, (hipStream_t)stream, k, h, P.pre, P.q);
+        else hipLaunchKernelGGL((convpair2_kernel<8, 32>), dim3(P.grid2), dim3(256), 0, (hipStream_t)stream, k, h, P.pre, P.q);
         return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
     }
-    if (output_block) hipLaunchKernelGGL((convpair_kernel<32, 16>), dim3(h.nblk), dim3(256), lds, (hipStream_t)stream, k, h, pre);
-    else hipLaunchKernelGGL((convpair_kernel<8, 32>), dim3(h.nblk), dim3(256), lds, (hipStream_t)stream, k, h, pre);
+    if (output_block) hipLaunchKernelGGL((convpair_kernel<32, 16>), dim3(h.nblk), dim3(256), P.lds, (hipStream_t)stream, k, h, P.pre);
+    else hipLaunchKernelGGL((convpair_kernel<8, 32>), dim3(h.nblk), dim3(256), P.lds, (hipStream_t)stream, k, h, P.pre);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
 extern "C" int llv_inputcvblock_fwd(const llv_inputcv_desc* p, void* stream) { return convpair_launch(p, stream, false); }
 extern "C" int llv_outputcvblock_fwd(const llv_inputcv_desc* p, void* stream) { return convpair_launch(p, stream, true); }
+
+#include "conv_extents.inc"

@@ -509,6 +509,7 @@ extern "C" const char* llv_strerror(int code) {
         case LLV_E_LAUNCH: return "kernel launch failed";
         case LLV_E_UNSUPPORTED: return "unsupported configuration";
         case LLV_E_WORKSPACE: return "workspace too small";
+        case LLV_E_EXTENT: return "buffer extent exceeded";
         default: return "unknown error";
     }
 }

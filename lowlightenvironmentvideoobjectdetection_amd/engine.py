@@ -102,6 +102,17 @@ class Plan:
             out.append((name, ms, fl, nb))
         return out
 
+    def check_extents(self):
+        """Replay, on the host, the addresses of every convolution launch of the plan (llv_conv2d_extents /
+        llv_convpair_extents) against the sizes of the buffers behind its descriptor. Returns [(step, pointer, needed, declared)]
+        for every violation: an empty list means no launch reads or writes outside its tensors."""
+        bad = []
+        for name, fn, args, _, _ in self.steps:
+            if getattr(fn, '__name__', '') in ('llv_conv2d_nhwc_fwd', 'llv_inputcvblock_fwd', 'llv_outputcvblock_fwd'):
+                for (ptr, need, have) in ops.extents_violations(args[0]._obj):
+                    bad.append((name, ptr, need, have))
+        return bad
+
     @property
     def flops(self):
         return sum(s[3] for s in self.steps)
@@ -140,7 +151,9 @@ class Builder:
                 self.plan.keep.append(self._ws)
                 for od in self._ws_descs:
                     od.workspace = self._ws.data_ptr()
+                    od._ext.workspace = self._ws.numel()
             d.workspace, d.workspace_bytes = self._ws.data_ptr(), wsb
+            d._ext.workspace = self._ws.numel()
             self._ws_descs.append(d)
         self.plan.keep += [pc, pc.w, pc.bias, d] + list(xs) + [y] + ([res] if res is not None else [])
         self.plan.add(name, self._fn_conv, (C.byref(d),), flops, nbytes, kernel=ops.conv_kernel_name(d))
@@ -464,7 +477,9 @@ def _denblock(b: Builder, sd, p, srcs, batch, tag, out):
         pc.to(b.dev)
         pc2.to(b.dev)
         d = InputCvDesc()
-        d.conv = ops.make_conv_desc(pc2, list(srcs), x0, n, [(hh, ww, hh, ww, 0, 0)], srcs[0].shape[-1], pc2.cout, flags=f)
+        cd = ops.make_conv_desc(pc2, list(srcs), x0, n, [(hh, ww, hh, ww, 0, 0)], srcs[0].shape[-1], pc2.cout, flags=f)
+        cd._ext.w_pre, cd._ext.bias_pre = ops.tensor_extent(pc.w_halo), ops.tensor_extent(pc.bias)
+        d.conv, d._keep, d._output_block = cd, cd, 0      # the copied descriptor points at cd's extents struct
         d.w_pre, d.bias_pre = pc.w_halo.data_ptr(), pc.bias.data_ptr()
         m = n * hh * ww
         b.plan.keep += [pc, pc2, d, x0] + list(srcs)
@@ -516,8 +531,10 @@ def _denblock(b: Builder, sd, p, srcs, batch, tag, out):
         pc0.to(b.dev)
         pc1.to(b.dev)
         d = InputCvDesc()
-        d.conv = ops.make_conv_desc(pc1, [x0s], out, n, [(hh, ww, hh, ww, 0, 0)], x0s.shape[-1], out.shape[-1], res, res.shape[-1],
-                                    CONV_RES_RSUB)
+        cd = ops.make_conv_desc(pc1, [x0s], out, n, [(hh, ww, hh, ww, 0, 0)], x0s.shape[-1], out.shape[-1], res, res.shape[-1],
+                                CONV_RES_RSUB)
+        cd._ext.w_pre, cd._ext.bias_pre = ops.tensor_extent(pc0.w_halo), ops.tensor_extent(pc0.bias)
+        d.conv, d._keep, d._output_block = cd, cd, 1
         d.w_pre, d.bias_pre = pc0.w_halo.data_ptr(), pc0.bias.data_ptr()
         m = n * hh * ww
         b.plan.keep += [pc0, pc1, d, x0s, out, res]

@@ -13,7 +13,7 @@ import torch
 from . import _lib
 from ._lib import CONV_PS_EMAJOR  # noqa: F401
 from ._lib import (CONV_LEAKY, CONV_OUT_F32, CONV_PIXSHUF, CONV_RELU, CONV_RES_ADD, CONV_RES_RSUB, CONV_RES_UPS,
-                   ConvDesc, DecodeDesc, LlvError, check, lib)
+                   ConvDesc, DecodeDesc, Extents, LlvError, check, lib)
 
 
 def _stream():
@@ -33,6 +33,14 @@ def _need_gpu(*ts):
 
 def round_up(v, m):
     return (v + m - 1) // m * m
+
+
+def tensor_extent(t: Optional[torch.Tensor]) -> int:
+    """Bytes addressable from t.data_ptr() to the end of the allocation behind t (a view's storage): what llv_extents declares."""
+    if t is None:
+        return 0
+    st = t.untyped_storage()
+    return int(st.nbytes() - (t.data_ptr() - st.data_ptr()))
 
 
 # ----------------------------------------------------------------------------------------------
@@ -248,7 +256,41 @@ def make_conv_desc(pc: PackedConv, xs: Sequence[torch.Tensor], y: torch.Tensor, 
         d.w_halo, d.halo_bn = pc.w_halo.data_ptr(), pc.halo_bn
     else:
         d.w_halo, d.halo_bn = 0, 0
+    # declared buffer sizes (llv_extents): checked against the kernels' replayed addresses by llv_conv2d_extents, and before
+    # every launch when LLV_CHECK_EXTENTS=1
+    e = Extents()
+    for i in range(_lib.LLV_MAX_SRC):
+        e.x[i] = tensor_extent(xs[i]) if i < len(xs) else 0
+    e.w, e.bias, e.res, e.y = tensor_extent(pc.w), tensor_extent(pc.bias), tensor_extent(res), tensor_extent(y)
+    e.w_halo = tensor_extent(pc.w_halo) if pc.w_halo is not None else 0
+    d._ext = e                      # keeps the struct alive as long as the descriptor
+    d.extents = C.pointer(e)
     return d
+
+
+def conv_extents(desc) -> Extents:
+    """llv_conv2d_extents / llv_convpair_extents: 1 + the highest byte the launch touches through each pointer (host replay)."""
+    need = Extents()
+    if isinstance(desc, _lib.InputCvDesc):
+        check(lib().llv_convpair_extents(C.byref(desc), int(desc._output_block), C.byref(need)), 'llv_convpair_extents')
+    else:
+        check(lib().llv_conv2d_extents(C.byref(desc), C.byref(need)), 'llv_conv2d_extents')
+    return need
+
+
+def extents_violations(desc):
+    """[(pointer name, bytes needed, bytes declared)] for the launch `desc` describes; an access below a pointer is reported
+    with needed = -1. Empty list: every replayed address lies inside its declared buffer."""
+    need = conv_extents(desc)
+    have = (desc._keep if isinstance(desc, _lib.InputCvDesc) else desc)._ext
+    out = []
+    n, h = need.as_dict(), have.as_dict()
+    for i, name in enumerate(Extents.NAMES):
+        if need.below & (1 << i):
+            out.append((name, -1, h[name]))
+        if h[name] and n[name] > h[name]:
+            out.append((name, n[name], h[name]))
+    return out
 
 
 def conv_workspace_bytes(desc: ConvDesc) -> int:
@@ -296,6 +338,7 @@ def conv2d(x, pc: PackedConv, res: Optional[torch.Tensor] = None, flags: int = 0
     if wsb:
         ws = torch.empty((wsb,), device=xs[0].device, dtype=torch.uint8)
         d.workspace, d.workspace_bytes = ws.data_ptr(), wsb
+        d._ext.workspace = wsb
     launch_conv(d)
     return out
 

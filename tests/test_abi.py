@@ -25,8 +25,24 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(h, n), f'{n} declared in include/llv.h but not exported by libllv.so'
         assert n in _lib.SIGNATURES, f'{n} has no ctypes signature in _lib.py'
     assert sorted(_lib.SIGNATURES) == names
-    assert _lib.lib().llv_abi_version() == 1
+    assert _lib.lib().llv_abi_version() == 2
     assert _lib.lib().llv_strerror(-1) == b'bad argument'
+
+
+def test_no_kernel_needs_scratch_memory_or_spills():
+    """Every kernel of libllv.so runs out of registers and LDS alone: private segment (scratch) 0 bytes, no VGPR spills. Round 1's
+    implicit-GEMM kernels indexed a table of their three source pointers per lane, which the compiler put in scratch memory
+    (32 B per lane: a scratch allocation and a scratch_load per k-step in every stem-conv launch); tools/code_objects.py reads
+    the code objects' metadata notes."""
+    import sys
+    sys.path.insert(0, os.path.join(ROOT, 'tools'))
+    from code_objects import kernels_metadata
+    from lowlightenvironmentvideoobjectdetection_amd import _lib
+    ks = kernels_metadata(_lib.LIB_PATH)
+    assert len(ks) >= 60
+    bad = [(k['name'], k['private_segment_fixed_size'], k['vgpr_spill_count']) for k in ks
+           if k['private_segment_fixed_size'] or k['vgpr_spill_count']]      # SGPR spills go to VGPR lanes, not to memory
+    assert bad == [], bad
 
 
 def test_bad_arguments_are_rejected_before_any_launch():
