@@ -6,17 +6,24 @@
   python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 --master-port P \
          bench.py --gpus N --steps K --warmup W
 
-A step = one pass of the hot path over `--frames-per-step` (default 4) consecutive frames of a clip that is
-already resident in HBM (preprocessed: Brighten -> Normalize -> Pad, as the reference's test pipeline does
-before the model; the reference's benchmark.py excludes data loading too). Timed: window copy, FastDVDnet
-(B+2 temp1 DenBlocks + B temp2 DenBlocks for the B frames of the step: every distinct temp1 result is computed
-once per step, nothing is carried between steps; B=1 is the reference's 3+1 per frame), ResNet-50, FPN,
-RetinaHead, decode/top-k, NMS and the D2H copy of the detections. The JSON line also carries the batch-1
-("latency mode", 4 DenBlocks per frame) rate. Rank 0 prints ONE JSON line.
+A step = one pass of the hot path over `--frames-per-step` (default 16: THROUGHPUT mode) consecutive frames of a clip
+that is already resident in HBM (preprocessed: Brighten -> Normalize -> Pad, as the reference's test pipeline does
+before the model; the reference's benchmark.py excludes data loading too). Timed: FastDVDnet reading its window
+straight out of the resident clip (B+2 temp1 DenBlocks + B temp2 DenBlocks for the B frames of the step: every
+distinct temp1 result is computed once per step, nothing is carried between steps; B=1 is the reference's 3+1 per
+frame), ResNet-50, FPN, RetinaHead, decode/top-k, NMS and the D2H copy of the detections. The JSON line also carries
+the reference's own per-frame protocol (benchmark.py:83-109: batch 1, >= 200 frames) as `latency_mode` (4 DenBlocks
+per frame) and `streaming_mode` (consecutive frames, 2 DenBlocks per frame). Rank 0 prints ONE JSON line.
+
+`--gpus N` with N > 1 and no WORLD_SIZE in the environment: this process starts the N ranks itself
+(`python -m torch.distributed.run --nproc-per-node N ... bench.py <same arguments>`, child processes, before any GPU
+call here), forwards their output and exits with their return code. Under torchrun, WORLD_SIZE must equal --gpus.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -445,6 +452,31 @@ def fgfa_bench(args, world, rank, dev):
         dist.destroy_process_group()
 
 
+def launcher_command(gpus, argv, port, script=None):
+    """The command that starts `gpus` ranks of this script on one node, one rank per GPU, RCCL rendezvous on 127.0.0.1
+    (the reference: mmtracking/tools/dist_train.sh / dist_test.sh -> torch.distributed.launch --nproc_per_node=$GPUS)."""
+    return [sys.executable, '-m', 'torch.distributed.run', '--nnodes=1', f'--nproc-per-node={int(gpus)}', '--master-addr', '127.0.0.1',
+            '--master-port', str(int(port)), script or os.path.abspath(__file__)] + list(argv)
+
+
+def _free_port():
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(('127.0.0.1', 0))
+        return s.getsockname()[1]
+
+
+def launch_ranks(args, argv):
+    """--gpus N > 1 outside torchrun: run the N ranks as a child process group and forward rank 0's JSON line. No GPU call has
+    happened in this process yet (it never initialises the device: the children do), and nothing is exec'ed."""
+    env = dict(os.environ)
+    env.setdefault('HSA_ENABLE_IPC_MODE_LEGACY', '0')
+    cmd = launcher_command(args.gpus, argv, _free_port())
+    r = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    sys.stdout.write(r.stdout)
+    sys.stdout.flush()
+    return r.returncode
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument('--gpus', type=int, default=1)
@@ -460,6 +492,9 @@ def main():
                     help='0 (default): the two halves of a step back to back on one stream, so that the per-kernel durations of '
                          'the roofline block are those of the timed region; 1: two-stage software pipeline (FastDVDnet of step i || '
                          'detector of step i-1 on two HIP streams, +1.2 %% measured)')
+    ap.add_argument('--copy-window', action='store_true',
+                    help="stage every step's window in the plan's own frame buffer (round 1's two copies per step) instead of reading "
+                         'it in place from the resident clip')
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-latency-mode', action='store_true')
@@ -468,7 +503,12 @@ def main():
     ap.add_argument('--train-batch', type=int, default=1, help='images per GPU per training step')
     args = ap.parse_args()
 
+    if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
+        sys.exit(launch_ranks(args, sys.argv[1:]))
     world = int(os.environ.get('WORLD_SIZE', '1'))
+    if world != args.gpus:
+        raise SystemExit(f'bench.py: --gpus {args.gpus} but WORLD_SIZE={world}: launch with --nproc-per-node {args.gpus} '
+                         f'(or without torchrun: bench.py starts the ranks itself)')
     rank = int(os.environ.get('RANK', '0'))
     local_rank = int(os.environ.get('LOCAL_RANK', '0'))
     if not torch.cuda.is_available():
@@ -494,6 +534,9 @@ def main():
             dist.init_process_group('gloo')
         else:
             dist.init_process_group('nccl', device_id=dev)
+        if dist.get_world_size() != args.gpus:
+            raise SystemExit(f'bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}')
+        world = dist.get_world_size()
 
     from lowlightenvironmentvideoobjectdetection_amd import data, engine
     from lowlightenvironmentvideoobjectdetection_amd.synthetic import calibrate_head_on_device
@@ -532,7 +575,10 @@ def main():
     calibrate_head_on_device(det, plan.det, target_cls_mean=-6.0, target_cls_std=1.3)
     del plan
     plan = make_plan(engine.PipelinedEnhanceDetectPlan if args.pipeline else engine.EnhanceDetectPlan)
-    plan.prepare(clip)
+    if args.pipeline:
+        plan.prepare(clip)
+    else:
+        plan.prepare(clip, zero_copy=not args.copy_window)      # the window is read in place: no copy inside or in front of the graph
     n_windows = T - B + 1
 
     def run_steps(k, start=0):
@@ -568,7 +614,7 @@ def main():
         p1 = engine.EnhanceDetectPlan(cleaner.state_dict(), det.state_dict(), NUM_CLASSES, 1, hp, wp, dev,
                                       detector_kwargs=dict(test_cfg=dict(det.bbox_head.test_cfg), img_shapes=[img_shape]),
                                       use_graph=not args.no_graph)
-        p1.prepare(clip)
+        p1.prepare(clip, zero_copy=not args.copy_window)
         for s_ in range(args.warmup):
             p1.step(clip, s_ % T)
         torch.cuda.synchronize()
@@ -613,7 +659,8 @@ def main():
                 'workload': 'Enhance-CNN (FastDVDnet 5-frame window) + RetinaNet R-50+FPN inference + decode + NMS, '
                             f'{args.width}x{args.height} clip (padded {wp}x{hp}), {NUM_CLASSES} classes, 1xMI355X per rank',
                 'clip_frames': T, 'frames_per_step': B, 'denblocks_per_frame': round((2 * B + 2) / B, 3),
-                'hip_graph': not args.no_graph,
+                'hip_graph': not args.no_graph, 'window': 'copied' if (args.copy_window or args.pipeline) else 'read in place (offset word)',
+                'mode': 'throughput' if B > 1 else 'per-frame',
                 'pipeline': ('2-stage: FastDVDnet(step i) || detector(step i-1) on two HIP streams, one graph per step'
                              if args.pipeline else 'none'),
                 'algorithmic_gflop_per_frame': round(flops_step / B / 1e9, 1),

@@ -157,6 +157,16 @@ typedef struct llv_conv_desc {
                                       last stage of the DC5 backbones of the SELSA configs (resnet.py `dilations=(1, 1, 1, 2)`); forward only,
                                       on the implicit-GEMM kernels */
     const llv_extents* extents;    /* optional declared sizes of the buffers behind the pointers above (NULL: none) */
+    /* Sliding window over a resident clip (llv_inputcvblock_fwd / llv_outputcvblock_fwd only; llv_conv2d_nhwc_fwd returns
+     * LLV_E_UNSUPPORTED): offset_dev != NULL is a DEVICE pointer to one int64, an offset in fp16 elements that the kernel adds,
+     * when it starts, to x[0..n_src-1] (offset_x != 0) and / or to res (offset_res != 0). A captured HIP graph then reads whichever
+     * window of the clip the caller last stored there (stream-ordered, e.g. a fill kernel in front of the replay): no staging copy
+     * of the window, no re-capture. The reference re-stacks the frames on the host for every key frame
+     * (mmtracking/mmtrack/models/vid/selsa_fastdvd_darkfarm.py:294-319). offset_max = the largest value the caller will store
+     * (used by the extent check). */
+    const int64_t* offset_dev;
+    int32_t offset_x, offset_res;
+    int64_t offset_max;
 } llv_conv_desc;
 
 #define LLV_TILE_AUTO 0

@@ -76,6 +76,7 @@ class ConvDesc(C.Structure):
         ('ps_out_h', C.c_int32), ('ps_out_w', C.c_int32),
         ('dilation', C.c_int32),
         ('extents', C.POINTER(Extents)),
+        ('offset_dev', C.c_void_p), ('offset_x', C.c_int32), ('offset_res', C.c_int32), ('offset_max', C.c_int64),
     ]
 
 

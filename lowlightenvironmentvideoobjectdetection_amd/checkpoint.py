@@ -1,4 +1,4 @@
-"""Checkpoint loading in the reference's format: torch.save({'meta', 'state_dict', 'optimizer'}) with module-path
+"""Checkpoint loading and saving in the reference's format: torch.save({'meta', 'state_dict', 'optimizer'}) with module-path
 keys (mmcv CheckpointHook; call sites mmdetection/mmdet/apis/train.py:166-169, mmtracking/mmtrack/models/vid/base.py:22-37).
 Remote schemes (torchvision://, open-mmlab://, http://) cannot be fetched here: they resolve only from a local
 directory given by $LLV_CHECKPOINT_DIR; otherwise the caller's random-init scheme stays in effect, with a warning."""
@@ -51,3 +51,26 @@ def load_checkpoint(model, filename, map_location='cpu', strict=False, logger=No
     if (missing or unexpected) and not strict:
         warnings.warn(f'load_checkpoint({filename}): missing keys {list(missing)[:8]}..., unexpected {list(unexpected)[:8]}...')
     return sd
+
+
+def save_checkpoint(model, filename, optimizer=None, meta=None):
+    """mmcv.runner.save_checkpoint (CheckpointHook; call site mmdetection/mmdet/apis/train.py:166-169): torch.save of
+    {'meta', 'state_dict', 'optimizer'} with module-path keys on the CPU and a DataParallel 'module.' prefix stripped, so that
+    load_checkpoint above -- and the reference's own loader -- read it back."""
+    sd = OrderedDict()
+    for k, v in model.state_dict().items():
+        sd[k[7:] if k.startswith('module.') else k] = v.detach().cpu()
+    m = dict(meta or {})
+    if getattr(model, 'CLASSES', None) is not None:
+        m.setdefault('CLASSES', model.CLASSES)
+    ckpt = {'meta': m, 'state_dict': sd}
+    if isinstance(optimizer, dict):
+        ckpt['optimizer'] = {k: o.state_dict() for k, o in optimizer.items()}
+    elif optimizer is not None:
+        ckpt['optimizer'] = optimizer.state_dict()
+    d = os.path.dirname(os.path.abspath(filename))
+    os.makedirs(d, exist_ok=True)
+    with open(filename, 'wb') as f:
+        torch.save(ckpt, f)
+        f.flush()
+    return filename

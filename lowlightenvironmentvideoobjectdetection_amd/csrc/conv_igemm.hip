@@ -56,6 +56,8 @@ struct ConvKArgs {
     int nk_per;
     float* ws;          // [k_splits][m_total][groups*cout] fp32 partial sums
     unsigned x_bytes, w_bytes;   // buffer-resource bounds of one source tensor / one group's weights (0: not usable)
+    const long* off_dev;         // convpair2 only: *off_dev (fp16 elements) is added to x0..x2 (off_x) / res (off_res) at kernel start
+    int off_x, off_res;
 };
 
 // source tensor s (0..2) of a multi-source launch, without a pointer table (see conv_igemm_glds_kernel)
@@ -1709,7 +1711,14 @@ __device__ __forceinline__ int patch_off32(int py, int px, int c8) {   // 64-B p
 }
 
 template <int CK0, int BN2>
-__global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a, const HaloArgs h, const PreArgs pre, const Pair2Args q) {
+__global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a_in, const HaloArgs h, const PreArgs pre, const Pair2Args q) {
+    // sliding window over a resident clip (llv_conv_desc.offset_dev): one scalar load, added to the source / residual bases
+    ConvKArgs a = a_in;
+    if (a_in.off_dev) {
+        const long xo = *a_in.off_dev;
+        if (a_in.off_x) { a.x0 = a_in.x0 + xo; a.x1 = a_in.x1 + xo; a.x2 = a_in.x2 + xo; }
+        if (a_in.off_res) a.res = a_in.res + xo;
+    }
     constexpr int G = CK0 == 8 ? 3 : 1;                      // groups of the first conv = 32-channel chunks of the second
     constexpr int TN2 = BN2 / 16, TM = 4;
     constexpr int NMT = (HALO_PX + 15) / 16;                 // 22 M-tiles of 16 halo pixels
@@ -2258,6 +2267,8 @@ static int conv_prepare(const llv_conv_desc* d, ConvPrepared& P) {
     if (d->kh < 1 || d->kw < 1 || d->stride < 1 || d->pad < 0 || d->groups < 1 || d->batch < 1) return LLV_E_BADARG;
     if (d->dilation < 0) return LLV_E_BADARG;
     if (d->dilation > 1 && (d->flags & LLV_CONV_PIXSHUF)) return LLV_E_UNSUPPORTED;
+    if (d->offset_dev) return LLV_E_UNSUPPORTED;           // the sliding-window offset exists on the fused CvBlock kernels only
+    k.off_dev = nullptr; k.off_x = 0; k.off_res = 0;
     if ((d->x_ld & 7) || (d->y_ld & 3)) return LLV_E_BADARG;
     if (d->n_src > 1 && d->groups == d->n_src) {
         if (d->src_cvec * 8 != d->cin || d->x_ld < d->cin) return LLV_E_BADARG;   // group g reads source g
@@ -2480,6 +2491,8 @@ static int convpair_prepare(const llv_inputcv_desc* p, bool output_block, PairPr
     k.seg_m0[LLV_MAX_SEG] = (int)px; k.m_total = (int)px;
     k.flags = d->flags; k.stage_out = 1; k.k_splits = 1; k.y_gstride = 0; k.src_per_group = 0;
     k.act_slope = 0.f; k.ps_h = 0; k.ps_w = 0;
+    k.off_dev = (const long*)d->offset_dev; k.off_x = d->offset_x; k.off_res = d->offset_res;
+    if (d->offset_dev && (d->offset_max < 0 || (!d->offset_x && !d->offset_res))) return LLV_E_BADARG;
     HaloArgs& h = P.h;
     h.w = (const _Float16*)d->w_halo;
     h.H = d->seg_h[0]; h.W = d->seg_w[0];
@@ -2495,6 +2508,7 @@ static int convpair_prepare(const llv_inputcv_desc* p, bool output_block, PairPr
     P.lds = lds;
     const size_t xb = (size_t)(d->seg_xoff[0] + px) * d->x_ld * 2;
     P.v2 = getenv("LLV_CONVPAIR_V1") == nullptr && xb < (1ull << 31);
+    if (d->offset_dev && !P.v2) return LLV_E_UNSUPPORTED;
     Pair2Args& q = P.q;
     q.x_bytes = (unsigned)xb;
     q.w0_bytes = (unsigned)((output_block ? 1 : 3) * 32 * pre.wrow * 2);

@@ -129,6 +129,7 @@ class Builder:
         self._ws = None              # one split-K workspace shared by all launches of the plan (they run in order)
         self._ws_descs = []
         self.tape = []               # every conv launch in order (training: the backward pass walks it in reverse)
+        self.window_descs = []       # fused-CvBlock descriptors that read the clip window directly (FastDVDnetPlan.bind_clip)
 
     def buf(self, *shape, dtype=torch.float16):
         t = torch.zeros(shape, device=self.dev, dtype=dtype)
@@ -481,6 +482,7 @@ def _denblock(b: Builder, sd, p, srcs, batch, tag, out):
         cd._ext.w_pre, cd._ext.bias_pre = ops.tensor_extent(pc.w_halo), ops.tensor_extent(pc.bias)
         d.conv, d._keep, d._output_block = cd, cd, 0      # the copied descriptor points at cd's extents struct
         d.w_pre, d.bias_pre = pc.w_halo.data_ptr(), pc.bias.data_ptr()
+        b.window_descs.append((tag, d, 'x'))
         m = n * hh * ww
         b.plan.keep += [pc, pc2, d, x0] + list(srcs)
         b.plan.add(f'{tag}.inputcv', lib().llv_inputcvblock_fwd, (C.byref(d),), 2.0 * m * (pc.true_macs_per_pixel + pc2.true_macs_per_pixel),
@@ -536,6 +538,7 @@ def _denblock(b: Builder, sd, p, srcs, batch, tag, out):
         cd._ext.w_pre, cd._ext.bias_pre = ops.tensor_extent(pc0.w_halo), ops.tensor_extent(pc0.bias)
         d.conv, d._keep, d._output_block = cd, cd, 1
         d.w_pre, d.bias_pre = pc0.w_halo.data_ptr(), pc0.bias.data_ptr()
+        b.window_descs.append((tag, d, 'res'))
         m = n * hh * ww
         b.plan.keep += [pc0, pc1, d, x0s, out, res]
         b.plan.add(f'{tag}.outputcv', lib().llv_outputcvblock_fwd, (C.byref(d),), 2.0 * m * (pc0.true_macs_per_pixel + pc1.true_macs_per_pixel),
@@ -571,6 +574,45 @@ class FastDVDnetPlan:
         srcs2 = [self.mid[s:s + batch] for s in range(3)]
         _denblock(b, sd, p2, srcs2, batch, 'temp2', self.out)
         self._sd, self._p1, self.plan_stream = sd, p1, None
+        self._window_descs = self._rel_window_descs(b)
+        self._stream_window_descs = []
+        self._clip = None
+
+    def _rel_window_descs(self, b):
+        """(descriptor, 'x' | 'res', byte offsets of its frame pointers from the start of self.frames) of the launches that read frames"""
+        out, base = [], self.frames.data_ptr()
+        for tag, d, kind in b.window_descs:
+            if tag == 'temp1':
+                out.append((d, kind, [d.conv.x[i] - base for i in range(3)] if kind == 'x' else [d.conv.res - base]))
+        return out
+
+    def bind_clip(self, clip, offset_word):
+        """Zero-copy windows: make the first-stage DenBlocks read the window straight out of `clip` ((T+4, H, W, 8) fp16, resident
+        in HBM) instead of out of `self.frames`. The launches that touch the frames -- the fused InputCvBlock (its three sources)
+        and the fused OutputCvBlock (the residual in1 of `in1 - x`) of temp1 -- are re-pointed at the clip's first window and get
+        `offset_word` (a device int64 holding t0 * H*W*8) as their llv_conv_desc.offset_dev, so one captured graph serves every
+        window: the caller stores the offset and replays. Needs the fused CvBlock launches (the default)."""
+        nf = self.batch + 4
+        if clip.dtype != torch.float16 or clip.dim() != 4 or clip.shape[1:] != self.frames.shape[1:] or clip.shape[0] < nf or not clip.is_contiguous():
+            raise LlvError(f'bind_clip: clip of shape (>= {nf}, {tuple(self.frames.shape[1:])}) fp16 contiguous expected, got {tuple(clip.shape)}')
+        if len(self._window_descs) != 2:
+            raise LlvError('bind_clip needs the fused InputCvBlock / OutputCvBlock launches (LLV_FUSE_INPUTCV / LLV_FUSE_OUTPUTCV / LLV_HALO)')
+        frame_elems = self.frames[0].numel()
+        off_max = (clip.shape[0] - nf) * frame_elems
+        total = ops.tensor_extent(clip)
+        for d, kind, rels in self._window_descs + self._stream_window_descs:
+            cd, ext = d.conv, d._keep._ext
+            if kind == 'x':
+                for i in range(3):
+                    cd.x[i] = clip.data_ptr() + rels[i]
+                    ext.x[i] = total - rels[i]
+                cd.offset_x = 1
+            else:
+                cd.res = clip.data_ptr() + rels[0]
+                ext.res = total - rels[0]
+                cd.offset_res = 1
+            cd.offset_dev, cd.offset_max = offset_word.data_ptr(), off_max
+        self._clip, self._offset_word, self.frame_elems = clip, offset_word, frame_elems
 
     def enable_stream(self):
         """Build `plan_stream`, the step for a window that directly FOLLOWS the previous step's window in the same video
@@ -602,6 +644,9 @@ class FastDVDnetPlan:
                     ps.kernel_of[st[0]] = self.plan.kernel_of[st[0]]
         ps.keep += self.plan.keep
         self.plan_stream = ps
+        self._stream_window_descs = self._rel_window_descs(bs)
+        if self._clip is not None:       # already bound: the new launches read the clip too
+            self.bind_clip(self._clip, self._offset_word)
         return ps
 
 
@@ -634,11 +679,14 @@ class EnhanceDetectPlan:
         self.res_host = torch.zeros((batch, k, 6), dtype=torch.float32).pin_memory()
         self.cnt_host = torch.zeros((batch,), dtype=torch.int32).pin_memory()
         self._graph = None
+        self._zero_copy = False
 
     def _enhance(self, window, carry=False):
         """FastDVDnet half of a step: the clip window -> denoised frames in the detector's input buffer. carry=True: the window
-        directly follows the previous step's (FastDVDnetPlan.enable_stream)."""
-        self.den.frames.copy_(window)
+        directly follows the previous step's (FastDVDnetPlan.enable_stream). window=None: the launches read the bound clip
+        at the offset the caller stored (zero-copy, prepare(clip, zero_copy=True))."""
+        if window is not None:
+            self.den.frames.copy_(window)
         (self.den.plan_stream if carry else self.den.plan).run()
 
     def _detect(self):
@@ -655,10 +703,19 @@ class EnhanceDetectPlan:
         self._enhance(window, carry)
         self._detect()
 
-    def prepare(self, clip):
-        """Warm up once (one-time kernel attribute calls) and capture the step into a HIP graph."""
-        self._window = torch.empty_like(self.den.frames)
-        self._window.copy_(clip[:self.batch + 4])
+    def prepare(self, clip, zero_copy=False):
+        """Warm up once (one-time kernel attribute calls) and capture the step into a HIP graph.
+        zero_copy=True: `clip` stays resident and every later step(clip, t0) must pass the same tensor; the first-stage launches
+        read frames t0 .. t0+batch+3 straight out of it through an offset word (FastDVDnetPlan.bind_clip), so a step moves no
+        window at all (round 1 copied it twice: clip -> staging buffer eagerly, staging buffer -> frames inside the graph)."""
+        self._zero_copy = bool(zero_copy)
+        if self._zero_copy:
+            self._off = torch.zeros((1,), device=self.dev, dtype=torch.int64)
+            self.den.bind_clip(clip, self._off)
+            self._window = None
+        else:
+            self._window = torch.empty_like(self.den.frames)
+            self._window.copy_(clip[:self.batch + 4])
         self._body(self._window)
         torch.cuda.synchronize()
         if self.use_graph:
@@ -682,7 +739,12 @@ class EnhanceDetectPlan:
 
     def step(self, clip, t0, carry=False):
         """Enqueue one step (no host sync). Results land in res_host/cnt_host after the stream drains."""
-        self._window.copy_(clip[t0:t0 + self.batch + 4])
+        if self._zero_copy:
+            if clip.data_ptr() != self.den._clip.data_ptr() or t0 < 0 or t0 + self.batch + 4 > clip.shape[0]:
+                raise LlvError('zero-copy plan: step() takes the clip given to prepare() and a window inside it')
+            self._off.fill_(t0 * self.den.frame_elems)
+        else:
+            self._window.copy_(clip[t0:t0 + self.batch + 4])
         if carry:
             if self._graph_stream is not None:
                 self._graph_stream.replay()

@@ -536,7 +536,20 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, r
     iou_thr = nms_cfg.get('iou_threshold', nms_cfg.get('iou_thr'))
     if nms_cfg.get('type', 'nms') != 'nms':
         raise LlvError(f"nms type {nms_cfg.get('type')} not supported")
-    cap = max_num if max_num > 0 else n * num_classes
+    # the per-class kept lists are merged in LDS: num_classes * cap <= 8192 keys (kMaxMerge, nms.hip) and n <= 8192 boxes. With
+    # max_num <= 0 (mmdet's default: keep everything) a class can keep at most n boxes, so cap = min(n, 8192 // num_classes) is
+    # exact whenever n * num_classes <= 8192 and refused otherwise (instead of failing inside the library with "unsupported")
+    if n > 8192:
+        raise LlvError(f'multiclass_nms: {n} boxes; the device NMS takes at most 8192 per image')
+    if max_num > 0:
+        cap = max_num
+    else:
+        cap = min(max(n, 1), 8192 // max(num_classes, 1))
+        if cap < n:
+            raise LlvError(f'multiclass_nms(max_num={max_num}): keeping all of {n} x {num_classes} candidates exceeds the merge limit '
+                           f'(num_classes * max_num <= 8192); pass max_num <= {8192 // max(num_classes, 1)}')
+    if num_classes * cap > 8192:
+        raise LlvError(f'multiclass_nms: num_classes * max_num = {num_classes * cap} > 8192 (merge limit of the device NMS)')
     bufs = NmsBuffers(max(n, 1), num_classes, max(cap, 1), multi_bboxes.device)
     if class_specific:
         bx, sc = multi_bboxes.float().contiguous(), multi_scores.float().contiguous()

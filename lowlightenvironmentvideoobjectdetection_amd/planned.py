@@ -13,11 +13,24 @@ class PlannedModule(torch.nn.Module):
         self._plans = {}
 
     def invalidate_plans(self):
-        self._plans = {}
+        """Drop the cached plans (packed weights, launch lists, graphs) of this module AND of every module below it:
+        nn.Module.load_state_dict on a parent never calls its children's overrides, so a container (TwoStageDetector, SELSA,
+        a video model) that is re-loaded, re-initialised or stepped by an optimizer has to reach its backbone / neck / heads
+        itself, or they keep serving convolutions packed from the old weights."""
+        for m in self.modules():
+            if isinstance(m, PlannedModule):
+                m._plans = {}
 
     def load_state_dict(self, *a, **k):
         self.invalidate_plans()
         return super().load_state_dict(*a, **k)
+
+    def train(self, mode=True):
+        """Switching between training and evaluation drops the plans: parameters are updated in place while training
+        (optimizer.step() outside forward_train), and the evaluation plans fold them at build time."""
+        if bool(mode) != self.training:
+            self.invalidate_plans()
+        return super().train(mode)
 
     def _apply(self, fn, *a, **k):
         self._plans = {}

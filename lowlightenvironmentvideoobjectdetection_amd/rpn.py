@@ -96,6 +96,10 @@ class RPNHead(AnchorHead):
     def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg=None, rescale=False, with_nms=True):
         """rpn_head.py:88-234. Returns list[N] of (k, 5) proposals (x1, y1, x2, y2, score) on the GPU, best first."""
         cfg = dict(_cfg(self.test_cfg if cfg is None else cfg))
+        if not getattr(self, 'use_sigmoid_cls', True) or self.cls_out_channels != 1:
+            # rpn_head.py:128-137 also has a softmax branch (2 channels per anchor, score = softmax[..., 0]); the decode plan below
+            # reads ONE sigmoid logit per anchor, so such a head would be decoded from misaligned logits
+            raise LlvError('RPNHead.get_bboxes: only the sigmoid objectness head (loss_cls use_sigmoid=True, 1 channel per anchor) is built')
         if 'nms' not in cfg:
             cfg['nms'] = dict(type='nms', iou_threshold=cfg['nms_thr'])                # deprecated spelling, rpn_head.py:189-213
         max_per_img = cfg.get('max_per_img', cfg.get('max_num'))

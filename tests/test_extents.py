@@ -163,11 +163,23 @@ def test_enhance_detect_plans_full_size(host_build):
         _assert_clean(plan.plan, 95)
         if B == 1:
             _assert_clean(plan.den.enable_stream(), 25)
-        # the window of a step may be a view into the resident clip (no staging copy): frames t0 .. t0+B+3 of a (T+4)-frame clip
+        # zero-copy windows: the first-stage launches read frames t0 .. t0+B+3 of the resident (T+4)-frame clip through the offset
+        # word; the replay adds the largest offset the plan will ever store (the last window of the clip)
         clip = torch.empty(32 + 4, hp, wp, 8, dtype=torch.float16)
-        den = engine.FastDVDnetPlan(cleaner.state_dict(), B, hp, wp, CPU, frames=clip[32 - B:32 - B + B + 4])
-        _assert_clean(den.plan, 25)
-        del plan, den, clip
+        off = torch.zeros(1, dtype=torch.int64)
+        plan.den.bind_clip(clip, off)
+        _assert_clean(plan.plan, 95)
+        if B == 1:
+            _assert_clean(plan.den.plan_stream, 25)
+        bound = [s for s in plan.plan.steps if s[0] in ('temp1.inputcv', 'temp1.outputcv')]
+        assert len(bound) == 2 and all(s[2][0]._obj.conv.offset_max == (32 - B) * hp * wp * 8 for s in bound)
+        need = ops.conv_extents(bound[0][2][0]._obj)
+        assert need.x[2] == (clip.numel() - 2 * hp * wp * 8) * 2   # the third source (2 frames in) of the last window ends with the clip
+        short = torch.empty(B + 4, hp, wp, 8, dtype=torch.float16)
+        plan.den.bind_clip(short, off)
+        bound[0][2][0]._obj.conv.offset_max = hp * wp * 8     # ... and a clip one frame too short for the offsets is caught
+        assert [v[1] for v in plan.plan.check_extents()] == ['x2']      # only the third source then runs past the end
+        del plan, clip, short
 
 
 def test_yolo_insert_flow_plans(host_build):

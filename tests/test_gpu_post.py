@@ -185,3 +185,23 @@ def test_multiclass_nms_class_specific_boxes_index_exact(dev, n, C):
     assert len(d_ref) > 20
     assert torch.equal(i.cpu(), i_ref) and torch.equal(l.cpu(), l_ref)
     torch.testing.assert_close(d.cpu(), d_ref, rtol=0, atol=0)
+
+
+def test_multiclass_nms_default_max_num_and_limits(dev):
+    """mmdet's default max_num=-1 keeps every surviving candidate (bbox_nms.py:86-91): exact while n * num_classes fits the device
+    merge (8192 keys), refused with a clear message beyond (it used to fail inside the library with 'unsupported')."""
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    from lowlightenvironmentvideoobjectdetection_amd._lib import LlvError
+    from oracle.nms import multiclass_nms as oracle_mnms
+    g = torch.Generator().manual_seed(5)
+    n, C = 300, 6
+    boxes = _clustered_boxes(n, g)
+    scores = torch.cat([torch.rand(n, C, generator=g), torch.zeros(n, 1)], 1)
+    cfg = dict(type='nms', iou_threshold=0.5)
+    d_ref, l_ref, k_ref = oracle_mnms(boxes, scores, 0.3, cfg, -1, return_inds=True)
+    d, l, k = ops.multiclass_nms(boxes.to(dev), scores.to(dev), 0.3, cfg, return_inds=True)
+    assert len(k_ref) > 150 and torch.equal(k.cpu(), k_ref) and torch.equal(d.cpu(), d_ref) and torch.equal(l.cpu(), l_ref)
+    with pytest.raises(LlvError, match='merge limit'):
+        ops.multiclass_nms(_clustered_boxes(4540, g).to(dev), torch.rand(4540, 81, generator=g).to(dev), 0.05, cfg)
+    with pytest.raises(LlvError, match='8192'):
+        ops.multiclass_nms(torch.rand(9000, 4).to(dev), torch.rand(9000, 2).to(dev), 0.05, cfg, 10)

@@ -200,3 +200,74 @@ def test_yolov3_stand_in_has_the_reference_parameter_tree():
     assert det.bbox_head.convs_pred[0].weight.shape == (255, 1024, 1, 1)
     assert det.neck.detect2.conv1.conv.weight.shape == (256, 768, 1, 1)
     assert [tuple(b[0].tolist()) for b in det.bbox_head.anchor_generator.base_anchors][0] == (16 - 58.0, 16 - 45.0, 16 + 58.0, 16 + 45.0)
+
+
+def test_invalidate_plans_cascades_and_train_switch_drops_plans():
+    """nn.Module.load_state_dict on a container never calls its children's overrides, so the container itself has to
+    reach every PlannedModule below it; train()/eval() switches drop the plans too (in-place optimizer updates)."""
+    import lowlightenvironmentvideoobjectdetection_amd.models as M
+    from lowlightenvironmentvideoobjectdetection_amd.planned import PlannedModule
+    cfg = dict(type='SELSA', pretrains=None, detector=dict(
+        type='FasterRCNN', pretrained=None,
+        backbone=dict(type='ResNet', depth=18, num_stages=4, out_indices=(3,), strides=(1, 2, 2, 1), dilations=(1, 1, 1, 2), frozen_stages=-1,
+                      norm_eval=True, style='pytorch'),
+        neck=dict(type='ChannelMapper', in_channels=[512], out_channels=64, kernel_size=3),
+        rpn_head=dict(type='RPNHead', in_channels=64, feat_channels=64,
+                      anchor_generator=dict(type='AnchorGenerator', scales=[4, 8], ratios=[0.5, 1.0, 2.0], strides=[16]),
+                      bbox_coder=dict(type='DeltaXYWHBBoxCoder', target_means=[.0, .0, .0, .0], target_stds=[1.0, 1.0, 1.0, 1.0])),
+        roi_head=dict(type='SelsaRoIHead',
+                      bbox_roi_extractor=dict(type='SingleRoIExtractor', roi_layer=dict(type='RoIAlign', output_size=7, sampling_ratio=2),
+                                              out_channels=64, featmap_strides=[16]),
+                      bbox_head=dict(type='SelsaBBoxHead', num_shared_fcs=2, aggregator=dict(type='SelsaAggregator', in_channels=128, num_attention_blocks=4),
+                                     in_channels=64, fc_out_channels=128, roi_feat_size=7, num_classes=3,
+                                     bbox_coder=dict(type='DeltaXYWHBBoxCoder', target_means=[0., 0., 0., 0.], target_stds=[0.2, 0.2, 0.2, 0.2]),
+                                     reg_class_agnostic=False)),
+        test_cfg=dict(rpn=dict(nms_across_levels=False, nms_pre=100, nms_post=20, max_num=20, nms_thr=0.7, min_bbox_size=0),
+                      rcnn=dict(score_thr=0.0001, nms=dict(type='nms', iou_threshold=0.5), max_per_img=10))))
+    model = M.build_model(cfg).eval()
+    planned = [m for m in model.modules() if isinstance(m, PlannedModule)]
+    assert len(planned) >= 4                       # SELSA, FasterRCNN, ResNet, ChannelMapper, RPNHead ...
+
+    def mark():
+        for m in planned:
+            m._plans = {'stale': object()}
+    mark()
+    model.load_state_dict(model.state_dict())      # the parent's override is the only one torch calls
+    assert all(m._plans == {} for m in planned)
+    mark()
+    model.detector.load_state_dict(model.detector.state_dict())
+    assert all(m._plans == {} for m in planned if m is not model)
+    mark()
+    model.train()
+    assert all(m._plans == {} for m in planned)
+    mark()
+    model.train()                                  # no switch: plans stay
+    assert all('stale' in m._plans for m in planned)
+    model.eval()
+    assert all(m._plans == {} for m in planned)
+
+
+def test_save_checkpoint_round_trip(tmp_path):
+    """The reference's checkpoint layout {'meta', 'state_dict', 'optimizer'} (mmcv CheckpointHook): what save_checkpoint writes,
+    load_checkpoint and a plain torch.load read back; a DataParallel 'module.' prefix is stripped."""
+    from lowlightenvironmentvideoobjectdetection_amd import registry
+    from lowlightenvironmentvideoobjectdetection_amd.checkpoint import load_checkpoint, save_checkpoint
+    from helpers import randomize, retinanet_cfg
+    a = randomize(registry.build_detector(retinanet_cfg(num_classes=3, depth=18, in_channels=(64, 128, 256, 512), stacked_convs=1, feat=32)), seed=1)
+    b = randomize(registry.build_detector(retinanet_cfg(num_classes=3, depth=18, in_channels=(64, 128, 256, 512), stacked_convs=1, feat=32)), seed=2)
+    a.CLASSES = ('x', 'y', 'z')
+    opt = torch.optim.SGD(a.parameters(), lr=0.01, momentum=0.9)
+    path = save_checkpoint(torch.nn.DataParallel(a) if False else a, str(tmp_path / 'sub' / 'epoch_1.pth'), optimizer=opt, meta=dict(epoch=1))
+    raw = torch.load(path, map_location='cpu', weights_only=False)
+    assert set(raw) == {'meta', 'state_dict', 'optimizer'} and raw['meta']['epoch'] == 1 and raw['meta']['CLASSES'] == ('x', 'y', 'z')
+    assert list(raw['state_dict']) == list(a.state_dict()) and 'param_groups' in raw['optimizer']
+    assert any(not torch.equal(p, q) for p, q in zip(a.state_dict().values(), b.state_dict().values()))
+    load_checkpoint(b, path, strict=True)
+    assert all(torch.equal(p, q) for p, q in zip(a.state_dict().values(), b.state_dict().values()))
+
+    class Wrapped(torch.nn.Module):
+        def __init__(self, m):
+            super().__init__()
+            self.module = m
+    p2 = save_checkpoint(Wrapped(a), str(tmp_path / 'wrapped.pth'))
+    assert list(torch.load(p2, weights_only=False)['state_dict']) == list(a.state_dict())

@@ -77,3 +77,18 @@ def test_rpn_proposals_vs_oracle(dev, fpn):
     assert torch.all(props[:-1, 4] >= props[1:, 4])                       # best first
     frac, tot = match_detections([props.numpy()], [ref.numpy()], iou_thr=0.95, score_tol=0.02)
     assert frac >= 0.9, f'{frac:.3f} of {tot} oracle proposals reproduced'
+
+
+def test_rpn_softmax_head_is_refused():
+    """rpn_head.py:128-137 has a softmax branch (use_sigmoid=False: 2 channels per anchor); the device decode reads one sigmoid logit
+    per anchor, so such a head is refused -- at construction (AnchorHead) and again in get_bboxes -- instead of decoding misaligned
+    logits."""
+    import lowlightenvironmentvideoobjectdetection_amd.models  # noqa: F401
+    from lowlightenvironmentvideoobjectdetection_amd import registry
+    from lowlightenvironmentvideoobjectdetection_amd._lib import LlvError
+    with pytest.raises(NotImplementedError, match='softmax'):
+        registry.build_head(dict(RPN, loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0)))
+    head = registry.build_head(dict(RPN))
+    head.use_sigmoid_cls, head.cls_out_channels = False, 2          # a head that slipped past the constructor
+    with pytest.raises(LlvError, match='sigmoid'):
+        head.get_bboxes([torch.zeros(1, 24, 4, 4)], [torch.zeros(1, 48, 4, 4)], [img_meta(64, 64)])
