@@ -538,7 +538,7 @@ def main():
             raise SystemExit(f'bench.py: process group has {dist.get_world_size()} ranks, --gpus {args.gpus}')
         world = dist.get_world_size()
 
-    from lowlightenvironmentvideoobjectdetection_amd import data, engine
+    from lowlightenvironmentvideoobjectdetection_amd import data, engine, ops
     from lowlightenvironmentvideoobjectdetection_amd.synthetic import calibrate_head_on_device
 
     if args.mode == 'train':
@@ -665,6 +665,7 @@ def main():
                              if args.pipeline else 'none'),
                 'algorithmic_gflop_per_frame': round(flops_step / B / 1e9, 1),
                 'candidates_above_score_thr': n_cand_thr, 'detections_last_step': n_det,
+                'postprocess_guard_trips': ops.guard_trips(),
                 'parallelism': f'clip-sharded x{world}, no data-path collective',
             },
         }

@@ -282,7 +282,8 @@ size_t llv_retina_decode_workspace_bytes(const llv_decode_desc* desc);
 int llv_retina_decode_topk(const llv_decode_desc* desc, void* stream);
 
 /*
- * multiclass_nms for one image. boxes [n][4] fp32, scores [n][c_ld] fp32 (first C columns used).
+ * multiclass_nms for one image. boxes [n][4] fp32, scores [n][c_ld] fp32 (first C columns used). n <= 16384 and
+ * num_classes * max_num <= 8192 (LLV_E_UNSUPPORTED beyond: the class lists are sorted and merged in LDS).
  * Output: dets [max_num][5], labels [max_num] int64, count[1] int32, keep_flat [max_num] int32
  * (flat index i*C + c of each kept detection, score-descending).
  */
@@ -300,7 +301,7 @@ int llv_multiclass_nms_batched(const float* boxes, const float* scores, int batc
                                int32_t* count, int32_t* keep_flat, void* workspace, size_t workspace_bytes,
                                void* stream);
 
-/* Plain single-class NMS: keep [n] int64 (score-descending kept indices), count[1] int32. n <= 8192. */
+/* Plain single-class NMS: keep [n] int64 (score-descending kept indices), count[1] int32. n <= 16384. */
 size_t llv_nms_workspace_bytes(int n);
 int llv_nms(const float* boxes, const float* scores, int n, float iou_thr, int64_t* keep, int32_t* count,
             void* workspace, size_t workspace_bytes, void* stream);
@@ -397,9 +398,23 @@ int llv_coco_match(const double* dets, const int* det_off, const double* gts, co
                    int n_ranges, const double* iou_thrs, int n_thrs, int64_t total_dets, uint8_t* dt_matched, uint8_t* dt_ignore,
                    int32_t* gt_valid, void* stream);
 
-/* Stream-ordered device-to-device copy (a launch-plan step: the streaming FastDVDnet plan carries the last two first-stage
- * DenBlock outputs of a step to the front of the next step's buffer). Regions must not overlap. */
+/* Stream-ordered copy done by a KERNEL (a launch-plan step: the streaming FastDVDnet plan carries the last two first-stage
+ * DenBlock outputs of a step to the front of the next step's buffer). Regions must not overlap; dst may be device-mapped host
+ * memory. Inside a captured graph it is a kernel node, not a memcpy node. */
 int llv_copy_d2d(void* dst, const void* src, size_t bytes, void* stream);
+
+/* bbox2result's device-to-host step (mmdetection/mmdet/core/bbox/transforms.py:99-116) as one kernel: the NMS outputs of `batch`
+ * images (dets [batch][max_num][5] fp32, labels [batch][max_num] int64, count [batch] int32) -> rows [batch][max_num][6] fp32
+ * (x1, y1, x2, y2, score, label) and count_out [batch] int32; rows / count_out may be device-mapped pinned host memory, which
+ * the host reads after synchronising the stream. */
+int llv_pack_results(const float* dets, const int64_t* labels, const int32_t* count, int batch, int max_num, float* rows,
+                     int32_t* count_out, void* stream);
+
+/* Capacity guards of the post-processing kernels: every data-dependent index (list positions drawn from atomic counters, anchor /
+ * box indices read back from memory) is clamped to its buffer, and clamps that fire are counted. *count_host = guards fired since
+ * the last reset (0 with consistent inputs; > 0 means launches of a step ran on counters that were not zeroed or on lists that
+ * changed between passes, which without the guards is an out-of-bounds store). Synchronises the device; never call while capturing. */
+int llv_guard_trips(uint64_t* count_host, int reset);
 
 /* Test-time image pipeline of the reference in one pass:
  * SeqBrighten (mmtracking/mmtrack/datasets/pipelines/transforms.py:376-432: one gain amp = m*h*w*3 / sum(frame0/255) for the

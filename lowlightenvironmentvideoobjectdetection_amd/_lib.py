@@ -156,6 +156,8 @@ SIGNATURES = {
     'llv_add_f16': (_I, [_P, _P, _P, _L, _I, _I, _I, _I, _P]),
     'llv_coco_match': (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _P, _I, _P, _I, _L, _P, _P, _P, _P]),
     'llv_copy_d2d': (_I, [_P, _P, _Z, _P]),
+    'llv_pack_results': (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
+    'llv_guard_trips': (_I, [C.POINTER(C.c_uint64), _I]),
     'llv_roi_align': (_I, [_P, _P, _P] + [_I] * 8 + [_F, _I, _I, _I, _P]),
     'llv_eval_tpfp': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _F, _I, _L, _P, _P, _P]),
     'llv_conv2d_nhwc_wgrad': (_I, [C.POINTER(ConvDesc), _P, _I, _P, _P, _P]),

@@ -16,6 +16,8 @@
 
 namespace {
 
+LLV_GUARD_DECL
+
 struct DecK {
     int n_levels, C, A, nms_pre;
     int h[LLV_MAX_SEG], w[LLV_MAX_SEG], sw[LLV_MAX_SEG], sh[LLV_MAX_SEG];
@@ -227,7 +229,9 @@ __global__ void topk_compact_kernel(const DecK k) {
                 base = __shfl(base, leader);
                 if (which == w && l == ll) {
                     const int pos = base + __popcll(same & ((1ull << lane) - 1ull));
-                    if (w == 1) listA_i[(long)ll * k.capA + pos] = key;
+                    const int cap = w == 1 ? k.capA : k.a0[ll + 1] - k.a0[ll];     // list A holds < nms_pre keys, list T at most the level
+                    if ((unsigned)pos >= (unsigned)cap) LLV_GUARD_TRIP();
+                    else if (w == 1) listA_i[(long)ll * k.capA + pos] = key;
                     else listT_i[k.a0[ll] + pos] = key;
                 }
                 active &= ~same;
@@ -255,8 +259,13 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const DecK k) {
     __shared__ unsigned hist[256];
     __shared__ uint64_t sh_sel[2];
     const int* meta = meta_i + l * 4;
-    const int nA = meta[2], nT = meta[3];
-    const int m = kk - nA;           // keys still needed, all from T (nT >= m by construction)
+    int nA = meta[2], nT = meta[3];
+    if (nA < 0 || nA >= kk || nT < kk - nA || nT > n) {           // impossible with consistent passes (see LLV_GUARD_DECL)
+        if (tid == 0) LLV_GUARD_TRIP();
+        nA = nA < 0 ? 0 : (nA > kk ? kk : nA);
+        nT = nT < 0 ? 0 : (nT > n ? n : nT);
+    }
+    const int m = kk - nA < nT ? kk - nA : nT;                    // keys still needed, all from T (nT >= kk - nA by construction)
     const uint64_t* A = listA_i + (long)l * k.capA;
     const uint64_t* Tl = listT_i + k.a0[l];
     for (int i = tid; i < np2k; i += blockDim.x) fin[i] = i < nA ? A[i] : 0ull;
@@ -274,7 +283,11 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const DecK k) {
         if (m > 0) llv::block_select_top(Tl, nT, m, fin + nA, hist, sh_sel);
     }
     llv::bitonic_sort_desc(fin, np2k);
-    for (int i = tid; i < kk; i += blockDim.x) sel[i] = k.a0[l] + (int)llv::key_index(fin[i]);
+    for (int i = tid; i < kk; i += blockDim.x) {
+        unsigned idx = llv::key_index(fin[i]);
+        if (idx >= (unsigned)n) { LLV_GUARD_TRIP(); idx = 0; }     // a padding key (0) or a corrupt one
+        sel[i] = k.a0[l] + (int)idx;
+    }
 }
 
 template <typename T>
@@ -285,7 +298,8 @@ __global__ void gather_decode_kernel(const DecK k) {
     for (int s = 1; s < LLV_MAX_SEG; ++s)
         if (s < k.n_levels && slot >= k.c0[s]) l = s;
     IMG_SETUP(k)
-    const int g = sel_i[slot];
+    int g = sel_i[slot];
+    if (g < k.a0[l] || g >= k.a0[l + 1]) { if (threadIdx.x == 0) LLV_GUARD_TRIP(); g = k.a0[l]; }
     const int loc = g - k.a0[l];
     const int cell = loc / k.A, an = loc - cell * k.A;
     const long ipix = (long)img * k.h[l] * k.w[l];
@@ -415,7 +429,8 @@ extern "C" int llv_retina_decode_topk(const llv_decode_desc* d, void* stream) {
         (void)hipFuncSetAttribute(reinterpret_cast<const void*>(topk_final_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
         attr_done = true;
     }
-    if (hipMemsetAsync(ws + w.hist, 0, w.ms - w.hist, st) != hipSuccess) return LLV_E_LAUNCH;
+    // histogram + counters: zeroed by a KERNEL (zero_words), so that a captured step consists of kernel nodes only
+    llv::zero_words(ws + w.hist, w.ms - w.hist, st);
     const int total = k.a0[d->n_levels];
     int grid = (total + 255) / 256;
     grid = grid > 2048 ? 2048 : grid;
@@ -445,4 +460,18 @@ extern "C" int llv_retina_decode_topk(const llv_decode_desc* d, void* stream) {
     if (k.f32) hipLaunchKernelGGL((gather_decode_kernel<float>), dim3(d->n_cand, batch), dim3(128), 0, st, k);
     else hipLaunchKernelGGL((gather_decode_kernel<_Float16>), dim3(d->n_cand, batch), dim3(128), 0, st, k);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+// ---- capacity-guard counter (sort_util.h): decode + NMS modules
+unsigned int llv_nms_guard_trips_(int reset);
+extern "C" int llv_guard_trips(uint64_t* count_host, int reset) {
+    if (!count_host) return LLV_E_BADARG;
+    unsigned int v = 0;
+    if (hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_guard_trips), sizeof(v)) != hipSuccess) return LLV_E_LAUNCH;
+    if (reset) {
+        const unsigned int z = 0;
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_guard_trips), &z, sizeof(z)) != hipSuccess) return LLV_E_LAUNCH;
+    }
+    *count_host = (uint64_t)v + (uint64_t)llv_nms_guard_trips_(reset);
+    return LLV_OK;
 }

@@ -494,10 +494,50 @@ extern "C" int llv_flow_warp(const void* x, const float* flow, void* y, int n, i
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
+// A copy done by a KERNEL (16 bytes per lane, byte tail by the first lanes): inside a captured step it is a kernel node like
+// every other launch of the plan, where hipMemcpyAsync would insert a memcpy node (the step graph is
+// kept homogeneous). dst may be host memory that is mapped for the device (torch pinned memory).
+namespace {
+__global__ void copy_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, size_t n16, size_t bytes) {
+    const size_t stride = (size_t)gridDim.x * blockDim.x;
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n16; i += stride)
+        reinterpret_cast<uint4*>(dst)[i] = reinterpret_cast<const uint4*>(src)[i];
+    for (size_t i = n16 * 16 + blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < bytes; i += stride) dst[i] = src[i];
+}
+
+// (dets [batch][max_num][5] f32, labels [batch][max_num] i64, count [batch] i32) -> rows [batch][max_num][6] f32 (x1, y1, x2, y2,
+// score, label) + counts [batch] i32, e.g. straight into pinned host memory: the D2H step of bbox2result
+// (mmdetection/mmdet/core/bbox/transforms.py:99-116) as one kernel node
+__global__ void pack_results_kernel(const float* __restrict__ dets, const long* __restrict__ labels, const int* __restrict__ count,
+                                    int total_rows, int batch, float* __restrict__ rows, int* __restrict__ count_out) {
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i < total_rows) {
+        const float* d = dets + (size_t)i * 5;
+        float* o = rows + (size_t)i * 6;
+        o[0] = d[0]; o[1] = d[1]; o[2] = d[2]; o[3] = d[3]; o[4] = d[4];
+        o[5] = (float)labels[i];
+    }
+    if (i < batch) count_out[i] = count[i];
+}
+}  // namespace
+
 extern "C" int llv_copy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
     if (!dst || !src) return LLV_E_BADARG;
     if (bytes == 0) return LLV_OK;
-    return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+    const bool aligned = ((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0;
+    const size_t n16 = aligned ? bytes / 16 : 0;
+    hipLaunchKernelGGL(copy_kernel, dim3(grid_for((long)(n16 ? n16 : bytes))), dim3(kBlock), 0, (hipStream_t)stream,
+                       (const unsigned char*)src, (unsigned char*)dst, n16, bytes);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_pack_results(const float* dets, const int64_t* labels, const int32_t* count, int batch, int max_num, float* rows,
+                                int32_t* count_out, void* stream) {
+    if (!dets || !labels || !count || !rows || !count_out || batch < 1 || max_num < 1) return LLV_E_BADARG;
+    const int total = batch * max_num;
+    hipLaunchKernelGGL(pack_results_kernel, dim3((total + kBlock - 1) / kBlock), dim3(kBlock), 0, (hipStream_t)stream, dets,
+                       (const long*)labels, count, total, batch, rows, count_out);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
 extern "C" int llv_abi_version(void) { return LLV_ABI_VERSION; }

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 namespace llv {
 
@@ -120,9 +121,36 @@ __device__ inline void block_select_top(const uint64_t* src, int n, int m, uint6
     __syncthreads();
     for (int i = tid; i < n; i += blockDim.x) {
         const uint64_t key = src[i];
-        if (key >= prefix) dst[atomicAdd(cnt, 1u)] = key;
+        if (key >= prefix) {
+            const unsigned p = atomicAdd(cnt, 1u);
+            if (p < (unsigned)m) dst[p] = key;                   // keys that are NOT distinct (corrupt input) cannot overrun dst
+        }
     }
     __syncthreads();
+}
+
+// Capacity guards. Every data-dependent index of the post-processing kernels (list positions drawn from atomic counters,
+// anchor / box indices read back from memory) is clamped to the capacity of the buffer it addresses, and each clamp that
+// actually fires is counted in a per-module device word (llv_guard_trips reads the sum). With consistent inputs no guard
+// can fire; a non-zero count means the kernels were fed counters that were not zeroed or lists that changed between two
+// passes -- i.e. launches of one step ran out of order or overlapped -- which without the guards is an out-of-bounds store.
+#define LLV_GUARD_DECL static __device__ unsigned int g_guard_trips = 0u;
+#define LLV_GUARD_TRIP() atomicAdd(&g_guard_trips, 1u)
+
+// zero n 32-bit words (a KERNEL node where hipMemsetAsync would put a memset node into a captured graph)
+static __global__ void zero_words_kernel(unsigned* p, size_t n) {
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) p[i] = 0u;
+}
+static inline int zero_words(void* p, size_t bytes, hipStream_t st) {
+    const size_t n = bytes / 4;
+    if (n == 0) return 0;
+    // LLV_GRAPH_MEMNODES=1 (diagnosis only): round 1's behaviour, a memset node inside the captured step
+    static const bool memnodes = getenv("LLV_GRAPH_MEMNODES") != nullptr && atoi(getenv("LLV_GRAPH_MEMNODES")) != 0;
+    if (memnodes) return hipMemsetAsync(p, 0, bytes, st) == hipSuccess ? 0 : -1;
+    size_t g = (n + 255) / 256;
+    g = g > 1024 ? 1024 : g;
+    hipLaunchKernelGGL(zero_words_kernel, dim3((unsigned)g), dim3(256), 0, st, (unsigned*)p, n);
+    return 0;
 }
 
 }  // namespace llv

@@ -693,11 +693,20 @@ class EnhanceDetectPlan:
         """Detector half of a step: backbone .. NMS on the denoised frames, results into pinned host memory."""
         self.det.plan.run()
         nb = self.det.post.nb
-        self.res_dev[:, :, :5].copy_(nb.dets.reshape(self.batch, -1, 5))
-        self.res_dev[:, :, 5].copy_(nb.labels.reshape(self.batch, -1))
-        self.cnt_dev.copy_(nb.count)
-        self.res_host.copy_(self.res_dev, non_blocking=True)
-        self.cnt_host.copy_(self.cnt_dev, non_blocking=True)
+        if _os.environ.get('LLV_GRAPH_MEMNODES', '0') != '0':      # diagnosis only: round 1's copies (memcpy nodes in the captured step)
+            self.res_dev[:, :, :5].copy_(nb.dets.reshape(self.batch, -1, 5))
+            self.res_dev[:, :, 5].copy_(nb.labels.reshape(self.batch, -1))
+            self.cnt_dev.copy_(nb.count)
+            self.res_host.copy_(self.res_dev, non_blocking=True)
+            self.cnt_host.copy_(self.cnt_dev, non_blocking=True)
+            return
+        # one kernel writes the <= max_per_img rows of every image straight into the pinned host buffers (device-mapped): the
+        # captured step then holds kernel nodes only -- no memcpy / memset node (DESIGN.md section 4)
+        rc = lib().llv_pack_results(C.c_void_p(nb.dets.data_ptr()), C.c_void_p(nb.labels.data_ptr()), C.c_void_p(nb.count.data_ptr()),
+                                    self.batch, nb.max_num, C.c_void_p(self.res_host.data_ptr()), C.c_void_p(self.cnt_host.data_ptr()),
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise LlvError(f'llv_pack_results: {lib().llv_strerror(rc).decode()} ({rc})')
 
     def _body(self, window, carry=False):
         self._enhance(window, carry)

@@ -268,6 +268,13 @@ def make_conv_desc(pc: PackedConv, xs: Sequence[torch.Tensor], y: torch.Tensor, 
     return d
 
 
+def guard_trips(reset: bool = False) -> int:
+    """llv_guard_trips: how many capacity guards of the decode / NMS kernels have fired (0 with consistent inputs)."""
+    v = C.c_uint64(0)
+    check(lib().llv_guard_trips(C.byref(v), 1 if reset else 0), 'llv_guard_trips')
+    return int(v.value)
+
+
 def conv_extents(desc) -> Extents:
     """llv_conv2d_extents / llv_convpair_extents: 1 + the highest byte the launch touches through each pointer (host replay)."""
     need = Extents()
@@ -536,11 +543,11 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, r
     iou_thr = nms_cfg.get('iou_threshold', nms_cfg.get('iou_thr'))
     if nms_cfg.get('type', 'nms') != 'nms':
         raise LlvError(f"nms type {nms_cfg.get('type')} not supported")
-    # the per-class kept lists are merged in LDS: num_classes * cap <= 8192 keys (kMaxMerge, nms.hip) and n <= 8192 boxes. With
+    # the per-class kept lists are merged in LDS: num_classes * cap <= 8192 keys (kMaxMerge, nms.hip) and n <= 16384 boxes. With
     # max_num <= 0 (mmdet's default: keep everything) a class can keep at most n boxes, so cap = min(n, 8192 // num_classes) is
     # exact whenever n * num_classes <= 8192 and refused otherwise (instead of failing inside the library with "unsupported")
-    if n > 8192:
-        raise LlvError(f'multiclass_nms: {n} boxes; the device NMS takes at most 8192 per image')
+    if n > 16384:
+        raise LlvError(f'multiclass_nms: {n} boxes; the device NMS takes at most 16384 per image')
     if max_num > 0:
         cap = max_num
     else:

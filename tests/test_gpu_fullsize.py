@@ -194,3 +194,43 @@ def test_full_size_nms_idempotent(dev):
     s2[torch.arange(k, device=dev), labels.long()] = dets[:, 4]
     dets2, labels2 = ops.multiclass_nms(dets[:, :4].contiguous(), s2, 0.05, cfg, 100)
     assert torch.equal(dets2, dets) and torch.equal(labels2, labels)
+
+
+def test_full_size_zero_copy_graph_steps(dev, calibrated):
+    """The configuration that ended two bench runs in a GPU memory-access fault (round 1: window copied eagerly in front of the
+    replay; round 2, first attempt: window read in place through the offset word): the 16-frame step as a captured graph that does
+    not start with a memcpy node, replayed back to back over different windows of the resident clip. With the step graph made of
+    kernel nodes only (counters zeroed and results delivered by kernels) and every data-dependent index of decode / NMS guarded,
+    it must (1) run, (2) give bit-identical detections and denoised frames to the plan that stages every window in its own buffer,
+    (3) never trip a capacity guard. DESIGN.md section 4 has the diagnosis."""
+    from lowlightenvironmentvideoobjectdetection_amd import engine, ops
+    det, cleaner, clip, img_shape, (hp, wp) = calibrated
+    B = 16
+    clip = torch.cat([clip[:18], clip[2:20]]).contiguous()        # 32 + 4 frames, as bench.py's clip
+    kw = dict(detector_kwargs=dict(test_cfg=dict(det.bbox_head.test_cfg), img_shapes=[img_shape] * B), use_graph=True)
+    ops.guard_trips(reset=True)
+    ref = engine.EnhanceDetectPlan(cleaner.state_dict(), det.state_dict(), NCLS, B, hp, wp, dev, **kw)
+    zc = engine.EnhanceDetectPlan(cleaner.state_dict(), det.state_dict(), NCLS, B, hp, wp, dev, **kw)
+    ref.prepare(clip)
+    zc.prepare(clip, zero_copy=True)
+    assert zc.plan.check_extents() == []
+    T = clip.shape[0] - 4
+    starts = [0, T - B, 1, 2, 0, T - B]
+    for t0 in starts:                      # back to back, no host synchronisation between the replays
+        zc.step(clip, t0)
+    got_last = [(d.clone(), l.clone()) for d, l in zc.results()]
+    den_last = zc.den.out.clone()
+    ref.step(clip, starts[-1])
+    exp_last = ref.results()
+    assert torch.equal(den_last, ref.den.out)
+    n = 0
+    for (d0, l0), (d1, l1) in zip(exp_last, got_last):
+        assert torch.equal(d0, d1) and torch.equal(l0, l1)
+        n += len(d0)
+    assert n > 50 * B // 2
+    for t0 in (1, 2):                      # and window by window
+        zc.step(clip, t0)
+        ref.step(clip, t0)
+        for (d0, l0), (d1, l1) in zip(ref.results(), zc.results()):
+            assert torch.equal(d0, d1) and torch.equal(l0, l1)
+    assert ops.guard_trips() == 0

@@ -203,5 +203,5 @@ def test_multiclass_nms_default_max_num_and_limits(dev):
     assert len(k_ref) > 150 and torch.equal(k.cpu(), k_ref) and torch.equal(d.cpu(), d_ref) and torch.equal(l.cpu(), l_ref)
     with pytest.raises(LlvError, match='merge limit'):
         ops.multiclass_nms(_clustered_boxes(4540, g).to(dev), torch.rand(4540, 81, generator=g).to(dev), 0.05, cfg)
-    with pytest.raises(LlvError, match='8192'):
-        ops.multiclass_nms(torch.rand(9000, 4).to(dev), torch.rand(9000, 2).to(dev), 0.05, cfg, 10)
+    with pytest.raises(LlvError, match='16384'):
+        ops.multiclass_nms(torch.rand(17000, 4).to(dev), torch.rand(17000, 2).to(dev), 0.05, cfg, 10)
