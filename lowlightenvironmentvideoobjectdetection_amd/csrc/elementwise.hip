@@ -2,6 +2,7 @@
 // model boundary, EmbedAggregator tail, flow warp. All NHWC, 16-byte (8 x fp16) per lane accesses.
 
 #include <hip/hip_runtime.h>
+#include <cstdlib>
 #include <hip/hip_fp16.h>
 #include "llv.h"
 
@@ -524,6 +525,9 @@ __global__ void pack_results_kernel(const float* __restrict__ dets, const long* 
 extern "C" int llv_copy_d2d(void* dst, const void* src, size_t bytes, void* stream) {
     if (!dst || !src) return LLV_E_BADARG;
     if (bytes == 0) return LLV_OK;
+    // LLV_GRAPH_MEMNODES=1 (diagnosis only): round 1's behaviour, a memcpy node inside the captured step
+    static const bool memnodes = getenv("LLV_GRAPH_MEMNODES") != nullptr && atoi(getenv("LLV_GRAPH_MEMNODES")) != 0;
+    if (memnodes) return hipMemcpyAsync(dst, src, bytes, hipMemcpyDeviceToDevice, (hipStream_t)stream) == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
     const bool aligned = ((((uintptr_t)dst) | ((uintptr_t)src)) & 15) == 0;
     const size_t n16 = aligned ? bytes / 16 : 0;
     hipLaunchKernelGGL(copy_kernel, dim3(grid_for((long)(n16 ? n16 : bytes))), dim3(kBlock), 0, (hipStream_t)stream,

@@ -174,6 +174,29 @@ class YOLOV3Head(PlannedModule):
     def loss(self, *a, **k):
         raise LlvError('YOLOV3Head.loss (training) is not built on this path; the config-#5 stand-in is inference only')
 
+    def get_bboxes(self, pred_maps, img_metas, cfg=None, rescale=False, with_nms=True):
+        """YOLOV3Head.get_bboxes / _get_bboxes (yolo_head.py:172-366) on raw prediction maps: list over levels of (N, A*(5+C), h, w)
+        tensors on the GPU -> per image (dets (k, 5), labels (k,)). llv_yolo_decode per level, then the same selection + NMS the
+        launch plan runs (YoloPlan.results)."""
+        if not with_nms:
+            raise LlvError('YOLOV3Head.get_bboxes: with_nms=False (ONNX export path) is outside the hot path')
+        ops._need_gpu(*pred_maps)
+        bs, dev = pred_maps[0].shape[0], pred_maps[0].device
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        pred, boxes, confs = [], [], []
+        for i, pm in enumerate(pred_maps):
+            n, c, h, w = pm.shape
+            assert c == self.num_anchors * self.num_attrib
+            p = pm.detach().float().permute(0, 2, 3, 1).contiguous()
+            bx = torch.empty(n, h * w * self.num_anchors, 4, device=dev)
+            cf = torch.empty(n, h * w * self.num_anchors, device=dev)
+            wh = np.asarray(self.anchor_generator.base_sizes[i], dtype=np.float32).reshape(-1)
+            whc = (C.c_float * len(wh))(*wh.tolist())
+            check(lib().llv_yolo_decode(C.c_void_p(p.data_ptr()), n, h, w, self.num_anchors, self.num_attrib, c, self.featmap_strides[i], whc,
+                                        C.c_void_p(bx.data_ptr()), C.c_void_p(cf.data_ptr()), stream), 'llv_yolo_decode')
+            pred.append(p); boxes.append(bx); confs.append(cf)
+        return _yolo_select_nms(self, pred, boxes, confs, self.num_anchors, self.num_attrib, bs, img_metas, rescale, self, cfg)
+
 
 # ------------------------------------------------------------------------------------------------
 # the HIP plan
@@ -281,43 +304,51 @@ class YoloPlan:
 
     def results(self, img_metas=None, rescale=False):
         """yolo_head.py:281-352 after the per-anchor decode: per-level top-k on objectness, gather, conf_thr, NMS."""
-        head, cfg = self.head, self.head.test_cfg
-        nc, bs = head.num_classes, self.batch
-        nms_pre = cfg.get('nms_pre', -1)
-        bl, sl, cl = [], [], []
-        for i, pm in enumerate(self.pred):
-            conf, box = self.conf[i], self.boxes[i]
-            pmf = pm.view(bs, -1, pm.shape[-1])[..., :self.A * self.na].reshape(bs, -1, self.na)
-            if nms_pre > 0 and conf.shape[1] > nms_pre:
-                _, ti = conf.topk(nms_pre)
-                bi = torch.arange(bs, device=conf.device).view(-1, 1).expand_as(ti)
-                box, conf, pmf = box[bi, ti, :], conf[bi, ti], pmf[bi, ti, :]
-            bl.append(box); cl.append(conf); sl.append(torch.sigmoid(pmf[..., 5:]))
-        boxes, scores, confs = torch.cat(bl, 1).contiguous(), torch.cat(sl, 1), torch.cat(cl, 1).contiguous()
-        if rescale and img_metas is not None:
-            sf = torch.tensor(np.stack([np.asarray(m['scale_factor'], dtype=np.float32).reshape(-1)[:4] * np.ones(4, np.float32)
-                                        for m in img_metas]), device=boxes.device)
-            boxes = (boxes / sf.unsqueeze(1)).contiguous()
-        thr = cfg.get('conf_thr', -1)
-        if thr > 0:       # dropping a row == making all its class scores fail the score threshold
-            scores = scores * confs.ge(thr).unsqueeze(-1)
-        scores = scores.contiguous()
-        n = boxes.shape[1]
-        nms_cfg = cfg['nms']
-        iou_thr = nms_cfg.get('iou_threshold', nms_cfg.get('iou_thr'))
-        max_num = cfg['max_per_img']
-        if self._nms is None or self._nms[0] != n:
-            wsb = int(lib().llv_multiclass_nms_batched_workspace_bytes(bs, n, nc, max_num))
-            self._nms = (n, torch.empty(wsb, dtype=torch.uint8, device=self.device),
-                         torch.zeros(bs, max_num, 5, device=self.device), torch.zeros(bs, max_num, dtype=torch.int64, device=self.device),
-                         torch.zeros(bs, dtype=torch.int32, device=self.device), torch.zeros(bs, max_num, dtype=torch.int32, device=self.device))
-        _, ws, dets, labels, count, keep = self._nms
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
-        check(lib().llv_multiclass_nms_batched_sf(boxes.data_ptr(), scores.data_ptr(), confs.data_ptr(), bs, n, nc, nc, cfg['score_thr'],
-                                                  iou_thr, max_num, dets.data_ptr(), labels.data_ptr(), count.data_ptr(),
-                                                  keep.data_ptr(), ws.data_ptr(), ws.numel(), stream), 'llv_multiclass_nms_batched_sf')
-        cnt = count.cpu().tolist()
-        return [(dets[i, :cnt[i]].clone(), labels[i, :cnt[i]].clone()) for i in range(bs)]
+        return _yolo_select_nms(self.head, self.pred, self.boxes, self.conf, self.A, self.na, self.batch, img_metas, rescale, self)
+
+
+def _yolo_select_nms(head, pred, boxes_l, conf_l, A, na, bs, img_metas, rescale, cache, cfg=None):
+    """The part of YOLOV3Head._get_bboxes behind the per-anchor decode (yolo_head.py:281-352): per-level top-k on objectness,
+    gather, conf_thr, multiclass NMS with the objectness as score_factors. pred: NHWC fp32 maps (bs, h, w, >= A*na) per level;
+    boxes_l / conf_l: llv_yolo_decode outputs per level. `cache` keeps the NMS buffers between calls."""
+    cfg = head.test_cfg if cfg is None else cfg
+    nc = head.num_classes
+    device = pred[0].device
+    nms_pre = cfg.get('nms_pre', -1)
+    bl, sl, cl = [], [], []
+    for i, pm in enumerate(pred):
+        conf, box = conf_l[i], boxes_l[i]
+        pmf = pm.view(bs, -1, pm.shape[-1])[..., :A * na].reshape(bs, -1, na)
+        if nms_pre > 0 and conf.shape[1] > nms_pre:
+            _, ti = conf.topk(nms_pre)
+            bi = torch.arange(bs, device=conf.device).view(-1, 1).expand_as(ti)
+            box, conf, pmf = box[bi, ti, :], conf[bi, ti], pmf[bi, ti, :]
+        bl.append(box); cl.append(conf); sl.append(torch.sigmoid(pmf[..., 5:]))
+    boxes, scores, confs = torch.cat(bl, 1).contiguous(), torch.cat(sl, 1), torch.cat(cl, 1).contiguous()
+    if rescale and img_metas is not None:
+        sf = torch.tensor(np.stack([np.asarray(m['scale_factor'], dtype=np.float32).reshape(-1)[:4] * np.ones(4, np.float32)
+                                    for m in img_metas]), device=boxes.device)
+        boxes = (boxes / sf.unsqueeze(1)).contiguous()
+    thr = cfg.get('conf_thr', -1)
+    if thr > 0:       # dropping a row == making all its class scores fail the score threshold
+        scores = scores * confs.ge(thr).unsqueeze(-1)
+    scores = scores.contiguous()
+    n = boxes.shape[1]
+    nms_cfg = cfg['nms']
+    iou_thr = nms_cfg.get('iou_threshold', nms_cfg.get('iou_thr'))
+    max_num = cfg['max_per_img']
+    if getattr(cache, '_nms', None) is None or cache._nms[0] != (n, bs, max_num):
+        wsb = int(lib().llv_multiclass_nms_batched_workspace_bytes(bs, n, nc, max_num))
+        cache._nms = ((n, bs, max_num), torch.empty(max(wsb, 256), dtype=torch.uint8, device=device),
+                      torch.zeros(bs, max_num, 5, device=device), torch.zeros(bs, max_num, dtype=torch.int64, device=device),
+                      torch.zeros(bs, dtype=torch.int32, device=device), torch.zeros(bs, max_num, dtype=torch.int32, device=device))
+    _, ws, dets, labels, count, keep = cache._nms
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    check(lib().llv_multiclass_nms_batched_sf(boxes.data_ptr(), scores.data_ptr(), confs.data_ptr(), bs, n, nc, nc, cfg['score_thr'],
+                                              iou_thr, max_num, dets.data_ptr(), labels.data_ptr(), count.data_ptr(),
+                                              keep.data_ptr(), ws.data_ptr(), ws.numel(), stream), 'llv_multiclass_nms_batched_sf')
+    cnt = count.cpu().tolist()
+    return [(dets[i, :cnt[i]].clone(), labels[i, :cnt[i]].clone()) for i in range(bs)]
 
 
 @DETECTORS.register_module()

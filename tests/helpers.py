@@ -118,3 +118,49 @@ def match_detections(res, ref, iou_thr=0.9, score_tol=0.03):
         ok = (iou > iou_thr) & (ds < score_tol)
         hit += int(ok.any(0).sum())
     return hit / max(tot, 1), tot
+
+
+def detection_parity_report(res, ref, iou_thr=0.9, score_tol=0.03):
+    """Distribution of the differences between the device's detections `res` and the oracle's `ref` (per-class lists of (k, 5)
+    arrays): each oracle detection is paired with the same-class device detection of highest IoU. Returns a dict with
+      matched / total, box corner error (pixels) and |score difference| over the matched pairs (max, mean, p95), and what became of
+      the unmatched oracle detections: 'score_only' (IoU > thr, score off by > tol), 'shifted' (0.5 < IoU <= thr: a neighbouring
+      anchor's box won the NMS), 'absent' (no device box of that class overlaps: it fell below score_thr / out of the top max_per_img),
+      plus 'extra' = device detections that pair with no oracle detection."""
+    corner, dscore = [], []
+    out = dict(total=0, matched=0, score_only=0, shifted=0, absent=0, extra=0)
+    for a, b in zip(res, ref):
+        a = np.asarray(a, dtype=np.float64).reshape(-1, 5)
+        b = np.asarray(b, dtype=np.float64).reshape(-1, 5)
+        out['total'] += len(b)
+        used = np.zeros(len(a), dtype=bool)
+        for r in b:
+            if len(a) == 0:
+                out['absent'] += 1
+                continue
+            lt = np.maximum(a[:, :2], r[:2])
+            rb = np.minimum(a[:, 2:4], r[2:4])
+            wh = np.clip(rb - lt, 0, None)
+            inter = wh[:, 0] * wh[:, 1]
+            iou = inter / np.maximum((a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]) + (r[2] - r[0]) * (r[3] - r[1]) - inter, 1e-6)
+            j = int(np.argmax(iou))
+            ds = abs(a[j, 4] - r[4])
+            if iou[j] > iou_thr and ds < score_tol:
+                out['matched'] += 1
+                used[j] = True
+                corner.append(float(np.abs(a[j, :4] - r[:4]).max()))
+                dscore.append(float(ds))
+            elif iou[j] > iou_thr:
+                out['score_only'] += 1
+                used[j] = True
+            elif iou[j] > 0.5:
+                out['shifted'] += 1
+                used[j] = True
+            else:
+                out['absent'] += 1
+        out['extra'] += int((~used).sum())
+    c, d = np.asarray(corner or [0.0]), np.asarray(dscore or [0.0])
+    out.update(frac=out['matched'] / max(out['total'], 1),
+               corner_px=dict(max=float(c.max()), mean=float(c.mean()), p95=float(np.percentile(c, 95))),
+               score=dict(max=float(d.max()), mean=float(d.mean()), p95=float(np.percentile(d, 95))))
+    return out

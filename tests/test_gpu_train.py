@@ -116,7 +116,7 @@ def _train_setup(dev, depth=50, s=(128, 160), classes=4, seed=0):
     return det, img, metas, gtb, gtl
 
 
-def _oracle_grads(det, img, metas, gtb, gtl, classes, depth):
+def _oracle_grads(det, img, metas, gtb, gtl, classes, depth, stacked_convs=2):
     from oracle import detector as OD
     from oracle.anchors import AnchorGenerator
     from oracle.training import retina_loss
@@ -126,11 +126,12 @@ def _oracle_grads(det, img, metas, gtb, gtl, classes, depth):
         sd[n].requires_grad_(True)
     feats = OD.resnet_forward(sd, img, depth=depth)
     outs = OD.fpn_forward(sd, feats)
-    cls, reg = OD.retina_head_forward(sd, outs, stacked_convs=2)
+    cls, reg = OD.retina_head_forward(sd, outs, stacked_convs=stacked_convs)
     ag = AnchorGenerator(octave_base_scale=4, scales_per_octave=3, ratios=[0.5, 1.0, 2.0], strides=[8, 16, 32, 64, 128])
     losses = retina_loss(cls, reg, gtb, gtl, metas, ag, classes)
     total = sum(losses['loss_cls']) + sum(losses['loss_bbox'])
     total.backward()
+    _oracle_grads.last_losses = {k: [float(v) for v in vs] for k, vs in losses.items()}
     return total.item(), {n: sd[n].grad for n in names}
 
 
@@ -311,3 +312,55 @@ def test_anchor_head_loss_with_giou_and_decoded_boxes(dev):
         assert abs(a.item() - 2.0 * b.item()) <= 1e-5 * abs(2.0 * b.item()) + 1e-7
     for a, b in zip(rd, rr):
         assert (a.grad.cpu() - b.grad).abs().max().item() <= 1e-4 * b.grad.abs().max().item() + 1e-9
+
+
+def test_full_size_training_step_vs_oracle(dev):
+    """BASELINE config #3 at its real geometry: ONE 1280x720 image (padded 736x1280), RetinaNet R-50+FPN with 80 classes, 4 tower
+    convs, 10 ground-truth boxes, 176,580 anchors: loss_cls / loss_bbox per pyramid level and the gradients of a sample of parameter
+    tensors from every part of the network (head, towers, FPN, every trainable ResNet stage, BN affine) from the device step against
+    torch autograd over the fp32 oracle (config #3 only ran at 128x160 under -m gpu)."""
+    import lowlightenvironmentvideoobjectdetection_amd.models as M
+    from lowlightenvironmentvideoobjectdetection_amd import train_engine as TE
+    H, W, NC = 736, 1280, 80
+    cfg = retinanet_cfg(num_classes=NC)
+    cfg['train_cfg'] = dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0, ignore_iof_thr=-1),
+                            allowed_border=-1, pos_weight=-1, debug=False)
+    det = randomize(M.build_detector(cfg), seed=11, cls_bias=-2.0)
+    img = smooth_image(1, H, W, seed=12)
+    metas = [dict(img_shape=(720, 1280, 3), pad_shape=(H, W, 3), scale_factor=1.0)]
+    rs = np.random.RandomState(0)                       # _demo_mm_inputs-style boxes (test_forward.py:326-401)
+    cx, cy = rs.rand(10) * 1280, rs.rand(10) * 720
+    bw, bh = rs.rand(10) * 1280 * 0.4 + 16, rs.rand(10) * 720 * 0.4 + 16
+    bx = np.stack([np.clip(cx - bw / 2, 0, 1280), np.clip(cy - bh / 2, 0, 720), np.clip(cx + bw / 2, 0, 1280), np.clip(cy + bh / 2, 0, 720)], 1)
+    gtb, gtl = [torch.from_numpy(bx.astype(np.float32))], [torch.from_numpy(rs.randint(0, NC, 10)).long()]
+    torch.set_num_threads(16)
+    ref_loss, ref = _oracle_grads(det, img, metas, gtb, gtl, NC, 50, stacked_convs=4)
+    ref_parts = _oracle_grads.last_losses
+    det = det.to(dev)
+    graph = TE.TrainGraph(det, 1, H, W, dev, loss_scale=512.0)
+    losses = TE.forward_train(det, graph, img.to(dev), metas, [b.to(dev) for b in gtb], [l.to(dev) for l in gtl])
+    for k in ('loss_cls', 'loss_bbox'):
+        got = [float(v) for v in losses[k]]
+        assert len(got) == 5
+        for a, b in zip(got, ref_parts[k]):
+            assert abs(a - b) <= 2e-2 * abs(b) + 1e-4, (k, got, ref_parts[k])
+    total = sum(losses['loss_cls']) + sum(losses['loss_bbox'])
+    assert abs(total.item() - ref_loss) < 1e-2 * abs(ref_loss)
+    total.backward()
+    params = dict(det.named_parameters())
+    sample = ['bbox_head.retina_cls.weight', 'bbox_head.retina_cls.bias', 'bbox_head.retina_reg.weight', 'bbox_head.cls_convs.0.conv.weight',
+              'bbox_head.cls_convs.3.conv.weight', 'bbox_head.reg_convs.2.conv.weight', 'neck.lateral_convs.0.conv.weight',
+              'neck.fpn_convs.0.conv.weight', 'neck.fpn_convs.3.conv.weight', 'backbone.layer4.2.conv3.weight', 'backbone.layer4.0.downsample.0.weight',
+              'backbone.layer4.1.bn2.weight', 'backbone.layer3.5.conv2.weight', 'backbone.layer3.0.conv1.weight', 'backbone.layer3.2.bn3.bias',
+              'backbone.layer2.3.conv3.weight', 'backbone.layer2.0.conv2.weight', 'backbone.layer2.1.bn1.weight']
+    top = max(ref[k].abs().max().item() for k in graph.trainable)
+    worst = {}
+    for k in sample:
+        assert k in graph.trainable, k
+        g, r = params[k].grad, ref[k]
+        scale = r.abs().max().item()
+        err = (g.float().cpu() - r).abs().max().item() / scale
+        worst[k] = err
+        assert err < (5e-2 if scale > 1e-4 * top else 1.5e-1), (k, err, scale)
+    print('full-size gradient errors (max |dev - ref| / max |ref|):', {k: round(v, 4) for k, v in worst.items()})
+    assert params['backbone.layer1.0.conv1.weight'].grad is None
