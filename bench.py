@@ -610,6 +610,7 @@ def main():
     # batch-1 latency mode (the reference's per-frame protocol: 3 temp1 + 1 temp2 DenBlocks per frame)
     lat = None
     stream = None
+    stream_pipe = None
     if rank == 0 and world == 1 and B != 1 and not args.no_latency_mode:
         p1 = engine.EnhanceDetectPlan(cleaner.state_dict(), det.state_dict(), NUM_CLASSES, 1, hp, wp, dev,
                                       detector_kwargs=dict(test_cfg=dict(det.bbox_head.test_cfg), img_shapes=[img_shape]),
@@ -645,6 +646,29 @@ def main():
                   'value': round(nlat / d1, 3), 'unit': 'frames/s', 'ms_per_frame': round(d1 / nlat * 1e3, 4),
                   'note': 'consecutive frames of one video; first-stage DenBlock results shared with the previous frame are carried over'}
         del p1
+        # the same consecutive frames as a two-stage pipeline: FastDVDnet streaming step of frame i || detector of frame i-1 on two
+        # HIP streams (engine.PipelinedStreamingPlan); one frame enters per step, its detections leave one step later
+        pp = engine.PipelinedStreamingPlan(cleaner.state_dict(), det.state_dict(), NUM_CLASSES, 1, hp, wp, dev,
+                                           detector_kwargs=dict(test_cfg=dict(det.bbox_head.test_cfg), img_shapes=[img_shape]),
+                                           use_graph=not args.no_graph)
+        pp.prepare(clip)
+        for s_ in range(args.warmup):
+            pp.step(clip, s_ % T, carry=(s_ % T) != 0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        full_steps = 0
+        for s_ in range(nlat):
+            t0_ = (args.warmup + s_) % T
+            full_steps += t0_ == 0
+            pp.step(clip, t0_, carry=t0_ != 0)
+        pp.flush()
+        torch.cuda.synchronize()
+        d1 = time.perf_counter() - t1
+        stream_pipe = {'frames_per_step': 1, 'frames': nlat, 'denblocks_per_frame': round((4 * full_steps + 2 * (nlat - full_steps)) / nlat, 3),
+                       'value': round(nlat / d1, 3), 'unit': 'frames/s', 'ms_per_frame': round(d1 / nlat * 1e3, 4),
+                       'note': 'streaming_mode with FastDVDnet(frame i) and the detector(frame i-1) on two HIP streams; detections of a '
+                               'frame are available one step later'}
+        del pp
     n_cand_thr = int((last.det.post.dp.scores.reshape(B, -1)[0] > 0.05).sum().item())
 
     out = None
@@ -710,6 +734,8 @@ def main():
             out['latency_mode'] = lat
         if stream is not None:
             out['streaming_mode'] = stream
+        if stream_pipe is not None:
+            out['streaming_pipelined_mode'] = stream_pipe
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(det, cleaner, clip.cpu(), img_shape)
         print(json.dumps(out), flush=True)

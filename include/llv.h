@@ -375,6 +375,24 @@ int llv_add_f16(const void* a, const void* b, void* y, int64_t rows, int c, int 
 int llv_roi_align(const void* feat, const float* rois, void* out, int n, int h, int w, int c, int ld, int k, int ph, int pw,
                   float spatial_scale, int sampling_ratio, int aligned, int out_f32, void* stream);
 
+/* ---- TemporalRoIAlign (the RoI extractor of the authors' own model: mmtracking/configs/vid/llvod/llvod_fastdvdnet_darkfarm.py:49-59,
+ * mmtracking/mmtrack/models/roi_heads/roi_extractors/temporal_roi_align.py). Its two dense products run on llv_conv2d_nhwc_fwd (the
+ * cosine similarity maps as a 1x1 convolution of the normalised reference maps with the normalised RoI points as weights, fp32 out;
+ * the 3x3 embed convolution over the 7x7 RoI maps); these are the remaining steps.
+ *   llv_l2norm_rows_f16     y[r] = x[r] / ||x[r]||_2 over c channels (:123-126); x fp32 (x_is_f32) or fp16, y fp16; row strides in
+ *                           elements; inv_norm (optional) receives 1 / ||x[r]||.
+ *   llv_msra_top2_gather    most_similar_roi_align :141-168 with num_most_similar_points = 2: sim [img_n*hw][sim_ld] fp32 (row = pixel p
+ *                           of reference image i, column = RoI point r), ref [img_n*hw][ref_ld] fp16 (un-normalised maps) ->
+ *                           out [img_n][rows][c] fp16 = softmax-weighted sum of the two most similar pixels' features; idx_out / w_out
+ *                           (optional, [img_n][rows][2]) receive the picks and weights. Ties: lower pixel index first.
+ *   llv_troi_attention_fuse temporal_attentional_feature_aggregation :76-96 behind the embed conv: x, emb [n_img][rows][c] fp16 (image 0
+ *                           = the key frame's RoI features), out [rows][c] fp32; `blocks` attention blocks (c / blocks channels each,
+ *                           a power-of-two multiple of 8), n_img <= 16. */
+int llv_l2norm_rows_f16(const void* x, int x_is_f32, void* y, int64_t rows, int c, int64_t x_ld, int64_t y_ld, float* inv_norm, void* stream);
+int llv_msra_top2_gather(const float* sim, const void* ref, void* out, int32_t* idx_out, float* w_out, int img_n, int hw, int rows,
+                         int sim_ld, int c, int ref_ld, void* stream);
+int llv_troi_attention_fuse(const void* x, const void* emb, float* out, int n_img, int64_t rows, int c, int blocks, void* stream);
+
 /* True/false-positive marking of eval_map (mean_ap.py:268-400 calls tpfp_default :154-244 or, for datasets 'det'/'vid',
  * tpfp_imagenet :60-151 once per class and image): all (class, image) cells in one launch, one wavefront per cell.
  * dets [total_dets][5] fp32 (x1,y1,x2,y2,score); cell c owns dets[det_off[c] .. det_off[c+1]) and gts[gt_off[c] .. gt_off[c+1])

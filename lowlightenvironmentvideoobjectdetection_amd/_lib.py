@@ -159,6 +159,9 @@ SIGNATURES = {
     'llv_pack_results': (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     'llv_guard_trips': (_I, [C.POINTER(C.c_uint64), _I]),
     'llv_roi_align': (_I, [_P, _P, _P] + [_I] * 8 + [_F, _I, _I, _I, _P]),
+    'llv_l2norm_rows_f16': (_I, [_P, _I, _P, _L, _I, _L, _L, _P, _P]),
+    'llv_msra_top2_gather': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
+    'llv_troi_attention_fuse': (_I, [_P, _P, _P, _I, _L, _I, _I, _P]),
     'llv_eval_tpfp': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _F, _I, _L, _P, _P, _P]),
     'llv_conv2d_nhwc_wgrad': (_I, [C.POINTER(ConvDesc), _P, _I, _P, _P, _P]),
     'llv_conv2d_nhwc_dgrad': (_I, [C.POINTER(ConvDesc), _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _Z, _P]),

@@ -843,6 +843,107 @@ class PipelinedEnhanceDetectPlan:
         return self.p[self._i & 1].results()
 
 
+class PipelinedStreamingPlan:
+    """The per-frame protocol (the reference's benchmark.py:83-109: one frame per step) as a two-stage software pipeline over the
+    CONSECUTIVE frames of a video:
+
+        step i:   FastDVDnet streaming step of window i (first-stage results shared with window i-1 are carried: `batch` new
+                  first-stage DenBlocks + `batch` second-stage ones)  ->  den.out  ->  copied into detector plan i % 2's input
+              ||  detector (backbone .. NMS .. results to pinned memory) of window i-1, on a second HIP stream
+
+    One FastDVDnetPlan (the carried first-stage results live in its `mid` buffer, so it cannot alternate between two copies the
+    way PipelinedEnhanceDetectPlan does), two detector plans. At one frame per step both halves leave most of the chip idle (a
+    184x320 map is 230 workgroups for 256 CUs; layer3/4 and the pyramid tops far fewer), so running them side by side nearly hides
+    the shorter one. Every frame still takes exactly the launches of the sequential streaming step: results are bit-identical, they
+    just become available one step later (`results()` after step i+1, or after `flush()`). Windows are read in place from the
+    resident clip (bind_clip); both halves of a step are one captured graph with two branches (kernel nodes only)."""
+
+    def __init__(self, cleaner_sd, detector_sd, num_classes, batch, height, width, device, detector_kwargs=None, use_graph=True):
+        self.batch, self.dev, self.use_graph = batch, device, use_graph
+        self.den = FastDVDnetPlan(cleaner_sd, batch, height, width, device)
+        self.dets = [RetinaNetPlan(detector_sd, num_classes, batch, height, width, device, **(detector_kwargs or {})) for _ in range(2)]
+        self.det = self.dets[0]
+        k = self.det.post.nb.max_num
+        self.res_host = [torch.zeros((batch, k, 6), dtype=torch.float32).pin_memory() for _ in range(2)]
+        self.cnt_host = [torch.zeros((batch,), dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.side = torch.cuda.Stream(device)
+        self._graphs = [None, None]
+        self._i = 0
+        self._off = torch.zeros((1,), device=device, dtype=torch.int64)
+        self._clip = None
+
+    def _enhance(self, k, carry):
+        (self.den.plan_stream if carry else self.den.plan).run()
+        rc = lib().llv_copy_d2d(C.c_void_p(self.dets[k].x_in.data_ptr()), C.c_void_p(self.den.out.data_ptr()),
+                                C.c_size_t(self.den.out.numel() * 2), C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise LlvError(f'llv_copy_d2d: {lib().llv_strerror(rc).decode()} ({rc})')
+
+    def _detect(self, k):
+        d = self.dets[k]
+        d.plan.run()
+        nb = d.post.nb
+        rc = lib().llv_pack_results(C.c_void_p(nb.dets.data_ptr()), C.c_void_p(nb.labels.data_ptr()), C.c_void_p(nb.count.data_ptr()),
+                                    self.batch, nb.max_num, C.c_void_p(self.res_host[k].data_ptr()), C.c_void_p(self.cnt_host[k].data_ptr()),
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream))
+        if rc != 0:
+            raise LlvError(f'llv_pack_results: {lib().llv_strerror(rc).decode()} ({rc})')
+
+    def _body(self, k, carry):
+        main = torch.cuda.current_stream()
+        self.side.wait_stream(main)
+        with torch.cuda.stream(self.side):
+            self._detect(1 - k)
+        self._enhance(k, carry)
+        main.wait_stream(self.side)
+
+    def prepare(self, clip):
+        self.den.bind_clip(clip, self._off)
+        self.den.enable_stream()
+        self._clip = clip
+        self._off.fill_(0)
+        for k in (0, 1):                       # warm-up outside capture: full step, then the streaming step, on both parities
+            self._body(k, False)
+            self._body(k, True)
+        torch.cuda.synchronize()
+        if self.use_graph:
+            for k in (0, 1):
+                g = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(g):
+                    self._body(k, True)
+                self._graphs[k] = g
+        self._i = 0
+
+    def step(self, clip, t0, carry):
+        """Enqueue: enhance window t0 (carry=True: it directly follows the previous step's window) and detect the previous step's
+        window. No host sync."""
+        if clip.data_ptr() != self._clip.data_ptr() or t0 < 0 or t0 + self.batch + 4 > clip.shape[0]:
+            raise LlvError('PipelinedStreamingPlan.step takes the clip given to prepare() and a window inside it')
+        k = self._i & 1
+        self._off.fill_(t0 * self.den.frame_elems)
+        if carry and self._graphs[k] is not None:
+            self._graphs[k].replay()
+        else:
+            self._body(k, carry)
+        self._i += 1
+
+    def flush(self):
+        """Detect the window the last step enhanced (drains the pipeline)."""
+        self._detect(1 - (self._i & 1))
+        self._i += 1
+
+    def results(self):
+        """Detections of the window most recently detected: [(dets (k, 5), labels (k,))] per image."""
+        torch.cuda.synchronize()
+        k = self._i & 1
+        out = []
+        for n in range(self.batch):
+            c = int(self.cnt_host[k][n])
+            r = self.res_host[k][n, :c]
+            out.append((r[:, :5].clone(), r[:, 5].long()))
+        return out
+
+
 # ------------------------------------------------------------------------------------------------
 # DenoisingAggregator (SURVEY.md 8f item 3): residual dense blocks + DCN-based temporal attention fusion
 # ------------------------------------------------------------------------------------------------

@@ -2,11 +2,14 @@
 constructor (mmdetection/mmdet/models/roi_heads/roi_extractors/single_level_roi_extractor.py:9-108, base_roi_extractor.py:17-83) over
 `llv_roi_align`. Every pyramid level is packed to NHWC fp16 once per call; the RoIs of a level go through one launch; the result comes
 back as (k, C, ph, pw) fp32 like mmcv's RoIAlign output under `force_fp32`. The RPN / RoI heads that would call it are not built yet."""
+import ctypes as C
+
 import torch
 import torch.nn as nn
 
 from . import ops
-from ._lib import LlvError
+from ._lib import CONV_OUT_F32, LlvError, check, lib
+from .planned import PlannedModule
 from .registry import ROI_EXTRACTORS
 
 
@@ -27,9 +30,17 @@ class RoIAlign(nn.Module):
         c = feat.shape[1]
         if c % 8:
             raise LlvError('RoIAlign: channel count must be a multiple of 8')
+        return self.forward_nhwc(feat, rois).permute(0, 3, 1, 2).contiguous()
+
+    def forward_nhwc(self, feat, rois):
+        """The same RoI features as the kernel writes them: (k, ph, pw, C) fp32 (TemporalRoIAlign works on rows of C channels)."""
+        if not feat.is_cuda:
+            raise LlvError('RoIAlign runs on an MI355X only (llv_roi_align)')
+        c = feat.shape[1]
+        if c % 8:
+            raise LlvError('RoIAlign: channel count must be a multiple of 8')
         x = ops.pack_input(feat.float().contiguous(), c)
-        out = ops.roi_align(x, rois.float(), self.output_size, self.spatial_scale, self.sampling_ratio, self.aligned, out_f32=True)
-        return out.permute(0, 3, 1, 2).contiguous()
+        return ops.roi_align(x, rois.float(), self.output_size, self.spatial_scale, self.sampling_ratio, self.aligned, out_f32=True)
 
 
 @ROI_EXTRACTORS.register_module()
@@ -78,3 +89,98 @@ class SingleRoIExtractor(nn.Module):
             if inds.numel() > 0:
                 roi_feats[inds] = self.roi_layers[i](feats[i], rois[inds])
         return roi_feats
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+@ROI_EXTRACTORS.register_module()
+class TemporalRoIAlign(SingleRoIExtractor, PlannedModule):
+    """mmtracking/mmtrack/models/roi_heads/roi_extractors/temporal_roi_align.py:9-207 (the extractor of the authors' own model,
+    configs/vid/llvod/llvod_fastdvdnet_darkfarm.py:49-59), same constructor and parameter names (`embed_network.conv.*`).
+
+    forward(feats, rois, ref_feats=None): RoIAlign features of the key frame; with `ref_feats` they are blended with the Most Similar
+    RoI features of every reference frame (last pyramid level): cosine similarity of every RoI point with every reference pixel, the
+    `num_most_similar_points` best pixels per reference image, softmax of their cosines, weighted sum of their features; then
+    temporal attention over {key, references} per attention block (or the plain mean with 0 blocks).
+
+    On the device: the similarity maps are ONE launch of the convolution engine (a 1x1 convolution of the L2-normalised reference
+    maps whose `weights` are the L2-normalised RoI points, fp32 out: llv_l2norm_rows_f16 writes them straight into the packed
+    weight layout), the pick + blend is llv_msra_top2_gather, the embed network a 3x3 convolution over the 7x7 RoI maps of all
+    images in one launch, the attention llv_troi_attention_fuse. num_most_similar_points must be 2 (the reference's default and the
+    authors' setting)."""
+
+    def __init__(self, num_most_similar_points=2, num_temporal_attention_blocks=4, *args, **kwargs):
+        SingleRoIExtractor.__init__(self, *args, **kwargs)
+        self._plans = {}
+        if num_most_similar_points != 2:
+            raise NotImplementedError('TemporalRoIAlign: num_most_similar_points = 2 (the reference default) is what the device kernel selects')
+        self.num_most_similar_points = num_most_similar_points
+        self.num_temporal_attention_blocks = num_temporal_attention_blocks
+        if num_temporal_attention_blocks > 0:
+            from .cnn import ConvModule
+            self.embed_network = ConvModule(self.out_channels, self.out_channels, 3, padding=1, conv_cfg=None, norm_cfg=None, act_cfg=None)
+
+    def most_similar_roi_align(self, roi_rows, ref_feats, return_picks=False):
+        """roi_rows (rows, C) fp32 = the RoI points (roi, y, x) x channels; ref_feats (img_n, C, H, W) fp32 -> (img_n, rows, C) fp16
+        (temporal_roi_align.py:98-168)."""
+        L = lib()
+        dev = roi_rows.device
+        rows, c = roi_rows.shape
+        img_n, _, h, w = ref_feats.shape
+        if c % 32:
+            raise LlvError('TemporalRoIAlign: channel count must be a multiple of 32')
+        ref = ops.pack_input(ref_feats.float().contiguous(), c)                       # (img_n, h, w, c) fp16, un-normalised
+        refn = torch.empty_like(ref)
+        check(L.llv_l2norm_rows_f16(ref.data_ptr(), 0, refn.data_ptr(), img_n * h * w, c, c, c, None, _stream()), 'llv_l2norm_rows_f16')
+        cout, w_rows = ops.round_up(rows, 4), ops.round_up(rows, 16)
+        wbuf = torch.zeros((1, w_rows, c), device=dev, dtype=torch.float16)           # the packed-weight layout of a 1x1 conv: [row][k = channel]
+        check(L.llv_l2norm_rows_f16(roi_rows.data_ptr(), 1, wbuf.data_ptr(), rows, c, c, c, None, _stream()), 'llv_l2norm_rows_f16')
+        pc = ops.PackedConv(w=wbuf, bias=torch.zeros(cout, device=dev), cin=c, cout=cout, w_rows=w_rows, k_pad=c, kh=1, kw=1, stride=1, pad=0,
+                            true_macs_per_pixel=rows * c)
+        sim = ops.conv2d(refn, pc, flags=CONV_OUT_F32)                                # (img_n, h, w, cout) fp32 cosines
+        out = torch.empty((img_n, rows, c), device=dev, dtype=torch.float16)
+        idx = torch.empty((img_n, rows, 2), device=dev, dtype=torch.int32) if return_picks else None
+        wts = torch.empty((img_n, rows, 2), device=dev, dtype=torch.float32) if return_picks else None
+        check(L.llv_msra_top2_gather(sim.data_ptr(), ref.data_ptr(), out.data_ptr(), idx.data_ptr() if idx is not None else None,
+                                     wts.data_ptr() if wts is not None else None, img_n, h * w, rows, cout, c, c, _stream()),
+              'llv_msra_top2_gather')
+        return (out, idx, wts, sim) if return_picks else out
+
+    def _embed_pc(self, dev):
+        def make():
+            conv = self.embed_network.conv
+            return ops.pack_conv(conv.weight, conv.bias, 1, 1).to(dev)
+        return self._plan(('embed', str(dev)), make)
+
+    def temporal_attentional_feature_aggregation(self, x_all, roi_hw):
+        """x_all (n_img, rows, C) fp16, image 0 = the key frame's RoI features -> (rows, C) fp32 (temporal_roi_align.py:46-96)."""
+        n_img, rows, c = x_all.shape
+        ph, pw = roi_hw
+        imgs = x_all.view(n_img * (rows // (ph * pw)), ph, pw, c)
+        emb = ops.conv2d(imgs, self._embed_pc(x_all.device))
+        out = torch.empty((rows, c), device=x_all.device, dtype=torch.float32)
+        check(lib().llv_troi_attention_fuse(x_all.data_ptr(), emb.data_ptr(), out.data_ptr(), n_img, rows, c, self.num_temporal_attention_blocks,
+                                            _stream()), 'llv_troi_attention_fuse')
+        return out
+
+    def forward(self, feats, rois, roi_scale_factor=None, ref_feats=None):
+        if ref_feats is None:          # proposals of the reference images: plain RoIAlign (temporal_roi_align.py:184-187)
+            return SingleRoIExtractor.forward(self, feats, rois, roi_scale_factor)
+        if len(feats) != 1:
+            raise LlvError('TemporalRoIAlign with ref_feats: one feature level (featmap_strides of the SELSA configs: [16])')
+        ph, pw = self.roi_layers[0].output_size
+        k = rois.size(0)
+        if k == 0:
+            return feats[0].new_zeros(0, self.out_channels, ph, pw)
+        roi_nhwc = self.roi_layers[0].forward_nhwc(feats[0], rois)                    # (k, ph, pw, C) fp32
+        c = roi_nhwc.shape[-1]
+        roi_rows = roi_nhwc.view(k * ph * pw, c)
+        ref_roi = self.most_similar_roi_align(roi_rows, ref_feats[-1])                # (img_n, rows, C) fp16
+        x_all = torch.cat([roi_rows.to(torch.float16).unsqueeze(0), ref_roi], dim=0).contiguous()
+        if self.num_temporal_attention_blocks > 0:
+            out = self.temporal_attentional_feature_aggregation(x_all, (ph, pw))
+        else:
+            out = x_all.float().mean(dim=0)
+        return out.view(k, ph, pw, c).permute(0, 3, 1, 2).contiguous()

@@ -8,7 +8,7 @@ constructors and parameter names:
 What is native here: RoI features through `llv_roi_align`, detections through `llv_multiclass_nms_batched_ex` with class-specific
 boxes. The fully connected layers and the attention of the aggregator are plain GEMMs and run as torch (rocBLAS / hipBLASLt) calls on
 the device; the element-wise decode is torch on the device. No CPU path: CPU inputs raise. Training (`forward_train`, sampling,
-losses), `TemporalRoIAlign` and the `SELSA` detector class that drives RPN + RoI head over key and reference frames are not built."""
+losses) is not built."""
 import numpy as np
 import torch
 import torch.nn as nn
@@ -142,8 +142,8 @@ class SelsaRoIHead(nn.Module):
         super().__init__()
         if mask_head is not None or shared_head is not None:
             raise NotImplementedError('SelsaRoIHead: mask / shared heads are not on this path')
-        if bbox_roi_extractor.get('type') != 'SingleRoIExtractor':
-            raise NotImplementedError(f"bbox_roi_extractor {bbox_roi_extractor.get('type')}: only SingleRoIExtractor is built")
+        if bbox_roi_extractor.get('type') not in ('SingleRoIExtractor', 'TemporalRoIAlign'):
+            raise NotImplementedError(f"bbox_roi_extractor {bbox_roi_extractor.get('type')}: SingleRoIExtractor and TemporalRoIAlign are built")
         self.bbox_roi_extractor = build(bbox_roi_extractor, ROI_EXTRACTORS)
         self.bbox_head = build(bbox_head, HEADS)
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
@@ -156,7 +156,11 @@ class SelsaRoIHead(nn.Module):
     def _bbox_forward(self, x, ref_x, rois, ref_rois):
         """selsa_roi_head.py:61-78."""
         n_in = self.bbox_roi_extractor.num_inputs
-        bbox_feats = self.bbox_roi_extractor(x[:n_in], rois)
+        from .roi_extractors import TemporalRoIAlign
+        if isinstance(self.bbox_roi_extractor, TemporalRoIAlign):       # selsa_roi_head.py:83-86: the key RoIs also see the reference maps
+            bbox_feats = self.bbox_roi_extractor(x[:n_in], rois, ref_feats=ref_x[:n_in])
+        else:
+            bbox_feats = self.bbox_roi_extractor(x[:n_in], rois)
         ref_bbox_feats = self.bbox_roi_extractor(ref_x[:n_in], ref_rois)
         cls_score, bbox_pred = self.bbox_head(bbox_feats, ref_bbox_feats)
         return dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=bbox_feats)
@@ -209,6 +213,7 @@ class TwoStageDetector(BaseDetector):
             rr.update(train_cfg=train_cfg['rcnn'] if train_cfg is not None else None, test_cfg=test_cfg['rcnn'] if test_cfg is not None else None)
             self.roi_head = build_head(rr)
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.init_weights(pretrained=pretrained)          # two_stage.py:48
 
     with_rpn = property(lambda self: hasattr(self, 'rpn_head') and self.rpn_head is not None)
     with_roi_head = property(lambda self: hasattr(self, 'roi_head') and self.roi_head is not None)
@@ -220,8 +225,17 @@ class TwoStageDetector(BaseDetector):
                 m.init_weights()
 
     def extract_feat(self, img):
+        """two_stage.py:80-95 of the reference tree: when the backbone returns MORE maps than the neck has convs (the authors'
+        config: out_indices=(3, 3) with a one-conv ChannelMapper) the leading maps are handed back beside the neck's output, as
+        (x[:ref_len], neck(x[ref_len:])); otherwise backbone + neck."""
         x = self.backbone(img)
-        return self.neck(x) if self.neck is not None else x
+        if self.neck is None:
+            return x
+        neck_len, backbone_len = len(self.neck.convs), len(self.backbone.out_indices)
+        if neck_len != backbone_len:
+            ref_len = backbone_len - neck_len
+            return tuple(x[:ref_len]), self.neck(tuple(x[ref_len:]))
+        return self.neck(x)
 
     def forward_train(self, *a, **k):
         raise LlvError('two-stage training is not built')
@@ -312,3 +326,129 @@ class SELSA(BaseVideoDetector):
             proposal_list, ref_proposals_list = proposals, ref_proposals
         outs = self.detector.roi_head.simple_test(x, ref_x, proposal_list, ref_proposals_list, img_metas, rescale=rescale)
         return dict(bbox_results=outs[0])
+
+
+@MODELS.register_module()
+class SelsaFastDVDnetDetect(BaseVideoDetector):
+    """The authors' own model (mmtracking/mmtrack/models/vid/selsa_fastdvd_darkfarm.py:17-45; config
+    mmtracking/configs/vid/llvod/llvod_fastdvdnet_darkfarm.py): FastDVDnet in front of the two-stage SELSA detector, same constructor.
+
+    Test time, adaptive stride (:294-319, the config's `test_with_adaptive_stride`): the four reference frames given with frame 0 stay
+    in the memo for the whole video; per key frame the five frames [ref0, ref1, key, ref2, ref3] are denoised, each from the CYCLIC
+    5-stack centred on it (:303-308: 20 DenBlocks in the reference; here one FastDVDnetPlan over the 9-frame cyclic sequence computes
+    the 7 first-stage results it needs once: 12 DenBlocks), all five go through the detector's backbone + neck, the key frame's
+    features are `x`, the other four + the key are the references; RPN on both, SelsaRoIHead (TemporalRoIAlign) on top.
+    The fixed-stride branch (:321-357) is the plain SELSA memo on NOT denoised frames, as the reference has it.
+
+    `plot_bbox` of the reference (:437-451, hard-wired True) draws the detections into ./result_fastdvdnet_out and, as a side
+    effect, multiplies every returned box by img_metas[0]['scale_factor'][0]. The drawing is not reproduced (UI); the multiplication
+    is, so that the returned arrays equal the reference's (`reference_box_rescale=False` turns it off)."""
+
+    reference_box_rescale = True
+
+    def __init__(self, detector, cleaner, pretrains=None, frozen_modules=None, train_cfg=None, test_cfg=None, loss_type=None):
+        super().__init__()
+        from .registry import build_cleaner
+        self.detector = build_detector(detector)
+        self.cleaner = build_cleaner(cleaner)
+        assert hasattr(self.detector, 'roi_head'), 'selsa video detector only supports two stage detector'
+        self.train_cfg, self.test_cfg, self.loss_type = train_cfg, test_cfg, loss_type
+        self.memo = None
+        self.init_weights(pretrains)
+        if frozen_modules is not None:
+            self.freeze_module(frozen_modules)
+
+    def init_weights(self, pretrain):
+        """selsa_fastdvd_darkfarm.py:47-63"""
+        if pretrain is None:
+            pretrain = dict()
+        assert isinstance(pretrain, dict), '`pretrain` must be a dict.'
+        if self.with_detector and pretrain.get('detector', False):
+            self.init_module('detector', pretrain['detector'])
+        if self.with_cleaner and pretrain.get('cleaner', False):
+            self.init_module('cleaner', pretrain['cleaner'])
+
+    def invalidate_plans(self):
+        super().invalidate_plans()
+        self.memo = None
+
+    def forward_train(self, *a, **k):
+        raise LlvError('SelsaFastDVDnetDetect.forward_train: the two-stage training path is not built')
+
+    def denoise_cyclic(self, noise_imgs):
+        """noise_imgs (5, 3, H, W) fp32 on the GPU -> (5, 3, H, W): frame i denoised from the stack of frames (i-2 .. i+2) mod 5
+        (selsa_fastdvd_darkfarm.py:303-308), through engine.FastDVDnetPlan on the 9-frame sequence [3, 4, 0, 1, 2, 3, 4, 0, 1]."""
+        from . import engine
+        n, c, h, w = noise_imgs.shape
+        assert n == 5 and c == 3
+        plan = self._plan(('den5', h, w, str(noise_imgs.device)), lambda: engine.FastDVDnetPlan(self.cleaner.state_dict(), 5, h, w, noise_imgs.device))
+        idx = torch.tensor([3, 4, 0, 1, 2, 3, 4, 0, 1], device=noise_imgs.device)
+        ops.pack_input(noise_imgs.float()[idx].contiguous(), 8, out=plan.frames)
+        plan.plan.run()
+        return ops.unpack_output(plan.out, 3)
+
+    def extract_feats(self, img, img_metas, ref_img, ref_img_metas):
+        """selsa_fastdvd_darkfarm.py:229-359."""
+        frame_id = img_metas[0].get('frame_id', -1)
+        assert frame_id >= 0
+        num_left_ref_imgs = img_metas[0].get('num_left_ref_imgs', -1)
+        frame_stride = img_metas[0].get('frame_stride', -1)
+        if frame_stride < 1:
+            if frame_id == 0:
+                assert ref_img is not None and ref_img[0].shape[0] == 4, 'FastDVDnet support frames is 4.'
+                self.memo = dict(img_metas=list(ref_img_metas[0]), ref_imgs=ref_img[0])
+            refs = self.memo['ref_imgs']
+            noise_imgs = torch.cat([refs[:2], img, refs[2:]], dim=0)
+            den = self.denoise_cyclic(noise_imgs)
+            _, all_x = self.detector.extract_feat(den)
+            self.memo['denoising_img'] = den[[2]]
+            x = [a[[2]] for a in all_x]
+            ref_x = [torch.cat([a[:2], a[3:], a[[2]]], dim=0) for a in all_x]
+            ref_metas = list(self.memo['img_metas']) + list(img_metas)
+        else:
+            if frame_id == 0:
+                _, ref = self.detector.extract_feat(ref_img[0])
+                self.memo = dict(img=ref_img[0], img_metas=list(ref_img_metas[0]), feats=list(ref))
+                x = [r[[num_left_ref_imgs]] for r in ref]
+            elif frame_id % frame_stride == 0:
+                assert ref_img is not None
+                ref_imgs = torch.cat([self.memo['img'], ref_img[0]], dim=0)[1:]
+                _, ref = self.detector.extract_feat(ref_imgs)
+                x = []
+                for i in range(len(ref)):
+                    self.memo['feats'][i] = ref[i]
+                    x.append(ref[i][[num_left_ref_imgs]])
+                self.memo['img_metas'] = (self.memo['img_metas'] + list(ref_img_metas[0]))[1:]
+                self.memo['img'] = ref_imgs
+            else:
+                assert ref_img is None
+                _, x = self.detector.extract_feat(img)       # the reference indexes ref_img (None) here and cannot run this branch
+            ref_x = [f.clone() for f in self.memo['feats']]
+            for i in range(len(x)):
+                ref_x[i][num_left_ref_imgs] = x[i][0]
+            ref_metas = list(self.memo['img_metas'])
+            ref_metas[num_left_ref_imgs] = img_metas[0]
+        return tuple(x), img_metas, tuple(ref_x), ref_metas
+
+    def simple_test(self, img, img_metas, ref_img=None, ref_img_metas=None, proposals=None, ref_proposals=None, rescale=False):
+        """selsa_fastdvd_darkfarm.py:361-453. Returns {'bbox_results': list[num_classes] of (k, 5) arrays}."""
+        self._check_input(img)
+        if ref_img is not None:
+            ref_img = ref_img[0]
+        if ref_img_metas is not None:
+            ref_img_metas = ref_img_metas[0]
+        x, img_metas, ref_x, ref_img_metas = self.extract_feats(img, img_metas, ref_img, ref_img_metas)
+        if proposals is None:
+            proposal_list = self.detector.rpn_head.simple_test_rpn(x, img_metas)
+            ref_proposals_list = self.detector.rpn_head.simple_test_rpn(ref_x, ref_img_metas)
+        else:
+            proposal_list, ref_proposals_list = proposals, ref_proposals
+        outs = self.detector.roi_head.simple_test(x, ref_x, proposal_list, ref_proposals_list, img_metas, rescale=rescale)
+        res = outs[0]
+        if self.reference_box_rescale:
+            sf = float(np.asarray(img_metas[0]['scale_factor'], dtype=np.float32).reshape(-1)[0])
+            res = [np.concatenate([r[:, :4] * sf, r[:, [4]]], axis=1) for r in res]
+        return dict(bbox_results=res)
+
+    def aug_test(self, imgs, img_metas, **kwargs):
+        raise NotImplementedError('test-time augmentation is outside the hot path')

@@ -287,6 +287,46 @@ def test_zero_copy_windows_equal_copied_windows(dev, B, use_graph):
         zc.step(clip.clone(), 0)                          # not the bound clip
 
 
+@pytest.mark.parametrize('B,use_graph', [(1, True), (2, False)])
+def test_pipelined_streaming_equals_sequential_streaming(dev, B, use_graph):
+    """engine.PipelinedStreamingPlan (per-frame protocol: FastDVDnet streaming step of window i || detector of window i-1 on two
+    HIP streams, one FastDVDnet plan, two detector plans, windows read in place) returns, window by window, the detections of the
+    sequential streaming step bit for bit -- one step later."""
+    reg = _registry()
+    from lowlightenvironmentvideoobjectdetection_amd import engine, ops
+    from lowlightenvironmentvideoobjectdetection_amd.synthetic import seeded_weights
+    ncls, h, w, T = 4, 64, 96, 12
+    det = seeded_weights(reg.build_detector(retinanet_cfg(num_classes=ncls)), seed=61, cls_bias=-1.0)
+    cleaner = seeded_weights(reg.build_cleaner(dict(type='FastDVDnet')), seed=62)
+    g = torch.Generator().manual_seed(63)
+    frames = smooth_image(T + 4, h, w, seed=64) + 0.2 * torch.randn(T + 4, 3, h, w, generator=g)
+    clip = ops.pack_input(frames.to(dev), 8)
+    kw = dict(detector_kwargs=dict(test_cfg=dict(det.bbox_head.test_cfg)), use_graph=use_graph)
+    seq = engine.EnhanceDetectPlan(cleaner.state_dict(), det.state_dict(), ncls, B, h, w, dev, **kw)
+    seq.prepare(clip)
+    seq.prepare_stream()
+    pipe = engine.PipelinedStreamingPlan(cleaner.state_dict(), det.state_dict(), ncls, B, h, w, dev, **kw)
+    pipe.prepare(clip)
+    starts = list(range(0, T - B + 1, B))
+    ref = []
+    for i, t0 in enumerate(starts):
+        seq.step(clip, t0, carry=i > 0)
+        ref.append([(d.clone(), l.clone()) for d, l in seq.results()])
+    assert sum(len(d) for r in ref for d, _ in r) > 20
+    got = []
+    for i, t0 in enumerate(starts):
+        pipe.step(clip, t0, carry=i > 0)
+        if i > 0:
+            got.append(pipe.results())
+    pipe.flush()
+    got.append(pipe.results())
+    assert len(got) == len(ref)
+    for r, q in zip(ref, got):
+        for (d0, l0), (d1, l1) in zip(r, q):
+            assert torch.equal(d0, d1) and torch.equal(l0, l1)
+    assert ops.guard_trips() == 0
+
+
 def test_resnet_dc5_dilated_stage_vs_oracle(dev):
     """The backbone of the reference's SELSA configs (mmtracking/configs/vid/llvod/*.py: strides (1, 2, 2, 1), dilations (1, 1, 1, 2),
     out_indices (3,)): the last stage keeps stride 16 with dilated 3x3 convs (`llv_conv_desc.dilation`)."""

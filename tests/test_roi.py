@@ -90,3 +90,54 @@ def test_single_roi_extractor_vs_oracle(dev):
         ref[sel] = roi_align(feats[i], rois[sel], 7, 1 / s, 2, True)
     out = m(tuple(f.to(dev) for f in feats), rois.to(dev)).cpu()
     assert out.shape == ref.shape and (out - ref).abs().max().item() < 2e-3 * ref.abs().max().item()
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize('blocks', [4, 0])
+def test_temporal_roi_align_vs_oracle(dev, blocks):
+    """TemporalRoIAlign (temporal_roi_align.py:46-207; the extractor of the authors' config) on the device -- similarity maps on the
+    conv engine, llv_msra_top2_gather, 3x3 embed conv over the 7x7 RoI maps, llv_troi_attention_fuse -- against oracle/selsa.py.
+    The cosines are formed from fp16-rounded unit vectors: where the oracle's 2nd and 3rd best pixels are closer than that rounding,
+    the pick may differ (and with it the blended feature vector), so picks must agree for >= 97 % of the (RoI point, image) pairs and
+    the values are compared on the agreeing ones; without reference maps the module is plain RoIAlign."""
+    import lowlightenvironmentvideoobjectdetection_amd.models  # noqa: F401
+    from lowlightenvironmentvideoobjectdetection_amd import registry
+    from oracle.selsa import most_similar_roi_align, temporal_roi_align
+    from oracle.roi import roi_align
+    C, H, W, NREF = 64, 24, 40, 3
+    ext = registry.build(dict(type='TemporalRoIAlign', num_most_similar_points=2, num_temporal_attention_blocks=blocks,
+                              roi_layer=dict(type='RoIAlign', output_size=7, sampling_ratio=2), out_channels=C, featmap_strides=[16]),
+                         registry.ROI_EXTRACTORS)
+    g = torch.Generator().manual_seed(5 + blocks)
+    if blocks:
+        with torch.no_grad():
+            ext.embed_network.conv.weight.copy_(torch.randn(C, C, 3, 3, generator=g) * (2.0 / (9 * C)) ** 0.5)
+            ext.embed_network.conv.bias.copy_(torch.randn(C, generator=g) * 0.1)
+    feat = torch.randn(1, C, H, W, generator=g)
+    ref = torch.randn(NREF, C, H, W, generator=g)
+    rois = torch.tensor([[0, 10., 12., 200., 150.], [0, 300., 40., 520., 300.], [0, 0., 0., 639., 383.], [0, 100., 200., 140., 260.],
+                         [0, 400., 100., 480., 140.]])
+    sd = {'e.' + k: v.detach().float() for k, v in ext.state_dict().items()}
+    ext = ext.to(dev)
+    # (1) no reference maps: RoIAlign
+    plain = ext((feat.to(dev),), rois.to(dev)).cpu()
+    assert (plain - roi_align(feat, rois, 7, 1 / 16, 2, True)).abs().max().item() < 2e-3 * feat.abs().max().item()
+    # (2) the picks and the blended Most Similar RoI features
+    rf = roi_align(feat.half().float(), rois, 7, 1 / 16, 2, True)
+    o_ref, o_idx, o_w, o_cos = most_similar_roi_align(rf, ref.half().float())
+    rows = rois.shape[0] * 49
+    got, idx, wts, sim = ext.most_similar_roi_align(rf.permute(0, 2, 3, 1).reshape(rows, C).contiguous().to(dev), ref.to(dev), return_picks=True)
+    torch.cuda.synchronize()
+    sim = sim.cpu().view(NREF, H * W, -1)[:, :, :rows].permute(0, 2, 1)                # (img, row, pixel)
+    assert (sim - o_cos).abs().max().item() < 2e-3                                      # cosines of fp16-rounded unit vectors
+    agree = (idx.cpu().long() == o_idx).all(-1)
+    assert agree.float().mean().item() >= 0.97, agree.float().mean().item()
+    assert (wts.cpu()[agree] - o_w[agree]).abs().max().item() < 2e-3
+    o_rows = o_ref.permute(0, 1, 3, 4, 2).reshape(NREF, rows, C)
+    assert (got.float().cpu()[agree] - o_rows[agree]).abs().max().item() < 1e-2 * o_rows.abs().max().item()
+    # (3) the whole module
+    out = ext((feat.to(dev),), rois.to(dev), ref_feats=(ref.to(dev),)).cpu()
+    exp = temporal_roi_align(sd, 'e.', feat, rois, ref, 16, blocks)
+    assert out.shape == exp.shape == (rois.shape[0], C, 7, 7)
+    err = (out - exp).abs().amax(dim=1) / exp.abs().max()                               # per RoI point
+    assert (err < 2e-2).float().mean().item() >= 0.9, (err < 2e-2).float().mean().item()
