@@ -159,8 +159,44 @@ class FastDVDnetDetect(BaseVideoDetector):
                                  target_means=d.bbox_head.bbox_coder.means, target_stds=d.bbox_head.bbox_coder.stds),
             use_graph=use_graph)
 
-    def forward_train(self, img, img_metas, **kwargs):
-        raise LlvError('FastDVDnetDetect.forward_train: the training path is not built yet in this round')
+    def denoise_cyclic(self, noise_imgs):
+        """(5, 3, H, W) fp32 on the GPU -> (5, 3, H, W): frame i denoised from the stack of frames (i-2 .. i+2) mod 5
+        (selsa_fastdvd_darkfarm.py:190-196,303-308), one FastDVDnetPlan over the 9-frame cyclic sequence [3, 4, 0, 1, 2, 3, 4, 0, 1]."""
+        n, c, h, w = noise_imgs.shape
+        assert n == 5 and c == 3
+        plan = self._plan(('den5', h, w, str(noise_imgs.device)), lambda: engine.FastDVDnetPlan(self.cleaner.state_dict(), 5, h, w, noise_imgs.device))
+        idx = torch.tensor([3, 4, 0, 1, 2, 3, 4, 0, 1], device=noise_imgs.device)
+        ops.pack_input(noise_imgs.float()[idx].contiguous(), 8, out=plan.frames)
+        plan.plan.run()
+        return ops.unpack_output(plan.out, 3)
+
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, ref_img, ref_img_metas=None, ref_gt_bboxes=None, ref_gt_labels=None,
+                      gt_bboxes_ignore=None, **kwargs):
+        """selsa_fastdvd_darkfarm.py:64-227 for a dense-head detector: `img` (1, 6, H, W) = noisy | clean frame stacked on the channel
+        axis, `ref_img` (1, 4, 6, H, W) the four reference frames likewise. The five noisy frames are denoised from their cyclic
+        5-stacks, `loss_denoising_<loss_type>` compares them with the clean ones, the detector is trained on the denoised key frame
+        (single_stage.py:68-96 through the device training graph). The cleaner must be frozen (`frozen_modules='cleaner'`, as in the
+        authors' config): its gradient path is not built."""
+        self._check_input(img)
+        assert len(img) == 1, 'selsa video detector only supports 1 batch size per gpu for now.'
+        assert ref_img.shape[1] == 4, 'FastDVDnet support frames is 4.'
+        if any(p.requires_grad for p in self.cleaner.parameters()):
+            raise LlvError("FastDVDnetDetect.forward_train: freeze the cleaner (frozen_modules='cleaner'); training it is not built")
+        if img.shape[1] % 4 == 0:
+            raise LlvError('FastDVDnetDetect.forward_train: 4-channel RAW input is outside the hot path')
+        noise_img, clean_img = img[:, :3], img[:, 3:]
+        noise_ref, clean_ref = ref_img[0][:, :3], ref_img[0][:, 3:]
+        clean_imgs = torch.cat([clean_ref[:2], clean_img, clean_ref[2:]], dim=0)
+        noise_imgs = torch.cat([noise_ref[:2], noise_img, noise_ref[2:]], dim=0)
+        den = self.denoise_cyclic(noise_imgs)
+        losses = dict()
+        fn = dict(l1=torch.nn.functional.l1_loss, l2=torch.nn.functional.mse_loss, smooth_l1=torch.nn.functional.smooth_l1_loss).get(self.loss_type)
+        if fn is None:
+            raise NotImplementedError(f'loss_type {self.loss_type}')
+        losses[f'loss_denoising_{self.loss_type}'] = fn(den, clean_imgs.float())
+        from .training import single_stage_forward_train
+        losses.update(single_stage_forward_train(self.detector, den[[2]].contiguous(), img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore))
+        return losses
 
     def simple_test(self, img, img_metas, ref_img=None, ref_img_metas=None, rescale=False, **kwargs):
         self._check_input(img)

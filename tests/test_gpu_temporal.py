@@ -295,3 +295,74 @@ def test_fastdvdnet_detect_model_api_vs_oracle(dev):
     frac, n = match_detections(res, oracle([idx0[0], idx0[1], 3, idx0[3], idx0[4]]))
     assert n > 5 and frac >= 0.8
     assert tot > 40
+
+
+def test_fastdvdnet_detect_forward_train_vs_oracle(dev):
+    """FastDVDnetDetect.forward_train (the dense-head form of selsa_fastdvd_darkfarm.py:64-227, row a16): noisy | clean frames stacked
+    on the channel axis, cyclic 5-stacks through the frozen FastDVDnet, loss_denoising_l2 against the clean frames, detector losses
+    on the denoised key frame; `.backward()` fills the detector's gradients through the device backward pass. Against the oracle:
+    FastDVDnet + RetinaNet forward + retina_loss in fp32 with torch autograd."""
+    import lowlightenvironmentvideoobjectdetection_amd.models as M
+    from lowlightenvironmentvideoobjectdetection_amd._lib import LlvError
+    from oracle import detector as OD
+    from oracle.anchors import AnchorGenerator
+    from oracle.cleaner import fastdvdnet_forward
+    from oracle.training import retina_loss
+    H, W, NC = 96, 128, 4
+    dcfg = retinanet_cfg(num_classes=NC, depth=18, in_channels=(64, 128, 256, 512), stacked_convs=2, feat=64)
+    dcfg['train_cfg'] = dict(assigner=dict(type='MaxIoUAssigner', pos_iou_thr=0.5, neg_iou_thr=0.4, min_pos_iou=0, ignore_iof_thr=-1),
+                             allowed_border=-1, pos_weight=-1, debug=False)
+    model = M.build_model(dict(type='FastDVDnetDetect', detector=dcfg, cleaner=dict(type='FastDVDnet'), frozen_modules='cleaner', loss_type='l2'))
+    randomize(model.cleaner, seed=71)
+    randomize(model.detector, seed=72, cls_bias=-2.0)
+    g = torch.Generator().manual_seed(73)
+    clean = smooth_image(5, H, W, seed=74)
+    noise = clean + 0.25 * torch.randn(5, 3, H, W, generator=g)
+    both = torch.cat([noise, clean], 1)                         # (5, 6, H, W): frame order [ref0, ref1, key, ref2, ref3]
+    img, ref_img = both[[2]], both[[0, 1, 3, 4]].unsqueeze(0)
+    metas = [dict(img_shape=(H, W, 3), pad_shape=(H, W, 3), scale_factor=1.0)]
+    gtb, gtl = [torch.tensor([[10., 12., 70., 80.], [60., 30., 120., 90.]])], [torch.tensor([1, 3])]
+    # ---- oracle
+    sd = {k: v.detach().clone().float() for k, v in model.state_dict().items()}
+    sd_c = {k[len('cleaner.'):]: v for k, v in sd.items() if k.startswith('cleaner.')}
+    sd_d = {k[len('detector.'):]: v for k, v in sd.items() if k.startswith('detector.')}
+    names = [n for n, p in model.detector.named_parameters()]
+    for n in names:
+        sd_d[n].requires_grad_(True)
+    stacks = torch.cat([torch.cat([noise[[(i + j) % 5]] for j in (-2, -1, 0, 1, 2)], 1) for i in range(5)], 0)
+    with torch.no_grad():
+        den = fastdvdnet_forward(sd_c, stacks)
+    outs = OD.fpn_forward(sd_d, OD.resnet_forward(sd_d, den[[2]], depth=18))
+    cls, reg = OD.retina_head_forward(sd_d, outs, stacked_convs=2)
+    ag = AnchorGenerator(octave_base_scale=4, scales_per_octave=3, ratios=[0.5, 1.0, 2.0], strides=[8, 16, 32, 64, 128])
+    ref = retina_loss(cls, reg, gtb, gtl, metas, ag, NC)
+    ref_total = sum(ref['loss_cls']) + sum(ref['loss_bbox'])
+    ref_total.backward()
+    ref_den_loss = torch.nn.functional.mse_loss(den, clean).item()
+    # ---- device
+    model = model.to(dev)
+    losses = model(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in gtb], gt_labels=[l.to(dev) for l in gtl],
+                   ref_img=ref_img.to(dev), ref_img_metas=[[metas[0]] * 4], return_loss=True)
+    assert set(losses) == {'loss_denoising_l2', 'loss_cls', 'loss_bbox'}
+    assert abs(losses['loss_denoising_l2'].item() - ref_den_loss) < 2e-2 * ref_den_loss
+    total = sum(losses['loss_cls']) + sum(losses['loss_bbox'])
+    assert abs(total.item() - ref_total.item()) < 3e-2 * abs(ref_total.item())
+    total.backward()
+    params = dict(model.detector.named_parameters())
+    checked = 0
+    for k in ('bbox_head.retina_cls.weight', 'bbox_head.cls_convs.1.conv.weight', 'neck.lateral_convs.1.conv.weight', 'backbone.layer4.1.conv2.weight',
+              'backbone.layer2.0.conv1.weight', 'backbone.layer3.1.bn2.weight'):
+        gdev, gref = params[k].grad, sd_d[k].grad
+        assert gdev is not None and gref is not None, k
+        scale = gref.abs().max().item()
+        assert (gdev.float().cpu() - gref).abs().max().item() < 6e-2 * scale, k
+        checked += 1
+    assert checked == 6 and all(p.grad is None for p in model.cleaner.parameters())
+    # parse_losses / train_step go through unchanged (base.py:158-220)
+    out = model.train_step(dict(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in gtb], gt_labels=[l.to(dev) for l in gtl],
+                                ref_img=ref_img.to(dev), ref_img_metas=[[metas[0]] * 4]), None)
+    assert set(out) == {'loss', 'log_vars', 'num_samples'} and 'loss_denoising_l2' in out['log_vars']
+    for p in model.cleaner.parameters():
+        p.requires_grad_(True)
+    with pytest.raises(LlvError, match='freeze the cleaner'):
+        model(img=img.to(dev), img_metas=metas, gt_bboxes=gtb, gt_labels=gtl, ref_img=ref_img.to(dev), return_loss=True)
