@@ -606,6 +606,7 @@ def main():
     if args.pipeline:
         plan.flush()
     n_det = sum(len(d) for d, _ in plan.results())
+    trips = {'throughput': ops.guard_trips()}            # capacity guards of decode / NMS that fired so far (0 = consistent inputs)
     last = plan.p[plan._i & 1] if args.pipeline else plan
     # batch-1 latency mode (the reference's per-frame protocol: 3 temp1 + 1 temp2 DenBlocks per frame)
     lat = None
@@ -625,6 +626,7 @@ def main():
             p1.step(clip, (args.warmup + s_) % T)
         torch.cuda.synchronize()
         d1 = time.perf_counter() - t1
+        trips['latency'] = ops.guard_trips()
         lat = {'frames_per_step': 1, 'frames': nlat, 'denblocks_per_frame': 4, 'value': round(nlat / d1, 3), 'unit': 'frames/s',
                'ms_per_frame': round(d1 / nlat * 1e3, 4), 'algorithmic_gflop_per_frame': round(p1.plan.flops / 1e9, 1)}
         # streaming mode: consecutive frames of one video, the two first-stage DenBlock results a frame shares with its
@@ -642,6 +644,7 @@ def main():
             p1.step(clip, t0_, carry=t0_ != 0)
         torch.cuda.synchronize()
         d1 = time.perf_counter() - t1
+        trips['streaming'] = ops.guard_trips()
         stream = {'frames_per_step': 1, 'frames': nlat, 'denblocks_per_frame': round((4 * full_steps + 2 * (nlat - full_steps)) / nlat, 3),
                   'value': round(nlat / d1, 3), 'unit': 'frames/s', 'ms_per_frame': round(d1 / nlat * 1e3, 4),
                   'note': 'consecutive frames of one video; first-stage DenBlock results shared with the previous frame are carried over'}
@@ -664,6 +667,7 @@ def main():
         pp.flush()
         torch.cuda.synchronize()
         d1 = time.perf_counter() - t1
+        trips['streaming_pipelined'] = ops.guard_trips()
         stream_pipe = {'frames_per_step': 1, 'frames': nlat, 'denblocks_per_frame': round((4 * full_steps + 2 * (nlat - full_steps)) / nlat, 3),
                        'value': round(nlat / d1, 3), 'unit': 'frames/s', 'ms_per_frame': round(d1 / nlat * 1e3, 4),
                        'note': 'streaming_mode with FastDVDnet(frame i) and the detector(frame i-1) on two HIP streams; detections of a '
@@ -689,7 +693,7 @@ def main():
                              if args.pipeline else 'none'),
                 'algorithmic_gflop_per_frame': round(flops_step / B / 1e9, 1),
                 'candidates_above_score_thr': n_cand_thr, 'detections_last_step': n_det,
-                'postprocess_guard_trips': ops.guard_trips(),
+                'postprocess_guard_trips': ops.guard_trips(), 'postprocess_guard_trips_after_phase': trips,
                 'parallelism': f'clip-sharded x{world}, no data-path collective',
             },
         }

@@ -393,6 +393,25 @@ int llv_msra_top2_gather(const float* sim, const void* ref, void* out, int32_t* 
                          int sim_ld, int c, int ref_ld, void* stream);
 int llv_troi_attention_fuse(const void* x, const void* emb, float* out, int n_img, int64_t rows, int c, int blocks, void* stream);
 
+/* One whole stride-1 Bottleneck (mmdet/models/backbones/resnet.py:260-299 with no downsample, dilation 1, plugins off; eval-mode
+ * BatchNorm folded into the weights as llv_conv2d_nhwc_fwd's callers do): y = relu(conv3(relu(conv2(relu(conv1(x))))) + x) in a single
+ * launch that keeps both narrow intermediates in LDS. x, y: (batch, h, w, 4*mid) NHWC fp16 with row strides x_ld / y_ld (elements,
+ * multiples of 8); x and y must not alias. w1 [mid][4*mid], w2 [mid][9*mid] (k = (ky*3 + kx)*mid + c), w3 [4*mid][mid] fp16;
+ * b1, b2 [mid], b3 [4*mid] fp32. mid = 64 or 128 (ResNet-50/101/152 layer1 and layer2); LLV_E_UNSUPPORTED otherwise. */
+typedef struct llv_bottleneck_desc {
+    const void* x;
+    void* y;
+    const void* w1;
+    const void* w2;
+    const void* w3;
+    const float* b1;
+    const float* b2;
+    const float* b3;
+    int32_t batch, h, w, mid;
+    int32_t x_ld, y_ld;
+} llv_bottleneck_desc;
+int llv_bottleneck_fwd(const llv_bottleneck_desc* desc, void* stream);
+
 /* True/false-positive marking of eval_map (mean_ap.py:268-400 calls tpfp_default :154-244 or, for datasets 'det'/'vid',
  * tpfp_imagenet :60-151 once per class and image): all (class, image) cells in one launch, one wavefront per cell.
  * dets [total_dets][5] fp32 (x1,y1,x2,y2,score); cell c owns dets[det_off[c] .. det_off[c+1]) and gts[gt_off[c] .. gt_off[c+1])

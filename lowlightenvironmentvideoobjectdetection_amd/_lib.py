@@ -47,6 +47,14 @@ class Extents(C.Structure):
         return d
 
 
+class BottleneckDesc(C.Structure):
+    """llv_bottleneck_desc (include/llv.h)."""
+    _fields_ = [('x', C.c_void_p), ('y', C.c_void_p), ('w1', C.c_void_p), ('w2', C.c_void_p), ('w3', C.c_void_p),
+                ('b1', C.c_void_p), ('b2', C.c_void_p), ('b3', C.c_void_p),
+                ('batch', C.c_int32), ('h', C.c_int32), ('w', C.c_int32), ('mid', C.c_int32),
+                ('x_ld', C.c_int32), ('y_ld', C.c_int32)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [
         ('x', C.c_void_p * LLV_MAX_SRC),
@@ -162,6 +170,7 @@ SIGNATURES = {
     'llv_l2norm_rows_f16': (_I, [_P, _I, _P, _L, _I, _L, _L, _P, _P]),
     'llv_msra_top2_gather': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'llv_troi_attention_fuse': (_I, [_P, _P, _P, _I, _L, _I, _I, _P]),
+    'llv_bottleneck_fwd': (_I, [C.POINTER(BottleneckDesc), _P]),
     'llv_eval_tpfp': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _F, _I, _L, _P, _P, _P]),
     'llv_conv2d_nhwc_wgrad': (_I, [C.POINTER(ConvDesc), _P, _I, _P, _P, _P]),
     'llv_conv2d_nhwc_dgrad': (_I, [C.POINTER(ConvDesc), _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _Z, _P]),

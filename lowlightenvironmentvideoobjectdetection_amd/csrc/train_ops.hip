@@ -22,9 +22,16 @@ __global__ void focal_fwd_kernel(const float* __restrict__ x, const int64_t* __r
         const long r = i / c;
         const int cls = (int)(i - r * c);
         const bool pos = t[r] == (int64_t)cls;
-        const float p = 1.f / (1.f + expf(-x[i]));
-        const float term_p = powf(1.f - p, gamma) * logf(fmaxf(p, FLT_MIN));
-        const float term_n = powf(p, gamma) * logf(fmaxf(1.f - p, FLT_MIN));
+        const float xi = x[i];
+        const float p = 1.f / (1.f + expf(-xi));
+        // log(p) and log(1 - p) as -softplus(-x) and -softplus(x): the reference's CPU path (py_sigmoid_focal_loss, focal_loss.py:11-56:
+        // binary_cross_entropy_with_logits times the modulating factor) is exact for any logit, whereas the published mmcv CUDA form
+        // log(max(1 - p, FLT_MIN)) saturates at -87.3 as soon as 1 - sigmoid(x) rounds to zero (x > 16.6: a negative with logit 20
+        // costs 65 instead of 15). North star: match the reference CPU path.
+        const float sp = log1pf(expf(-fabsf(xi)));
+        const float log_p = -(fmaxf(-xi, 0.f) + sp), log_1mp = -(fmaxf(xi, 0.f) + sp);
+        const float term_p = powf(1.f - p, gamma) * log_p;
+        const float term_n = powf(p, gamma) * log_1mp;
         out[i] = pos ? -alpha * term_p : -(1.f - alpha) * term_n;
     }
 }
@@ -36,9 +43,12 @@ __global__ void focal_bwd_kernel(const float* __restrict__ x, const int64_t* __r
         const long r = i / c;
         const int cls = (int)(i - r * c);
         const bool pos = t[r] == (int64_t)cls;
-        const float p = 1.f / (1.f + expf(-x[i]));
-        const float gp = powf(1.f - p, gamma) * (1.f - p - gamma * p * logf(fmaxf(p, FLT_MIN)));
-        const float gn = powf(p, gamma) * (gamma * (1.f - p) * logf(fmaxf(1.f - p, FLT_MIN)) - p);
+        const float xi = x[i];
+        const float p = 1.f / (1.f + expf(-xi));
+        const float sp = log1pf(expf(-fabsf(xi)));
+        const float log_p = -(fmaxf(-xi, 0.f) + sp), log_1mp = -(fmaxf(xi, 0.f) + sp);
+        const float gp = powf(1.f - p, gamma) * (1.f - p - gamma * p * log_p);
+        const float gn = powf(p, gamma) * (gamma * (1.f - p) * log_1mp - p);
         g[i] = pos ? -alpha * gp : -(1.f - alpha) * gn;
     }
 }

@@ -111,6 +111,15 @@ class Plan:
             if getattr(fn, '__name__', '') in ('llv_conv2d_nhwc_fwd', 'llv_inputcvblock_fwd', 'llv_outputcvblock_fwd'):
                 for (ptr, need, have) in ops.extents_violations(args[0]._obj):
                     bad.append((name, ptr, need, have))
+            elif getattr(fn, '__name__', '') == 'llv_bottleneck_fwd':
+                # closed form (bottleneck.hip): in-image pixels x all channels of x and y, whole weight / bias arrays
+                d = args[0]._obj
+                c, px = 4 * d.mid, d.batch * d.h * d.w
+                need = dict(x=((px - 1) * d.x_ld + c) * 2, y=((px - 1) * d.y_ld + c) * 2, w1=d.mid * c * 2, w2=9 * d.mid * d.mid * 2,
+                            w3=c * d.mid * 2, b1=d.mid * 4, b2=d.mid * 4, b3=c * 4)
+                for k, v in need.items():
+                    if v > d._have[k]:
+                        bad.append((name, k, v, d._have[k]))
         return bad
 
     @property
@@ -178,6 +187,27 @@ class Builder:
                        res.shape[-1] if res is not None else 0, flags, res_hw, tile)
         return out
 
+    def bottleneck(self, name, x, pc1, pc2, pc3):
+        """A stride-1 Bottleneck without downsample as ONE launch (llv_bottleneck_fwd): both narrow intermediates stay in LDS."""
+        from ._lib import BottleneckDesc
+        n, h, w, c = x.shape
+        mid = pc1.cout
+        assert pc3.cout == c == 4 * mid and pc2.cin == mid and pc1.k_pad == c and pc2.k_pad == 9 * mid and pc3.k_pad == mid
+        out = self.buf(n, h, w, c)
+        for pc in (pc1, pc2, pc3):
+            pc.to(self.dev)
+        d = BottleneckDesc(x=x.data_ptr(), y=out.data_ptr(), w1=pc1.w.data_ptr(), w2=pc2.w.data_ptr(), w3=pc3.w.data_ptr(),
+                           b1=pc1.bias.data_ptr(), b2=pc2.bias.data_ptr(), b3=pc3.bias.data_ptr(),
+                           batch=n, h=h, w=w, mid=mid, x_ld=c, y_ld=c)
+        d._have = dict(x=ops.tensor_extent(x), y=ops.tensor_extent(out), w1=ops.tensor_extent(pc1.w), w2=ops.tensor_extent(pc2.w),
+                       w3=ops.tensor_extent(pc3.w), b1=ops.tensor_extent(pc1.bias), b2=ops.tensor_extent(pc2.bias), b3=ops.tensor_extent(pc3.bias))
+        px = n * h * w
+        flops = 2.0 * px * (pc1.true_macs_per_pixel + pc2.true_macs_per_pixel + pc3.true_macs_per_pixel)
+        nbytes = 2.0 * 2 * px * c + 2.0 * (pc1.w.numel() + pc2.w.numel() + pc3.w.numel())
+        self.plan.keep += [pc1, pc2, pc3, d, x, out]
+        self.plan.add(name, lib().llv_bottleneck_fwd, (C.byref(d),), flops, nbytes, kernel='bottleneck_kernel')
+        return out
+
     def maxpool(self, name, x):
         n, h, w, c = x.shape
         out = self.buf(n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c)
@@ -201,10 +231,11 @@ def _cpu_sd(sd):
 
 
 def build_resnet(b: Builder, sd, x, depth=50, strides=(1, 2, 2, 2), style='pytorch', out_indices=(0, 1, 2, 3), p='',
-                 num_stages=4, after_stage=None, dilations=(1, 1, 1, 1)):
+                 num_stages=4, after_stage=None, dilations=(1, 1, 1, 1), fuse_blocks=False):
     """x: (N,H,W,8) fp16 NHWC normalised image (3 real channels). Returns the out_indices stage outputs.
     resnet.py:622-640 with every BatchNorm folded (norm_eval, running stats) and ReLU / identity-add fused
-    into the producing conv's epilogue."""
+    into the producing conv's epilogue. fuse_blocks (inference plans only: the training tape needs every activation) runs
+    the stride-1 blocks of layer1 / layer2 as one launch each (Builder.bottleneck)."""
     kind, blocks = ARCH[depth]
     blocks = blocks[:num_stages]
     # stem: 7x7/s2 conv (Cin 3 -> padded 8) + BN + ReLU, then 3x3/s2 max pool (resnet.py:559-570)
@@ -220,7 +251,13 @@ def build_resnet(b: Builder, sd, x, depth=50, strides=(1, 2, 2, 2), style='pytor
             if (q + 'downsample.0.weight') in sd:          # res_layer.py:36-58: conv1x1(stride) + BN
                 identity = b.conv(q + 'downsample', x, ops.pack_conv(sd[q + 'downsample.0.weight'], None, stride, 0,
                                                                      bn=_bn(sd, q + 'downsample.1'), eps=BN_EPS))
-            if kind == 'bottleneck':
+            if kind == 'bottleneck' and fuse_blocks and identity is x and stride == 1 and dil == 1 and \
+                    sd[q + 'conv1.weight'].shape[0] in (64, 128) and x.shape[-1] == 4 * sd[q + 'conv1.weight'].shape[0]:
+                x = b.bottleneck(q + 'fused', x,
+                                 ops.pack_conv(sd[q + 'conv1.weight'], None, 1, 0, bn=_bn(sd, q + 'bn1'), eps=BN_EPS),
+                                 ops.pack_conv(sd[q + 'conv2.weight'], None, 1, 1, bn=_bn(sd, q + 'bn2'), eps=BN_EPS),
+                                 ops.pack_conv(sd[q + 'conv3.weight'], None, 1, 0, bn=_bn(sd, q + 'bn3'), eps=BN_EPS))
+            elif kind == 'bottleneck':
                 s1, s2 = (1, stride) if style == 'pytorch' else (stride, 1)          # resnet.py:151-156
                 o = b.conv(q + 'conv1', x, ops.pack_conv(sd[q + 'conv1.weight'], None, s1, 0, bn=_bn(sd, q + 'bn1'),
                                                          eps=BN_EPS), CONV_RELU)
@@ -419,7 +456,8 @@ class RetinaNetPlan:
         self.num_classes, self.batch = num_classes, batch
         sd = _cpu_sd(sd)
         self.x_in = x_in if x_in is not None else b.buf(batch, height, width, 8)
-        self.backbone_feats = build_resnet(b, sd, self.x_in, depth, strides, style, out_indices, p=prefix + 'backbone.')
+        self.backbone_feats = build_resnet(b, sd, self.x_in, depth, strides, style, out_indices, p=prefix + 'backbone.',
+                                           fuse_blocks=_os.environ.get("LLV_FUSED_BOTTLENECK", "1") != '0')
         self.pyramid = build_fpn(b, sd, self.backbone_feats, start_level, -1, num_outs, add_extra_convs,
                                  relu_before_extra_convs, p=prefix + 'neck.')
         self.cls_buf, self.reg_buf = build_retina_head(b, sd, self.pyramid, stacked_convs, logits_f32, p=prefix + 'bbox_head.')

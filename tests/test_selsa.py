@@ -380,12 +380,12 @@ def test_selsa_fastdvdnet_detect_vs_oracle(dev):
         from oracle.bbox import delta2bbox
         from oracle.nms import multiclass_nms as oracle_mnms
         from oracle.selsa import bbox2roi as bbox2roi_ref
-        cs, bp = cap['cls_score'].float().cpu(), cap['bbox_pred'].float().cpu()
+        cs, bp = cap["cls_score"].detach().float().cpu(), cap["bbox_pred"].detach().float().cpu()
         b_own = delta2bbox(bbox2roi_ref([p_key])[:, 1:], bp, (0., 0., 0., 0.), (0.2, 0.2, 0.2, 0.2), max_shape=(H, W, 3))
         d_own, l_own = oracle_mnms(b_own, torch.softmax(cs, -1), CFG['test_cfg']['score_thr'], CFG['test_cfg']['nms'], CFG['test_cfg']['max_per_img'])
         own = [np.concatenate([d_own[l_own == c][:, :4].numpy() * SF, d_own[l_own == c][:, 4:].numpy()], 1) for c in range(NCLS)]
         frac_own, n_own = match_detections(out, own, iou_thr=0.95, score_tol=0.01)
-        assert n_own >= 30 and frac_own >= 0.9 and sum(len(o) for o in out) == len(d_own), f'frame {t}: own logits {frac_own:.2f} of {n_own}'
+        assert n_own >= 30 and frac_own >= 0.9 and sum(len(o) for o in out) == len(d_own), f'frame {t}: own logits {frac_own:.2f} of {n_own}; n_out {sum(len(o) for o in out)} n_own {len(d_own)}; out0 {out[0][:4]} own0 {own[0][:4]}; out1 {out[1][:4]} own1 {own[1][:4]}'
         # (b) against the pure oracle: greedy NMS over 60 heavily overlapping random-weight proposals x 6 classes flips on small logit
         # differences (and TemporalRoIAlign's picks add some); a third of the oracle's detections reproduced is the floor here
         ref = [np.concatenate([d_ref[l_ref == c][:, :4].numpy() * SF, d_ref[l_ref == c][:, 4:].numpy()], 1) for c in range(NCLS)]
