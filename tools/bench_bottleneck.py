@@ -32,3 +32,23 @@ for mid, n, h, w in ((64, 16, 184, 320), (128, 16, 92, 160)):
         tot = sum(r[1] for r in rows)
         fl = sum(r[2] for r in rows)
         print(f'  {label:9s} {tot * 1e3:8.1f} us  {fl / tot / 1e9:7.1f} TFLOP/s   ' + '  '.join(f'{r[0]}={r[1] * 1e3:.1f}us' for r in rows))
+    # stage breakdown from the diagnostic launch (s_memtime stamps per workgroup)
+    import ctypes as C
+    from lowlightenvironmentvideoobjectdetection_amd._lib import lib, BottleneckDesc
+    fn = lib().llv_dbg_bottleneck_stamps
+    fn.restype = C.c_int
+    fn.argtypes = [C.c_void_p, C.c_void_p, C.c_void_p]
+    d = [s_[2][0]._obj for s_ in b2.plan.steps][0]
+    import os
+    tw = 32 if (mid == 64 and os.environ.get('LLV_BNK_SMALL', '1') == '0') else 16
+    nblk = n * ((h + 7) // 8) * ((w + tw - 1) // tw)
+    st = torch.zeros(nblk, 4, dtype=torch.int64, device=dev)
+    rc = fn(C.addressof(d), st.data_ptr(), None)
+    torch.cuda.synchronize()
+    assert rc == 0
+    t = st.cpu().double()
+    t0 = t[:, 0].min()
+    dur = (t[:, 3] - t[:, 0])
+    print(f'  stamps (ticks): kernel span {t[:, 3].max() - t0:.0f}; per workgroup: total mean {dur.mean():.0f} (min {dur.min():.0f} max {dur.max():.0f}); '
+          f'stage1 {(t[:, 1] - t[:, 0]).mean():.0f}  stage2 {(t[:, 2] - t[:, 1]).mean():.0f}  stage3 {(t[:, 3] - t[:, 2]).mean():.0f}; '
+          f'workgroups {nblk} = {nblk / 256:.1f} per CU; sum of workgroup time / 256 = {dur.sum() / 256:.0f}')
