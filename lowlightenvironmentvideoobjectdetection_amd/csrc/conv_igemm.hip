@@ -1192,8 +1192,14 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
     constexpr int WPW = BN / 64;                             // weight pieces per wave per step
     constexpr int HPW = (TAP_HPIECES + 3) / 4;               // halo pieces per wave per chunk (<= 6)
     constexpr int TS = BN + 8;
-    constexpr int RING = 2 * TAP_HBYTES + R * WBYTES;
-    constexpr int D = R - 1;                                 // prefetch distance in steps
+    // R = 0: the grouped main loop -- one barrier per tap ROW (3 taps, 3 * TN * TM MFMAs per wave), weight ring of 3 groups requested
+    // two groups ahead, counted s_waitcnt vmcnt(N) and a barrier that leaves the DMA queue alone (lds_barrier: __syncthreads() drains
+    // vmcnt to 0, which is what kept R > 2 from helping). Same k order (chunk-major, tap-minor), so the results are bit-identical.
+    constexpr bool G3 = R == 0;
+    constexpr int NWS = G3 ? 9 : R;                          // weight slices resident
+    constexpr int RING = 2 * TAP_HBYTES + NWS * WBYTES;
+    constexpr int D = G3 ? 1 : R - 1;                        // prefetch distance in steps (stepwise loop)
+    static_assert(!G3 || (BN == 64 && HPW == 6), "grouped loop: 64-channel tiles, two halo pieces per wave per group");
     constexpr int EPI0 = 256 * TS * 2;
     constexpr int EPI1 = 256 * 4 * (BN / 4 + 8) * 2;         // PixelShuffle: rows in (pixel, sub-pixel) order
     constexpr int EPI = EPI0 > EPI1 ? EPI0 : EPI1;
@@ -1231,7 +1237,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
     int hv[HPW];
 #pragma unroll
     for (int i = 0; i < HPW; ++i) {
-        const int px = (wave + 4 * i) * 16 + (lane >> 2);
+        // grouped loop: every wave issues HPW pieces (the counted waits need equal counts); a wave without a last piece repeats
+        // its previous one (same bytes to the same place)
+        const int pc = (G3 && wave + 4 * i >= TAP_HPIECES) ? wave + 4 * (i - 1) : wave + 4 * i;
+        const int px = pc * 16 + (lane >> 2);
         hv[i] = (int)h.x_bytes;                              // out of range: zeros
         if (px < HALO_PX) {
             const int hy = px / (HALO_TW + 2), hx = px - hy * (HALO_TW + 2);
@@ -1257,9 +1266,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
         for (int i = 0; i < WPW; ++i) dma16(rW, sWgt + buf * WBYTES + (wave + 4 * i) * 1024, wv[i], soff);
     };
     auto issue_h = [&](int c, int i, int buf) __attribute__((always_inline)) {   // piece wave + 4i of chunk c's halo (i static)
-        if (wave + 4 * i >= TAP_HPIECES) return;              // wave-uniform
+        if (!G3 && wave + 4 * i >= TAP_HPIECES) return;       // wave-uniform
+        const int pc = (G3 && wave + 4 * i >= TAP_HPIECES) ? wave + 4 * (i - 1) : wave + 4 * i;
         int cv = c * 4;
-        unsigned char* dst = sHalo + buf * TAP_HBYTES + (wave + 4 * i) * 1024;
+        unsigned char* dst = sHalo + buf * TAP_HBYTES + pc * 1024;
         if (MSRC) {
             // the chunk's source tensor: a resource built from a masked pointer sum (scalar), not a choice among three
             // resources (which the compiler turned into a table in scratch memory: 512 / 1040 B of private segment)
@@ -1274,9 +1284,18 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
 #pragma unroll
     for (int i = 0; i < HPW; ++i) issue_h(0, i, 0);
     const int nsteps = h.n_chunks * 9;
+    auto issue_wg = [&](int c, int tr) __attribute__((always_inline)) {   // the three slices of tap row tr of chunk c -> ring group tr
 #pragma unroll
-    for (int s0 = 0; s0 < D; ++s0)
-        if (s0 < nsteps) issue_w(s0 / 9, s0 % 9, s0 % R);
+        for (int tq = 0; tq < 3; ++tq) issue_w(c, tr * 3 + tq, tr * 3 + tq);
+    };
+    if (G3) {
+        issue_wg(0, 0);
+        issue_wg(0, 1);
+    } else {
+#pragma unroll
+        for (int s0 = 0; s0 < D; ++s0)
+            if (s0 < nsteps) issue_w(s0 / 9, s0 % 9, s0 % (G3 ? 1 : R));
+    }
 
     const int frow = lane & 15, fch = lane >> 4;
     // MFMA fragment read addresses: weights row i*16 + frow -> wa + i*1024; halo pixel (2*wave + (j>>1) + tr,
@@ -1329,13 +1348,52 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
     TAP_STEP(3, HB, c, more) TAP_STEP(4, HB, c, more) TAP_STEP(5, HB, c, more)                                \
     TAP_STEP(6, HB, c, more) TAP_STEP(7, HB, c, more) TAP_STEP(8, HB, c, more)
 
+    // grouped loop, tap row TR of chunk c in halo buffer HB. Issue order per group: next chunk's halo pieces, then the weights of the
+    // group after next; so at the top of a group everything older than [those halo pieces (tap rows 1, 2 only: row 0 needs them),
+    // the next group's weights] has to have landed.
+#define TAP_GROUP(TR, HB, c, more)                                                                            \
+    {                                                                                                         \
+        const int gi = (c) * 3 + (TR);                                                                        \
+        const int allow = (gi + 1 < ngroups ? 3 * WPW : 0) + (((TR) != 0 && (more)) ? 2 : 0);                 \
+        if (allow >= 5) asm volatile("s_waitcnt vmcnt(5)" ::: "memory");                                      \
+        else if (allow >= 3) asm volatile("s_waitcnt vmcnt(3)" ::: "memory");                                 \
+        else if (allow >= 2) asm volatile("s_waitcnt vmcnt(2)" ::: "memory");                                 \
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                                                 \
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                                       \
+        if (more) { issue_h((c) + 1, 2 * (TR), (HB) ^ 1); issue_h((c) + 1, 2 * (TR) + 1, (HB) ^ 1); }         \
+        if (gi + 2 < ngroups) issue_wg((c) + ((TR) + 2) / 3, ((TR) + 2) % 3);                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+        _Pragma("unroll") for (int tq = 0; tq < 3; ++tq) {                                                    \
+            const unsigned char* sWc = sWgt + ((TR) * 3 + tq) * WBYTES + wa;                                  \
+            f16x8 af[TN], bf[TM];                                                                             \
+            _Pragma("unroll") for (int j = 0; j < TM; ++j)                                                    \
+                bf[j] = *reinterpret_cast<const f16x8*>(sHalo + (HB) * TAP_HBYTES + (TR) * ROWB + hb[j][tq]); \
+            _Pragma("unroll") for (int i = 0; i < TN; ++i)                                                    \
+                af[i] = *reinterpret_cast<const f16x8*>(sWc + i * 1024);                                      \
+            _Pragma("unroll") for (int i = 0; i < TN; ++i)                                                    \
+                _Pragma("unroll") for (int j = 0; j < TM; ++j)                                                \
+                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);     \
+        }                                                                                                     \
+    }
+#define TAP_GCHUNK(HB, c, more) TAP_GROUP(0, HB, c, more) TAP_GROUP(1, HB, c, more) TAP_GROUP(2, HB, c, more)
+
     int sidx = 0;
-    for (int c = 0; c < h.n_chunks; c += 2) {
-        { const bool more = c + 1 < h.n_chunks; TAP_CHUNK(0, c, more) }
-        if (c + 1 < h.n_chunks) { const bool more = c + 2 < h.n_chunks; TAP_CHUNK(1, c + 1, more) }
+    if (G3) {
+        const int ngroups = h.n_chunks * 3;
+        for (int c = 0; c < h.n_chunks; c += 2) {
+            { const bool more = c + 1 < h.n_chunks; TAP_GCHUNK(0, c, more) }
+            if (c + 1 < h.n_chunks) { const bool more = c + 2 < h.n_chunks; TAP_GCHUNK(1, c + 1, more) }
+        }
+    } else {
+        for (int c = 0; c < h.n_chunks; c += 2) {
+            { const bool more = c + 1 < h.n_chunks; TAP_CHUNK(0, c, more) }
+            if (c + 1 < h.n_chunks) { const bool more = c + 2 < h.n_chunks; TAP_CHUNK(1, c + 1, more) }
+        }
     }
 #undef TAP_STEP
 #undef TAP_CHUNK
+#undef TAP_GROUP
+#undef TAP_GCHUNK
     __syncthreads();
 
     // ---- epilogue through the LDS tile (rows = ty*32 + tx); the tile's position is known, no row -> pixel search
@@ -2142,7 +2200,8 @@ void tile_dims(int tile, int& bn, int& bm) {
     switch (tile) {
         case LLV_TILE_128x128: case LLV_TILE_128x128_REGSTAGE: case LLV_TILE_128x128_K64: bn = 128; bm = 128; break;
         case LLV_TILE_TAP128: bn = 128; bm = 256; break;
-        case LLV_TILE_TAP64: case LLV_TILE_TAP64_R4: bn = 64; bm = 256; break;
+        case LLV_TILE_TAP64: case LLV_TILE_TAP64_R4: case LLV_TILE_TAP64_STEP: bn = 64; bm = 256; break;
+        case LLV_TILE_TAPQ64: bn = 64; bm = 512; break;
         case LLV_TILE_64x256: case LLV_TILE_64x256_K64: bn = 64; bm = 256; break;
         case LLV_TILE_32x256: bn = 32; bm = 256; break;
         case LLV_TILE_16x256: bn = 16; bm = 256; break;
@@ -2175,6 +2234,8 @@ int pick_tile(int co, long m, int groups) {
 
 }  // namespace
 
+#include "conv_tapq.inc"
+
 struct LaunchPlan { int tile, splits, nk_per; long m; };
 
 static int tile_bk(int tile) { return (tile == LLV_TILE_128x128_K64 || tile == LLV_TILE_64x256_K64) ? 64 : 32; }
@@ -2204,6 +2265,9 @@ static int plan_launch(const llv_conv_desc* d, LaunchPlan& lp) {
             if (lp.tile == LLV_TILE_TAP64 && !(d->flags & LLV_CONV_PIXSHUF) && d->cin >= tap128_cin && d->cout % 128 == 0 &&
                 blocks / ((d->cout + 63) / 64) * (d->cout / 128) >= 1500)
                 lp.tile = LLV_TILE_TAP128;
+            static const bool stepwise = getenv("LLV_TAP64_STEP") && atoi(getenv("LLV_TAP64_STEP"));      // A/B: the one-barrier-per-tap loop
+            if (stepwise && lp.tile == LLV_TILE_TAP64) lp.tile = LLV_TILE_TAP64_STEP;
+            if (lp.tile == LLV_TILE_TAP64 && tapq_eligible(d)) lp.tile = LLV_TILE_TAPQ64;      // one persistent workgroup per CU
             lp.splits = 1;
             lp.nk_per = (d->k_pad + 31) / 32;
             return LLV_OK;
@@ -2397,10 +2461,11 @@ static int conv_prepare(const llv_conv_desc* d, ConvPrepared& P) {
         return LLV_OK;
     }
     const int tile = lp.tile;
-    if ((f & LLV_CONV_PS_EMAJOR) && !(tile == LLV_TILE_TAP64 && tap_eligible(d))) return LLV_E_UNSUPPORTED;
+    if ((f & LLV_CONV_PS_EMAJOR) && !((tile == LLV_TILE_TAP64 || tile == LLV_TILE_TAP64_STEP) && tap_eligible(d))) return LLV_E_UNSUPPORTED;
     if ((f & LLV_CONV_PIXSHUF) && tile == LLV_TILE_16x256) k.stage_out = 0;
-    if ((tile == LLV_TILE_TAP128 || tile == LLV_TILE_TAP64 || tile == LLV_TILE_TAP64_R4) && !tap_eligible(d)) return LLV_E_BADARG;
-    if (tile < LLV_TILE_128x128 || tile > LLV_TILE_TAP64_R4) return LLV_E_UNSUPPORTED;
+    if ((tile == LLV_TILE_TAP128 || tile == LLV_TILE_TAP64 || tile == LLV_TILE_TAP64_R4 || tile == LLV_TILE_TAP64_STEP) && !tap_eligible(d)) return LLV_E_BADARG;
+    if (tile == LLV_TILE_TAPQ64 && !tapq_supported(d)) return LLV_E_UNSUPPORTED;
+    if (tile < LLV_TILE_128x128 || tile > LLV_TILE_TAPQ64) return LLV_E_UNSUPPORTED;
     return LLV_OK;
 }
 
@@ -2442,8 +2507,10 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
         case LLV_TILE_128x128_REGSTAGE: return launch<128, 128, 64, 64>(k, d->groups, st);   // register-staged loop, kept for A/B
         case LLV_TILE_128x128_K64: return launch_glds<128, 128, 64, 64, 64>(k, d->groups, st);
         case LLV_TILE_TAP128: return tap_eligible(d) ? launch_tap<128>(k, d, st) : LLV_E_BADARG;
-        case LLV_TILE_TAP64:  return tap_eligible(d) ? launch_tap<64>(k, d, st) : LLV_E_BADARG;      // the only kernel that reads LLV_CONV_PS_EMAJOR
+        case LLV_TILE_TAP64:  return tap_eligible(d) ? launch_tap<64, 0>(k, d, st) : LLV_E_BADARG;   // the tap kernels are the only ones that read LLV_CONV_PS_EMAJOR
         case LLV_TILE_TAP64_R4: return tap_eligible(d) ? launch_tap<64, 4>(k, d, st) : LLV_E_BADARG;
+        case LLV_TILE_TAP64_STEP: return tap_eligible(d) ? launch_tap<64>(k, d, st) : LLV_E_BADARG;
+        case LLV_TILE_TAPQ64: return tapq_supported(d) ? launch_tapq(k, d, st) : LLV_E_UNSUPPORTED;
         case LLV_TILE_64x256_K64:  return launch_glds<64, 256, 64, 64, 64>(k, d->groups, st);
         default: return LLV_E_UNSUPPORTED;
     }

@@ -384,15 +384,20 @@ def test_selsa_fastdvdnet_detect_vs_oracle(dev):
         b_own = delta2bbox(bbox2roi_ref([p_key])[:, 1:], bp, (0., 0., 0., 0.), (0.2, 0.2, 0.2, 0.2), max_shape=(H, W, 3))
         d_own, l_own = oracle_mnms(b_own, torch.softmax(cs, -1), CFG['test_cfg']['score_thr'], CFG['test_cfg']['nms'], CFG['test_cfg']['max_per_img'])
         own = [np.concatenate([d_own[l_own == c][:, :4].numpy() * SF, d_own[l_own == c][:, 4:].numpy()], 1) for c in range(NCLS)]
-        frac_own, n_own = match_detections(out, own, iou_thr=0.95, score_tol=0.01)
-        assert n_own >= 30 and frac_own >= 0.9 and sum(len(o) for o in out) == len(d_own), f'frame {t}: own logits {frac_own:.2f} of {n_own}; n_out {sum(len(o) for o in out)} n_own {len(d_own)}; out0 {out[0][:4]} own0 {own[0][:4]}; out1 {out[1][:4]} own1 {own[1][:4]}'
+        # identical logits: the same detections row for row (boxes clipped to zero width by the random weights included, which an IoU
+        # matcher cannot pair)
+        assert sum(len(o) for o in out) == len(d_own) >= 30
+        same = sum(int(np.isclose(o, w, atol=2e-3).all(axis=1).sum()) for o, w in zip(out, own) if o.shape == w.shape)
+        assert same >= 0.97 * len(d_own), f'frame {t}: {same} of {len(d_own)} rows equal on the device\'s own logits'
         # (b) against the pure oracle: greedy NMS over 60 heavily overlapping random-weight proposals x 6 classes flips on small logit
-        # differences (and TemporalRoIAlign's picks add some); a third of the oracle's detections reproduced is the floor here
+        # differences (and TemporalRoIAlign picks add some); measured 1.00 and 0.98 of the non-degenerate detections, 0.9 is the floor
         ref = [np.concatenate([d_ref[l_ref == c][:, :4].numpy() * SF, d_ref[l_ref == c][:, 4:].numpy()], 1) for c in range(NCLS)]
-        frac, n = match_detections(out, ref, iou_thr=0.85, score_tol=0.05)
-        assert n >= 30 and frac >= 0.3 and sum(len(o) for o in out) == len(d_ref), f'frame {t}: {frac:.2f} of {n}'
+        ref_nd = [r[((r[:, 2] - r[:, 0]) >= 1) & ((r[:, 3] - r[:, 1]) >= 1)] for r in ref]      # drop zero-area (fully clipped) boxes
+        frac, n = match_detections(out, ref_nd, iou_thr=0.85, score_tol=0.05)
+        print(f'frame {t}: {frac:.2f} of {n} non-degenerate oracle detections reproduced')
+        assert n >= 20 and frac >= 0.9 and sum(len(o) for o in out) == len(d_ref), f'frame {t}: {frac:.2f} of {n}'
         tot += n
         if t == 1:                                   # own RPN proposals end to end (shape / count only, as for SELSA)
             own = model(return_loss=False, img=[key.to(dev)], img_metas=[[meta]])['bbox_results']
             assert len(own) == NCLS and sum(len(r) for r in own) >= 30
-    assert tot > 60
+    assert tot >= 40

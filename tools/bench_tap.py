@@ -1,0 +1,28 @@
+"""Times the 3x3 tap kernel at the FastDVDnet / RetinaNet inner-layer shapes of the 16-frame step (HIP events around each launch).
+Usage (GPU box): python tools/bench_tap.py [tile ...]      (tiles: 10 grouped loop, 12 stepwise loop, 9 128-channel)"""
+import sys
+import torch
+sys.path.insert(0, '.')
+from lowlightenvironmentvideoobjectdetection_amd import ops
+
+dev = torch.device('cuda:0')
+tiles = [int(t) for t in sys.argv[1:]] or [13, 10, 12]
+shapes = [(16, 64, 64, 368, 640), (16, 128, 128, 184, 320), (16, 256, 256, 92, 160), (16, 32, 32, 736, 1280)]
+for (n, cin, cout, h, w) in shapes:
+    g = torch.Generator().manual_seed(1)
+    wt = torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5
+    pc = ops.pack_conv(wt, torch.randn(cout, generator=g), stride=1, pad=1).to(dev)
+    x = torch.randn(n, h, w, cin, device=dev).half()
+    for tile in tiles:
+        y = ops.conv2d(x, pc, flags=ops.CONV_RELU, tile=tile)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        iters = 20
+        e0.record()
+        for _ in range(iters):
+            ops.conv2d(x, pc, flags=ops.CONV_RELU, tile=tile, out=y)
+        e1.record()
+        torch.cuda.synchronize()
+        ms = e0.elapsed_time(e1) / iters
+        fl = 2.0 * 9 * cin * cout * n * h * w
+        print(f'{n}x{h}x{w} {cin}->{cout} tile {tile}: {ms * 1e3:8.1f} us  {fl / ms / 1e9:7.1f} TFLOP/s')
