@@ -179,10 +179,8 @@ typedef struct llv_conv_desc {
 #define LLV_TILE_64x256_K64 8
 #define LLV_TILE_TAP128 9 /* 3x3/s1/p1 tap-streamed kernel: 8x32-pixel tile x 128 channels, halo resident in LDS */
 #define LLV_TILE_TAP64_R4 11 /* tap kernel, 64 channels, weight ring of 4 (slices requested 3 steps ahead; 2 workgroups per CU) */
-#define LLV_TILE_TAP64 10  /* same, 64 output channels per workgroup; grouped main loop: one barrier per tap row, weights two groups ahead */
-#define LLV_TILE_TAPQ64 13 /* 3x3/s1/p1, one persistent workgroup per CU: 16x32-pixel tile x 64 channels, a whole 32-channel chunk (halo +
-                            * nine weight slices) per barrier, streamed one unit ahead across tiles; bias [+ ReLU] epilogue only */
-#define LLV_TILE_TAP64_STEP 12 /* TAP64 with the stepwise main loop (one barrier per tap; kept for A/B) */
+#define LLV_TILE_TAP64 10  /* same, 64 output channels per workgroup */
+#define LLV_TILE_TAP64_G3 12 /* TAP64 with the grouped main loop (one barrier per tap row, weights two groups ahead; A/B: not faster) */
 #define LLV_TILE_128x128_REGSTAGE 6 /* 128x128 with register-staged loads (the round's first kernel; kept for A/B) */
 
 int llv_abi_version(void);

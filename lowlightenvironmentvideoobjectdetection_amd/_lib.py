@@ -29,8 +29,7 @@ TILE_128x128_REGSTAGE = 6
 TILE_128x128_K64, TILE_64x256_K64 = 7, 8
 TILE_TAP128, TILE_TAP64 = 9, 10
 TILE_TAP64_R4 = 11
-TILE_TAP64_STEP = 12
-TILE_TAPQ64 = 13
+TILE_TAP64_G3 = 12
 
 
 class LlvError(RuntimeError):

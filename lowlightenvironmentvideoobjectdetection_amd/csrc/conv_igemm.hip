@@ -1193,8 +1193,10 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
     constexpr int HPW = (TAP_HPIECES + 3) / 4;               // halo pieces per wave per chunk (<= 6)
     constexpr int TS = BN + 8;
     // R = 0: the grouped main loop -- one barrier per tap ROW (3 taps, 3 * TN * TM MFMAs per wave), weight ring of 3 groups requested
-    // two groups ahead, counted s_waitcnt vmcnt(N) and a barrier that leaves the DMA queue alone (lds_barrier: __syncthreads() drains
-    // vmcnt to 0, which is what kept R > 2 from helping). Same k order (chunk-major, tap-minor), so the results are bit-identical.
+    // two groups ahead, counted s_waitcnt vmcnt(N) and a barrier that leaves the DMA queue alone (__syncthreads() drains vmcnt to 0).
+    // Same k order (chunk-major, tap-minor): bit-identical results. Measured 3 % SLOWER than the stepwise loop (80 KiB of LDS: two
+    // workgroups per CU instead of three): the kernel is bound by the CU's vector-memory path (one 1-KiB LDS-DMA piece per ~72 cycles,
+    // one 1-KiB store per ~114 cycles), which pipelining does not touch. Kept as LLV_TILE_TAP64_G3 for A/B.
     constexpr bool G3 = R == 0;
     constexpr int NWS = G3 ? 9 : R;                          // weight slices resident
     constexpr int RING = 2 * TAP_HBYTES + NWS * WBYTES;
@@ -2200,8 +2202,7 @@ void tile_dims(int tile, int& bn, int& bm) {
     switch (tile) {
         case LLV_TILE_128x128: case LLV_TILE_128x128_REGSTAGE: case LLV_TILE_128x128_K64: bn = 128; bm = 128; break;
         case LLV_TILE_TAP128: bn = 128; bm = 256; break;
-        case LLV_TILE_TAP64: case LLV_TILE_TAP64_R4: case LLV_TILE_TAP64_STEP: bn = 64; bm = 256; break;
-        case LLV_TILE_TAPQ64: bn = 64; bm = 512; break;
+        case LLV_TILE_TAP64: case LLV_TILE_TAP64_R4: case LLV_TILE_TAP64_G3: bn = 64; bm = 256; break;
         case LLV_TILE_64x256: case LLV_TILE_64x256_K64: bn = 64; bm = 256; break;
         case LLV_TILE_32x256: bn = 32; bm = 256; break;
         case LLV_TILE_16x256: bn = 16; bm = 256; break;
@@ -2234,8 +2235,6 @@ int pick_tile(int co, long m, int groups) {
 
 }  // namespace
 
-#include "conv_tapq.inc"
-
 struct LaunchPlan { int tile, splits, nk_per; long m; };
 
 static int tile_bk(int tile) { return (tile == LLV_TILE_128x128_K64 || tile == LLV_TILE_64x256_K64) ? 64 : 32; }
@@ -2265,9 +2264,8 @@ static int plan_launch(const llv_conv_desc* d, LaunchPlan& lp) {
             if (lp.tile == LLV_TILE_TAP64 && !(d->flags & LLV_CONV_PIXSHUF) && d->cin >= tap128_cin && d->cout % 128 == 0 &&
                 blocks / ((d->cout + 63) / 64) * (d->cout / 128) >= 1500)
                 lp.tile = LLV_TILE_TAP128;
-            static const bool stepwise = getenv("LLV_TAP64_STEP") && atoi(getenv("LLV_TAP64_STEP"));      // A/B: the one-barrier-per-tap loop
-            if (stepwise && lp.tile == LLV_TILE_TAP64) lp.tile = LLV_TILE_TAP64_STEP;
-            if (lp.tile == LLV_TILE_TAP64 && tapq_eligible(d)) lp.tile = LLV_TILE_TAPQ64;      // one persistent workgroup per CU
+            static const bool grouped = getenv("LLV_TAP64_G3") && atoi(getenv("LLV_TAP64_G3"));      // A/B: the one-barrier-per-tap-row loop
+            if (grouped && lp.tile == LLV_TILE_TAP64) lp.tile = LLV_TILE_TAP64_G3;
             lp.splits = 1;
             lp.nk_per = (d->k_pad + 31) / 32;
             return LLV_OK;
@@ -2461,11 +2459,10 @@ static int conv_prepare(const llv_conv_desc* d, ConvPrepared& P) {
         return LLV_OK;
     }
     const int tile = lp.tile;
-    if ((f & LLV_CONV_PS_EMAJOR) && !((tile == LLV_TILE_TAP64 || tile == LLV_TILE_TAP64_STEP) && tap_eligible(d))) return LLV_E_UNSUPPORTED;
+    if ((f & LLV_CONV_PS_EMAJOR) && !((tile == LLV_TILE_TAP64 || tile == LLV_TILE_TAP64_G3) && tap_eligible(d))) return LLV_E_UNSUPPORTED;
     if ((f & LLV_CONV_PIXSHUF) && tile == LLV_TILE_16x256) k.stage_out = 0;
-    if ((tile == LLV_TILE_TAP128 || tile == LLV_TILE_TAP64 || tile == LLV_TILE_TAP64_R4 || tile == LLV_TILE_TAP64_STEP) && !tap_eligible(d)) return LLV_E_BADARG;
-    if (tile == LLV_TILE_TAPQ64 && !tapq_supported(d)) return LLV_E_UNSUPPORTED;
-    if (tile < LLV_TILE_128x128 || tile > LLV_TILE_TAPQ64) return LLV_E_UNSUPPORTED;
+    if ((tile == LLV_TILE_TAP128 || tile == LLV_TILE_TAP64 || tile == LLV_TILE_TAP64_R4 || tile == LLV_TILE_TAP64_G3) && !tap_eligible(d)) return LLV_E_BADARG;
+    if (tile < LLV_TILE_128x128 || tile > LLV_TILE_TAP64_G3) return LLV_E_UNSUPPORTED;
     return LLV_OK;
 }
 
@@ -2507,10 +2504,9 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
         case LLV_TILE_128x128_REGSTAGE: return launch<128, 128, 64, 64>(k, d->groups, st);   // register-staged loop, kept for A/B
         case LLV_TILE_128x128_K64: return launch_glds<128, 128, 64, 64, 64>(k, d->groups, st);
         case LLV_TILE_TAP128: return tap_eligible(d) ? launch_tap<128>(k, d, st) : LLV_E_BADARG;
-        case LLV_TILE_TAP64:  return tap_eligible(d) ? launch_tap<64, 0>(k, d, st) : LLV_E_BADARG;   // the tap kernels are the only ones that read LLV_CONV_PS_EMAJOR
+        case LLV_TILE_TAP64:  return tap_eligible(d) ? launch_tap<64>(k, d, st) : LLV_E_BADARG;      // the tap kernels are the only ones that read LLV_CONV_PS_EMAJOR
         case LLV_TILE_TAP64_R4: return tap_eligible(d) ? launch_tap<64, 4>(k, d, st) : LLV_E_BADARG;
-        case LLV_TILE_TAP64_STEP: return tap_eligible(d) ? launch_tap<64>(k, d, st) : LLV_E_BADARG;
-        case LLV_TILE_TAPQ64: return tapq_supported(d) ? launch_tapq(k, d, st) : LLV_E_UNSUPPORTED;
+        case LLV_TILE_TAP64_G3: return tap_eligible(d) ? launch_tap<64, 0>(k, d, st) : LLV_E_BADARG;
         case LLV_TILE_64x256_K64:  return launch_glds<64, 256, 64, 64, 64>(k, d->groups, st);
         default: return LLV_E_UNSUPPORTED;
     }
