@@ -2255,12 +2255,12 @@ static int plan_launch(const llv_conv_desc* d, LaunchPlan& lp) {
             // PixelShuffle layers take the 128-channel tile: a workgroup then owns 32 output channels of both
             // dx sub-pixels = whole 128-byte lines of the shuffled output (and of the skip tensor it adds)
             lp.tile = ((d->flags & LLV_CONV_PIXSHUF) && !(d->flags & LLV_CONV_PS_EMAJOR) && d->cout % 128 == 0) ? LLV_TILE_TAP128 : LLV_TILE_TAP64;
-            // deep layers (Cin >= 256: head towers, FPN output convs) are bound by the L2 -> LDS stream of their weight slices (a
-            // 64-channel workgroup re-streams 64 x K x 2 B for 256 pixels; phase knock-outs: the DMA stream alone or the MFMAs alone
-            // each take ~80 % of the launch); the 128-channel tile halves the halo traffic per flop: 13 % faster on 256 -> 256 at
-            // 92x160x4 in isolation, 3.5 % on the 16-frame head towers (0.4 % of the step), slower on launches of a few hundred
-            // workgroups (layer3/4 conv2). Off by default (one kernel instantiation on the 3x3 path); LLV_TAP128_CIN=256 enables it.
-            static const int tap128_cin = getenv("LLV_TAP128_CIN") ? atoi(getenv("LLV_TAP128_CIN")) : (1 << 30);
+            // The tap kernel is bound by the CU's vector-memory path (every 1-KiB LDS-DMA piece costs ~72 cycles of
+            // it, every 1-KiB store ~114): per (chunk, tile) a 64-channel workgroup requests 22 halo + 36 weight pieces, a 128-channel
+            // one 22 + 72 for twice the MFMAs. Where Cout allows, the 128-channel tile is 9-10 % faster in isolation (128 -> 128 at
+            // 16x184x320: 276 vs 303 us; 256 -> 256 at 16x92x160: 256 vs 282 us), slower on launches of a few hundred workgroups
+            // (layer3/4 conv2) and on narrow layers (its LDS holds one workgroup per CU less). LLV_TAP128_CIN sets the Cin threshold.
+            static const int tap128_cin = getenv("LLV_TAP128_CIN") ? atoi(getenv("LLV_TAP128_CIN")) : 128;
             if (lp.tile == LLV_TILE_TAP64 && !(d->flags & LLV_CONV_PIXSHUF) && d->cin >= tap128_cin && d->cout % 128 == 0 &&
                 blocks / ((d->cout + 63) / 64) * (d->cout / 128) >= 1500)
                 lp.tile = LLV_TILE_TAP128;
