@@ -6,7 +6,7 @@ Convolutions run on the conv engine. `RPNHead.get_bboxes` is the dense-head deco
 top nms_pre -> delta2bbox -> clip, `llv_retina_decode_topk`) followed by `llv_multiclass_nms` with the pyramid LEVEL in the role of
 the class, which is exactly mmcv's `batched_nms(proposals, scores, level_ids)`; a level can contribute at most max_per_img
 proposals to the final list, so the per-class cap of that kernel is exact here too. The RoI heads that consume the proposals
-(`SelsaRoIHead`, `SelsaBBoxHead`, `SelsaAggregator`, `TemporalRoIAlign`) are not built."""
+(`SelsaRoIHead`, `SelsaBBoxHead`, `SelsaAggregator`: selsa.py; `TemporalRoIAlign`: roi_extractors.py) are built for test time."""
 import torch
 import torch.nn as nn
 

@@ -3,7 +3,9 @@ constructors and parameter names:
   SelsaAggregator   mmtracking/mmtrack/models/aggregators/selsa_aggregator.py:8-73
   SelsaBBoxHead     mmtracking/mmtrack/models/roi_heads/bbox_heads/selsa_bbox_head.py:8-84 (over mmdet ConvFCBBoxHead / BBoxHead.get_bboxes,
                     mmdetection/mmdet/models/roi_heads/bbox_heads/bbox_head.py:270-371)
-  SelsaRoIHead      mmtracking/mmtrack/models/roi_heads/selsa_roi_head.py:61-78,113-187 (simple_test)
+  SelsaRoIHead      mmtracking/mmtrack/models/roi_heads/selsa_roi_head.py:61-78,113-187 (simple_test; SingleRoIExtractor or TemporalRoIAlign)
+  TwoStageDetector / FasterRCNN, SELSA (mmtracking/mmtrack/models/vid/selsa.py) and the authors' SelsaFastDVDnetDetect
+                    (mmtracking/mmtrack/models/vid/selsa_fastdvd_darkfarm.py:294-319,361-453)
 
 What is native here: RoI features through `llv_roi_align`, detections through `llv_multiclass_nms_batched_ex` with class-specific
 boxes. The fully connected layers and the attention of the aggregator are plain GEMMs and run as torch (rocBLAS / hipBLASLt) calls on

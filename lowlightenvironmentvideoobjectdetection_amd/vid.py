@@ -278,7 +278,8 @@ class LLVOD(BaseVideoDetector):
                 m.invalidate_plans()
 
     def forward_train(self, img, img_metas, **kwargs):
-        raise LlvError('LLVOD.forward_train: the training path is not built yet in this round')
+        raise LlvError('LLVOD.forward_train has no runnable reference: llvod.py:91 calls general_clean_noise_pairs, which the module never '
+                       'imports (NameError in the reference itself); not built (DESIGN.md, scope table)')
 
     def _make_plan(self, h, w, device):
         from .aggregators import embed_packed_convs
@@ -437,7 +438,7 @@ class DFF(BaseVideoDetector):
                 m.invalidate_plans()
 
     def forward_train(self, img, img_metas, **kwargs):
-        raise LlvError('DFF.forward_train: the training path is not built yet in this round')
+        raise LlvError('DFF.forward_train is not built: it needs backward kernels for llv_flow_warp and FlowNetSimple (DESIGN.md section 8)')
 
     def simple_test(self, img, img_metas, ref_img=None, ref_img_metas=None, rescale=False, **kwargs):
         self._check_input(img)
@@ -501,7 +502,8 @@ class FGFA(BaseVideoDetector):
                 m.invalidate_plans()
 
     def forward_train(self, img, img_metas, **kwargs):
-        raise LlvError('FGFA.forward_train: the training path is not built yet in this round')
+        raise LlvError('FGFA.forward_train is not built: it needs backward kernels for llv_flow_warp, llv_embed_aggregate and FlowNetSimple '
+                       '(DESIGN.md section 8)')
 
     def _agg_plan(self, st, n_slots, key_slot, device):
         """Embedding convs over the n_slots frames of every level in one multi-segment launch + the tail per level.
