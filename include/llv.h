@@ -180,6 +180,8 @@ typedef struct llv_conv_desc {
 #define LLV_TILE_TAP128 9 /* 3x3/s1/p1 tap-streamed kernel: 8x32-pixel tile x 128 channels, halo resident in LDS */
 #define LLV_TILE_TAP64_R4 11 /* tap kernel, 64 channels, weight ring of 4 (slices requested 3 steps ahead; 2 workgroups per CU) */
 #define LLV_TILE_TAP64 10  /* same, 64 output channels per workgroup */
+#define LLV_TILE_TAP512 13 /* tap kernel on a 16x32-pixel tile x 64 channels, a whole 32-channel chunk (halo + nine weight slices) per load phase,
+                            * two workgroups per CU; bias [+ ReLU] -> fp16 epilogue and one source only (LLV_E_UNSUPPORTED otherwise) */
 #define LLV_TILE_TAP64_G3 12 /* TAP64 with the grouped main loop (one barrier per tap row, weights two groups ahead; A/B: not faster) */
 #define LLV_TILE_128x128_REGSTAGE 6 /* 128x128 with register-staged loads (the round's first kernel; kept for A/B) */
 

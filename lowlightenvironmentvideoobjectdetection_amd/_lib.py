@@ -30,6 +30,7 @@ TILE_128x128_K64, TILE_64x256_K64 = 7, 8
 TILE_TAP128, TILE_TAP64 = 9, 10
 TILE_TAP64_R4 = 11
 TILE_TAP64_G3 = 12
+TILE_TAP512 = 13
 
 
 class LlvError(RuntimeError):

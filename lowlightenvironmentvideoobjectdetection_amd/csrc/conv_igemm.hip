@@ -2203,6 +2203,7 @@ void tile_dims(int tile, int& bn, int& bm) {
         case LLV_TILE_128x128: case LLV_TILE_128x128_REGSTAGE: case LLV_TILE_128x128_K64: bn = 128; bm = 128; break;
         case LLV_TILE_TAP128: bn = 128; bm = 256; break;
         case LLV_TILE_TAP64: case LLV_TILE_TAP64_R4: case LLV_TILE_TAP64_G3: bn = 64; bm = 256; break;
+        case LLV_TILE_TAP512: bn = 64; bm = 512; break;
         case LLV_TILE_64x256: case LLV_TILE_64x256_K64: bn = 64; bm = 256; break;
         case LLV_TILE_32x256: bn = 32; bm = 256; break;
         case LLV_TILE_16x256: bn = 16; bm = 256; break;
@@ -2235,6 +2236,8 @@ int pick_tile(int co, long m, int groups) {
 
 }  // namespace
 
+#include "conv_tap512.inc"
+
 struct LaunchPlan { int tile, splits, nk_per; long m; };
 
 static int tile_bk(int tile) { return (tile == LLV_TILE_128x128_K64 || tile == LLV_TILE_64x256_K64) ? 64 : 32; }
@@ -2266,6 +2269,12 @@ static int plan_launch(const llv_conv_desc* d, LaunchPlan& lp) {
                 lp.tile = LLV_TILE_TAP128;
             static const bool grouped = getenv("LLV_TAP64_G3") && atoi(getenv("LLV_TAP64_G3"));      // A/B: the one-barrier-per-tap-row loop
             if (grouped && lp.tile == LLV_TILE_TAP64) lp.tile = LLV_TILE_TAP64_G3;
+            // 64-channel layers with the plain epilogue: the 16 x 32-pixel tile (39 + 36 DMA pieces per chunk for 512 pixels instead of
+            // 22 + 36 for 256), when the launch still gives every CU several of the twice-as-large workgroups. Same-box A/B per launch:
+            // 64 -> 64 at 16x368x640 331 vs 376 us, 32 -> 32 at 16x736x1280 633 vs 671 us, 128 -> 128 285 vs 304 us (the 128-channel tile
+            // above takes that one: 276 us). LLV_TAP512=0 turns it off.
+            static const int tap512 = getenv("LLV_TAP512") ? atoi(getenv("LLV_TAP512")) : 1;
+            if (tap512 && lp.tile == LLV_TILE_TAP64 && tap512_supported(d) && blocks >= 4096) lp.tile = LLV_TILE_TAP512;
             lp.splits = 1;
             lp.nk_per = (d->k_pad + 31) / 32;
             return LLV_OK;
@@ -2462,7 +2471,8 @@ static int conv_prepare(const llv_conv_desc* d, ConvPrepared& P) {
     if ((f & LLV_CONV_PS_EMAJOR) && !((tile == LLV_TILE_TAP64 || tile == LLV_TILE_TAP64_G3) && tap_eligible(d))) return LLV_E_UNSUPPORTED;
     if ((f & LLV_CONV_PIXSHUF) && tile == LLV_TILE_16x256) k.stage_out = 0;
     if ((tile == LLV_TILE_TAP128 || tile == LLV_TILE_TAP64 || tile == LLV_TILE_TAP64_R4 || tile == LLV_TILE_TAP64_G3) && !tap_eligible(d)) return LLV_E_BADARG;
-    if (tile < LLV_TILE_128x128 || tile > LLV_TILE_TAP64_G3) return LLV_E_UNSUPPORTED;
+    if (tile == LLV_TILE_TAP512 && !tap512_supported(d)) return LLV_E_UNSUPPORTED;
+    if (tile < LLV_TILE_128x128 || tile > LLV_TILE_TAP512) return LLV_E_UNSUPPORTED;
     return LLV_OK;
 }
 
@@ -2507,6 +2517,7 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
         case LLV_TILE_TAP64:  return tap_eligible(d) ? launch_tap<64>(k, d, st) : LLV_E_BADARG;      // the tap kernels are the only ones that read LLV_CONV_PS_EMAJOR
         case LLV_TILE_TAP64_R4: return tap_eligible(d) ? launch_tap<64, 4>(k, d, st) : LLV_E_BADARG;
         case LLV_TILE_TAP64_G3: return tap_eligible(d) ? launch_tap<64, 0>(k, d, st) : LLV_E_BADARG;
+        case LLV_TILE_TAP512: return tap512_supported(d) ? launch_tap512(k, d, st) : LLV_E_UNSUPPORTED;
         case LLV_TILE_64x256_K64:  return launch_glds<64, 256, 64, 64, 64>(k, d->groups, st);
         default: return LLV_E_UNSUPPORTED;
     }

@@ -354,7 +354,7 @@ _TILE_KERNEL = {
     -1: 'conv3x3_halo_kernel', 1: 'conv_igemm_glds_kernel<128,128>', 2: 'conv_igemm_glds_kernel<64,256>',
     3: 'conv_igemm_glds_kernel<32,256>', 4: 'conv_igemm_glds_kernel<16,256>', 5: 'conv_igemm_glds_kernel<64,64>',
     6: 'conv_igemm_kernel<128,128>', 7: 'conv_igemm_glds_kernel<128,128,K64>', 8: 'conv_igemm_glds_kernel<64,256,K64>',
-    9: 'conv3x3_tap_kernel<128>', 10: 'conv3x3_tap_kernel<64>', 11: 'conv3x3_tap_kernel<64,R4>', 12: 'conv3x3_tap_kernel<64,G3>',
+    9: 'conv3x3_tap_kernel<128>', 10: 'conv3x3_tap_kernel<64>', 11: 'conv3x3_tap_kernel<64,R4>', 12: 'conv3x3_tap_kernel<64,G3>', 13: 'conv3x3_tap512_kernel',
 }
 
 

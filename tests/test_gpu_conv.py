@@ -422,7 +422,7 @@ def test_fused_outputcvblock(dev, n, h, w):
 
 
 # ---- tap-streamed 3x3 kernel (halo resident in LDS, weights streamed per tap); tiles 9 (BN=128) and 10 (BN=64)
-@pytest.mark.parametrize('tile', [9, 10, 11, 12])
+@pytest.mark.parametrize('tile', [9, 10, 11, 12, 13])
 @pytest.mark.parametrize('cfg', [
     # n, cin, cout, h, w   (3x3 / stride 1 / pad 1)
     (1, 64, 64, 20, 33),      # ragged tile edges in both directions
@@ -434,11 +434,13 @@ def test_fused_outputcvblock(dev, n, h, w):
 ])
 def test_conv3x3_tap_kernel(dev, cfg, tile):
     n, cin, cout, h, w = cfg
+    if tile == 13 and cout % 8:
+        pytest.skip('the 16x32-tile kernel stores 16-byte channel runs: cout % 8 == 0 (LLV_E_UNSUPPORTED otherwise)')
     y, ref, _ = _run_conv(dev, n, cin, cout, h, w, 3, 1, 1, tile=tile)
     _check(y, ref, cout)
 
 
-@pytest.mark.parametrize('tile', [9, 10, 12])
+@pytest.mark.parametrize('tile', [9, 10, 12, 13])
 def test_conv3x3_tap_segments_shared_weights(dev, tile):
     """One launch over three pyramid levels with shared weights (the RetinaNet tower layout)."""
     from lowlightenvironmentvideoobjectdetection_amd import ops
@@ -579,3 +581,23 @@ def test_conv3x3_tap_grouped_loop_is_bit_identical_to_stepwise(dev):
         ya, _, _ = _run_conv(dev, n, cin, cout, h, w, 3, 1, 1, tile=10, seed=5)
         yb, _, _ = _run_conv(dev, n, cin, cout, h, w, 3, 1, 1, tile=12, seed=5)
         assert torch.equal(ya, yb)
+
+
+@pytest.mark.parametrize('cfg', [(2, 64, 64, 200, 330), (4, 64, 128, 40, 70), (3, 32, 64, 50, 90), (2, 96, 72, 33, 65)])
+def test_conv3x3_tap512_is_bit_identical_to_tap_kernel(dev, cfg):
+    """Tile 13 (16 x 32-pixel tile, whole chunks per load phase, two workgroups per CU) against tile 10: same k order, same bits; and
+    the fp32 reference. Ragged tiles, one / two / three chunks, a ragged channel tile."""
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    n, cin, cout, h, w = cfg
+    for relu in (0, 1):
+        ya, ref, _ = _run_conv(dev, n, cin, cout, h, w, 3, 1, 1, tile=13, seed=9, flags=ops.CONV_RELU * relu)
+        yb, _, _ = _run_conv(dev, n, cin, cout, h, w, 3, 1, 1, tile=10, seed=9, flags=ops.CONV_RELU * relu)
+        assert torch.equal(ya, yb)
+        _check(ya, ref.relu() if relu else ref, cout)
+
+
+def test_conv3x3_tap512_refuses_other_epilogues(dev):
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    from lowlightenvironmentvideoobjectdetection_amd._lib import LlvError
+    with pytest.raises(LlvError):
+        _run_conv(dev, 1, 64, 128, 16, 32, 3, 1, 1, tile=13, flags=ops.CONV_PIXSHUF)

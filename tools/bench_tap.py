@@ -6,7 +6,7 @@ sys.path.insert(0, '.')
 from lowlightenvironmentvideoobjectdetection_amd import ops
 
 dev = torch.device('cuda:0')
-tiles = [int(t) for t in sys.argv[1:]] or [10, 12, 9]
+tiles = [int(t) for t in sys.argv[1:]] or [10, 13, 9]
 shapes = [(16, 64, 64, 368, 640), (16, 128, 128, 184, 320), (16, 256, 256, 92, 160), (16, 32, 32, 736, 1280)]
 for (n, cin, cout, h, w) in shapes:
     g = torch.Generator().manual_seed(1)
