@@ -136,8 +136,67 @@ __device__ inline int greedy_scan(const uint64_t* keys, int cnt, float thr, int 
     return nkept;
 }
 
-// one workgroup per class: sort its candidate list in LDS, greedy scan by wave 0
-__global__ __launch_bounds__(256) void nms_class_kernel(const float* __restrict__ boxes, int n, int C, float iou_thr,
+// The same greedy scan by the whole workgroup (blockDim = 64 * NW threads; every thread calls it). A batch is blockDim candidates:
+// all of them are first tested against the boxes kept before the batch (the long loop, now blockDim-wide instead of 64-wide), then
+// the batch's waves resolve their 64 candidates one after the other exactly as greedy_scan does, and after each wave the later
+// waves test their candidates against that wave's newly kept boxes. A candidate is suppressed by exactly the kept boxes that precede
+// it in score order: the result equals the one-wave scan's.
+template <typename BoxFn>
+__device__ inline int greedy_scan_block(const uint64_t* keys, int cnt, float thr, int max_keep, float4* kept,
+                                        uint64_t* out_keys, BoxFn box_of, int* s_nkept) {
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
+    if (threadIdx.x == 0) *s_nkept = 0;
+    __syncthreads();
+    for (int base = 0; base < cnt; base += blockDim.x) {
+        int nk0 = *s_nkept;
+        if (nk0 >= max_keep) break;                          // uniform: read behind a barrier
+        const int i = base + threadIdx.x;
+        const bool valid = i < cnt;
+        uint64_t key = 0;
+        float4 b = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (valid) {
+            key = keys[i];
+            b = box_of(llv::key_index(key));
+        }
+        bool alive = valid;
+        for (int j = 0; j < nk0; ++j)
+            if (alive && iou_gt(kept[j], b, thr)) alive = false;
+        for (int w = 0; w < nw; ++w) {
+            if (wave == w) {
+                int nkept = nk0;
+                unsigned long long mask = __ballot(alive);
+                int start = 0;
+                while (nkept < max_keep) {
+                    const unsigned long long rem = start >= 64 ? 0ull : (mask >> start) << start;
+                    if (!rem) break;
+                    const int t = __ffsll((long long)rem) - 1;
+                    float4 kb;
+                    kb.x = __shfl(b.x, t); kb.y = __shfl(b.y, t); kb.z = __shfl(b.z, t); kb.w = __shfl(b.w, t);
+                    const uint64_t kk = __shfl((unsigned long long)key, t);
+                    if (lane == 0) { kept[nkept] = kb; out_keys[nkept] = kk; }
+                    ++nkept;
+                    if (alive && lane > t && iou_gt(kb, b, thr)) alive = false;
+                    mask = __ballot(alive);
+                    start = t + 1;
+                }
+                if (lane == 0) *s_nkept = nkept;
+            }
+            __syncthreads();
+            const int nk1 = *s_nkept;
+            if (wave > w)
+                for (int j = nk0; j < nk1; ++j)
+                    if (alive && iou_gt(kept[j], b, thr)) alive = false;
+            nk0 = nk1;
+            if (nk1 >= max_keep) break;                      // uniform
+        }
+        __syncthreads();
+    }
+    __syncthreads();
+    return *s_nkept;
+}
+
+// one workgroup per class: sort its candidate list in LDS, greedy scan by the whole workgroup
+__global__ __launch_bounds__(1024) void nms_class_kernel(const float* __restrict__ boxes, int n, int C, float iou_thr,
                                                         int max_num, const unsigned* maxc_u, const int* cnt_in,
                                                         const uint64_t* cand, int* cls_cnt, uint64_t* cls_keys, long ws_stride, int cs) {
     const int c = blockIdx.x;
@@ -164,8 +223,9 @@ __global__ __launch_bounds__(256) void nms_class_kernel(const float* __restrict_
     for (int i = threadIdx.x; i < np2; i += blockDim.x) keys[i] = i < cnt ? src[i] : 0ull;
     __syncthreads();
     llv::bitonic_sort_desc(keys, np2);
-    if (threadIdx.x < 64) {
+    {
         // boxes_for_nms = boxes + idxs.to(boxes) * (max_coordinate + 1)   (mmcv batched_nms)
+        __shared__ int s_nkept;
         const float off = (float)c * (llv::f32_unordered(*maxc_u) + 1.0f);
         const unsigned nflat = (unsigned)n * (unsigned)C;
         auto box_of = [&](unsigned flat) {
@@ -174,7 +234,7 @@ __global__ __launch_bounds__(256) void nms_class_kernel(const float* __restrict_
             b.x += off; b.y += off; b.z += off; b.w += off;
             return b;
         };
-        const int nk = greedy_scan(keys, cnt, iou_thr, max_num, kept, cls_keys + (long)c * max_num, box_of);
+        const int nk = greedy_scan_block(keys, cnt, iou_thr, max_num, kept, cls_keys + (long)c * max_num, box_of, &s_nkept);
         if (threadIdx.x == 0) cls_cnt[c] = nk;
     }
 }
@@ -346,7 +406,9 @@ extern "C" int llv_multiclass_nms_batched_ex(const float* boxes, const float* sc
         int np2 = 1;
         while (np2 < n) np2 <<= 1;
         const size_t lds = (size_t)np2 * 8 + (size_t)max_num * 16;
-        hipLaunchKernelGGL(nms_class_kernel, dim3(num_classes, batch), dim3(256), lds, st, boxes, n, num_classes, iou_thr, max_num,
+        // a class list of a few hundred candidates (the 80-class heads) gains nothing from 16 waves; the RPN's single 6000-box list does
+        const int cls_threads = n >= 2048 && num_classes <= 8 ? 1024 : 256;
+        hipLaunchKernelGGL(nms_class_kernel, dim3(num_classes, batch), dim3(cls_threads), lds, st, boxes, n, num_classes, iou_thr, max_num,
                            maxc_u, cnt_in, cand, cls_cnt, cls_keys, stride, cs);
     }
     int mp2 = 1;

@@ -323,7 +323,16 @@ class SELSA(BaseVideoDetector):
         x, img_metas, ref_x, ref_img_metas = self.extract_feats(img, img_metas, ref_img, ref_img_metas)
         if proposals is None:
             proposal_list = self.detector.rpn_head.simple_test_rpn(x, img_metas)
-            ref_proposals_list = self.detector.rpn_head.simple_test_rpn(ref_x, ref_img_metas)
+            if img_metas[0].get('frame_stride', -1) < 1:
+                # ref_x = the memo's reference frames followed by the key frame (extract_feats above). The reference runs the RPN over
+                # all of them for every key frame (selsa.py:312-315); the memo frames do not change during the video and the key
+                # frame's proposals have just been computed, so their proposals are taken from the memo / from proposal_list: the
+                # same kernels on the same inputs, computed once.
+                if 'proposals' not in self.memo:
+                    self.memo['proposals'] = self.detector.rpn_head.simple_test_rpn(tuple(self.memo['feats']), list(self.memo['img_metas']))
+                ref_proposals_list = list(self.memo['proposals']) + list(proposal_list)
+            else:
+                ref_proposals_list = self.detector.rpn_head.simple_test_rpn(ref_x, ref_img_metas)
         else:
             proposal_list, ref_proposals_list = proposals, ref_proposals
         outs = self.detector.roi_head.simple_test(x, ref_x, proposal_list, ref_proposals_list, img_metas, rescale=rescale)
