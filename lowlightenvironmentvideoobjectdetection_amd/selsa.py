@@ -38,14 +38,20 @@ class SelsaAggregator(nn.Module):
         self.ref_fc = nn.Linear(in_channels, in_channels)
         self.num_attention_blocks = num_attention_blocks
 
-    def forward(self, x, ref_x):
+    def ref_side(self, ref_x):
+        """The two projections of the reference features, (ref_fc_embed(ref_x), ref_fc(ref_x)), each [M, C]: they do not depend on the
+        key frame, so a caller may keep them for reference frames that stay in the memo (SelsaBBoxHead.ref_branch)."""
+        return self.ref_fc_embed(ref_x), self.ref_fc(ref_x)
+
+    def forward(self, x, ref_x, ref_side=None):
         """x [N, C] key-frame proposal features, ref_x [M, C] reference ones -> [N, C] (selsa_aggregator.py:29-73)."""
         _gpu(x, ref_x)
         n, m, nb = x.shape[0], ref_x.shape[0], self.num_attention_blocks
+        r_embed, r_new = self.ref_side(ref_x) if ref_side is None else ref_side
         x_embed = self.fc_embed(x).view(n, nb, -1).permute(1, 0, 2)
-        ref_embed = self.ref_fc_embed(ref_x).view(m, nb, -1).permute(1, 2, 0)
+        ref_embed = r_embed.view(m, nb, -1).permute(1, 2, 0)
         weights = (torch.bmm(x_embed, ref_embed) / (x_embed.shape[-1] ** 0.5)).softmax(dim=2)
-        ref_new = self.ref_fc(ref_x).view(m, nb, -1).permute(1, 0, 2)
+        ref_new = r_new.view(m, nb, -1).permute(1, 0, 2)
         x_new = torch.bmm(weights, ref_new).permute(1, 0, 2).contiguous()
         return self.fc(x_new.view(n, -1))
 
@@ -82,14 +88,34 @@ class SelsaBBoxHead(nn.Module):
         for m in self.shared_fcs:
             nn.init.xavier_uniform_(m.weight); nn.init.constant_(m.bias, 0)
 
-    def forward(self, x, ref_x):
-        """x [N, C, H, W] key-frame RoI features, ref_x [M, C, H, W] -> (cls_score [N, classes+1], bbox_pred [N, 4*classes])."""
-        _gpu(x, ref_x)
-        x, ref_x = x.flatten(1), ref_x.flatten(1)
+    def ref_branch(self, ref_x):
+        """Everything the head computes from the reference RoI features alone (selsa_bbox_head.py:60-84: the reference side of the loop
+        never sees the key frame): per shared fc the pre-activation features [M, fc_out] and the aggregator's two projections of them.
+        Rows are independent, so branches of disjoint row sets concatenate (`cat_branches`)."""
+        _gpu(ref_x)
+        ref_x = ref_x.flatten(1)
+        out = []
         for i, fc in enumerate(self.shared_fcs):
-            x, ref_x = fc(x), fc(ref_x)
-            x = x + self.aggregator[i](x, ref_x)
-            ref_x, x = F.relu(ref_x), F.relu(x)
+            ref_x = fc(ref_x)
+            out.append((ref_x,) + tuple(self.aggregator[i].ref_side(ref_x)))
+            ref_x = F.relu(ref_x)
+        return out
+
+    @staticmethod
+    def cat_branches(a, b):
+        return [tuple(torch.cat((u, v), 0) for u, v in zip(la, lb)) for la, lb in zip(a, b)]
+
+    def forward(self, x, ref_x, ref_branch=None):
+        """x [N, C, H, W] key-frame RoI features, ref_x [M, C, H, W] (or None with a precomputed `ref_branch` over the same M rows)
+        -> (cls_score [N, classes+1], bbox_pred [N, 4*classes])."""
+        _gpu(x, ref_x)
+        if ref_branch is None:
+            ref_branch = self.ref_branch(ref_x)
+        x = x.flatten(1)
+        for i, fc in enumerate(self.shared_fcs):
+            ref_pre, r_embed, r_new = ref_branch[i]
+            x = fc(x)
+            x = F.relu(x + self.aggregator[i](x, ref_pre, ref_side=(r_embed, r_new)))
         return self.fc_cls(x), self.fc_reg(x)
 
     def _decode(self, rois, deltas, max_shape):
@@ -155,25 +181,42 @@ class SelsaRoIHead(nn.Module):
     def init_weights(self):
         self.bbox_head.init_weights()
 
-    def _bbox_forward(self, x, ref_x, rois, ref_rois):
-        """selsa_roi_head.py:61-78."""
+    def _bbox_forward(self, x, ref_x, rois, ref_rois, static_refs=0, static_rows=0, cache=None):
+        """selsa_roi_head.py:61-78. `static_refs` / `cache` (SELSA.simple_test, memo mode): the first `static_refs` images of ref_x and
+        their RoIs are the memo's reference frames, unchanged for the whole video; their RoI features and the head's reference branch
+        are computed once per video and kept in `cache` -- same kernels on the same inputs as recomputing them per key frame."""
         n_in = self.bbox_roi_extractor.num_inputs
         from .roi_extractors import TemporalRoIAlign
         if isinstance(self.bbox_roi_extractor, TemporalRoIAlign):       # selsa_roi_head.py:83-86: the key RoIs also see the reference maps
             bbox_feats = self.bbox_roi_extractor(x[:n_in], rois, ref_feats=ref_x[:n_in])
         else:
             bbox_feats = self.bbox_roi_extractor(x[:n_in], rois)
-        ref_bbox_feats = self.bbox_roi_extractor(ref_x[:n_in], ref_rois)
-        cls_score, bbox_pred = self.bbox_head(bbox_feats, ref_bbox_feats)
+        if static_refs > 0 and cache is not None:
+            # bbox2roi lists the RoIs image by image: the first static_rows rows belong to the static frames
+            if 'ref_branch' not in cache:
+                static_feats = self.bbox_roi_extractor(tuple(f[:static_refs] for f in ref_x[:n_in]), ref_rois[:static_rows])
+                cache['ref_branch'] = self.bbox_head.ref_branch(static_feats)
+            live_rois = ref_rois[static_rows:].clone()
+            live_rois[:, 0] -= static_refs
+            live_feats = self.bbox_roi_extractor(tuple(f[static_refs:] for f in ref_x[:n_in]), live_rois)
+            branch = self.bbox_head.cat_branches(cache['ref_branch'], self.bbox_head.ref_branch(live_feats))
+            cls_score, bbox_pred = self.bbox_head(bbox_feats, None, ref_branch=branch)
+        else:
+            ref_bbox_feats = self.bbox_roi_extractor(ref_x[:n_in], ref_rois)
+            cls_score, bbox_pred = self.bbox_head(bbox_feats, ref_bbox_feats)
         return dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=bbox_feats)
 
     def forward_train(self, *a, **k):
         raise LlvError('SelsaRoIHead.forward_train: the two-stage training path is not built')
 
-    def simple_test_bboxes(self, x, ref_x, proposals, ref_proposals, img_metas, rcnn_test_cfg, rescale=False):
+    def simple_test_bboxes(self, x, ref_x, proposals, ref_proposals, img_metas, rcnn_test_cfg, rescale=False, static_refs=0, cache=None):
         """selsa_roi_head.py:134-187."""
         rois, ref_rois = bbox2roi(proposals), bbox2roi(ref_proposals)
-        res = self._bbox_forward(x, ref_x, rois, ref_rois)
+        if static_refs > 0 and cache is not None:
+            res = self._bbox_forward(x, ref_x, rois, ref_rois, static_refs=static_refs,
+                                     static_rows=sum(len(p) for p in ref_proposals[:static_refs]), cache=cache)
+        else:
+            res = self._bbox_forward(x, ref_x, rois, ref_rois)
         counts = tuple(len(p) for p in proposals)
         rois_s, cls_s, reg_s = rois.split(counts, 0), res['cls_score'].split(counts, 0), res['bbox_pred'].split(counts, 0)
         det_bboxes, det_labels = [], []
@@ -183,9 +226,10 @@ class SelsaRoIHead(nn.Module):
             det_bboxes.append(d); det_labels.append(l)
         return det_bboxes, det_labels
 
-    def simple_test(self, x, ref_x, proposals_list, ref_proposals_list, img_metas, proposals=None, rescale=False):
+    def simple_test(self, x, ref_x, proposals_list, ref_proposals_list, img_metas, proposals=None, rescale=False, static_refs=0, cache=None):
         """selsa_roi_head.py:113-132: list per image of list[num_classes] of (k, 5) arrays."""
-        det_bboxes, det_labels = self.simple_test_bboxes(x, ref_x, proposals_list, ref_proposals_list, img_metas, self.test_cfg, rescale)
+        det_bboxes, det_labels = self.simple_test_bboxes(x, ref_x, proposals_list, ref_proposals_list, img_metas, self.test_cfg, rescale,
+                                                         static_refs, cache)
         return [bbox2result(det_bboxes[i], det_labels[i], self.bbox_head.num_classes) for i in range(len(det_bboxes))]
 
 
@@ -275,6 +319,8 @@ class SELSA(BaseVideoDetector):
         if self.with_detector and pretrain.get('detector', False):
             self.init_module('detector', pretrain['detector'])
 
+    cache_static_refs = True      # memo mode: keep the memo frames' proposals / RoI features / reference branch for the video (simple_test)
+
     def forward_train(self, *a, **k):
         raise LlvError('SELSA.forward_train: the two-stage training path is not built')
 
@@ -323,7 +369,7 @@ class SELSA(BaseVideoDetector):
         x, img_metas, ref_x, ref_img_metas = self.extract_feats(img, img_metas, ref_img, ref_img_metas)
         if proposals is None:
             proposal_list = self.detector.rpn_head.simple_test_rpn(x, img_metas)
-            if img_metas[0].get('frame_stride', -1) < 1:
+            if img_metas[0].get('frame_stride', -1) < 1 and self.cache_static_refs:
                 # ref_x = the memo's reference frames followed by the key frame (extract_feats above). The reference runs the RPN over
                 # all of them for every key frame (selsa.py:312-315); the memo frames do not change during the video and the key
                 # frame's proposals have just been computed, so their proposals are taken from the memo / from proposal_list: the
@@ -331,8 +377,11 @@ class SELSA(BaseVideoDetector):
                 if 'proposals' not in self.memo:
                     self.memo['proposals'] = self.detector.rpn_head.simple_test_rpn(tuple(self.memo['feats']), list(self.memo['img_metas']))
                 ref_proposals_list = list(self.memo['proposals']) + list(proposal_list)
-            else:
-                ref_proposals_list = self.detector.rpn_head.simple_test_rpn(ref_x, ref_img_metas)
+                # ... and so are those frames' RoI features and the head's reference branch over them (SelsaRoIHead._bbox_forward)
+                outs = self.detector.roi_head.simple_test(x, ref_x, proposal_list, ref_proposals_list, img_metas, rescale=rescale,
+                                                          static_refs=len(self.memo['proposals']), cache=self.memo.setdefault('roi_cache', {}))
+                return dict(bbox_results=outs[0])
+            ref_proposals_list = self.detector.rpn_head.simple_test_rpn(ref_x, ref_img_metas)
         else:
             proposal_list, ref_proposals_list = proposals, ref_proposals
         outs = self.detector.roi_head.simple_test(x, ref_x, proposal_list, ref_proposals_list, img_metas, rescale=rescale)
