@@ -2468,7 +2468,7 @@ static int conv_prepare(const llv_conv_desc* d, ConvPrepared& P) {
         return LLV_OK;
     }
     const int tile = lp.tile;
-    if ((f & LLV_CONV_PS_EMAJOR) && !((tile == LLV_TILE_TAP64 || tile == LLV_TILE_TAP64_G3) && tap_eligible(d))) return LLV_E_UNSUPPORTED;
+    if ((f & LLV_CONV_PS_EMAJOR) && !((tile == LLV_TILE_TAP64 || tile == LLV_TILE_TAP64_G3 || tile == LLV_TILE_TAP512) && tap_eligible(d))) return LLV_E_UNSUPPORTED;
     if ((f & LLV_CONV_PIXSHUF) && tile == LLV_TILE_16x256) k.stage_out = 0;
     if ((tile == LLV_TILE_TAP128 || tile == LLV_TILE_TAP64 || tile == LLV_TILE_TAP64_R4 || tile == LLV_TILE_TAP64_G3) && !tap_eligible(d)) return LLV_E_BADARG;
     if (tile == LLV_TILE_TAP512 && !tap512_supported(d)) return LLV_E_UNSUPPORTED;

@@ -546,6 +546,14 @@ def test_conv3x3_tap_pixel_shuffle_subpixel_major(dev):
         ref = F.pixel_shuffle(F.conv2d(x, wt, bias, 1, 1), 2) + res.float().permute(0, 3, 1, 2)
         assert y.shape == (2, 2 * h, 2 * w, cout // 4)
         _check(y, ref, cout // 4)
+        # the 16 x 32-tile kernel's epilogue of the same name (tile 13) against the 8 x 32 kernel (tile 10): same bits, with and without
+        # the skip tensor and the activation
+        for flags in (ops.CONV_PIXSHUF | ops.CONV_RES_ADD | ops.CONV_PS_EMAJOR, ops.CONV_PIXSHUF | ops.CONV_PS_EMAJOR | ops.CONV_RELU,
+                      ops.CONV_PIXSHUF | ops.CONV_RES_ADD | ops.CONV_PS_EMAJOR | ops.CONV_RELU):
+            r = res.to(dev) if flags & ops.CONV_RES_ADD else None
+            ya = ops.conv2d(_nhwc(x).half().to(dev), pc, res=r, flags=flags, tile=13)
+            yb = ops.conv2d(_nhwc(x).half().to(dev), pc, res=r, flags=flags, tile=10)
+            assert torch.equal(ya, yb)
 
 
 @pytest.mark.parametrize('tile', [0, 1, 2, 5, 6, 7])
@@ -600,4 +608,4 @@ def test_conv3x3_tap512_refuses_other_epilogues(dev):
     from lowlightenvironmentvideoobjectdetection_amd import ops
     from lowlightenvironmentvideoobjectdetection_amd._lib import LlvError
     with pytest.raises(LlvError):
-        _run_conv(dev, 1, 64, 128, 16, 32, 3, 1, 1, tile=13, flags=ops.CONV_PIXSHUF)
+        _run_conv(dev, 1, 64, 128, 16, 32, 3, 1, 1, tile=13, flags=ops.CONV_PIXSHUF)      # channel-major PixelShuffle: not on this kernel
