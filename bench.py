@@ -612,6 +612,7 @@ def main():
     lat = None
     stream = None
     stream_pipe = None
+    stream_pipe3 = None
     if rank == 0 and world == 1 and B != 1 and not args.no_latency_mode:
         p1 = engine.EnhanceDetectPlan(cleaner.state_dict(), det.state_dict(), NUM_CLASSES, 1, hp, wp, dev,
                                       detector_kwargs=dict(test_cfg=dict(det.bbox_head.test_cfg), img_shapes=[img_shape]),
@@ -672,6 +673,30 @@ def main():
                        'value': round(nlat / d1, 3), 'unit': 'frames/s', 'ms_per_frame': round(d1 / nlat * 1e3, 4),
                        'note': 'streaming_mode with FastDVDnet(frame i) and the detector(frame i-1) on two HIP streams; detections of a '
                                'frame are available one step later'}
+        del pp
+        # three stages: backbone + neck of frame i-1 and head .. NMS of frame i-2 on two more streams
+        pp = engine.PipelinedStreamingPlan(cleaner.state_dict(), det.state_dict(), NUM_CLASSES, 1, hp, wp, dev,
+                                           detector_kwargs=dict(test_cfg=dict(det.bbox_head.test_cfg), img_shapes=[img_shape]),
+                                           use_graph=not args.no_graph, stages=3)
+        pp.prepare(clip)
+        for s_ in range(args.warmup):
+            pp.step(clip, s_ % T, carry=(s_ % T) != 0)
+        torch.cuda.synchronize()
+        t1 = time.perf_counter()
+        full_steps = 0
+        for s_ in range(nlat):
+            t0_ = (args.warmup + s_) % T
+            full_steps += t0_ == 0
+            pp.step(clip, t0_, carry=t0_ != 0)
+        pp.flush()
+        pp.flush()
+        torch.cuda.synchronize()
+        d1 = time.perf_counter() - t1
+        trips['streaming_pipelined3'] = ops.guard_trips()
+        stream_pipe3 = {'frames_per_step': 1, 'frames': nlat, 'denblocks_per_frame': round((4 * full_steps + 2 * (nlat - full_steps)) / nlat, 3),
+                        'value': round(nlat / d1, 3), 'unit': 'frames/s', 'ms_per_frame': round(d1 / nlat * 1e3, 4),
+                        'note': 'streaming_mode on three HIP streams: FastDVDnet(frame i), backbone + neck(frame i-1), head .. NMS(frame i-2); '
+                                'detections of a frame are available two steps later'}
         del pp
     n_cand_thr = int((last.det.post.dp.scores.reshape(B, -1)[0] > 0.05).sum().item())
 
@@ -740,6 +765,8 @@ def main():
             out['streaming_mode'] = stream
         if stream_pipe is not None:
             out['streaming_pipelined_mode'] = stream_pipe
+        if stream_pipe3 is not None:
+            out['streaming_pipelined3_mode'] = stream_pipe3
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(det, cleaner, clip.cpu(), img_shape)
         print(json.dumps(out), flush=True)

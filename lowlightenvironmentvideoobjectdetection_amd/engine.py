@@ -896,17 +896,25 @@ class PipelinedStreamingPlan:
     just become available one step later (`results()` after step i+1, or after `flush()`). Windows are read in place from the
     resident clip (bind_clip); both halves of a step are one captured graph with two branches (kernel nodes only)."""
 
-    def __init__(self, cleaner_sd, detector_sd, num_classes, batch, height, width, device, detector_kwargs=None, use_graph=True):
-        self.batch, self.dev, self.use_graph = batch, device, use_graph
+    def __init__(self, cleaner_sd, detector_sd, num_classes, batch, height, width, device, detector_kwargs=None, use_graph=True, stages=2):
+        """stages = 3 splits the detector between two more streams: backbone + neck of window i-1 beside head + decode + NMS of window
+        i-2 (the pyramid of detector plan k is written in one step and read in the next; the two plans alternate, so the halves never
+        touch the same buffers inside a step). Results then leave two steps after their frame entered."""
+        assert stages in (2, 3)
+        self.batch, self.dev, self.use_graph, self.stages = batch, device, use_graph, stages
         self.den = FastDVDnetPlan(cleaner_sd, batch, height, width, device)
         self.dets = [RetinaNetPlan(detector_sd, num_classes, batch, height, width, device, **(detector_kwargs or {})) for _ in range(2)]
         self.det = self.dets[0]
+        names = [st[0] for st in self.det.plan.steps]
+        self._head0 = next(i for i, nm in enumerate(names) if nm.startswith('head'))      # first launch that reads the pyramid
         k = self.det.post.nb.max_num
         self.res_host = [torch.zeros((batch, k, 6), dtype=torch.float32).pin_memory() for _ in range(2)]
         self.cnt_host = [torch.zeros((batch,), dtype=torch.int32).pin_memory() for _ in range(2)]
         self.side = torch.cuda.Stream(device)
+        self.side2 = torch.cuda.Stream(device) if stages == 3 else None
         self._graphs = [None, None]
         self._i = 0
+        self._last = 0                       # parity whose res_host holds the most recent detections
         self._off = torch.zeros((1,), device=device, dtype=torch.int64)
         self._clip = None
 
@@ -917,22 +925,45 @@ class PipelinedStreamingPlan:
         if rc != 0:
             raise LlvError(f'llv_copy_d2d: {lib().llv_strerror(rc).decode()} ({rc})')
 
-    def _detect(self, k):
-        d = self.dets[k]
-        d.plan.run()
-        nb = d.post.nb
+    def _run_range(self, k, lo, hi):
+        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+        for name, fn, args, _, _ in self.dets[k].plan.steps[lo:hi]:
+            rc = fn(*args, stream)
+            if rc != 0:
+                raise LlvError(f'{name}: {lib().llv_strerror(rc).decode()} ({rc})')
+
+    def _pack(self, k):
+        nb = self.dets[k].post.nb
         rc = lib().llv_pack_results(C.c_void_p(nb.dets.data_ptr()), C.c_void_p(nb.labels.data_ptr()), C.c_void_p(nb.count.data_ptr()),
                                     self.batch, nb.max_num, C.c_void_p(self.res_host[k].data_ptr()), C.c_void_p(self.cnt_host[k].data_ptr()),
                                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
             raise LlvError(f'llv_pack_results: {lib().llv_strerror(rc).decode()} ({rc})')
 
-    def _body(self, k, carry):
+    def _detect(self, k):
+        self._run_range(k, 0, len(self.dets[k].plan.steps))
+        self._pack(k)
+
+    def _body(self, k, carry, enhance=True, front=True):
+        """Step with parity k. Two stages: detector of window i-1 (plan 1-k) beside FastDVDnet of window i. Three stages: backbone +
+        neck of window i-1 (plan 1-k), head .. results of window i-2 (plan k), FastDVDnet of window i (into plan k's input, which
+        the head half does not read)."""
         main = torch.cuda.current_stream()
         self.side.wait_stream(main)
-        with torch.cuda.stream(self.side):
-            self._detect(1 - k)
-        self._enhance(k, carry)
+        if self.stages == 2:
+            with torch.cuda.stream(self.side):
+                self._detect(1 - k)
+        else:
+            self.side2.wait_stream(main)
+            if front:
+                with torch.cuda.stream(self.side):
+                    self._run_range(1 - k, 0, self._head0)
+            with torch.cuda.stream(self.side2):
+                self._run_range(k, self._head0, len(self.dets[k].plan.steps))
+                self._pack(k)
+            main.wait_stream(self.side2)
+        if enhance:
+            self._enhance(k, carry)
         main.wait_stream(self.side)
 
     def prepare(self, clip):
@@ -953,8 +984,8 @@ class PipelinedStreamingPlan:
         self._i = 0
 
     def step(self, clip, t0, carry):
-        """Enqueue: enhance window t0 (carry=True: it directly follows the previous step's window) and detect the previous step's
-        window. No host sync."""
+        """Enqueue: enhance window t0 (carry=True: it directly follows the previous step's window) and run the detector stage(s) of
+        the previous window(s). No host sync."""
         if clip.data_ptr() != self._clip.data_ptr() or t0 < 0 or t0 + self.batch + 4 > clip.shape[0]:
             raise LlvError('PipelinedStreamingPlan.step takes the clip given to prepare() and a window inside it')
         k = self._i & 1
@@ -963,17 +994,29 @@ class PipelinedStreamingPlan:
             self._graphs[k].replay()
         else:
             self._body(k, carry)
+        self._last = 1 - k if self.stages == 2 else k
         self._i += 1
 
     def flush(self):
-        """Detect the window the last step enhanced (drains the pipeline)."""
-        self._detect(1 - (self._i & 1))
+        """Advance the detector stage(s) once without a new window: after `stages - 1` calls the last window's detections are out."""
+        k = self._i & 1
+        if self.stages == 2:
+            self._detect(1 - k)
+            self._last = 1 - k
+        else:
+            self._body(k, False, enhance=False)
+            self._last = k
         self._i += 1
+
+    @property
+    def lag(self):
+        """Steps between a window entering and its detections leaving."""
+        return self.stages - 1
 
     def results(self):
         """Detections of the window most recently detected: [(dets (k, 5), labels (k,))] per image."""
         torch.cuda.synchronize()
-        k = self._i & 1
+        k = self._last
         out = []
         for n in range(self.batch):
             c = int(self.cnt_host[k][n])

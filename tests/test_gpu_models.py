@@ -305,25 +305,28 @@ def test_pipelined_streaming_equals_sequential_streaming(dev, B, use_graph):
     seq = engine.EnhanceDetectPlan(cleaner.state_dict(), det.state_dict(), ncls, B, h, w, dev, **kw)
     seq.prepare(clip)
     seq.prepare_stream()
-    pipe = engine.PipelinedStreamingPlan(cleaner.state_dict(), det.state_dict(), ncls, B, h, w, dev, **kw)
-    pipe.prepare(clip)
     starts = list(range(0, T - B + 1, B))
     ref = []
     for i, t0 in enumerate(starts):
         seq.step(clip, t0, carry=i > 0)
         ref.append([(d.clone(), l.clone()) for d, l in seq.results()])
     assert sum(len(d) for r in ref for d, _ in r) > 20
-    got = []
-    for i, t0 in enumerate(starts):
-        pipe.step(clip, t0, carry=i > 0)
-        if i > 0:
+    for stages in (2, 3):                    # 3: backbone + neck and head .. NMS of consecutive windows on two more streams
+        pipe = engine.PipelinedStreamingPlan(cleaner.state_dict(), det.state_dict(), ncls, B, h, w, dev, stages=stages, **kw)
+        pipe.prepare(clip)
+        assert pipe.lag == stages - 1
+        got = []
+        for i, t0 in enumerate(starts):
+            pipe.step(clip, t0, carry=i > 0)
+            if i >= pipe.lag:
+                got.append(pipe.results())
+        for _ in range(pipe.lag):
+            pipe.flush()
             got.append(pipe.results())
-    pipe.flush()
-    got.append(pipe.results())
-    assert len(got) == len(ref)
-    for r, q in zip(ref, got):
-        for (d0, l0), (d1, l1) in zip(r, q):
-            assert torch.equal(d0, d1) and torch.equal(l0, l1)
+        assert len(got) == len(ref)
+        for r, q in zip(ref, got):
+            for (d0, l0), (d1, l1) in zip(r, q):
+                assert torch.equal(d0, d1) and torch.equal(l0, l1)
     assert ops.guard_trips() == 0
 
 
