@@ -173,3 +173,62 @@ class DenoisingAggregator(PlannedModule):
         ops.pack_input(x.float().contiguous(), c, out=x_in)
         plan.run()
         return ops.unpack_output(out, c)
+
+
+@AGGREGATORS.register_module()
+class Denoising2Aggergator(PlannedModule):
+    """The authors' multi-stage denoising aggregator (mmtracking/mmtrack/models/aggregators/denoising2_aggregator.py:157-244; the class
+    name is the reference's spelling, its configs say `type='Denoising2Aggergator'`): for every backbone stage conv1 (from the second
+    stage on over the stage's features concatenated with the previous stage's output) -> residual dense blocks of three layers ->
+    TemporalAttentionFusion over the N frames -> + the stage's features; conv2 (stride 2 where `downsample`) feeds the next stage.
+
+    forward(x_noise, all_x): x_noise = tuple of (N, C_i, H_i, W_i) fp32 NCHW stage features on the GPU, all_x = tuple whose last
+    entry (N, out_channel[-1], H, W) receives the last stage's output -> (tuple of x_noise_out, tuple of len(all_x) copies of the sum),
+    as the reference returns them. One launch plan (engine.build_denoising2_aggregator)."""
+
+    def __init__(self, in_channel=(256, 512, 1024, 2048), mid_channel=(64, 128, 256, 512), out_channel=(512, 1024, 2048, 512),
+                 layer_name=('layer1', 'layer2', 'layer3', 'layer4'), rdb_blocks=(2, 2, 4, 2), rdb_channel_growth=(64, 64, 64, 64),
+                 taf_embs=(3, 3, 3, 3), downsample=(True, True, False, False), with_rdb=(True, True, True, True),
+                 with_taf=(True, True, True, True)):
+        super().__init__()
+        self.num_stage = len(in_channel)
+        self.in_channel, self.mid_channel, self.out_channel = list(in_channel), list(mid_channel), list(out_channel)
+        self.layer_name, self.rdb_blocks, self.taf_embs = list(layer_name), list(rdb_blocks), list(taf_embs)
+        self.downsample, self.with_rdb, self.with_taf = list(downsample), list(with_rdb), list(with_taf)
+        for i in range(self.num_stage):
+            if in_channel[i] % 8 or out_channel[i] % 8 or rdb_channel_growth[i] % 8 or (with_taf[i] and mid_channel[i] % 64):
+                raise NotImplementedError('Denoising2Aggergator: channel counts must keep 8-channel vectors whole and each of the 8 '
+                                          'deformable groups a multiple of 8 channels')
+        self.layers = nn.ModuleDict()
+        for i in range(self.num_stage):
+            l = layer_name[i]
+            self.layers[l + '_conv1'] = _conv3(in_channel[0] if i == 0 else in_channel[i] + out_channel[i - 1], in_channel[i])
+            if with_rdb[i]:
+                self.layers[l + '_rdb'] = nn.Sequential(*[RDB(in_channel[i], rdb_channel_growth[i], 3) for _ in range(rdb_blocks[i])])
+            if with_taf[i]:
+                self.layers[l + '_taf'] = TemporalAttentionFusion(in_channel[i], mid_channel[i], emb_nums=taf_embs[i])
+            self.layers[l + '_conv2'] = nn.Conv2d(in_channel[i], out_channel[i], kernel_size=3, padding=1, stride=2 if downsample[i] else 1)
+
+    def make_plan(self, n, shapes, last_shape, device):
+        b = engine.Builder(device)
+        xs = [b.buf(n, h, w, c) for (c, h, w) in shapes]
+        last = b.buf(n, last_shape[1], last_shape[2], last_shape[0])
+        outs, total = engine.build_denoising2_aggregator(b, engine._cpu_sd(self.state_dict()), xs, last, n, self.in_channel, self.out_channel,
+                                                         self.layer_name, self.rdb_blocks, self.taf_embs, self.downsample, self.with_rdb,
+                                                         self.with_taf)
+        return b.plan, xs, last, outs, total
+
+    def forward(self, x_noise, all_x):
+        for t in tuple(x_noise) + (all_x[-1],):
+            self._check_input(t)
+        n = x_noise[0].shape[0]
+        shapes = tuple(tuple(t.shape[1:]) for t in x_noise)
+        last_shape = tuple(all_x[-1].shape[1:])
+        dev = x_noise[0].device
+        plan, xs, last, outs, total = self._plan((n, shapes, last_shape, str(dev)), lambda: self.make_plan(n, shapes, last_shape, dev))
+        for t, buf in zip(x_noise, xs):
+            ops.pack_input(t.float().contiguous(), t.shape[1], out=buf)
+        ops.pack_input(all_x[-1].float().contiguous(), last_shape[0], out=last)
+        plan.run()
+        s = ops.unpack_output(total, last_shape[0])
+        return tuple(ops.unpack_output(o, o.shape[-1]) for o in outs), tuple(s for _ in all_x)

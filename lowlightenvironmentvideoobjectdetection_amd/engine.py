@@ -1105,6 +1105,91 @@ def build_denoising_aggregator(b: Builder, sd, x, n, num_blocks=1, num_layers=6,
     return b.conv(f'{tag}.conv3', t, cv('conv3'), CONV_RELU | CONV_RES_ADD | CONV_ACT_FIRST, res=x)
 
 
+def build_denoising2_aggregator(b: Builder, sd, x_noise, last_all_x, n, in_channel, out_channel, layer_name, rdb_blocks, taf_embs,
+                                downsample, with_rdb, with_taf, deform_groups=8, p='layers.', tag='agg2'):
+    """Denoising2Aggergator.forward (mmtracking/mmtrack/models/aggregators/denoising2_aggregator.py:214-244) on the NHWC fp16 stage
+    features x_noise[i] (n, h_i, w_i, C_i) and last_all_x (n, h, w, out_channel[-1]); returns (x_noise_out buffers, the sum
+    all_x[-1] + x_list[-1]). The concatenation in front of conv1 is a two-source launch (in_channel[i] == out_channel[i-1] in every
+    config of the reference: equal-width sources), a dense block's concatenations are channel slices of one buffer, the RDB's local
+    residual is the lff conv's epilogue, the temporal fusion is the plan of build_denoising_aggregator's."""
+    L = lib()
+    cv = lambda q, pad=1, stride=1: ops.pack_conv(sd[p + q + '.weight'], sd.get(p + q + '.bias'), stride, pad)
+
+    def add(name, a0, a1):
+        nn_, h, w, c = a0.shape
+        y = b.buf(nn_, h, w, c)
+        b.plan.add(name, L.llv_add_f16, (C.c_void_p(a0.data_ptr()), C.c_void_p(a1.data_ptr()), C.c_void_p(y.data_ptr()),
+                                         C.c_int64(nn_ * h * w), c, c, c, c), 0.0, 6.0 * y.numel())
+        b.plan.keep += [a0, a1]
+        return y
+    ns = len(in_channel)
+    outs, prev = [], None
+    for i in range(ns):
+        l = layer_name[i]
+        xi = x_noise[i]
+        _, h, w, c = xi.shape
+        m = in_channel[i]
+        growth = sd[f'{p}{l}_rdb.0.layers.0.conv.weight'].shape[0] if with_rdb[i] else 0
+        tot = m + growth * 3
+        pc1 = cv(f'{l}_conv1')
+        if i > 0 and prev.shape[-1] != c:
+            raise LlvError('Denoising2Aggergator: in_channel[i] must equal out_channel[i-1] (two equal-width sources of conv1)')
+        if i > 0:
+            pc1 = ops.pack_conv(sd[f'{p}{l}_conv1.weight'], sd.get(f'{p}{l}_conv1.bias'), 1, 1, n_src=2)
+        t = b.buf(n, h, w, tot)
+        b.conv_desc(f'{tag}.{l}.conv1', pc1, [xi] if i == 0 else [xi, prev], t, n, [(h, w, h, w, 0, 0)], c, tot)
+        t_ld = tot
+        if with_rdb[i]:
+            for bi in range(rdb_blocks[i]):
+                q = f'{l}_rdb.{bi}'
+                cat = t
+                for k in range(3):
+                    cin = m + growth * k
+                    b.conv_desc(f'{tag}.{q}.layers.{k}', cv(f'{q}.layers.{k}.conv'), [cat], cat[..., cin:], n, [(h, w, h, w, 0, 0)], tot, tot,
+                                flags=CONV_RELU)
+                last = bi == rdb_blocks[i] - 1
+                t = b.buf(n, h, w, m if last else tot)
+                t_ld = m if last else tot
+                b.conv_desc(f'{tag}.{q}.lff', cv(f'{q}.lff', 0), [cat], t, n, [(h, w, h, w, 0, 0)], tot, t_ld, res=cat, res_ld=tot,
+                            flags=CONV_RES_ADD)
+        if with_taf[i]:
+            t = _plan_taf(b, sd, t, n, p + f'{l}_taf.', f'{tag}.{l}.taf', taf_embs[i], deform_groups, CONV_RELU, None)
+        xa = add(f'{tag}.{l}.add_noise', t, xi)
+        outs.append(xa)
+        prev = b.conv(f'{tag}.{l}.conv2', t if i == ns - 1 else xa, cv(f'{l}_conv2', 1, 2 if downsample[i] else 1))
+    return outs, add(f'{tag}.all_x', last_all_x, prev)
+
+
+def _plan_taf(b, sd, t, n, p, tag, emb_nums, deform_groups, out_flags, res):
+    """TemporalAttentionFusion.forward (denoising_aggregator.py:135-152) on t (n, h, w, c): returns the conv2 launch's output with
+    `out_flags` / `res` as its epilogue (relu(conv2(.)) for the bare module)."""
+    L = lib()
+    _, h, w, c = t.shape
+    cv = lambda q, pad=1: ops.pack_conv(sd[p + q + '.weight'], sd.get(p + q + '.bias'), 1, pad)
+    xt = b.conv(f'{tag}.conv1', t, cv('conv1'), CONV_RELU)
+    mt = xt.shape[-1]
+    pairs = b.buf(n * n, h, w, 2 * mt)
+    b.plan.add(f'{tag}.pairs', L.llv_taf_pair_concat, (C.c_void_p(xt.data_ptr()), C.c_void_p(pairs.data_ptr()), n, h, w, mt),
+               0.0, 2.0 * (xt.numel() + pairs.numel()))
+    x_set = b.conv(f'{tag}.offset_conv', pairs, cv('offset_conv'))
+    om = b.conv(f'{tag}.conv_offset', x_set, cv('dcn_pack.conv_offset'), CONV_OUT_F32)
+    col = b.buf(n * n, h, w, 9 * mt)
+    b.plan.add(f'{tag}.dcn_im2col', L.llv_modulated_deform_im2col,
+               (C.c_void_p(pairs.data_ptr()), C.c_void_p(om.data_ptr()), C.c_void_p(col.data_ptr()), n * n, h, w, mt, 2 * mt,
+                om.shape[-1], 9 * mt, 3, 3, 1, 1, 1, deform_groups, h, w), 0.0, 2.0 * col.numel() + 4.0 * om.numel())
+    x_dcn = b.conv(f'{tag}.dcn_gemm', col, ops.pack_dcn_weight(sd[p + 'dcn_pack.weight'], sd.get(p + 'dcn_pack.bias')))
+    x_cor = b.buf(n * n, h, w, mt)
+    b.plan.add(f'{tag}.mul_ref', L.llv_taf_mul_ref, (C.c_void_p(x_dcn.data_ptr()), C.c_void_p(xt.data_ptr()),
+                                                      C.c_void_p(x_cor.data_ptr()), n, h, w, mt), 0.0, 4.0 * x_cor.numel())
+    for e in range(emb_nums):
+        x_cor = b.conv(f'{tag}.emb_conv.{e}', x_cor, cv(f'emb_conv.{e}'))
+    fused = b.buf(n, h, w, mt)
+    b.plan.add(f'{tag}.softmax_fuse', L.llv_taf_softmax_fuse, (C.c_void_p(x_cor.data_ptr()), C.c_void_p(xt.data_ptr()),
+                                                                C.c_void_p(fused.data_ptr()), n, h, w, mt), 0.0, 2.0 * x_cor.numel())
+    b.plan.keep += [x_cor, x_dcn, om, x_set]
+    return b.conv(f'{tag}.conv2', fused, cv('conv2'), out_flags, res=res)
+
+
 # ------------------------------------------------------------------------------------------------
 # FlowNetSimple
 # ------------------------------------------------------------------------------------------------

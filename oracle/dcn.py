@@ -121,3 +121,26 @@ def denoising_aggregator_forward(sd, x, num_blocks=1, num_layers=6, emb_nums=3, 
         x = temporal_attention_fusion(sd, p + 'taf', x, emb_nums)
     x = _conv(x + x_m, sd, p + 'conv3', relu=True)
     return x + identity
+
+
+def denoising2_aggregator_forward(sd, x_noise, all_x, in_channel, layer_name, rdb_blocks, taf_embs, downsample, with_rdb, with_taf, prefix=''):
+    """Denoising2Aggergator.forward (mmtracking/mmtrack/models/aggregators/denoising2_aggregator.py:214-244): per backbone stage
+    conv1 (on the stage's noisy features, from the second stage on concatenated with the previous stage's output) -> RDBs (3 dense
+    layers each) -> TemporalAttentionFusion -> + the stage's features; conv2 (stride 2 where `downsample`) feeds the next stage;
+    every entry of all_x gets all_x[-1] + the last stage's output. x_noise: tuple of (N, C_i, H_i, W_i)."""
+    p = prefix + 'layers.'
+    x_noise_out, x_list = [], []
+    ns = len(in_channel)
+    for i in range(ns):
+        l = layer_name[i]
+        f = x_noise[0] if i == 0 else torch.cat([x_noise[i], x_list[i - 1]], 1)
+        x = _conv(f, sd, f'{p}{l}_conv1')
+        if with_rdb[i]:
+            for b in range(rdb_blocks[i]):
+                x = rdb(sd, f'{p}{l}_rdb.{b}', x, 3)
+        if with_taf[i]:
+            x = temporal_attention_fusion(sd, f'{p}{l}_taf', x, taf_embs[i])
+        x_noise_out.append(x + x_noise[i])
+        w, bias = sd[f'{p}{l}_conv2.weight'], sd.get(f'{p}{l}_conv2.bias')
+        x_list.append(F.conv2d(x if i == ns - 1 else x + x_noise[i], w, bias, 2 if downsample[i] else 1, 1))
+    return tuple(x_noise_out), tuple(all_x[-1] + x_list[-1] for _ in all_x)
