@@ -152,6 +152,8 @@ def _aggregator(dev, **kw):
             m.taf.dcn_pack.conv_offset.weight.mul_(0.25)      # offsets of about a pixel, mask logits O(1)
             g = torch.Generator().manual_seed(8)
             m.taf.dcn_pack.bias.copy_(torch.randn(m.taf.dcn_pack.bias.shape, generator=g) * 0.05)
+            dw = m.taf.dcn_pack.weight                         # a plain Parameter: randomize() does not reach it
+            dw.copy_(torch.randn(dw.shape, generator=g) * (2.0 / (9 * dw.shape[1])) ** 0.5)
     return m
 
 
@@ -257,16 +259,33 @@ def test_denoising2_aggregator_builds_from_reference_cfg_with_reference_paramete
 @pytest.mark.gpu
 def test_denoising2_aggregator_vs_oracle(dev):
     """Denoising2Aggergator.forward on the device against the oracle with the same seeded weights: three stages (dense blocks only,
-    both, fusion only), a stride-2 hand-over and two stride-1 ones; 3e-2 of each output's scale (fp16 feature storage through three
-    chained stages, ~30 convolutions; the single-stage DenoisingAggregator test holds 2e-2)."""
+    both, fusion only), a stride-2 hand-over and two stride-1 ones; 2e-2 of each output's scale, as the single-stage DenoisingAggregator
+    test."""
     import lowlightenvironmentvideoobjectdetection_amd.models  # noqa: F401
     from lowlightenvironmentvideoobjectdetection_amd import registry
     from helpers import randomize
     from oracle.dcn import denoising2_aggregator_forward
-    m = randomize(registry.build_aggregator(dict(D2_CFG)), seed=21)
-    with torch.no_grad():
-        for l in ('layer2', 'layer3'):
-            m.layers[l + '_taf'].dcn_pack.conv_offset.weight.mul_(0.25)
+    def build():
+        m_ = randomize(registry.build_aggregator(dict(D2_CFG)), seed=21)
+        with torch.no_grad():
+            # keep the case well conditioned: with plain random weights the activations grow from stage to stage (13 -> 65 -> 80), the
+            # fusion's softmax over frames saturates, and rounding the INPUTS to fp16 alone moves the oracle's own last-stage output by
+            # 20 %; with these scales that sensitivity is < 1e-3 and the comparison measures the device, not the test case
+            gw = torch.Generator().manual_seed(23)
+            for l in ('layer2', 'layer3'):
+                dp = m_.layers[l + '_taf'].dcn_pack
+                dp.conv_offset.weight.mul_(0.25)
+                # ModulatedDCNPack's own weight / bias are plain Parameters (not an nn.Conv2d): helpers.randomize leaves them at their
+                # unseeded initialisation, so they are set here
+                dp.weight.copy_(torch.randn(dp.weight.shape, generator=gw) * (2.0 / (9 * dp.weight.shape[1])) ** 0.5)
+                dp.bias.copy_(torch.randn(dp.bias.shape, generator=gw) * 0.05)
+                for e in m_.layers[l + '_taf'].emb_conv:
+                    e.weight.mul_(0.1)
+            for k, p_ in m_.named_parameters():
+                if k.endswith('conv2.weight') and 'taf' not in k:
+                    p_.mul_(0.3)
+        return m_
+    m = build()
     g = torch.Generator().manual_seed(22)
     n = 3
     x_noise = (torch.randn(n, 32, 24, 32, generator=g), torch.randn(n, 64, 12, 16, generator=g), torch.randn(n, 64, 12, 16, generator=g))
@@ -274,10 +293,19 @@ def test_denoising2_aggregator_vs_oracle(dev):
     sd = {k: v.detach().float().cpu() for k, v in m.state_dict().items()}
     ref_noise, ref_all = denoising2_aggregator_forward(sd, x_noise, all_x, D2_CFG['in_channel'], D2_CFG['layer_name'], D2_CFG['rdb_blocks'],
                                                        D2_CFG['taf_embs'], D2_CFG['downsample'], D2_CFG['with_rdb'], D2_CFG['with_taf'])
-    out_noise, out_all = m.to(dev)(tuple(t.to(dev) for t in x_noise), tuple(t.to(dev) for t in all_x))
+    m = m.to(dev)
+    xd, ad = tuple(t.to(dev) for t in x_noise), tuple(t.to(dev) for t in all_x)
+    out_noise, out_all = m(xd, ad)
+    out_noise, out_all = tuple(o.clone() for o in out_noise), tuple(o.clone() for o in out_all)
     assert len(out_noise) == 3 and len(out_all) == 2
-    for o, r in zip(tuple(out_noise) + tuple(out_all), tuple(ref_noise) + tuple(ref_all)):
+    errs = []
+    for o, r in zip(out_noise + out_all, tuple(ref_noise) + tuple(ref_all)):
         assert o.shape == r.shape
-        err = (o.cpu() - r).abs().max().item() / r.abs().max().item()
-        assert err < 3e-2, err
+        errs.append((o.cpu() - r).abs().max().item() / r.abs().max().item())
+    assert max(errs) < 2e-2, errs
     assert (ref_all[0] - all_x[-1]).abs().max().item() > 0.1 * ref_all[0].abs().max().item()
+    # the plan is deterministic: a replay and a freshly built module give the same bits
+    again = m(xd, ad)
+    fresh = build().to(dev)(xd, ad)
+    for o, o2, o3 in zip(out_noise + out_all, tuple(again[0]) + tuple(again[1]), tuple(fresh[0]) + tuple(fresh[1])):
+        assert torch.equal(o, o2) and torch.equal(o, o3)
