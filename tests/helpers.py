@@ -44,6 +44,13 @@ def randomize(model, seed=0, cls_bias=-2.0):
                     m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.05)
                     if name.endswith('retina_cls'):
                         m.bias.add_(cls_bias)
+            elif isinstance(getattr(m, 'weight', None), nn.Parameter) and m.weight.dim() == 4:
+                # a module that owns a conv weight without being an nn.Conv2d (ModulatedDCNPack): left alone it would keep its UNSEEDED
+                # initialisation and make a comparison differ from run to run
+                fan_in = m.weight.shape[1] * m.weight.shape[2] * m.weight.shape[3]
+                m.weight.copy_(torch.randn(m.weight.shape, generator=g) * math.sqrt(2.0 / fan_in))
+                if getattr(m, 'bias', None) is not None:
+                    m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.05)
             elif isinstance(m, nn.BatchNorm2d):
                 m.weight.copy_(torch.rand(m.weight.shape, generator=g) * 0.5 + 0.5)
                 m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
