@@ -190,12 +190,13 @@ class ResNet(PlannedModule):
         def make():
             b = engine.Builder(x.device)
             x_in = b.buf(n, h, w, 8)
-            feats = engine.build_resnet(b, engine._cpu_sd(self.state_dict()), x_in, **self.plan_kwargs())
+            # inference plan: the stride-1 Bottlenecks of layer1 / layer2 as one launch each (bit-identical to the three launches)
+            feats = engine.build_resnet(b, engine._cpu_sd(self.state_dict()), x_in, fuse_blocks=True, **self.plan_kwargs())
             return b.plan, x_in, feats
         plan, x_in, feats = self._plan((n, h, w, str(x.device)), make)
         ops.pack_input(x.float().contiguous(), 8, out=x_in)
         plan.run()
-        return tuple(ops.unpack_output(f, f.shape[-1]) for f in feats)
+        return tuple(ops.unpack_output(f, f.shape[-1], owner=plan) for f in feats)
 
 
 @BACKBONES.register_module()
@@ -245,4 +246,4 @@ class InsertResNet(ResNet):
         plan, x_in, feats = self._plan((n, h, w, str(x.device)), make)
         ops.pack_input(x.float().contiguous(), 8, out=x_in)
         plan.run()
-        return tuple(ops.unpack_output(f, f.shape[-1]) for f in feats)
+        return tuple(ops.unpack_output(f, f.shape[-1], owner=plan) for f in feats)

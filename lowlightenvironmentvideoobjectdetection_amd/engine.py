@@ -46,6 +46,7 @@ class Plan:
         self.keep = []           # tensors the launches point into
         self.kernel_of = {}      # step name -> device kernel it launches (for per-kernel rooflines)
         self.graph = None
+        self.epoch = 0           # bumped by every run / replay: which generation of values the buffers hold
 
     def add(self, name, fn, args, flops=0.0, nbytes=0.0, kernel=None):
         self.steps.append((name, fn, args, flops, nbytes))
@@ -58,6 +59,7 @@ class Plan:
         self.kernel_of.update(other.kernel_of)
 
     def run(self):
+        self.epoch += 1          # the buffers are about to be rewritten (ops._nhwc_source)
         stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         for name, fn, args, _, _ in self.steps:
             rc = fn(*args, stream)
@@ -77,6 +79,7 @@ class Plan:
         if self.graph is None:
             self.run()
         else:
+            self.epoch += 1
             self.graph.replay()
 
     def run_timed(self, iters=3):

@@ -85,4 +85,4 @@ class FPN(PlannedModule):
         for t, buf in zip(inputs, ins):
             ops.pack_input(t.float().contiguous(), buf.shape[-1], out=buf)
         plan.run()
-        return tuple(ops.unpack_output(pyr.level(i).contiguous(), self.out_channels) for i in range(len(pyr.level_hw)))
+        return tuple(ops.unpack_output(pyr.level(i).contiguous(), self.out_channels, owner=plan) for i in range(len(pyr.level_hw)))

@@ -390,6 +390,12 @@ def pack_input(x: torch.Tensor, c_pad: int = 8, scale: Optional[torch.Tensor] = 
     _need_gpu(x)
     assert x.dtype == torch.float32 and x.is_contiguous()
     n, c, h, w = x.shape
+    src = _nhwc_source(x, (n, h, w, c_pad)) if scale is None and shift is None else None
+    if src is not None:            # x was unpacked from this very NHWC fp16 buffer, which still holds it: no conversion
+        if out is None:
+            return src
+        out.copy_(src)
+        return out
     if out is None:
         out = torch.empty((n, h, w, c_pad), device=x.device, dtype=torch.float16)
     check(lib().llv_pack_nchw_f32_to_nhwc_f16(_ptr(x), _ptr(out), n, c, h, w, c_pad, _ptr(scale), _ptr(shift),
@@ -397,8 +403,23 @@ def pack_input(x: torch.Tensor, c_pad: int = 8, scale: Optional[torch.Tensor] = 
     return out
 
 
-def unpack_output(x: torch.Tensor, c: int) -> torch.Tensor:
-    """NHWC fp16/fp32 (first c channels) -> NCHW fp32."""
+def _nhwc_source(x: torch.Tensor, shape):
+    """The NHWC fp16 plan buffer `x` (an NCHW fp32 module output) was unpacked from, if it still holds the same values: its plan has not
+    run since (Plan.epoch), x has not been written to (tensor version), and the layout asked for is the buffer's. Module-level calls
+    hand NCHW fp32 tensors to each other as the reference's modules do; between two modules of this package the consumer would only
+    convert them back."""
+    tag = getattr(x, '_llv_nhwc', None)
+    if tag is None:
+        return None
+    buf, owner, epoch, version = tag
+    if owner.epoch != epoch or x._version != version or tuple(buf.shape) != tuple(shape) or buf.device != x.device:
+        return None
+    return buf
+
+
+def unpack_output(x: torch.Tensor, c: int, owner=None) -> torch.Tensor:
+    """NHWC fp16/fp32 (first c channels) -> NCHW fp32. `owner` = the engine.Plan whose run() wrote x: the result then remembers where
+    it came from (_nhwc_source), so that a pack_input of it by the next module is free."""
     _need_gpu(x)
     assert x.is_contiguous()
     n, h, w, ld = x.shape
@@ -409,6 +430,8 @@ def unpack_output(x: torch.Tensor, c: int) -> torch.Tensor:
         check(lib().llv_unpack_nhwc_f32_to_nchw_f32(_ptr(x), _ptr(out), n, c, h, w, ld, _stream()), 'unpack f32')
     else:
         raise LlvError('unpack_output: fp16 or fp32 only')
+    if owner is not None and x.dtype == torch.float16:
+        out._llv_nhwc = (x, owner, owner.epoch, out._version)
     return out
 
 

@@ -18,12 +18,19 @@ from .planned import PlannedModule
 from .registry import HEADS, NECKS
 
 
+class _FreshBuffer:
+    """Owner tag of a buffer that is written once and never again (ops._nhwc_source)."""
+    epoch = 0
+
+
 def _conv_nchw(x, pc, flags=0):
-    """(N, C, H, W) fp32 on the GPU -> conv engine -> (N, Cout, Ho, Wo) fp32 (API boundary of the module-level calls)."""
+    """(N, C, H, W) fp32 on the GPU -> conv engine -> (N, Cout_stored, Ho, Wo) fp32 (API boundary of the module-level calls). The map is
+    produced in NHWC fp16, the layout and type every consumer of this package converts it to anyway; the NCHW fp32 tensor handed out
+    remembers that buffer, so such a consumer's pack_input is free."""
     c = x.shape[1]
     cp = ops.round_up(c, 8)
-    y = ops.conv2d(ops.pack_input(x.float().contiguous(), cp), pc, flags=flags | CONV_OUT_F32)
-    return y.permute(0, 3, 1, 2).contiguous()
+    y = ops.conv2d(ops.pack_input(x.float().contiguous(), cp), pc, flags=flags)
+    return ops.unpack_output(y, y.shape[-1], owner=_FreshBuffer)
 
 
 @NECKS.register_module()
@@ -52,7 +59,8 @@ class ChannelMapper(PlannedModule):
             pc = self._plan(('pc', i, str(x.device)),
                             lambda: ops.pack_conv(conv.weight.detach().cpu(), None if conv.bias is None else conv.bias.detach().cpu(), 1,
                                                   (conv.kernel_size[0] - 1) // 2).to(x.device))
-            outs.append(_conv_nchw(x, pc, CONV_RELU if self.act else 0)[:, :conv.out_channels])
+            y = _conv_nchw(x, pc, CONV_RELU if self.act else 0)
+            outs.append(y if y.shape[1] == conv.out_channels else y[:, :conv.out_channels])
         return tuple(outs)
 
 

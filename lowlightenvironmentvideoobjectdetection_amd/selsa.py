@@ -9,7 +9,7 @@ constructors and parameter names:
 
 What is native here: RoI features through `llv_roi_align`, detections through `llv_multiclass_nms_batched_ex` with class-specific
 boxes. The fully connected layers and the attention of the aggregator are plain GEMMs and run as torch (rocBLAS / hipBLASLt) calls on
-the device; the element-wise decode is torch on the device. No CPU path: CPU inputs raise. Training (`forward_train`, sampling,
+the device (fp16 operands, fp32 accumulation: `_lin`); the element-wise decode is torch on the device. No CPU path: CPU inputs raise. Training (`forward_train`, sampling,
 losses) is not built."""
 import numpy as np
 import torch
@@ -20,6 +20,18 @@ from . import ops
 from ._lib import LlvError
 from .core.bbox import bbox2result
 from .registry import AGGREGATORS, HEADS, ROI_EXTRACTORS, build, build_aggregator
+
+
+def _lin(fc, x):
+    """fc(x) as a library GEMM with fp16 operands and fp32 accumulation (the arithmetic type of the rest of the path: fp16 storage, fp32
+    accumulate); the fp16 copy of the weight is kept on the layer until the weight changes. Returns fp32."""
+    w = fc.weight
+    key = (w.data_ptr(), w._version, str(w.device))
+    if getattr(fc, '_llv_half_key', None) != key:
+        fc._llv_half = (w.detach().half(), fc.bias.detach().half() if fc.bias is not None else None)
+        fc._llv_half_key = key
+    wh, bh = fc._llv_half
+    return F.linear(x.half(), wh, bh).float()
 
 
 def _gpu(*ts):
@@ -41,19 +53,19 @@ class SelsaAggregator(nn.Module):
     def ref_side(self, ref_x):
         """The two projections of the reference features, (ref_fc_embed(ref_x), ref_fc(ref_x)), each [M, C]: they do not depend on the
         key frame, so a caller may keep them for reference frames that stay in the memo (SelsaBBoxHead.ref_branch)."""
-        return self.ref_fc_embed(ref_x), self.ref_fc(ref_x)
+        return _lin(self.ref_fc_embed, ref_x), _lin(self.ref_fc, ref_x)
 
     def forward(self, x, ref_x, ref_side=None):
         """x [N, C] key-frame proposal features, ref_x [M, C] reference ones -> [N, C] (selsa_aggregator.py:29-73)."""
         _gpu(x, ref_x)
         n, m, nb = x.shape[0], ref_x.shape[0], self.num_attention_blocks
         r_embed, r_new = self.ref_side(ref_x) if ref_side is None else ref_side
-        x_embed = self.fc_embed(x).view(n, nb, -1).permute(1, 0, 2)
+        x_embed = _lin(self.fc_embed, x).view(n, nb, -1).permute(1, 0, 2)
         ref_embed = r_embed.view(m, nb, -1).permute(1, 2, 0)
         weights = (torch.bmm(x_embed, ref_embed) / (x_embed.shape[-1] ** 0.5)).softmax(dim=2)
         ref_new = r_new.view(m, nb, -1).permute(1, 0, 2)
         x_new = torch.bmm(weights, ref_new).permute(1, 0, 2).contiguous()
-        return self.fc(x_new.view(n, -1))
+        return _lin(self.fc, x_new.view(n, -1))
 
 
 @HEADS.register_module()
@@ -96,7 +108,7 @@ class SelsaBBoxHead(nn.Module):
         ref_x = ref_x.flatten(1)
         out = []
         for i, fc in enumerate(self.shared_fcs):
-            ref_x = fc(ref_x)
+            ref_x = _lin(fc, ref_x)
             out.append((ref_x,) + tuple(self.aggregator[i].ref_side(ref_x)))
             ref_x = F.relu(ref_x)
         return out
@@ -114,9 +126,9 @@ class SelsaBBoxHead(nn.Module):
         x = x.flatten(1)
         for i, fc in enumerate(self.shared_fcs):
             ref_pre, r_embed, r_new = ref_branch[i]
-            x = fc(x)
+            x = _lin(fc, x)
             x = F.relu(x + self.aggregator[i](x, ref_pre, ref_side=(r_embed, r_new)))
-        return self.fc_cls(x), self.fc_reg(x)
+        return _lin(self.fc_cls, x), _lin(self.fc_reg, x)
 
     def _decode(self, rois, deltas, max_shape):
         """delta_xywh_bbox_coder.py:134-237 for (n, 4) rois and (n, 4k) deltas, on the device."""

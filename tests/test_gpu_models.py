@@ -366,3 +366,29 @@ def test_bench_gpus_flag_starts_the_ranks(dev):
     assert len(lines) == 1, r.stdout
     out = json.loads(lines[0])
     assert out['n_gpus'] == 2 and out['steps'] == 2 and out['value'] > 0 and out['scaling'] == 'weak'
+
+
+def test_module_outputs_remember_their_nhwc_buffer_only_while_it_is_valid(dev):
+    """ops.unpack_output(..., owner=plan) / ops.pack_input: a module output (NCHW fp32) packs back for free as long as the plan buffer
+    it was unpacked from still holds it -- not after the plan ran again, not after the tensor was written to."""
+    reg = _registry()
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    m = randomize(reg.build_backbone(dict(type='ResNet', depth=18)), seed=5).to(dev).eval()
+    x1, x2 = smooth_image(1, 64, 96, seed=1).to(dev), smooth_image(1, 64, 96, seed=2).to(dev)
+    o1 = m(x1)[3]
+    c = o1.shape[1]
+    p1 = ops.pack_input(o1, c)
+    assert getattr(o1, '_llv_nhwc', None) is not None and p1.data_ptr() == o1._llv_nhwc[0].data_ptr()      # no conversion
+    ref1 = ops.unpack_output(p1, c).clone()
+    assert torch.equal(ref1, o1)
+    keep = p1.clone()
+    o2 = m(x2)[3]                                   # the plan ran again: its buffers hold frame 2 now
+    assert not torch.equal(o2, o1)
+    p1_again = ops.pack_input(o1, c)                # must be converted from o1's own values, not taken from the overwritten buffer
+    assert p1_again.data_ptr() != o1._llv_nhwc[0].data_ptr() and torch.equal(p1_again, keep)
+    p2 = ops.pack_input(o2, c)
+    assert p2.data_ptr() == o2._llv_nhwc[0].data_ptr()
+    o2.mul_(2.0)                                    # written to: the buffer no longer matches the tensor
+    p2b = ops.pack_input(o2, c)
+    assert p2b.data_ptr() != o2._llv_nhwc[0].data_ptr()
+    assert torch.allclose(ops.unpack_output(p2b, c), o2, rtol=2e-3, atol=1e-3)
