@@ -552,6 +552,9 @@ def multiclass_nms_into(boxes, scores, score_thr, iou_thr, bufs: NmsBuffers, num
           'llv_multiclass_nms_batched')
 
 
+_NMS_BUFFERS = {}
+
+
 def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, return_inds=False):
     """Same signature and return values as mmdet.core.multiclass_nms (bbox_nms.py:7-93).
 
@@ -580,7 +583,13 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, r
                            f'(num_classes * max_num <= 8192); pass max_num <= {8192 // max(num_classes, 1)}')
     if num_classes * cap > 8192:
         raise LlvError(f'multiclass_nms: num_classes * max_num = {num_classes * cap} > 8192 (merge limit of the device NMS)')
-    bufs = NmsBuffers(max(n, 1), num_classes, max(cap, 1), multi_bboxes.device)
+    # the buffers of a (n, classes, cap) geometry are kept between calls (stream-ordered reuse; the results are cloned out below)
+    bkey = (max(n, 1), num_classes, max(cap, 1), str(multi_bboxes.device))
+    bufs = _NMS_BUFFERS.get(bkey)
+    if bufs is None:
+        if len(_NMS_BUFFERS) >= 16:
+            _NMS_BUFFERS.clear()
+        bufs = _NMS_BUFFERS[bkey] = NmsBuffers(max(n, 1), num_classes, max(cap, 1), multi_bboxes.device)
     if class_specific:
         bx, sc = multi_bboxes.float().contiguous(), multi_scores.float().contiguous()
         check(lib().llv_multiclass_nms_batched_ex(_ptr(bx), _ptr(sc), None, 1, 1, n, num_classes, sc.shape[-1], float(score_thr),

@@ -118,28 +118,43 @@ class RPNHead(AnchorHead):
         A = self.num_anchors
         results = []
         for n in range(batch):
-            cls_buf = torch.cat([c[n:n + 1].detach().float().permute(0, 2, 3, 1).reshape(-1, A) for c in cls_scores]).contiguous()
-            reg_buf = torch.cat([r[n:n + 1].detach().float().permute(0, 2, 3, 1).reshape(-1, A * 4) for r in bbox_preds]).contiguous()
-            offs, tot = [], 0
-            for h, w in level_hw:
-                offs.append(tot)
-                tot += h * w
-            plan = ops.make_decode_plan(cls_buf, reg_buf, level_hw, self.anchor_generator.strides, offs, offs, A, A * 4, 1, A,
-                                        self.anchor_generator.base_anchors, nms_pre, self.bbox_coder.means, self.bbox_coder.stds,
-                                        16 / 1000, img_metas[n]['img_shape'], (1., 1., 1., 1.), False)
-            boxes, scores = ops.retina_decode_topk(plan)
-            counts = [min(nms_pre, h * w * A) if nms_pre > 0 else h * w * A for h, w in level_hw]
-            lvl = torch.cat([torch.full((c,), i, dtype=torch.long) for i, c in enumerate(counts)]).to(dev)
+            # everything that depends only on the pyramid geometry and the image shape is built once and kept: the logit buffers the
+            # decode descriptor points into, the descriptor and its workspace, the level index of every candidate row
+            img_shape = tuple(int(v) for v in img_metas[n]['img_shape'])
+            st = self._plan(('decode', tuple(level_hw), img_shape, nms_pre, str(dev)), lambda: self._decode_state(level_hw, img_shape, nms_pre, dev))
+            o = 0
+            for c, r in zip(cls_scores, bbox_preds):
+                k = c.shape[-2] * c.shape[-1]
+                st['cls'][o:o + k].copy_(c[n].detach().permute(1, 2, 0).reshape(-1, A))
+                st['reg'][o:o + k].copy_(r[n].detach().permute(1, 2, 0).reshape(-1, A * 4))
+                o += k
+            boxes, scores = ops.retina_decode_topk(st['plan'])
             s = scores[:, 0]
             if cfg.get('min_bbox_size', 0) > 0:
                 ok = ((boxes[:, 2] - boxes[:, 0]) >= cfg['min_bbox_size']) & ((boxes[:, 3] - boxes[:, 1]) >= cfg['min_bbox_size'])
                 s = s * ok
-            L = len(level_hw)
-            multi = torch.zeros(boxes.shape[0], L + 1, device=dev)                      # one column per level + the ignored background column
-            multi[torch.arange(boxes.shape[0], device=dev), lvl] = s
+            multi = st['multi']                                                        # one column per level + the ignored background column
+            multi.zero_()
+            multi[st['rows'], st['lvl']] = s
             dets, _ = ops.multiclass_nms(boxes.contiguous(), multi, 0.0, cfg['nms'], max_per_img)
             results.append(dets)
         return results
+
+    def _decode_state(self, level_hw, img_shape, nms_pre, dev):
+        A = self.num_anchors
+        offs, tot = [], 0
+        for h, w in level_hw:
+            offs.append(tot)
+            tot += h * w
+        cls_buf = torch.zeros((tot, A), device=dev, dtype=torch.float32)
+        reg_buf = torch.zeros((tot, A * 4), device=dev, dtype=torch.float32)
+        plan = ops.make_decode_plan(cls_buf, reg_buf, level_hw, self.anchor_generator.strides, offs, offs, A, A * 4, 1, A,
+                                    self.anchor_generator.base_anchors, nms_pre, self.bbox_coder.means, self.bbox_coder.stds,
+                                    16 / 1000, img_shape, (1., 1., 1., 1.), False)
+        counts = [min(nms_pre, h * w * A) if nms_pre > 0 else h * w * A for h, w in level_hw]
+        lvl = torch.cat([torch.full((c,), i, dtype=torch.long) for i, c in enumerate(counts)]).to(dev)
+        return dict(cls=cls_buf, reg=reg_buf, plan=plan, lvl=lvl, rows=torch.arange(sum(counts), device=dev),
+                    multi=torch.zeros(sum(counts), len(level_hw) + 1, device=dev))
 
     def simple_test_rpn(self, x, img_metas):
         """rpn_test_mixin.py:27-41."""
