@@ -751,6 +751,10 @@ def main():
                 'algorithmic_gflop_per_launch': round(dfl / dn / 1e9, 2),
                 'algorithmic_bytes_per_launch': round(dnb / dn),
                 'share_of_step_kernel_time': round(dms / all_ms, 3),
+                # the same kernel against the memory roof (its 32/64-channel layers have fewer FLOP per byte than the machine's ridge):
+                # algorithmic bytes per launch / average launch duration, peak 8 TB/s
+                'hbm_view': {'achieved': round(dnb / (dms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
+                             'frac': round(dnb / (dms * 1e-3) / 1e9 / 8000.0, 4)},
                 'all_conv_kernels': {'achieved': round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                                      'frac': round(conv_fl / (conv_ms * 1e-3) / 1e12 / peak, 4),
                                      'launches_per_step': len(convs), 'ms_per_step': round(conv_ms, 4)},
