@@ -2274,7 +2274,8 @@ static int plan_launch(const llv_conv_desc* d, LaunchPlan& lp) {
             // 64 -> 64 at 16x368x640 331 vs 376 us, 32 -> 32 at 16x736x1280 633 vs 671 us, 128 -> 128 285 vs 304 us (the 128-channel tile
             // above takes that one: 276 us). LLV_TAP512=0 turns it off.
             static const int tap512 = getenv("LLV_TAP512") ? atoi(getenv("LLV_TAP512")) : 1;
-            if (tap512 && lp.tile == LLV_TILE_TAP64 && tap512_supported(d) && blocks >= 4096) lp.tile = LLV_TILE_TAP512;
+            static const long tap512_min = getenv("LLV_TAP512_MIN_BLOCKS") ? atol(getenv("LLV_TAP512_MIN_BLOCKS")) : 4096;
+            if (tap512 && lp.tile == LLV_TILE_TAP64 && tap512_supported(d) && blocks >= tap512_min) lp.tile = LLV_TILE_TAP512;
             lp.splits = 1;
             lp.nk_per = (d->k_pad + 31) / 32;
             return LLV_OK;
