@@ -77,6 +77,65 @@ class MaxIoUAssigner(object):
         return AssignResult(k, gt_inds, max_ov, labels)
 
 
+def _bbox_overlaps(b1, b2, eps=1e-6):
+    """BboxOverlaps2D, mode 'iou' (iou2d_calculator.py:43-159), (k, 4) x (n, 4) -> (k, n), on the boxes' device."""
+    a1 = (b1[:, 2] - b1[:, 0]) * (b1[:, 3] - b1[:, 1])
+    a2 = (b2[:, 2] - b2[:, 0]) * (b2[:, 3] - b2[:, 1])
+    lt = torch.max(b1[:, None, :2], b2[None, :, :2])
+    rb = torch.min(b1[:, None, 2:], b2[None, :, 2:])
+    wh = (rb - lt).clamp(min=0)
+    ov = wh[..., 0] * wh[..., 1]
+    union = torch.max(a1[:, None] + a2[None, :] - ov, ov.new_tensor([eps]))
+    return ov / union
+
+
+@BBOX_ASSIGNERS.register_module()
+class GridAssigner(object):
+    """mmdetection/mmdet/core/bbox/assigners/grid_assigner.py:9-155 (the YOLOv3 head's assigner): as MaxIoUAssigner, but only the
+    anchors of the grid cell a ground-truth centre falls in (`box_responsible_flags`) can become positive. Tensor operations on the
+    boxes' device (the (k, n) overlap matrix is tiny next to the convolutions that produced the predictions)."""
+
+    def __init__(self, pos_iou_thr, neg_iou_thr, min_pos_iou=.0, gt_max_assign_all=True, iou_calculator=dict(type='BboxOverlaps2D')):
+        self.pos_iou_thr, self.neg_iou_thr, self.min_pos_iou, self.gt_max_assign_all = pos_iou_thr, neg_iou_thr, min_pos_iou, gt_max_assign_all
+
+    def assign(self, bboxes, box_responsible_flags, gt_bboxes, gt_labels=None):
+        num_gts, num_bboxes = gt_bboxes.size(0), bboxes.size(0)
+        overlaps = _bbox_overlaps(gt_bboxes[:, :4], bboxes[:, :4])
+        assigned_gt_inds = overlaps.new_full((num_bboxes,), -1, dtype=torch.long)
+        if num_gts == 0 or num_bboxes == 0:
+            max_overlaps = overlaps.new_zeros((num_bboxes,))
+            if num_gts == 0:
+                assigned_gt_inds[:] = 0
+            labels = None if gt_labels is None else overlaps.new_full((num_bboxes,), -1, dtype=torch.long)
+            return AssignResult(num_gts, assigned_gt_inds, max_overlaps, labels)
+        max_overlaps, _ = overlaps.max(dim=0)
+        if isinstance(self.neg_iou_thr, float):
+            assigned_gt_inds[(max_overlaps >= 0) & (max_overlaps <= self.neg_iou_thr)] = 0
+        else:
+            assert len(self.neg_iou_thr) == 2
+            assigned_gt_inds[(max_overlaps > self.neg_iou_thr[0]) & (max_overlaps <= self.neg_iou_thr[1])] = 0
+        flags = box_responsible_flags.type(torch.bool)
+        overlaps[:, ~flags] = -1.
+        max_overlaps, argmax_overlaps = overlaps.max(dim=0)
+        gt_max_overlaps, gt_argmax_overlaps = overlaps.max(dim=1)
+        pos_inds = (max_overlaps > self.pos_iou_thr) & flags
+        assigned_gt_inds[pos_inds] = argmax_overlaps[pos_inds] + 1
+        for i in range(num_gts):
+            if gt_max_overlaps[i] > self.min_pos_iou:
+                if self.gt_max_assign_all:
+                    assigned_gt_inds[(overlaps[i, :] == gt_max_overlaps[i]) & flags] = i + 1
+                elif flags[gt_argmax_overlaps[i]]:
+                    assigned_gt_inds[gt_argmax_overlaps[i]] = i + 1
+        if gt_labels is not None:
+            labels = assigned_gt_inds.new_full((num_bboxes,), -1)
+            pos = torch.nonzero(assigned_gt_inds > 0, as_tuple=False).squeeze(-1)
+            if pos.numel() > 0:
+                labels[pos] = gt_labels[assigned_gt_inds[pos] - 1]
+        else:
+            labels = None
+        return AssignResult(num_gts, assigned_gt_inds, max_overlaps, labels)
+
+
 @BBOX_SAMPLERS.register_module()
 class PseudoSampler(object):
     def __init__(self, **kwargs):

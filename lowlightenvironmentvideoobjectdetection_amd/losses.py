@@ -282,11 +282,34 @@ class BoundedIoULoss(nn.Module):
 
 @LOSSES.register_module()
 class CrossEntropyLoss(nn.Module):
-    """Constructor only (AnchorHead's default loss_cls names it, anchor_head.py:49-52); the RetinaNet path uses FocalLoss."""
+    """mmdetection/mmdet/models/losses/cross_entropy_loss.py:139-214, the sigmoid form (use_sigmoid=True -> binary_cross_entropy :58-91:
+    F.binary_cross_entropy_with_logits, element weights, weight_reduce_loss). The YOLOv3 head's class / objectness / centre terms.
+    Softmax and mask cross entropy are not on this path."""
 
     def __init__(self, use_sigmoid=False, use_mask=False, reduction='mean', class_weight=None, loss_weight=1.0):
         super().__init__()
-        self.use_sigmoid, self.reduction, self.loss_weight = use_sigmoid, reduction, loss_weight
+        self.use_sigmoid, self.use_mask, self.reduction, self.class_weight, self.loss_weight = use_sigmoid, use_mask, reduction, class_weight, loss_weight
 
-    def forward(self, *a, **k):
-        raise NotImplementedError('CrossEntropyLoss is outside the dense-head hot path (RetinaNet uses FocalLoss)')
+    def forward(self, cls_score, label, weight=None, avg_factor=None, reduction_override=None, **kwargs):
+        if not self.use_sigmoid or self.use_mask:          # constructible (AnchorHead / bbox-head defaults name it), not computable
+            raise NotImplementedError('CrossEntropyLoss: only use_sigmoid=True is built (softmax / mask cross entropy are outside the path)')
+        assert reduction_override in (None, 'none', 'mean', 'sum')
+        reduction = reduction_override if reduction_override else self.reduction
+        if cls_score.dim() != label.dim():
+            raise NotImplementedError('CrossEntropyLoss: index labels (one-hot expansion) are not used on this path')
+        cw = cls_score.new_tensor(self.class_weight) if self.class_weight is not None else None
+        loss = nn.functional.binary_cross_entropy_with_logits(cls_score, label.float(), pos_weight=cw, reduction='none')
+        return self.loss_weight * weight_reduce_loss(loss, weight.float() if weight is not None else None, reduction, avg_factor)
+
+
+@LOSSES.register_module()
+class MSELoss(nn.Module):
+    """mmdetection/mmdet/models/losses/mse_loss.py:8-49."""
+
+    def __init__(self, reduction='mean', loss_weight=1.0):
+        super().__init__()
+        self.reduction, self.loss_weight = reduction, loss_weight
+
+    def forward(self, pred, target, weight=None, avg_factor=None):
+        loss = nn.functional.mse_loss(pred, target, reduction='none')
+        return self.loss_weight * weight_reduce_loss(loss, weight, self.reduction, avg_factor)

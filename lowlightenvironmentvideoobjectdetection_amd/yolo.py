@@ -12,7 +12,8 @@ All convolutions run on the HIP conv engine (conv + folded BN + LeakyReLU(0.1) e
 activation: LLV_CONV_ACT_FIRST; the neck's upsample + concat is llv_upsample2x_nhwc into a channel slice of the buffer the
 backbone stage already wrote its half of). Box decode = llv_yolo_decode, NMS = llv_multiclass_nms_batched_sf (objectness as
 score factor). The per-level top-k on objectness and the gather of the <= 3000 selected rows are torch ops on the device
-(selection plumbing on small tensors). Training (YOLOV3Head.loss) is not built.
+(selection plumbing on small tensors). YOLOV3Head.loss (targets + the four loss terms, element-wise torch on the device) is built; the
+backward pass through Darknet / the neck is not (the training engine's tape covers the RetinaNet graph).
 """
 import ctypes as C
 
@@ -56,11 +57,49 @@ class YOLOAnchorGenerator:
             out.append(torch.stack([torch.Tensor([xc - 0.5 * w, yc - 0.5 * h, xc + 0.5 * w, yc + 0.5 * h]) for w, h in sizes], 0))
         return out
 
+    def grid_anchors(self, featmap_sizes, device='cuda'):
+        """anchor_generator.py:207-270: per level (h*w*A, 4), (y, x, anchor) order. Only the training targets need the grid; inference
+        adds the shifts inside llv_yolo_decode."""
+        out = []
+        for (h, w), base, (sw, sh) in zip(featmap_sizes, self.base_anchors, self.strides):
+            base = base.to(device)
+            sx = torch.arange(0, w, device=device) * sw
+            sy = torch.arange(0, h, device=device) * sh
+            xx = sx.repeat(len(sy))
+            yy = sy.view(-1, 1).repeat(1, len(sx)).view(-1)
+            shifts = torch.stack([xx, yy, xx, yy], dim=-1).type_as(base)
+            out.append((base[None, :, :] + shifts[:, None, :]).view(-1, 4))
+        return out
+
+    def responsible_flags(self, featmap_sizes, gt_bboxes, device='cuda'):
+        """anchor_generator.py:667-728: flag = 1 for the anchors of the grid cell a ground-truth centre falls in."""
+        out = []
+        for (h, w), (sw, sh), nb in zip(featmap_sizes, self.strides, self.num_base_anchors):
+            cx = ((gt_bboxes[:, 0] + gt_bboxes[:, 2]) * 0.5).to(device)
+            cy = ((gt_bboxes[:, 1] + gt_bboxes[:, 3]) * 0.5).to(device)
+            idx = torch.floor(cy / sh).long() * w + torch.floor(cx / sw).long()
+            grid = torch.zeros(h * w, dtype=torch.uint8, device=device)
+            grid[idx] = 1
+            out.append(grid[:, None].expand(grid.size(0), nb).contiguous().view(-1))
+        return out
+
 
 @BBOX_CODERS.register_module()
 class YOLOBBoxCoder:
     def __init__(self, eps=1e-6):
         self.eps = eps
+
+    def encode(self, bboxes, gt_bboxes, stride):
+        """yolo_bbox_coder.py:26-58: centre offsets inside the cell (clamped to (eps, 1 - eps)) and log size ratios."""
+        assert bboxes.size(0) == gt_bboxes.size(0) and bboxes.size(-1) == gt_bboxes.size(-1) == 4
+        xg, yg = (gt_bboxes[..., 0] + gt_bboxes[..., 2]) * 0.5, (gt_bboxes[..., 1] + gt_bboxes[..., 3]) * 0.5
+        wg, hg = gt_bboxes[..., 2] - gt_bboxes[..., 0], gt_bboxes[..., 3] - gt_bboxes[..., 1]
+        xc, yc = (bboxes[..., 0] + bboxes[..., 2]) * 0.5, (bboxes[..., 1] + bboxes[..., 3]) * 0.5
+        w, h = bboxes[..., 2] - bboxes[..., 0], bboxes[..., 3] - bboxes[..., 1]
+        wt, ht = torch.log((wg / w).clamp(min=self.eps)), torch.log((hg / h).clamp(min=self.eps))
+        xt = ((xg - xc) / stride + 0.5).clamp(self.eps, 1 - self.eps)
+        yt = ((yg - yc) / stride + 0.5).clamp(self.eps, 1 - self.eps)
+        return torch.stack([xt, yt, wt, ht], dim=-1)
 
 
 class ResBlock(nn.Module):
@@ -154,6 +193,15 @@ class YOLOV3Head(PlannedModule):
         self.num_classes, self.in_channels, self.out_channels = num_classes, in_channels, out_channels
         self.featmap_strides, self.train_cfg, self.test_cfg = featmap_strides, train_cfg, test_cfg
         self.one_hot_smoother = one_hot_smoother
+        from .registry import BBOX_ASSIGNERS, BBOX_SAMPLERS, LOSSES, build
+        bce = dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0)                  # yolo_head.py:68-82 defaults
+        self.loss_cls = build(dict(loss_cls or bce), LOSSES)
+        self.loss_conf = build(dict(loss_conf or bce), LOSSES)
+        self.loss_xy = build(dict(loss_xy or bce), LOSSES)
+        self.loss_wh = build(dict(loss_wh or dict(type='MSELoss', loss_weight=1.0)), LOSSES)
+        if train_cfg:                                                                             # yolo_head.py:91-98
+            self.assigner = build(dict(train_cfg['assigner']), BBOX_ASSIGNERS)
+            self.sampler = build(dict(train_cfg['sampler']) if 'sampler' in train_cfg else dict(type='PseudoSampler'), BBOX_SAMPLERS)
         self.bbox_coder = build_bbox_coder(bbox_coder)
         self.anchor_generator = build_anchor_generator(anchor_generator)
         self.num_anchors = self.anchor_generator.num_base_anchors[0]
@@ -171,8 +219,61 @@ class YOLOV3Head(PlannedModule):
         for m in self.convs_pred:
             normal_init(m, std=0.01)
 
-    def loss(self, *a, **k):
-        raise LlvError('YOLOV3Head.loss (training) is not built on this path; the config-#5 stand-in is inference only')
+    def loss(self, pred_maps, gt_bboxes, gt_labels, img_metas, gt_bboxes_ignore=None):
+        """yolo_head.py:369-417: targets from GridAssigner + YOLOBBoxCoder.encode, then per level the four terms. pred_maps: list over
+        levels of (N, A*(5+C), h, w) tensors on the GPU (gradients flow back to them through torch autograd: the terms are
+        element-wise torch on the device); returns dict of four per-level lists, as the reference."""
+        ops._need_gpu(*pred_maps)
+        from .core.anchor import images_to_levels
+        num_imgs, device = len(img_metas), pred_maps[0].device
+        featmap_sizes = [tuple(pm.shape[-2:]) for pm in pred_maps]
+        anchors = self.anchor_generator.grid_anchors(featmap_sizes, device)
+        anchor_list = [anchors for _ in range(num_imgs)]
+        flag_list = [self.anchor_generator.responsible_flags(featmap_sizes, gt_bboxes[i], device) for i in range(num_imgs)]
+        target_maps_list, neg_maps_list = self.get_targets(anchor_list, flag_list, gt_bboxes, gt_labels)
+        out = dict(loss_cls=[], loss_conf=[], loss_xy=[], loss_wh=[])
+        for pm, tm, nm in zip(pred_maps, target_maps_list, neg_maps_list):
+            lc, lo, lxy, lwh = self.loss_single(pm, tm, nm)
+            out['loss_cls'].append(lc); out['loss_conf'].append(lo); out['loss_xy'].append(lxy); out['loss_wh'].append(lwh)
+        return out
+
+    def loss_single(self, pred_map, target_map, neg_map):
+        """yolo_head.py:419-462."""
+        num_imgs = len(pred_map)
+        pred_map = pred_map.permute(0, 2, 3, 1).reshape(num_imgs, -1, self.num_attrib)
+        pos_mask = target_map[..., 4]
+        pos_and_neg_mask = (neg_map.float() + pos_mask).clamp(min=0., max=1.)
+        pos_mask = pos_mask.unsqueeze(dim=-1)
+        loss_cls = self.loss_cls(pred_map[..., 5:], target_map[..., 5:], weight=pos_mask)
+        loss_conf = self.loss_conf(pred_map[..., 4], target_map[..., 4], weight=pos_and_neg_mask)
+        loss_xy = self.loss_xy(pred_map[..., :2], target_map[..., :2], weight=pos_mask)
+        loss_wh = self.loss_wh(pred_map[..., 2:4], target_map[..., 2:4], weight=pos_mask)
+        return loss_cls, loss_conf, loss_xy, loss_wh
+
+    def get_targets(self, anchor_list, responsible_flag_list, gt_bboxes_list, gt_labels_list):
+        """yolo_head.py:464-498."""
+        from .core.anchor import images_to_levels
+        num_level_anchors = [a.size(0) for a in anchor_list[0]]
+        res = [self._get_targets_single(a, f, b, l) for a, f, b, l in zip(anchor_list, responsible_flag_list, gt_bboxes_list, gt_labels_list)]
+        return images_to_levels([r[0] for r in res], num_level_anchors), images_to_levels([r[1] for r in res], num_level_anchors)
+
+    def _get_targets_single(self, anchors, responsible_flags, gt_bboxes, gt_labels):
+        """yolo_head.py:500-560."""
+        strides = torch.cat([torch.tensor(self.featmap_strides[i], device=gt_bboxes.device).repeat(len(anchors[i])) for i in range(len(anchors))])
+        concat_anchors, concat_flags = torch.cat(anchors), torch.cat(responsible_flags)
+        assert len(strides) == len(concat_anchors) == len(concat_flags)
+        assign_result = self.assigner.assign(concat_anchors, concat_flags, gt_bboxes)
+        sr = self.sampler.sample(assign_result, concat_anchors, gt_bboxes)
+        target_map = concat_anchors.new_zeros(concat_anchors.size(0), self.num_attrib)
+        target_map[sr.pos_inds, :4] = self.bbox_coder.encode(sr.pos_bboxes, sr.pos_gt_bboxes, strides[sr.pos_inds])
+        target_map[sr.pos_inds, 4] = 1
+        one_hot = nn.functional.one_hot(gt_labels, num_classes=self.num_classes).float()
+        if self.one_hot_smoother != 0:
+            one_hot = one_hot * (1 - self.one_hot_smoother) + self.one_hot_smoother / self.num_classes
+        target_map[sr.pos_inds, 5:] = one_hot[sr.pos_assigned_gt_inds]
+        neg_map = concat_anchors.new_zeros(concat_anchors.size(0), dtype=torch.uint8)
+        neg_map[sr.neg_inds] = 1
+        return target_map, neg_map
 
     def get_bboxes(self, pred_maps, img_metas, cfg=None, rescale=False, with_nms=True):
         """YOLOV3Head.get_bboxes / _get_bboxes (yolo_head.py:172-366) on raw prediction maps: list over levels of (N, A*(5+C), h, w)

@@ -133,3 +133,111 @@ def yolov3_simple_test(sd, img, num_classes, base_sizes, strides, test_cfg, scal
     feats = darknet_forward(sd, img)
     feats = yolo_neck_forward(sd, feats)
     return yolo_get_bboxes(yolo_head_forward(sd, feats), base_sizes, strides, num_classes, test_cfg, scale_factors, rescale)
+
+
+# ---------------------------------------------------------------------------------------------------------------------
+# training targets and losses of YOLOV3Head (yolo_head.py:369-560), restated on the CPU
+# ---------------------------------------------------------------------------------------------------------------------
+def yolo_responsible_flags(featmap_sizes, gt_bboxes, strides, num_base_anchors):
+    """YOLOAnchorGenerator.responsible_flags (anchor_generator.py:667-728): the anchors of the grid cell a ground-truth centre falls in."""
+    out = []
+    for (h, w), st, nb in zip(featmap_sizes, strides, num_base_anchors):
+        cx = (gt_bboxes[:, 0] + gt_bboxes[:, 2]) * 0.5
+        cy = (gt_bboxes[:, 1] + gt_bboxes[:, 3]) * 0.5
+        gx = torch.floor(cx / st).long()
+        gy = torch.floor(cy / st).long()
+        grid = torch.zeros(h * w, dtype=torch.uint8)
+        grid[gy * w + gx] = 1
+        out.append(grid[:, None].expand(h * w, nb).contiguous().view(-1))
+    return out
+
+
+def grid_assign(bboxes, flags, gt_bboxes, pos_iou_thr, neg_iou_thr, min_pos_iou=0.0, gt_max_assign_all=True):
+    """GridAssigner.assign (grid_assigner.py:42-155): 1-based gt index per box, 0 negative, -1 ignored."""
+    from .bbox import bbox_overlaps
+    k, n = gt_bboxes.size(0), bboxes.size(0)
+    overlaps = bbox_overlaps(gt_bboxes, bboxes)
+    assigned = overlaps.new_full((n,), -1, dtype=torch.long)
+    if k == 0 or n == 0:
+        if k == 0:
+            assigned[:] = 0
+        return assigned
+    max_ov, _ = overlaps.max(dim=0)
+    assigned[(max_ov >= 0) & (max_ov <= neg_iou_thr)] = 0
+    fl = flags.type(torch.bool)
+    overlaps[:, ~fl] = -1.
+    max_ov, argmax_ov = overlaps.max(dim=0)
+    gt_max, gt_argmax = overlaps.max(dim=1)
+    pos = (max_ov > pos_iou_thr) & fl
+    assigned[pos] = argmax_ov[pos] + 1
+    for i in range(k):
+        if gt_max[i] > min_pos_iou:
+            if gt_max_assign_all:
+                assigned[(overlaps[i, :] == gt_max[i]) & fl] = i + 1
+            elif fl[gt_argmax[i]]:
+                assigned[gt_argmax[i]] = i + 1
+    return assigned
+
+
+def yolo_encode(bboxes, gt_bboxes, stride, eps=1e-6):
+    """YOLOBBoxCoder.encode (yolo_bbox_coder.py:26-58)."""
+    xg = (gt_bboxes[..., 0] + gt_bboxes[..., 2]) * 0.5
+    yg = (gt_bboxes[..., 1] + gt_bboxes[..., 3]) * 0.5
+    wg = gt_bboxes[..., 2] - gt_bboxes[..., 0]
+    hg = gt_bboxes[..., 3] - gt_bboxes[..., 1]
+    xc = (bboxes[..., 0] + bboxes[..., 2]) * 0.5
+    yc = (bboxes[..., 1] + bboxes[..., 3]) * 0.5
+    w = bboxes[..., 2] - bboxes[..., 0]
+    h = bboxes[..., 3] - bboxes[..., 1]
+    wt = torch.log((wg / w).clamp(min=eps))
+    ht = torch.log((hg / h).clamp(min=eps))
+    xt = ((xg - xc) / stride + 0.5).clamp(eps, 1 - eps)
+    yt = ((yg - yc) / stride + 0.5).clamp(eps, 1 - eps)
+    return torch.stack([xt, yt, wt, ht], dim=-1)
+
+
+def yolo_loss(pred_maps, gt_bboxes, gt_labels, base_sizes, strides, num_classes, pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0.0,
+              one_hot_smoother=0.0, w_cls=1.0, w_conf=1.0, w_xy=2.0, w_wh=2.0):
+    """YOLOV3Head.loss (yolo_head.py:369-462) with the losses of configs/yolo/yolov3_d53_mstrain-608_273e_coco.py:27-60: sigmoid cross
+    entropy for classes / objectness / centre offsets, MSE for log sizes, all reduction='sum'. Returns the four per-level lists."""
+    na = 5 + num_classes
+    sizes = [tuple(p.shape[-2:]) for p in pred_maps]
+    anchors = yolo_grid_anchors(sizes, base_sizes, strides)
+    nb = [len(b) for b in base_sizes]
+    nlev = [a.size(0) for a in anchors]
+    targets, negs = [], []
+    for img in range(pred_maps[0].shape[0]):
+        flags = torch.cat(yolo_responsible_flags(sizes, gt_bboxes[img], strides, nb))
+        cat = torch.cat(anchors)
+        st = torch.cat([torch.full((a.size(0),), float(s)) for a, s in zip(anchors, strides)])
+        assigned = grid_assign(cat, flags, gt_bboxes[img], pos_iou_thr, neg_iou_thr, min_pos_iou)
+        pos = torch.nonzero(assigned > 0, as_tuple=False).squeeze(-1).unique()
+        neg = torch.nonzero(assigned == 0, as_tuple=False).squeeze(-1).unique()
+        tm = cat.new_zeros(cat.size(0), na)
+        gi = assigned[pos] - 1
+        tm[pos, :4] = yolo_encode(cat[pos], gt_bboxes[img][gi], st[pos])
+        tm[pos, 4] = 1
+        oh = F.one_hot(gt_labels[img], num_classes=num_classes).float()
+        if one_hot_smoother != 0:
+            oh = oh * (1 - one_hot_smoother) + one_hot_smoother / num_classes
+        tm[pos, 5:] = oh[gi]
+        nm = cat.new_zeros(cat.size(0), dtype=torch.uint8)
+        nm[neg] = 1
+        targets.append(tm); negs.append(nm)
+    out = dict(loss_cls=[], loss_conf=[], loss_xy=[], loss_wh=[])
+    o = 0
+    for l, pm in enumerate(pred_maps):
+        n = pm.shape[0]
+        tmap = torch.stack([t[o:o + nlev[l]] for t in targets])            # images_to_levels
+        nmap = torch.stack([t[o:o + nlev[l]] for t in negs])
+        o += nlev[l]
+        p = pm.permute(0, 2, 3, 1).reshape(n, -1, na)
+        pos_mask = tmap[..., 4]
+        pn = (nmap.float() + pos_mask).clamp(min=0., max=1.)
+        pm1 = pos_mask.unsqueeze(-1)
+        bce = lambda a, b: F.binary_cross_entropy_with_logits(a, b, reduction='none')
+        out['loss_cls'].append(w_cls * (bce(p[..., 5:], tmap[..., 5:]) * pm1).sum())
+        out['loss_conf'].append(w_conf * (bce(p[..., 4], tmap[..., 4]) * pn).sum())
+        out['loss_xy'].append(w_xy * (bce(p[..., :2], tmap[..., :2]) * pm1).sum())
+        out['loss_wh'].append(w_wh * (F.mse_loss(p[..., 2:4], tmap[..., 2:4], reduction='none') * pm1).sum())
+    return out

@@ -204,3 +204,33 @@ def test_oracle_nms_hand_checked():
     # class 0 keeps boxes 0 (.9) and 3 (.7); class 1 keeps box 1 (.6); box 4 and the duplicates are suppressed
     assert l.tolist() == [0, 0, 1] and inds.tolist() == [0, 6, 3]
     assert torch.equal(d[:, 4], torch.tensor([0.9, 0.7, 0.6]))
+
+
+def test_oracle_yolo_targets_hand_computed():
+    """oracle/yolo.py training side (parity unpinned: the reference holds no test for GridAssigner / YOLOBBoxCoder.encode): properties
+    that tie it to pinned pieces. encode is the inverse of the (pinned-by-use) decode away from the clamps; responsible flags mark
+    exactly the cell of the box centre; with one ground-truth box the grid assigner's positives are a subset of that cell's anchors
+    and contain the best-overlapping one."""
+    from oracle.yolo import grid_assign, yolo_decode, yolo_encode, yolo_grid_anchors, yolo_responsible_flags
+    base = [[(116, 90), (156, 198), (373, 326)], [(30, 61), (62, 45), (59, 119)], [(10, 13), (16, 30), (33, 23)]]
+    sizes, strides = [(4, 6), (8, 12), (16, 24)], [32, 16, 8]
+    anchors = yolo_grid_anchors(sizes, base, strides)
+    gt = torch.tensor([[70., 40., 130., 110.]])                      # centre (100, 75): cell (3, 2) at stride 32, (6, 4) at 16, (12, 9) at 8
+    flags = yolo_responsible_flags(sizes, gt, strides, [3, 3, 3])
+    for f, (h, w), s in zip(flags, sizes, strides):
+        cell = (75 // s) * w + (100 // s)
+        assert int(f.sum()) == 3 and bool(f[cell * 3:cell * 3 + 3].all())
+    cat, fl = torch.cat(anchors), torch.cat(flags)
+    a = grid_assign(cat, fl, gt, 0.5, 0.5, 0.0)
+    pos = torch.nonzero(a > 0).squeeze(-1)
+    assert len(pos) >= 1 and bool(fl[pos].all())
+    from oracle.bbox import bbox_overlaps
+    ov = bbox_overlaps(gt, cat)[0]
+    best = int(torch.where(fl.bool(), ov, ov.new_full(ov.shape, -1.)).argmax())
+    assert best in pos.tolist()
+    assert int((a == 0).sum()) + int((a == -1).sum()) + len(pos) == len(cat) and int((a == -1).sum()) > 0    # 0.5 < iou or irresponsible: ignored
+    # encode / decode round trip on the positives (x, y targets lie strictly inside (0, 1): no clamp)
+    st = torch.cat([torch.full((x.size(0),), float(s)) for x, s in zip(anchors, strides)])
+    enc = yolo_encode(cat[pos], gt.expand(len(pos), 4), st[pos])
+    dec = yolo_decode(cat[pos], enc, st[pos])
+    assert torch.allclose(dec, gt.expand(len(pos), 4), atol=1e-3)
