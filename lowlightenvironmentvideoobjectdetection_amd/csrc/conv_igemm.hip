@@ -2217,7 +2217,9 @@ int pick_splits(int tile, int cout, long m, int groups, int nk, int flags) {
     int bn, bm;
     tile_dims(tile, bn, bm);
     const long blocks = ((cout + bn - 1) / bn) * ((m + bm - 1) / bm) * groups;
-    if (blocks >= 256 || nk < 16) return 1;
+    // at 160-255 workgroups a short reduction (< 48 k-steps) is not worth the extra epilogue launch (single-image layer3 conv1, 232
+    // workgroups, K = 1024: 14.7 us unsplit against 24.9 us split in three, in isolation); a long one is (layer3 conv2, K = 2304)
+    if (blocks >= 256 || nk < 16 || (blocks >= 160 && nk < 48)) return 1;
     long s = (512 + blocks - 1) / blocks;
     if (s > nk / 8) s = nk / 8;
     if (s > 32) s = 32;
@@ -2280,6 +2282,12 @@ static int plan_launch(const llv_conv_desc* d, LaunchPlan& lp) {
             lp.nk_per = (d->k_pad + 31) / 32;
             return LLV_OK;
         }
+    }
+    // a long reduction on a small map (the dilated 3x3 512 -> 512 of a DC5 stage on one frame: K = 4608, 3680 pixels): 128x128 tiles with
+    // split K instead of four times as many 64x64 tiles that each stream all of K (45 us against 65 us)
+    if (!d->tile && lp.tile == LLV_TILE_64x64 && d->cout >= 128 && d->k_pad >= 2048) {
+        const long blocks128 = ((d->cout + 127) / 128) * ((m + 127) / 128) * d->groups;
+        if (blocks128 >= 64) lp.tile = LLV_TILE_128x128;
     }
     const int bk = tile_bk(lp.tile);
     const int nk = (d->k_pad + bk - 1) / bk;
