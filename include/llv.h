@@ -396,6 +396,13 @@ int llv_msra_top2_gather(const float* sim, const void* ref, void* out, int32_t* 
                          int sim_ld, int c, int ref_ld, void* stream);
 int llv_troi_attention_fuse(const void* x, const void* emb, float* out, int n_img, int64_t rows, int c, int blocks, void* stream);
 
+/* DeltaXYWHBBoxCoder.decode = delta2bbox (mmdet/core/bbox/coder/delta_xywh_bbox_coder.py:134-237) for (n, 4) boxes and (n, 4*k) deltas
+ * (k = 1: class-agnostic, k = #classes: the class-specific decode of BBoxHead.get_bboxes, bbox_head.py:337-340): out (n, 4*k) fp32.
+ * means / stds: 4 host floats each; clip != 0: clamp to [0, img_w] x [0, img_h] (max_shape); scale_factor (4 host floats) or NULL:
+ * divide the decoded corners by it (rescale=True). Same fp32 operation order as the reference (no FMA contraction). */
+int llv_delta2bbox(const float* rois, const float* deltas, float* out, int64_t n, int k, const float* means, const float* stds,
+                   float wh_ratio_clip, float img_h, float img_w, int clip, const float* scale_factor, void* stream);
+
 /* One whole stride-1 Bottleneck (mmdet/models/backbones/resnet.py:260-299 with no downsample, dilation 1, plugins off; eval-mode
  * BatchNorm folded into the weights as llv_conv2d_nhwc_fwd's callers do): y = relu(conv3(relu(conv2(relu(conv1(x))))) + x) in a single
  * launch that keeps both narrow intermediates in LDS. x, y: (batch, h, w, 4*mid) NHWC fp16 with row strides x_ld / y_ld (elements,

@@ -173,6 +173,7 @@ SIGNATURES = {
     'llv_msra_top2_gather': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'llv_troi_attention_fuse': (_I, [_P, _P, _P, _I, _L, _I, _I, _P]),
     'llv_bottleneck_fwd': (_I, [C.POINTER(BottleneckDesc), _P]),
+    'llv_delta2bbox': (_I, [_P, _P, _P, _L, _I, _P, _P, _F, _F, _F, _I, _P, _P]),
     'llv_eval_tpfp': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _F, _I, _L, _P, _P, _P]),
     'llv_conv2d_nhwc_wgrad': (_I, [C.POINTER(ConvDesc), _P, _I, _P, _P, _P]),
     'llv_conv2d_nhwc_dgrad': (_I, [C.POINTER(ConvDesc), _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _Z, _P]),

@@ -475,3 +475,52 @@ extern "C" int llv_guard_trips(uint64_t* count_host, int reset) {
     *count_host = (uint64_t)v + (uint64_t)llv_nms_guard_trips_(reset);
     return LLV_OK;
 }
+
+// delta2bbox for (n, 4) boxes and (n, 4k) deltas: the bbox heads' class-specific decode (delta_xywh_bbox_coder.py:134-237), the same
+// fp32 operation order as gather_decode_kernel above; optional clip to (img_h, img_w) and division by a scale factor
+namespace {
+__global__ __launch_bounds__(256) void delta2bbox_kernel(const float* __restrict__ rois, const float* __restrict__ deltas, float* __restrict__ out,
+                                                         long n, int k, float m0, float m1, float m2, float m3, float s0, float s1, float s2,
+                                                         float s3, float max_ratio, float img_h, float img_w, int clip, float f0, float f1,
+                                                         float f2, float f3, int rescale) {
+    const long i = (long)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n * k) return;
+    const long r = i / k;
+    const float4 b = *reinterpret_cast<const float4*>(rois + r * 4);
+    const float4 d = *reinterpret_cast<const float4*>(deltas + i * 4);
+    const float dx = d.x * s0 + m0, dy = d.y * s1 + m1;
+    float dw = d.z * s2 + m2, dh = d.w * s3 + m3;
+    dw = fminf(fmaxf(dw, -max_ratio), max_ratio);
+    dh = fminf(fmaxf(dh, -max_ratio), max_ratio);
+    const float px = (b.x + b.z) * 0.5f, py = (b.y + b.w) * 0.5f;
+    const float pw = b.z - b.x, ph = b.w - b.y;
+    const float gw = pw * expf(dw), gh = ph * expf(dh);
+    const float gx = px + pw * dx, gy = py + ph * dy;
+    float o[4] = {gx - gw * 0.5f, gy - gh * 0.5f, gx + gw * 0.5f, gy + gh * 0.5f};
+    if (clip) {
+        const float mx[4] = {img_w, img_h, img_w, img_h};
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            o[e] = o[e] < 0.f ? 0.f : o[e];
+            o[e] = o[e] > mx[e] ? mx[e] : o[e];
+        }
+    }
+    if (rescale) { o[0] = o[0] / f0; o[1] = o[1] / f1; o[2] = o[2] / f2; o[3] = o[3] / f3; }
+    *reinterpret_cast<float4*>(out + i * 4) = make_float4(o[0], o[1], o[2], o[3]);
+}
+}  // namespace
+
+extern "C" int llv_delta2bbox(const float* rois, const float* deltas, float* out, int64_t n, int k, const float* means, const float* stds,
+                              float wh_ratio_clip, float img_h, float img_w, int clip, const float* scale_factor, void* stream) {
+    if (n < 0 || k < 1 || !means || !stds || wh_ratio_clip <= 0.f) return LLV_E_BADARG;
+    if (n == 0) return LLV_OK;
+    if (!rois || !deltas || !out) return LLV_E_BADARG;
+    if (n * k > 0x7fffffffL) return LLV_E_UNSUPPORTED;
+    const float mr = fabsf(logf(wh_ratio_clip));
+    const long tot = n * k;
+    hipLaunchKernelGGL(delta2bbox_kernel, dim3((unsigned)((tot + 255) / 256)), dim3(256), 0, (hipStream_t)stream, rois, deltas, out, (long)n, k,
+                       means[0], means[1], means[2], means[3], stds[0], stds[1], stds[2], stds[3], mr, img_h, img_w, clip,
+                       scale_factor ? scale_factor[0] : 1.f, scale_factor ? scale_factor[1] : 1.f, scale_factor ? scale_factor[2] : 1.f,
+                       scale_factor ? scale_factor[3] : 1.f, scale_factor ? 1 : 0);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}

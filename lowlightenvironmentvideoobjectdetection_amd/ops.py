@@ -606,6 +606,25 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, r
     return dets, labels
 
 
+
+def delta2bbox(rois: torch.Tensor, deltas: torch.Tensor, means=(0., 0., 0., 0.), stds=(1., 1., 1., 1.), max_shape=None,
+               wh_ratio_clip=16 / 1000, clip_border=True, scale_factor=None) -> torch.Tensor:
+    """mmdet delta2bbox (delta_xywh_bbox_coder.py:134-237) on the device: rois (n, 4), deltas (n, 4k) fp32 -> (n, 4k) fp32;
+    max_shape (h, w[, c]) clips, scale_factor (4 values) divides (the `rescale=True` of get_bboxes). One launch (llv_delta2bbox)."""
+    _need_gpu(rois, deltas)
+    n, k4 = deltas.shape
+    assert rois.shape == (n, 4) and k4 % 4 == 0
+    rois, deltas = rois.float().contiguous(), deltas.float().contiguous()
+    out = torch.empty_like(deltas)
+    f4 = C.c_float * 4
+    clip = 1 if (clip_border and max_shape is not None) else 0
+    sf = f4(*[float(v) for v in np.asarray(scale_factor, dtype=np.float32).reshape(-1)[:4]]) if scale_factor is not None else None
+    check(lib().llv_delta2bbox(_ptr(rois), _ptr(deltas), _ptr(out), n, k4 // 4, f4(*[float(m) for m in means]), f4(*[float(v) for v in stds]),
+                               float(wh_ratio_clip), float(max_shape[0]) if clip else 0.0, float(max_shape[1]) if clip else 0.0, clip, sf,
+                               _stream()), 'llv_delta2bbox')
+    return out
+
+
 def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float, offset: int = 0):
     """mmcv.ops.nms(boxes, scores, iou_threshold, offset=0) -> (dets (k,5), keep (k,) int64)."""
     _need_gpu(boxes, scores)

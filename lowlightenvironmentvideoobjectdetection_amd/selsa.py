@@ -130,33 +130,17 @@ class SelsaBBoxHead(nn.Module):
             x = F.relu(x + self.aggregator[i](x, ref_pre, ref_side=(r_embed, r_new)))
         return _lin(self.fc_cls, x), _lin(self.fc_reg, x)
 
-    def _decode(self, rois, deltas, max_shape):
-        """delta_xywh_bbox_coder.py:134-237 for (n, 4) rois and (n, 4k) deltas, on the device."""
-        k4 = deltas.size(-1) // 4
-        means = deltas.new_tensor(self.bbox_coder.means).repeat(k4)
-        stds = deltas.new_tensor(self.bbox_coder.stds).repeat(k4)
-        d = deltas * stds + means
-        dx, dy, dw, dh = d[:, 0::4], d[:, 1::4], d[:, 2::4], d[:, 3::4]
-        max_ratio = float(np.abs(np.log(16 / 1000)))
-        dw, dh = dw.clamp(min=-max_ratio, max=max_ratio), dh.clamp(min=-max_ratio, max=max_ratio)
-        px, py = ((rois[:, 0] + rois[:, 2]) * 0.5).unsqueeze(-1), ((rois[:, 1] + rois[:, 3]) * 0.5).unsqueeze(-1)
-        pw, ph = (rois[:, 2] - rois[:, 0]).unsqueeze(-1), (rois[:, 3] - rois[:, 1]).unsqueeze(-1)
-        gw, gh = pw * dw.exp(), ph * dh.exp()
-        gx, gy = px + pw * dx, py + ph * dy
-        b = torch.stack([gx - gw * 0.5, gy - gh * 0.5, gx + gw * 0.5, gy + gh * 0.5], dim=-1)
-        if self.bbox_coder.clip_border and max_shape is not None:
-            lim = b.new_tensor([max_shape[1], max_shape[0], max_shape[1], max_shape[0]])
-            b = torch.minimum(b.clamp(min=0), lim)
-        return b.view(deltas.size())
+    def _decode(self, rois, deltas, max_shape, scale_factor=None):
+        """delta_xywh_bbox_coder.py:134-237 for (n, 4) rois and (n, 4k) deltas: one llv_delta2bbox launch (clip to max_shape, optional
+        division by the scale factor)."""
+        return ops.delta2bbox(rois, deltas, self.bbox_coder.means, self.bbox_coder.stds,
+                              max_shape if self.bbox_coder.clip_border else None, 16 / 1000, self.bbox_coder.clip_border, scale_factor)
 
     def get_bboxes(self, rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=False, cfg=None):
         """bbox_head.py:270-371 (one image): softmax, per-class delta2bbox clipped to the image, optional rescale, multiclass NMS."""
         _gpu(rois, cls_score, bbox_pred)
         scores = F.softmax(cls_score.float(), dim=-1)
-        bboxes = self._decode(rois[:, 1:].float(), bbox_pred.float(), img_shape)
-        if rescale and bboxes.size(0) > 0:
-            sf = bboxes.new_tensor(np.asarray(scale_factor, dtype=np.float32).reshape(-1)[:4]).repeat(bboxes.size(-1) // 4)
-            bboxes = bboxes / sf
+        bboxes = self._decode(rois[:, 1:].float(), bbox_pred.float(), img_shape, scale_factor if rescale else None)
         if cfg is None:
             return bboxes, scores
         if bboxes.size(0) == 0:
