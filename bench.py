@@ -774,9 +774,13 @@ def main():
         if world == 1 and not args.no_cpu_baseline:
             out['cpu_baseline'] = cpu_baseline(det, cleaner, clip.cpu(), img_shape)
         print(json.dumps(out), flush=True)
+    trips_end = ops.guard_trips()
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+    if trips_end:      # a capacity guard fired: some step's detections were computed on inconsistent lists -> the run is not a measurement
+        print(f'bench.py: {trips_end} post-processing capacity guard(s) fired on rank {rank}; exiting non-zero', file=sys.stderr, flush=True)
+        sys.exit(3)
     return out
 
 

@@ -299,6 +299,11 @@ int llv_multiclass_nms(const float* boxes, const float* scores, int n, int num_c
 /* The same for `batch` images in one set of launches: boxes [batch][n][4], scores [batch][n][c_ld],
  * dets [batch][max_num][5], labels / keep_flat [batch][max_num], count [batch]. */
 size_t llv_multiclass_nms_batched_workspace_bytes(int batch, int n, int num_classes, int max_num);
+/* LDS one class list needs (candidate keys padded to a power of two + max_num kept boxes) and the limit a launch may use:
+ * a geometry above the limit is refused with LLV_E_UNSUPPORTED before anything is launched (a failed launch would poison a
+ * stream capture). n <= 8192 always fits; 8192 < n <= 16384 fits for max_num <= 1536. */
+size_t llv_multiclass_nms_lds_bytes(int n, int max_num);
+size_t llv_multiclass_nms_lds_limit(void);
 int llv_multiclass_nms_batched(const float* boxes, const float* scores, int batch, int n, int num_classes, int c_ld,
                                float score_thr, float iou_thr, int max_num, float* dets, int64_t* labels,
                                int32_t* count, int32_t* keep_flat, void* workspace, size_t workspace_bytes,
@@ -340,6 +345,15 @@ int llv_sigmoid_focal_loss_fwd(const float* logits, const int64_t* labels, float
                                float gamma, float alpha, void* stream);
 int llv_sigmoid_focal_loss_bwd(const float* logits, const int64_t* labels, float* grad, int64_t n, int c,
                                float gamma, float alpha, void* stream);
+
+/* softmax cross entropy of the two-stage heads (RPN with use_sigmoid=False, BBoxHead.loss_cls): cross_entropy
+ * (mmdetection/mmdet/models/losses/cross_entropy_loss.py:9-40) = F.cross_entropy(pred, label, weight=class_weight, reduction='none').
+ * logits [n][ld] fp32 (c <= ld columns used), labels [n] int64 (outside [0, c): ignored, loss and gradient 0), class_weight [c]
+ * or NULL. fwd writes loss [n]; bwd writes grad [n][ld] (columns < c) = grad_loss[r] * dloss[r]/dlogit. */
+int llv_softmax_ce_fwd(const float* logits, const int64_t* labels, const float* class_weight, float* loss, int64_t n, int c,
+                       int ld, void* stream);
+int llv_softmax_ce_bwd(const float* logits, const int64_t* labels, const float* class_weight, const float* grad_loss,
+                       float* grad, int64_t n, int c, int ld, void* stream);
 
 /* MaxIoUAssigner on device. gt [k][4], anchors [n][4], valid [n] uint8 (may be NULL) ->
  * assigned_gt_inds [n] int64 (-1 ignore / 0 negative / 1-based gt), max_overlaps [n] fp32. */

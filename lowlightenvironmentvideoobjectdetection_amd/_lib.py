@@ -142,6 +142,8 @@ SIGNATURES = {
     'llv_multiclass_nms_workspace_bytes': (_Z, [_I, _I, _I]),
     'llv_multiclass_nms': (_I, [_P, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
     'llv_multiclass_nms_batched_workspace_bytes': (_Z, [_I, _I, _I, _I]),
+    'llv_multiclass_nms_lds_bytes': (_Z, [_I, _I]),
+    'llv_multiclass_nms_lds_limit': (_Z, []),
     'llv_multiclass_nms_batched': (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
     'llv_multiclass_nms_batched_sf': (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
     'llv_multiclass_nms_batched_ex': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
@@ -157,6 +159,8 @@ SIGNATURES = {
     'llv_flow_warp': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'llv_sigmoid_focal_loss_fwd': (_I, [_P, _P, _P, _L, _I, _F, _F, _P]),
     'llv_sigmoid_focal_loss_bwd': (_I, [_P, _P, _P, _L, _I, _F, _F, _P]),
+    'llv_softmax_ce_fwd': (_I, [_P, _P, _P, _P, _L, _I, _I, _P]),
+    'llv_softmax_ce_bwd': (_I, [_P, _P, _P, _P, _P, _L, _I, _I, _P]),
     'llv_iou_assign_workspace_bytes': (_Z, [_I, _L]),
     'llv_iou_assign': (_I, [_P, _I, _P, _P, _L, _F, _F, _F, _I, _I, _P, _P, _P, _Z, _P]),
     'llv_modulated_deform_im2col': (_I, [_P, _P, _P] + [_I] * 15 + [_P]),

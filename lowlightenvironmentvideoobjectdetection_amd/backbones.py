@@ -28,14 +28,12 @@ class BasicBlock(nn.Module):
         super().__init__()
         assert dcn is None, 'Not implemented yet.'
         assert plugins is None, 'Not implemented yet.'
-        if dilation != 1:
-            raise NotImplementedError('dilated blocks are outside the hot path')
-        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=1, bias=False)
+        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=dilation, dilation=dilation, bias=False)   # resnet.py:38-46
         self.bn1 = _norm(norm_cfg, planes)
         self.conv2 = nn.Conv2d(planes, planes, 3, padding=1, bias=False)
         self.bn2 = _norm(norm_cfg, planes)
         self.downsample = downsample
-        self.stride = stride
+        self.stride, self.dilation = stride, dilation
 
     norm1 = property(lambda self: self.bn1)
     norm2 = property(lambda self: self.bn2)
@@ -48,13 +46,13 @@ class Bottleneck(nn.Module):
                  conv_cfg=None, norm_cfg=dict(type='BN'), dcn=None, plugins=None):
         super().__init__()
         assert style in ['pytorch', 'caffe']
-        if dcn is not None or plugins is not None or dilation != 1:
-            raise NotImplementedError('dcn / plugins / dilation are outside the hot path')
+        if dcn is not None or plugins is not None:
+            raise NotImplementedError('dcn / plugins are outside the hot path')
         self.style = style
         s1, s2 = (1, stride) if style == 'pytorch' else (stride, 1)
         self.conv1 = nn.Conv2d(inplanes, planes, 1, stride=s1, bias=False)
         self.bn1 = _norm(norm_cfg, planes)
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride=s2, padding=1, bias=False)
+        self.conv2 = nn.Conv2d(planes, planes, 3, stride=s2, padding=dilation, dilation=dilation, bias=False)   # resnet.py:163-171
         self.bn2 = _norm(norm_cfg, planes)
         self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
         self.bn3 = _norm(norm_cfg, planes * self.expansion)
@@ -127,7 +125,7 @@ class ResNet(PlannedModule):
         for i, num_blocks in enumerate(self.stage_blocks):
             planes = base_channels * 2 ** i
             layer = ResLayer(block=self.block, inplanes=self.inplanes, planes=planes, num_blocks=num_blocks,
-                             stride=strides[i], style=style, norm_cfg=norm_cfg)
+                             stride=strides[i], dilation=dilations[i], style=style, norm_cfg=norm_cfg)
             self.inplanes = planes * self.block.expansion
             name = f'layer{i + 1}'
             self.add_module(name, layer)

@@ -58,6 +58,7 @@ struct ConvKArgs {
     unsigned x_bytes, w_bytes;   // buffer-resource bounds of one source tensor / one group's weights (0: not usable)
     const long* off_dev;         // convpair2 only: *off_dev (fp16 elements) is added to x0..x2 (off_x) / res (off_res) at kernel start
     int off_x, off_res;
+    long off_max;                // the largest offset the caller declared (llv_conv_desc.offset_max): the word is clamped to [0, off_max]
 };
 
 // source tensor s (0..2) of a multi-source launch, without a pointer table (see conv_igemm_glds_kernel)
@@ -1762,6 +1763,8 @@ __global__ __launch_bounds__(256) void convpair_kernel(const ConvKArgs a, const 
 // LDS (bytes): patch[2] | w0[2] | halo | w1     InputCvBlock 2x7168 + 2x7168 + 22528 + 19456 = 70656
 //                                               OutputCvBlock 27648 + 19456 + 22528 + 10240 = 79872   (2 per CU)
 // ------------------------------------------------------------------------------------------------
+static __device__ unsigned int g_conv_guard_trips = 0u;   // clamps of the sliding-window offset word (llv_guard_trips sums it in)
+
 struct Pair2Args {
     unsigned x_bytes, w0_bytes, w1_bytes;   // buffer-resource bounds: one source tensor, ALL first-conv weights, ALL second-conv weights
 };
@@ -1775,7 +1778,13 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a_in,
     // sliding window over a resident clip (llv_conv_desc.offset_dev): one scalar load, added to the source / residual bases
     ConvKArgs a = a_in;
     if (a_in.off_dev) {
-        const long xo = *a_in.off_dev;
+        long xo = *a_in.off_dev;
+        // the extents replay (conv_extents.inc) vouches for offsets in [0, offset_max] only: a stale or foreign word is clamped
+        // and counted (llv_guard_trips), never followed
+        if (xo < 0 || xo > a_in.off_max) {
+            if (threadIdx.x == 0 && blockIdx.x == 0) atomicAdd(&g_conv_guard_trips, 1u);
+            xo = xo < 0 ? 0 : a_in.off_max;
+        }
         if (a_in.off_x) { a.x0 = a_in.x0 + xo; a.x1 = a_in.x1 + xo; a.x2 = a_in.x2 + xo; }
         if (a_in.off_res) a.res = a_in.res + xo;
     }
@@ -2238,6 +2247,17 @@ int pick_tile(int co, long m, int groups) {
 
 }  // namespace
 
+// clamps of the sliding-window offset word since the last reset (summed into llv_guard_trips, decode.hip)
+unsigned int llv_conv_guard_trips_(int reset) {
+    unsigned int v = 0;
+    (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_conv_guard_trips), sizeof(v));
+    if (reset) {
+        const unsigned int z = 0;
+        (void)hipMemcpyToSymbol(HIP_SYMBOL(g_conv_guard_trips), &z, sizeof(z));
+    }
+    return v;
+}
+
 #include "conv_tap512.inc"
 
 struct LaunchPlan { int tile, splits, nk_per; long m; };
@@ -2348,7 +2368,7 @@ static int conv_prepare(const llv_conv_desc* d, ConvPrepared& P) {
     if (d->dilation < 0) return LLV_E_BADARG;
     if (d->dilation > 1 && (d->flags & LLV_CONV_PIXSHUF)) return LLV_E_UNSUPPORTED;
     if (d->offset_dev) return LLV_E_UNSUPPORTED;           // the sliding-window offset exists on the fused CvBlock kernels only
-    k.off_dev = nullptr; k.off_x = 0; k.off_res = 0;
+    k.off_dev = nullptr; k.off_x = 0; k.off_res = 0; k.off_max = 0;
     if ((d->x_ld & 7) || (d->y_ld & 3)) return LLV_E_BADARG;
     if (d->n_src > 1 && d->groups == d->n_src) {
         if (d->src_cvec * 8 != d->cin || d->x_ld < d->cin) return LLV_E_BADARG;   // group g reads source g
@@ -2574,7 +2594,7 @@ static int convpair_prepare(const llv_inputcv_desc* p, bool output_block, PairPr
     k.seg_m0[LLV_MAX_SEG] = (int)px; k.m_total = (int)px;
     k.flags = d->flags; k.stage_out = 1; k.k_splits = 1; k.y_gstride = 0; k.src_per_group = 0;
     k.act_slope = 0.f; k.ps_h = 0; k.ps_w = 0;
-    k.off_dev = (const long*)d->offset_dev; k.off_x = d->offset_x; k.off_res = d->offset_res;
+    k.off_dev = (const long*)d->offset_dev; k.off_x = d->offset_x; k.off_res = d->offset_res; k.off_max = d->offset_max;
     if (d->offset_dev && (d->offset_max < 0 || (!d->offset_x && !d->offset_res))) return LLV_E_BADARG;
     HaloArgs& h = P.h;
     h.w = (const _Float16*)d->w_halo;

@@ -464,6 +464,7 @@ extern "C" int llv_retina_decode_topk(const llv_decode_desc* d, void* stream) {
 
 // ---- capacity-guard counter (sort_util.h): decode + NMS modules
 unsigned int llv_nms_guard_trips_(int reset);
+unsigned int llv_conv_guard_trips_(int reset);
 extern "C" int llv_guard_trips(uint64_t* count_host, int reset) {
     if (!count_host) return LLV_E_BADARG;
     unsigned int v = 0;
@@ -472,7 +473,7 @@ extern "C" int llv_guard_trips(uint64_t* count_host, int reset) {
         const unsigned int z = 0;
         if (hipMemcpyToSymbol(HIP_SYMBOL(g_guard_trips), &z, sizeof(z)) != hipSuccess) return LLV_E_LAUNCH;
     }
-    *count_host = (uint64_t)v + (uint64_t)llv_nms_guard_trips_(reset);
+    *count_host = (uint64_t)v + (uint64_t)llv_nms_guard_trips_(reset) + (uint64_t)llv_conv_guard_trips_(reset);
     return LLV_OK;
 }
 

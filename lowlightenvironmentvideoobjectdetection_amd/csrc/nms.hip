@@ -27,6 +27,7 @@ LLV_GUARD_DECL
 constexpr int kMaxN = 16384;     // boxes per class list (LDS keys: 128 KiB of the CU's 160; test_cfg without nms_pre keeps every anchor: the reference's own
                                  // get_bboxes fixture has 12,276 of them, mmdetection/tests/test_onnx/test_head.py:86-131)
 constexpr int kMaxMerge = 8192;  // C * max_num
+constexpr size_t kLdsLimit = 160 * 1024 - 8 * 1024;   // dynamic LDS the kernels opt in to (allow_big_lds)
 
 struct NmsWs {
     float* maxc;        // [1] max coordinate over candidate boxes (ordered-uint encoded)
@@ -145,11 +146,12 @@ template <typename BoxFn>
 __device__ inline int greedy_scan_block(const uint64_t* keys, int cnt, float thr, int max_keep, float4* kept,
                                         uint64_t* out_keys, BoxFn box_of, int* s_nkept) {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, nw = blockDim.x >> 6;
-    if (threadIdx.x == 0) *s_nkept = 0;
-    __syncthreads();
+    // The kept count travels in a register that every wave updates from the word the resolving wave published; two words are
+    // used alternately, so the wave that resolves next (and publishes into the other word) can never overwrite a count that a
+    // slower wave has not read yet: every wave sees the same nk1 and the `break`s below stay uniform.
+    int nk0 = 0, slot = 0;
     for (int base = 0; base < cnt; base += blockDim.x) {
-        int nk0 = *s_nkept;
-        if (nk0 >= max_keep) break;                          // uniform: read behind a barrier
+        if (nk0 >= max_keep) break;                          // uniform: nk0 is the same in every wave
         const int i = base + threadIdx.x;
         const bool valid = i < cnt;
         uint64_t key = 0;
@@ -179,10 +181,11 @@ __device__ inline int greedy_scan_block(const uint64_t* keys, int cnt, float thr
                     mask = __ballot(alive);
                     start = t + 1;
                 }
-                if (lane == 0) *s_nkept = nkept;
+                if (lane == 0) s_nkept[slot] = nkept;
             }
             __syncthreads();
-            const int nk1 = *s_nkept;
+            const int nk1 = s_nkept[slot];
+            slot ^= 1;
             if (wave > w)
                 for (int j = nk0; j < nk1; ++j)
                     if (alive && iou_gt(kept[j], b, thr)) alive = false;
@@ -192,7 +195,7 @@ __device__ inline int greedy_scan_block(const uint64_t* keys, int cnt, float thr
         __syncthreads();
     }
     __syncthreads();
-    return *s_nkept;
+    return nk0;
 }
 
 // one workgroup per class: sort its candidate list in LDS, greedy scan by the whole workgroup
@@ -225,7 +228,7 @@ __global__ __launch_bounds__(1024) void nms_class_kernel(const float* __restrict
     llv::bitonic_sort_desc(keys, np2);
     {
         // boxes_for_nms = boxes + idxs.to(boxes) * (max_coordinate + 1)   (mmcv batched_nms)
-        __shared__ int s_nkept;
+        __shared__ int s_nkept[2];
         const float off = (float)c * (llv::f32_unordered(*maxc_u) + 1.0f);
         const unsigned nflat = (unsigned)n * (unsigned)C;
         auto box_of = [&](unsigned flat) {
@@ -234,7 +237,7 @@ __global__ __launch_bounds__(1024) void nms_class_kernel(const float* __restrict
             b.x += off; b.y += off; b.z += off; b.w += off;
             return b;
         };
-        const int nk = greedy_scan_block(keys, cnt, iou_thr, max_num, kept, cls_keys + (long)c * max_num, box_of, &s_nkept);
+        const int nk = greedy_scan_block(keys, cnt, iou_thr, max_num, kept, cls_keys + (long)c * max_num, box_of, s_nkept);
         if (threadIdx.x == 0) cls_cnt[c] = nk;
     }
 }
@@ -337,7 +340,7 @@ inline size_t al(size_t v) { return (v + 255) & ~(size_t)255; }
 // gfx950 has 160 KiB of LDS per CU; HIP caps dynamic LDS at 64 KiB unless the kernel opts in.
 template <typename K>
 inline void allow_big_lds(K kernel) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024 - 8 * 1024);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit);
 }
 inline void nms_init_once() {
     static bool done = false;
@@ -349,6 +352,14 @@ inline void nms_init_once() {
 }
 
 }  // namespace
+
+extern "C" size_t llv_multiclass_nms_lds_bytes(int n, int max_num) {
+    // nms_class_kernel: the class's candidate keys padded to a power of two + the kept boxes
+    int np2 = 1;
+    while (np2 < n) np2 <<= 1;
+    return (size_t)np2 * 8 + (size_t)(max_num > 0 ? max_num : 0) * 16;
+}
+extern "C" size_t llv_multiclass_nms_lds_limit(void) { return kLdsLimit; }
 
 static size_t mnms_ws_one(int n, int num_classes, int max_num) {
     // [maxc | cnt_in[C]] | cls_cnt[C] (memset together) | cls_keys[C][max_num] | cand[C][n]
@@ -384,6 +395,7 @@ extern "C" int llv_multiclass_nms_batched_ex(const float* boxes, const float* sc
     if (n > 0 && (!boxes || !scores)) return LLV_E_BADARG;
     if (workspace_bytes < llv_multiclass_nms_batched_workspace_bytes(batch, n, num_classes, max_num)) return LLV_E_WORKSPACE;
     if (n > kMaxN || (long)num_classes * max_num > kMaxMerge || (long)n * num_classes > 0x7fffffffL || batch > 65535) return LLV_E_UNSUPPORTED;
+    if (llv_multiclass_nms_lds_bytes(n, max_num) > kLdsLimit) return LLV_E_UNSUPPORTED;   // refused here, not as a failed launch
     hipStream_t st = (hipStream_t)stream;
     nms_init_once();
     char* ws = (char*)workspace;

@@ -148,6 +148,57 @@ inline int grid1d(long n, int b) {
     return (int)(g < 1 ? 1 : g);
 }
 
+
+// softmax cross entropy (F.cross_entropy(pred, label, weight=class_weight, reduction='none'), cross_entropy_loss.py:9-40):
+// one wavefront per row; labels outside [0, c) (F.cross_entropy's ignore_index = -100) give loss 0 / gradient 0.
+__global__ void softmax_ce_fwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ t, const float* __restrict__ cw,
+                                      float* __restrict__ loss, long n, int c, int ld) {
+    const long r = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int lane = threadIdx.x & 63;
+    const float* row = x + r * ld;
+    float m = -FLT_MAX;
+    for (int j = lane; j < c; j += 64) m = fmaxf(m, row[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float s = 0.f;
+    for (int j = lane; j < c; j += 64) s += expf(row[j] - m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    if (lane == 0) {
+        const int64_t y = t[r];
+        float v = 0.f;
+        if (y >= 0 && y < c) {
+            v = (m + logf(s)) - row[y];
+            if (cw) v *= cw[y];
+        }
+        loss[r] = v;
+    }
+}
+
+// grad[r][j] = gout[r] * cw[y] * (softmax(x[r])[j] - [j == y])
+__global__ void softmax_ce_bwd_kernel(const float* __restrict__ x, const int64_t* __restrict__ t, const float* __restrict__ cw,
+                                      const float* __restrict__ gout, float* __restrict__ g, long n, int c, int ld) {
+    const long r = blockIdx.x * (long)(blockDim.x >> 6) + (threadIdx.x >> 6);
+    if (r >= n) return;
+    const int lane = threadIdx.x & 63;
+    const float* row = x + r * ld;
+    float* grow = g + r * ld;
+    const int64_t y = t[r];
+    const bool live = y >= 0 && y < c;
+    float m = -FLT_MAX;
+    for (int j = lane; j < c; j += 64) m = fmaxf(m, row[j]);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    float s = 0.f;
+    for (int j = lane; j < c; j += 64) s += expf(row[j] - m);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+    const float k = live ? gout[r] * (cw ? cw[y] : 1.f) : 0.f;
+    const float inv = 1.f / s;
+    for (int j = lane; j < c; j += 64) grow[j] = k * (expf(row[j] - m) * inv - (j == (int)y ? 1.f : 0.f));
+}
+
 }  // namespace
 
 extern "C" int llv_sigmoid_focal_loss_fwd(const float* logits, const int64_t* labels, float* loss, int64_t n, int c,
@@ -171,6 +222,28 @@ extern "C" int llv_sigmoid_focal_loss_bwd(const float* logits, const int64_t* la
     g = g > 8192 ? 8192 : g;
     hipLaunchKernelGGL(focal_bwd_kernel, dim3((int)g), dim3(256), 0, (hipStream_t)stream, logits, labels, grad,
                        (long)n, c, gamma, alpha);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_softmax_ce_fwd(const float* logits, const int64_t* labels, const float* class_weight, float* loss, int64_t n,
+                                  int c, int ld, void* stream) {
+    if (n < 0 || c < 1 || ld < c) return LLV_E_BADARG;
+    if (n == 0) return LLV_OK;
+    if (!logits || !labels || !loss) return LLV_E_BADARG;
+    if ((n + 3) / 4 > 0x7fffffffL) return LLV_E_UNSUPPORTED;
+    hipLaunchKernelGGL(softmax_ce_fwd_kernel, dim3((int)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, labels,
+                       class_weight, loss, (long)n, c, ld);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_softmax_ce_bwd(const float* logits, const int64_t* labels, const float* class_weight, const float* grad_loss,
+                                  float* grad, int64_t n, int c, int ld, void* stream) {
+    if (n < 0 || c < 1 || ld < c) return LLV_E_BADARG;
+    if (n == 0) return LLV_OK;
+    if (!logits || !labels || !grad_loss || !grad) return LLV_E_BADARG;
+    if ((n + 3) / 4 > 0x7fffffffL) return LLV_E_UNSUPPORTED;
+    hipLaunchKernelGGL(softmax_ce_bwd_kernel, dim3((int)((n + 3) / 4)), dim3(256), 0, (hipStream_t)stream, logits, labels,
+                       class_weight, grad_loss, grad, (long)n, c, ld);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 

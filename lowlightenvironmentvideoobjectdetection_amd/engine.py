@@ -436,6 +436,7 @@ class PostProcess:
     def results(self):
         """D2H of the detections: [(dets (k,5), labels (k,)), ...] per image."""
         counts = self.nb.count.cpu().tolist()
+        ops.raise_on_guard_trips('PostPlan.results')
         d = self.nb.dets.cpu().reshape(self.batch, -1, 5)
         l = self.nb.labels.cpu().reshape(self.batch, -1)
         return [(d[n, :k], l[n, :k]) for n, k in enumerate(counts)]
@@ -807,6 +808,7 @@ class EnhanceDetectPlan:
 
     def results(self):
         torch.cuda.current_stream().synchronize()
+        ops.raise_on_guard_trips('EnhanceDetectPlan.results')
         out = []
         for n in range(self.batch):
             k = int(self.cnt_host[n])
@@ -1019,6 +1021,7 @@ class PipelinedStreamingPlan:
     def results(self):
         """Detections of the window most recently detected: [(dets (k, 5), labels (k,))] per image."""
         torch.cuda.synchronize()
+        ops.raise_on_guard_trips('PipelinedStreamingPlan.results')
         k = self._last
         out = []
         for n in range(self.batch):

@@ -280,26 +280,108 @@ class BoundedIoULoss(nn.Module):
                                                    avg_factor=avg_factor, **kwargs)
 
 
+class _SoftmaxCE(torch.autograd.Function):
+    """F.cross_entropy(..., reduction='none') forward/backward on the llv kernels (one wavefront per row)."""
+
+    @staticmethod
+    def forward(ctx, pred, label, class_weight):
+        ctx.save_for_backward(pred, label, class_weight)
+        return ops.softmax_ce_fwd(pred, label, class_weight)
+
+    @staticmethod
+    def backward(ctx, grad_out):
+        pred, label, cw = ctx.saved_tensors
+        return ops.softmax_ce_bwd(pred, label, grad_out, cw), None, None
+
+
+def cross_entropy(pred, label, weight=None, reduction='mean', avg_factor=None, class_weight=None):
+    """cross_entropy_loss.py:9-40"""
+    loss = _SoftmaxCE.apply(pred.contiguous().float(), label, class_weight)
+    if weight is not None:
+        weight = weight.float()
+    return weight_reduce_loss(loss, weight=weight, reduction=reduction, avg_factor=avg_factor)
+
+
+def _expand_onehot_labels(labels, label_weights, label_channels):
+    """cross_entropy_loss.py:43-56"""
+    bin_labels = labels.new_full((labels.size(0), label_channels), 0)
+    inds = torch.nonzero((labels >= 0) & (labels < label_channels), as_tuple=False).squeeze()
+    if inds.numel() > 0:
+        bin_labels[inds, labels[inds]] = 1
+    bin_label_weights = None if label_weights is None else label_weights.view(-1, 1).expand(label_weights.size(0), label_channels)
+    return bin_labels, bin_label_weights
+
+
+def binary_cross_entropy(pred, label, weight=None, reduction='mean', avg_factor=None, class_weight=None):
+    """cross_entropy_loss.py:59-91 (element-wise torch on the device, like the a12 box losses)."""
+    if pred.dim() != label.dim():
+        label, weight = _expand_onehot_labels(label, weight, pred.size(-1))
+    if weight is not None:
+        weight = weight.float()
+    loss = nn.functional.binary_cross_entropy_with_logits(pred, label.float(), pos_weight=class_weight, reduction='none')
+    return weight_reduce_loss(loss, weight, reduction=reduction, avg_factor=avg_factor)
+
+
 @LOSSES.register_module()
 class CrossEntropyLoss(nn.Module):
-    """mmdetection/mmdet/models/losses/cross_entropy_loss.py:139-214, the sigmoid form (use_sigmoid=True -> binary_cross_entropy :58-91:
-    F.binary_cross_entropy_with_logits, element weights, weight_reduce_loss). The YOLOv3 head's class / objectness / centre terms.
-    Softmax and mask cross entropy are not on this path."""
+    """mmdetection/mmdet/models/losses/cross_entropy_loss.py:139-214. use_sigmoid=True -> binary_cross_entropy (:58-91; the YOLOv3
+    head's class / objectness / centre terms), default -> softmax cross_entropy (:9-40) on llv_softmax_ce_{fwd,bwd} (the RPN / bbox heads
+    of the two-stage path; pinned by the reference's test_losses.py:7-31). Mask cross entropy is not on this path."""
 
     def __init__(self, use_sigmoid=False, use_mask=False, reduction='mean', class_weight=None, loss_weight=1.0):
         super().__init__()
+        assert (use_sigmoid is False) or (use_mask is False)
         self.use_sigmoid, self.use_mask, self.reduction, self.class_weight, self.loss_weight = use_sigmoid, use_mask, reduction, class_weight, loss_weight
+        if use_mask:
+            self.cls_criterion = None
+        else:
+            self.cls_criterion = binary_cross_entropy if use_sigmoid else cross_entropy
 
     def forward(self, cls_score, label, weight=None, avg_factor=None, reduction_override=None, **kwargs):
-        if not self.use_sigmoid or self.use_mask:          # constructible (AnchorHead / bbox-head defaults name it), not computable
-            raise NotImplementedError('CrossEntropyLoss: only use_sigmoid=True is built (softmax / mask cross entropy are outside the path)')
+        if self.use_mask:
+            raise NotImplementedError('CrossEntropyLoss: mask cross entropy is outside the path (no mask heads)')
         assert reduction_override in (None, 'none', 'mean', 'sum')
         reduction = reduction_override if reduction_override else self.reduction
-        if cls_score.dim() != label.dim():
-            raise NotImplementedError('CrossEntropyLoss: index labels (one-hot expansion) are not used on this path')
         cw = cls_score.new_tensor(self.class_weight) if self.class_weight is not None else None
-        loss = nn.functional.binary_cross_entropy_with_logits(cls_score, label.float(), pos_weight=cw, reduction='none')
-        return self.loss_weight * weight_reduce_loss(loss, weight.float() if weight is not None else None, reduction, avg_factor)
+        return self.loss_weight * self.cls_criterion(cls_score, label, weight, class_weight=cw, reduction=reduction,
+                                                     avg_factor=avg_factor, **kwargs)
+
+
+def accuracy(pred, target, topk=1, thresh=None):
+    """mmdetection/mmdet/models/losses/accuracy.py:5-50 (logging only; a top-k over <= 81 columns, torch on the device)."""
+    assert isinstance(topk, (int, tuple))
+    if isinstance(topk, int):
+        topk, return_single = (topk, ), True
+    else:
+        return_single = False
+    maxk = max(topk)
+    if pred.size(0) == 0:
+        accu = [pred.new_tensor(0.) for _ in range(len(topk))]
+        return accu[0] if return_single else accu
+    assert pred.ndim == 2 and target.ndim == 1
+    assert pred.size(0) == target.size(0)
+    assert maxk <= pred.size(1), f'maxk {maxk} exceeds pred dimension {pred.size(1)}'
+    pred_value, pred_label = pred.topk(maxk, dim=1)
+    pred_label = pred_label.t()
+    correct = pred_label.eq(target.view(1, -1).expand_as(pred_label))
+    if thresh is not None:
+        correct = correct & (pred_value > thresh).t()
+    res = []
+    for k in topk:
+        correct_k = correct[:k].reshape(-1).float().sum(0, keepdim=True)
+        res.append(correct_k.mul_(100.0 / pred.size(0)))
+    return res[0] if return_single else res
+
+
+class Accuracy(nn.Module):
+    """accuracy.py:53-78"""
+
+    def __init__(self, topk=(1, ), thresh=None):
+        super().__init__()
+        self.topk, self.thresh = topk, thresh
+
+    def forward(self, pred, target):
+        return accuracy(pred, target, self.topk, self.thresh)
 
 
 @LOSSES.register_module()

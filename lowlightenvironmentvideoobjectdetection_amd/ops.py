@@ -275,6 +275,18 @@ def guard_trips(reset: bool = False) -> int:
     return int(v.value)
 
 
+def raise_on_guard_trips(what: str):
+    """Called by every results() hand-over after its synchronisation: a capacity guard that fired means the step's decode / NMS
+    launches ran on counters or lists that were not consistent (include/llv.h, llv_guard_trips); the kernels stayed inside their
+    buffers by clamping, so the detections of the step are wrong. Refuse to return them (the counter is reset so that the next
+    step is judged on its own)."""
+    n = guard_trips()
+    if n:
+        guard_trips(reset=True)
+        raise LlvError(f'{what}: {n} post-processing capacity guard(s) fired during the step(s) since the last check; the '
+                       f'detections are not trustworthy and are withheld (see DESIGN.md section 4)')
+
+
 def conv_extents(desc) -> Extents:
     """llv_conv2d_extents / llv_convpair_extents: 1 + the highest byte the launch touches through each pointer (host replay)."""
     need = Extents()
@@ -454,6 +466,9 @@ class DecodePlan:
 def set_decode_image_params(d: DecodeDesc, img_shapes, scale_factors, rescale, clip=True):
     """Per-image clip size / scale factor of a (batched) decode descriptor; host-side struct edit, no launch."""
     batch = max(int(d.batch), 1)
+    if batch > _lib.LLV_MAX_BATCH:
+        raise LlvError(f'decode descriptor: {batch} images per step; the post-processing descriptors take at most LLV_MAX_BATCH = '
+                       f'{_lib.LLV_MAX_BATCH} (include/llv.h); split the step')
     for n in range(batch):
         shp = img_shapes[n] if img_shapes is not None else None
         sf = np.asarray(scale_factors[n] if scale_factors is not None else 1.0, dtype=np.float32).reshape(-1)
@@ -477,6 +492,9 @@ def make_decode_plan(cls: torch.Tensor, reg: torch.Tensor, level_hw, strides, cl
     """batch > 1: img_shape / scale_factor are per-image lists; level l of image n starts n*h*w pixels after cls_off[l];
     outputs are (batch, n_cand, ...)."""
     _need_gpu(cls, reg)
+    if batch > _lib.LLV_MAX_BATCH:
+        raise LlvError(f'{batch} images per step: the post-processing descriptors take at most LLV_MAX_BATCH = {_lib.LLV_MAX_BATCH} '
+                       f'(include/llv.h); split the step')
     d = DecodeDesc()
     d.n_levels = len(level_hw)
     d.num_classes, d.num_anchors, d.nms_pre = num_classes, num_anchors, nms_pre
@@ -583,8 +601,12 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, r
                            f'(num_classes * max_num <= 8192); pass max_num <= {8192 // max(num_classes, 1)}')
     if num_classes * cap > 8192:
         raise LlvError(f'multiclass_nms: num_classes * max_num = {num_classes * cap} > 8192 (merge limit of the device NMS)')
-    # the buffers of a (n, classes, cap) geometry are kept between calls (stream-ordered reuse; the results are cloned out below)
-    bkey = (max(n, 1), num_classes, max(cap, 1), str(multi_bboxes.device))
+    if lib().llv_multiclass_nms_lds_bytes(n, cap) > lib().llv_multiclass_nms_lds_limit():
+        raise LlvError(f'multiclass_nms: {n} boxes with max_num={cap} need {lib().llv_multiclass_nms_lds_bytes(n, cap)} bytes of LDS per class '
+                       f'list (limit {lib().llv_multiclass_nms_lds_limit()}); lists above 8192 boxes take max_num <= 1536')
+    # the buffers of a (n, classes, cap) geometry are kept between calls, per device and per stream (reuse is stream-ordered; the
+    # results are cloned out below, so a caller on another stream never sees a buffer this one is still writing)
+    bkey = (max(n, 1), num_classes, max(cap, 1), str(multi_bboxes.device), torch.cuda.current_stream().cuda_stream)
     bufs = _NMS_BUFFERS.get(bkey)
     if bufs is None:
         if len(_NMS_BUFFERS) >= 16:
@@ -697,6 +719,29 @@ def sigmoid_focal_loss_bwd(logits, labels, gamma=2.0, alpha=0.25):
     out = torch.empty_like(logits)
     check(lib().llv_sigmoid_focal_loss_bwd(_ptr(logits), _ptr(labels), _ptr(out), n, c, gamma, alpha, _stream()),
           'llv_sigmoid_focal_loss_bwd')
+    return out
+
+
+def softmax_ce_fwd(logits, labels, class_weight=None):
+    """F.cross_entropy(logits, labels, weight=class_weight, reduction='none') -> (n,) fp32 (llv_softmax_ce_fwd)."""
+    _need_gpu(logits, labels, class_weight)
+    logits = logits.float().contiguous()
+    labels = labels.long().contiguous()
+    n, c = logits.shape
+    out = torch.empty(n, dtype=torch.float32, device=logits.device)
+    check(lib().llv_softmax_ce_fwd(_ptr(logits), _ptr(labels), _ptr(class_weight), _ptr(out), n, c, c, _stream()), 'llv_softmax_ce_fwd')
+    return out
+
+
+def softmax_ce_bwd(logits, labels, grad_loss, class_weight=None):
+    _need_gpu(logits, labels, grad_loss, class_weight)
+    logits = logits.float().contiguous()
+    labels = labels.long().contiguous()
+    grad_loss = grad_loss.float().contiguous()
+    n, c = logits.shape
+    out = torch.empty_like(logits)
+    check(lib().llv_softmax_ce_bwd(_ptr(logits), _ptr(labels), _ptr(class_weight), _ptr(grad_loss), _ptr(out), n, c, c, _stream()),
+          'llv_softmax_ce_bwd')
     return out
 
 

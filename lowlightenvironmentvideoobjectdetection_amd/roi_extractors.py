@@ -1,7 +1,8 @@
 """RoI feature extraction for the two-stage path (first piece): `SingleRoIExtractor` with the reference's
 constructor (mmdetection/mmdet/models/roi_heads/roi_extractors/single_level_roi_extractor.py:9-108, base_roi_extractor.py:17-83) over
 `llv_roi_align`. Every pyramid level is packed to NHWC fp16 once per call; the RoIs of a level go through one launch; the result comes
-back as (k, C, ph, pw) fp32 like mmcv's RoIAlign output under `force_fp32`. The RPN / RoI heads that would call it are not built yet."""
+back as (k, C, ph, pw) fp32 like mmcv's RoIAlign output under `force_fp32`. Callers: `selsa.SelsaRoIHead` (proposals from `rpn.RPNHead`);
+`TemporalRoIAlign` below is the extractor of the authors' own model."""
 import ctypes as C
 
 import torch
@@ -170,6 +171,8 @@ class TemporalRoIAlign(SingleRoIExtractor, PlannedModule):
             return SingleRoIExtractor.forward(self, feats, rois, roi_scale_factor)
         if len(feats) != 1:
             raise LlvError('TemporalRoIAlign with ref_feats: one feature level (featmap_strides of the SELSA configs: [16])')
+        # roi_scale_factor: with one level the reference returns before its roi_rescale (single_level_roi_extractor.py:73-76), so
+        # the argument has no effect there either
         ph, pw = self.roi_layers[0].output_size
         k = rois.size(0)
         if k == 0:

@@ -26,7 +26,7 @@ def _lin(fc, x):
     """fc(x) as a library GEMM with fp16 operands and fp32 accumulation (the arithmetic type of the rest of the path: fp16 storage, fp32
     accumulate); the fp16 copy of the weight is kept on the layer until the weight changes. Returns fp32."""
     w = fc.weight
-    key = (w.data_ptr(), w._version, str(w.device))
+    key = (w.data_ptr(), w._version, str(w.device), None if fc.bias is None else (fc.bias.data_ptr(), fc.bias._version))
     if getattr(fc, '_llv_half_key', None) != key:
         fc._llv_half = (w.detach().half(), fc.bias.detach().half() if fc.bias is not None else None)
         fc._llv_half_key = key
@@ -307,6 +307,13 @@ class SELSA(BaseVideoDetector):
         self.init_weights(pretrains)
         if frozen_modules is not None:
             self.freeze_module(frozen_modules)
+
+    def invalidate_plans(self):
+        """Parameters may have changed (load_state_dict, train() / eval(), an optimizer step): besides the plans, the per-video memo
+        holds feature maps, proposals and RoI-head reference branches computed with the old weights -- drop it, the next frame 0
+        (or the next call, which then raises on the missing memo instead of mixing weights) rebuilds it."""
+        super().invalidate_plans()
+        self.memo = None
 
     def init_weights(self, pretrain):
         if pretrain is None:

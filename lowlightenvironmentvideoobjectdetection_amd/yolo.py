@@ -101,6 +101,16 @@ class YOLOBBoxCoder:
         yt = ((yg - yc) / stride + 0.5).clamp(self.eps, 1 - self.eps)
         return torch.stack([xt, yt, wt, ht], dim=-1)
 
+    def decode(self, bboxes, pred_bboxes, stride):
+        """yolo_bbox_coder.py:61-89 on explicit anchors (the reference's coder API, pinned by its test_coder.py:8-23); the head's
+        test path decodes against the grid inside llv_yolo_decode instead."""
+        assert pred_bboxes.size(0) == bboxes.size(0) and pred_bboxes.size(-1) == bboxes.size(-1) == 4
+        xc, yc = (bboxes[..., 0] + bboxes[..., 2]) * 0.5, (bboxes[..., 1] + bboxes[..., 3]) * 0.5
+        w, h = bboxes[..., 2] - bboxes[..., 0], bboxes[..., 3] - bboxes[..., 1]
+        xcp, ycp = (pred_bboxes[..., 0] - 0.5) * stride + xc, (pred_bboxes[..., 1] - 0.5) * stride + yc
+        wp, hp = torch.exp(pred_bboxes[..., 2]) * w, torch.exp(pred_bboxes[..., 3]) * h
+        return torch.stack((xcp - wp / 2, ycp - hp / 2, xcp + wp / 2, ycp + hp / 2), dim=-1)
+
 
 class ResBlock(nn.Module):
     def __init__(self, in_channels, **cfg):
@@ -275,6 +285,22 @@ class YOLOV3Head(PlannedModule):
         neg_map[sr.neg_inds] = 1
         return target_map, neg_map
 
+    def decode_level(self, pred_nhwc, level):
+        """yolo_head.py:262-279 for one level on llv_yolo_decode: raw prediction map (n, h, w, A*(5+C)) fp32 NHWC on the GPU ->
+        boxes (n, h*w*A, 4) decoded against the level's anchor grid (YOLOBBoxCoder.decode) and objectness (n, h*w*A) = sigmoid(attr 4)."""
+        ops._need_gpu(pred_nhwc)
+        n, h, w, c = pred_nhwc.shape
+        assert c >= self.num_anchors * self.num_attrib and pred_nhwc.dtype == torch.float32 and pred_nhwc.is_contiguous()
+        dev = pred_nhwc.device
+        bx = torch.empty(n, h * w * self.num_anchors, 4, device=dev)
+        cf = torch.empty(n, h * w * self.num_anchors, device=dev)
+        wh = np.asarray(self.anchor_generator.base_sizes[level], dtype=np.float32).reshape(-1)
+        whc = (C.c_float * len(wh))(*wh.tolist())
+        check(lib().llv_yolo_decode(C.c_void_p(pred_nhwc.data_ptr()), n, h, w, self.num_anchors, self.num_attrib, c, self.featmap_strides[level],
+                                    whc, C.c_void_p(bx.data_ptr()), C.c_void_p(cf.data_ptr()),
+                                    C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'llv_yolo_decode')
+        return bx, cf
+
     def get_bboxes(self, pred_maps, img_metas, cfg=None, rescale=False, with_nms=True):
         """YOLOV3Head.get_bboxes / _get_bboxes (yolo_head.py:172-366) on raw prediction maps: list over levels of (N, A*(5+C), h, w)
         tensors on the GPU -> per image (dets (k, 5), labels (k,)). llv_yolo_decode per level, then the same selection + NMS the
@@ -283,18 +309,11 @@ class YOLOV3Head(PlannedModule):
             raise LlvError('YOLOV3Head.get_bboxes: with_nms=False (ONNX export path) is outside the hot path')
         ops._need_gpu(*pred_maps)
         bs, dev = pred_maps[0].shape[0], pred_maps[0].device
-        stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
         pred, boxes, confs = [], [], []
         for i, pm in enumerate(pred_maps):
-            n, c, h, w = pm.shape
-            assert c == self.num_anchors * self.num_attrib
+            assert pm.shape[1] == self.num_anchors * self.num_attrib
             p = pm.detach().float().permute(0, 2, 3, 1).contiguous()
-            bx = torch.empty(n, h * w * self.num_anchors, 4, device=dev)
-            cf = torch.empty(n, h * w * self.num_anchors, device=dev)
-            wh = np.asarray(self.anchor_generator.base_sizes[i], dtype=np.float32).reshape(-1)
-            whc = (C.c_float * len(wh))(*wh.tolist())
-            check(lib().llv_yolo_decode(C.c_void_p(p.data_ptr()), n, h, w, self.num_anchors, self.num_attrib, c, self.featmap_strides[i], whc,
-                                        C.c_void_p(bx.data_ptr()), C.c_void_p(cf.data_ptr()), stream), 'llv_yolo_decode')
+            bx, cf = self.decode_level(p, i)
             pred.append(p); boxes.append(bx); confs.append(cf)
         return _yolo_select_nms(self, pred, boxes, confs, self.num_anchors, self.num_attrib, bs, img_metas, rescale, self, cfg)
 

@@ -132,6 +132,33 @@ def focal_loss_labels(pred, labels, weight=None, gamma=2.0, alpha=0.25, reductio
     return loss_weight * py_sigmoid_focal_loss(pred, target, weight, gamma, alpha, reduction, avg_factor)
 
 
+def cross_entropy(pred, label, weight=None, reduction='mean', avg_factor=None, class_weight=None):
+    """mmdetection/mmdet/models/losses/cross_entropy_loss.py:9-40 (softmax cross entropy; pinned by the reference's
+    tests/test_metrics/test_losses.py:7-31: 40. with class weights [0.8, 0.2], 200. without)."""
+    loss = F.cross_entropy(pred, label, weight=class_weight, reduction='none')
+    if weight is not None:
+        weight = weight.float()
+    return weight_reduce_loss(loss, weight=weight, reduction=reduction, avg_factor=avg_factor)
+
+
+def accuracy(pred, target, topk=1, thresh=None):
+    """mmdetection/mmdet/models/losses/accuracy.py:5-50 (pinned by test_losses.py:81-139)."""
+    single = isinstance(topk, int)
+    topk = (topk,) if single else topk
+    maxk = max(topk)
+    if pred.size(0) == 0:
+        accu = [pred.new_tensor(0.) for _ in topk]
+        return accu[0] if single else accu
+    assert pred.ndim == 2 and target.ndim == 1 and pred.size(0) == target.size(0) and maxk <= pred.size(1)
+    pred_value, pred_label = pred.topk(maxk, dim=1)
+    pred_label = pred_label.t()
+    correct = pred_label.eq(target.view(1, -1).expand_as(pred_label))
+    if thresh is not None:
+        correct = correct & (pred_value > thresh).t()
+    res = [correct[:k].reshape(-1).float().sum(0, keepdim=True).mul_(100.0 / pred.size(0)) for k in topk]
+    return res[0] if single else res
+
+
 def unmap(data, count, inds, fill=0):
     """mmdetection/mmdet/core/utils/misc.py:31-42"""
     if data.dim() == 1:

@@ -6,7 +6,10 @@
   YOLOAnchorGenerator     mmdetection/mmdet/core/anchor/anchor_generator.py:590-665 (+ grid_anchors of the base class)
   YOLOBBoxCoder.decode    mmdetection/mmdet/core/bbox/coder/yolo_bbox_coder.py:61-89
 ConvModule here = conv (no bias) -> BatchNorm (eval) -> LeakyReLU(0.1) (mmcv, not vendored: semantics restated).
-Parity unpinned: the reference holds no known-answer test for this head.
+Pinning: YOLOBBoxCoder.decode by the reference's mmdetection/tests/test_utils/test_coder.py:8-23 (four expected boxes) and the
+YOLOAnchorGenerator base anchors by tests/test_utils/test_anchor.py:148-188 (tests/test_oracle_known_answers.py runs both through this
+file and through the product). The reference holds no vector for Darknet / the neck / _get_bboxes' selection or the grid assigner:
+those stay unpinned restatements (F.conv2d / F.batch_norm compositions + the pinned pieces + oracle/nms.py).
 """
 import torch
 import torch.nn.functional as F

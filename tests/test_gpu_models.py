@@ -285,6 +285,20 @@ def test_zero_copy_windows_equal_copied_windows(dev, B, use_graph):
         zc.step(clip, T - B + 1)                          # window past the end of the clip
     with pytest.raises(LlvError):
         zc.step(clip.clone(), 0)                          # not the bound clip
+    # a stale / foreign offset word (what the host-side checks above cannot see) is clamped into the clip by the kernel, counted,
+    # and the step's detections are withheld: results() raises instead of returning boxes computed on the wrong window
+    assert ops.guard_trips(reset=True) == 0
+    zc.step(clip, 0)
+    zc._off.fill_(-12345)                                 # after step() stored a valid offset: corrupt the word behind its back
+    (zc._graph.replay() if zc._graph is not None else zc._body(zc._window))
+    with pytest.raises(LlvError, match='capacity guard'):
+        zc.results()
+    zc._off.fill_(1 << 40)
+    (zc._graph.replay() if zc._graph is not None else zc._body(zc._window))
+    torch.cuda.synchronize()
+    assert ops.guard_trips(reset=True) > 0
+    zc.step(clip, 3)                                      # and the plan is usable again
+    assert ops.guard_trips() == 0 and len(zc.results()) == B
 
 
 @pytest.mark.parametrize('B,use_graph', [(1, True), (2, False)])

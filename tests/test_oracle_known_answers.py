@@ -234,3 +234,159 @@ def test_oracle_yolo_targets_hand_computed():
     enc = yolo_encode(cat[pos], gt.expand(len(pos), 4), st[pos])
     dec = yolo_decode(cat[pos], enc, st[pos])
     assert torch.allclose(dec, gt.expand(len(pos), 4), atol=1e-3)
+
+
+# ------------------------------------------------------------------ round 3: the reference-held vectors left unused until now
+YOLO_BOXES = [[-42., -29., 74., 61.], [-10., -29., 106., 61.], [22., -29., 138., 61.], [54., -29., 170., 61.]]
+YOLO_PRED = [[0.4709, 0.6152, 0.1690, -0.4056], [0.5399, 0.6653, 0.1162, -0.4162], [0.4654, 0.6618, 0.1548, -0.4301],
+             [0.4786, 0.6197, 0.1896, -0.4479]]
+YOLO_EXPECTED = [[-53.6102, -10.3096, 83.7478, 49.6824], [-15.8700, -8.3901, 114.4236, 50.9693],
+                 [11.1822, -8.0924, 146.6034, 50.4476], [41.2068, -8.9232, 181.4236, 48.5840]]
+YOLO_BASE_SIZES = [[(116, 90), (156, 198), (373, 326)], [(30, 61), (62, 45), (59, 119)], [(10, 13), (16, 30), (33, 23)]]
+YOLO_BASE_ANCHORS = [
+    [[-42.0000, -29.0000, 74.0000, 61.0000], [-62.0000, -83.0000, 94.0000, 115.0000], [-170.5000, -147.0000, 202.5000, 179.0000]],
+    [[-7.0000, -22.5000, 23.0000, 38.5000], [-23.0000, -14.5000, 39.0000, 30.5000], [-21.5000, -51.5000, 37.5000, 67.5000]],
+    [[-1.0000, -2.5000, 9.0000, 10.5000], [-4.0000, -11.0000, 12.0000, 19.0000], [-12.5000, -7.5000, 20.5000, 15.5000]]]
+
+
+def test_yolo_bbox_coder():
+    """mmdetection/tests/test_utils/test_coder.py:8-23 through the oracle and the product's coder class."""
+    from oracle.yolo import yolo_decode
+    from lowlightenvironmentvideoobjectdetection_amd.yolo import YOLOBBoxCoder
+    expected = torch.Tensor(YOLO_EXPECTED)
+    assert expected.allclose(yolo_decode(torch.Tensor(YOLO_BOXES), torch.Tensor(YOLO_PRED), 32))
+    assert expected.allclose(YOLOBBoxCoder().decode(torch.Tensor(YOLO_BOXES), torch.Tensor(YOLO_PRED), 32))
+
+
+@pytest.mark.gpu
+def test_yolo_bbox_coder_device_kernel(dev):
+    """The same vectors through llv_yolo_decode: the four boxes are the first base anchor of the stride-32 level (116 x 90, centred at
+    (16, 16)) on a 1 x 4 grid; the kernel applies the sigmoid of yolo_head.py:266 itself, so it is fed logit(x), logit(y)."""
+    from lowlightenvironmentvideoobjectdetection_amd.yolo import YOLOV3Head
+    pred = torch.tensor(YOLO_PRED, dtype=torch.float64)
+    raw = pred.clone()
+    raw[:, :2] = torch.log(pred[:, :2] / (1 - pred[:, :2]))
+    na = 5 + 3
+    maps = torch.zeros(1, 1, 4, na, dtype=torch.float32)
+    maps[0, 0, :, :4] = raw.float()
+    head = YOLOV3Head(num_classes=3, in_channels=[16], out_channels=[16], featmap_strides=[32],
+                      anchor_generator=dict(type='YOLOAnchorGenerator', base_sizes=[[(116, 90)]], strides=[32]))
+    boxes, conf = head.decode_level(maps.to(dev), 0)
+    assert boxes.shape == (1, 4, 4) and conf.shape == (1, 4)
+    assert torch.allclose(boxes[0].cpu(), torch.Tensor(YOLO_EXPECTED), rtol=1e-5, atol=2e-4)
+    assert torch.allclose(conf.cpu(), torch.full((1, 4), 0.5))
+
+
+def test_yolo_anchor_generator():
+    """mmdetection/tests/test_utils/test_anchor.py:148-188 through the oracle's grid function and the product's generator."""
+    from oracle.yolo import yolo_grid_anchors
+    from lowlightenvironmentvideoobjectdetection_amd.registry import build_anchor_generator
+    import lowlightenvironmentvideoobjectdetection_amd.models  # noqa: F401
+    strides = [32, 16, 8]
+    ag = build_anchor_generator(dict(type='YOLOAnchorGenerator', strides=strides, base_sizes=YOLO_BASE_SIZES))
+    for i, b in enumerate(ag.base_anchors):
+        assert b.allclose(torch.Tensor(YOLO_BASE_ANCHORS[i]))
+    assert ag.num_base_anchors == [3, 3, 3]
+    featmap_sizes = [(14, 18), (28, 36), (56, 72)]
+    anchors = ag.grid_anchors(featmap_sizes, 'cpu')
+    assert len(anchors) == 3
+    want = yolo_grid_anchors(featmap_sizes, YOLO_BASE_SIZES, strides)
+    for i, (a, w) in enumerate(zip(anchors, want)):
+        assert w[:3].allclose(torch.Tensor(YOLO_BASE_ANCHORS[i]))          # cell (0, 0) of the grid = the base anchors
+        assert a.shape == (featmap_sizes[i][0] * featmap_sizes[i][1] * 3, 4) and torch.equal(a, w)
+
+
+def _dummy_perfect_results():
+    """_create_dummy_coco_json / _create_dummy_custom_pkl / _create_dummy_results, mmdetection/tests/test_data/test_datasets/
+    test_common.py:20-101: four ground truths of one class and four detections that coincide with them."""
+    gts = np.array([[50, 60, 70, 80], [100, 120, 130, 150], [150, 160, 190, 200], [250, 260, 350, 360]], np.float32)
+    ann = [dict(bboxes=gts, labels=np.array([0, 0, 0, 0]))]
+    det = [[np.array([[50, 60, 70, 80, 1.0], [100, 120, 130, 150, 0.98], [150, 160, 190, 200, 0.96], [250, 260, 350, 360, 0.95]],
+                     np.float32)]]
+    return det, ann
+
+
+def test_perfect_detections_give_map_one_oracle():
+    """test_common.py:120-221: CustomDataset.evaluate -> eval_map gives mAP == 1, CocoDataset.evaluate -> COCOeval gives
+    bbox_mAP == bbox_mAP_50 == bbox_mAP_75 == 1 on the dummy data (the COCO json's xywh boxes are the same four xyxy boxes)."""
+    from oracle.coco_eval import coco_bbox_eval
+    from oracle.evaluation import eval_map
+    det, ann = _dummy_perfect_results()
+    mean_ap, _ = eval_map(det, ann, scale_ranges=None, iou_thr=0.5, dataset=None)
+    assert mean_ap == 1
+    out = coco_bbox_eval(det, ann)
+    assert out['bbox_mAP'] == 1 and out['bbox_mAP_50'] == 1 and out['bbox_mAP_75'] == 1
+    det2, ann2 = det + det, ann + ann                                      # the concatenated datasets of :150-165
+    assert eval_map(det2, ann2)[0] == 1 and coco_bbox_eval(det2, ann2)['bbox_mAP'] == 1
+
+
+@pytest.mark.gpu
+def test_perfect_detections_give_map_one_device(dev):
+    from lowlightenvironmentvideoobjectdetection_amd.core.coco_eval import coco_bbox_eval
+    from lowlightenvironmentvideoobjectdetection_amd.core.evaluation import eval_map
+    det, ann = _dummy_perfect_results()
+    assert eval_map(det, ann, scale_ranges=None, iou_thr=0.5, dataset=None, logger='silent')[0] == 1
+    out = coco_bbox_eval(det, ann)
+    assert out['bbox_mAP'] == 1 and out['bbox_mAP_50'] == 1 and out['bbox_mAP_75'] == 1
+    assert eval_map(det + det, ann + ann, logger='silent')[0] == 1 and coco_bbox_eval(det + det, ann + ann)['bbox_mAP'] == 1
+
+
+def test_ce_loss_oracle():
+    """mmdetection/tests/test_metrics/test_losses.py:7-31"""
+    from oracle.training import cross_entropy
+    fake_pred, fake_label = torch.Tensor([[100, -100]]), torch.Tensor([1]).long()
+    assert torch.allclose(cross_entropy(fake_pred, fake_label, class_weight=torch.tensor([0.8, 0.2])), torch.tensor(40.))
+    assert torch.allclose(cross_entropy(fake_pred, fake_label), torch.tensor(200.))
+
+
+def test_ce_loss_constructor_rule():
+    """test_losses.py:8-15: use_mask and use_sigmoid cannot both be true."""
+    from lowlightenvironmentvideoobjectdetection_amd.registry import build_loss
+    import lowlightenvironmentvideoobjectdetection_amd.models  # noqa: F401
+    with pytest.raises(AssertionError):
+        build_loss(dict(type='CrossEntropyLoss', use_mask=True, use_sigmoid=True, loss_weight=1.0))
+
+
+@pytest.mark.gpu
+def test_ce_loss_device(dev):
+    """test_losses.py:17-31 through the product's CrossEntropyLoss (llv_softmax_ce_fwd), + its gradient against autograd over the oracle."""
+    from oracle.training import cross_entropy
+    from lowlightenvironmentvideoobjectdetection_amd.registry import build_loss
+    import lowlightenvironmentvideoobjectdetection_amd.models  # noqa: F401
+    fake_pred, fake_label = torch.Tensor([[100, -100]]).to(dev), torch.Tensor([1]).long().to(dev)
+    loss_cls = build_loss(dict(type='CrossEntropyLoss', use_sigmoid=False, class_weight=[0.8, 0.2], loss_weight=1.0))
+    assert torch.allclose(loss_cls(fake_pred, fake_label).cpu(), torch.tensor(40.))
+    loss_cls = build_loss(dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0))
+    assert torch.allclose(loss_cls(fake_pred, fake_label).cpu(), torch.tensor(200.))
+    g = torch.Generator().manual_seed(0)
+    x = torch.randn(257, 31, generator=g) * 3
+    y = torch.randint(0, 31, (257,), generator=g)
+    w = torch.rand(257, generator=g)
+    cw = torch.rand(31, generator=g) + 0.5
+    xr = x.clone().requires_grad_(True)
+    want = cross_entropy(xr, y, w, avg_factor=7.0, class_weight=cw)
+    want.backward()
+    xd = x.to(dev).requires_grad_(True)
+    got = build_loss(dict(type='CrossEntropyLoss', class_weight=cw.tolist(), loss_weight=1.0))(xd, y.to(dev), w.to(dev), avg_factor=7.0)
+    got.backward()
+    assert torch.allclose(got.cpu(), want.detach(), rtol=1e-5, atol=1e-6)
+    assert torch.allclose(xd.grad.cpu(), xr.grad, rtol=1e-4, atol=1e-6)
+
+
+def test_accuracy():
+    """mmdetection/tests/test_metrics/test_losses.py:81-139 through the oracle and the product's Accuracy (host logic on torch)."""
+    from oracle.training import accuracy as oracle_accuracy
+    from lowlightenvironmentvideoobjectdetection_amd.losses import Accuracy
+    for make in (lambda **k: Accuracy(**k), lambda **k: (lambda p, t: oracle_accuracy(p, t, **k))):
+        assert make(topk=1)(torch.empty(0, 4), torch.empty(0)).item() == 0
+        pred = torch.Tensor([[0.2, 0.3, 0.6, 0.5], [0.1, 0.1, 0.2, 0.6], [0.9, 0.0, 0.0, 0.1], [0.4, 0.7, 0.1, 0.1], [0.0, 0.0, 0.99, 0]])
+        true_label = torch.Tensor([2, 3, 0, 1, 2]).long()
+        assert make(topk=1)(pred, true_label).item() == 100
+        assert make(topk=1, thresh=0.8)(pred, true_label).item() == 40
+        assert make(topk=2)(pred, torch.Tensor([3, 2, 0, 0, 2]).long()).item() == 100
+        for a in make(topk=(1, 2))(pred, true_label):
+            assert a.item() == 100
+        with pytest.raises(AssertionError):
+            make(topk=5)(pred, true_label)
+        with pytest.raises(AssertionError):
+            make(topk=1)(pred, torch.Tensor([2, 3, 0, 1, 2, 0]).long())
