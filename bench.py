@@ -501,6 +501,12 @@ def main():
     ap.add_argument('--mode', choices=['infer', 'train', 'yolo', 'fgfa', 'insert', 'selsa'], default='infer',
                     help="'train' = BASELINE.json config #3: RetinaNet fwd + loss + bwd + gradient all-reduce + SGD, one image per GPU")
     ap.add_argument('--train-batch', type=int, default=1, help='images per GPU per training step')
+    ap.add_argument('--shard', choices=['frames', 'clips'], default='frames',
+                    help="infer mode, N > 1 ranks: 'frames' (default) = ONE clip of clip-frames * N frames cut into N contiguous segments, "
+                         "each rank its segment + 2+2 halo frames (north_star: clips shard by frame); 'clips' = every rank its own "
+                         'clip of clip-frames frames (whole-video sharding, the reference\'s DistributedVideoSampler unit)')
+    ap.add_argument('--dump-results', default=None,
+                    help="write the detections of every frame of the clip, gathered on rank 0 in frame order, to this .npz ('frames' sharding)")
     args = ap.parse_args()
 
     if args.gpus > 1 and 'WORLD_SIZE' not in os.environ:
@@ -554,12 +560,37 @@ def main():
 
     B, T = args.frames_per_step, args.clip_frames
     det, cleaner = build_models(seed=0)
-    # each rank gets its own clip (clips shard across ranks; a video's frames stay on one device)
-    clean = data.synth_clean_clip(T, args.height, args.width, seed=100 + rank)
-    dark = data.darken_and_add_noise(clean, seed=200 + rank)
-    # Brighten -> Normalize -> Pad on the device kernel (llv_brighten_normalize_pad_u8), outside the timed region as in the
-    # reference's benchmark (data loading excluded)
-    clip, img_shape, pad_shape = data.preprocess_clip_device(dark.to(torch.uint8).to(dev))
+    from lowlightenvironmentvideoobjectdetection_amd import dist_utils
+    frame_sharded = args.shard == 'frames'
+    if frame_sharded:
+        # ONE clip of T * world frames, defined frame by frame by (seed, frame index); rank r owns the contiguous segment
+        # [seg0, seg1) and reads two halo frames on either side (FastDVDnet's 5-frame window; the clip's own ends are replicated, as
+        # the reference's test-time sampler clamps). Frames 0..2 travel with every rank: the Brighten gain is the clip's (taken from
+        # frame 0, transforms.py:421-430) and the head calibration below runs on the window of frame 0, so every rank computes with
+        # the same numbers the one-rank run uses -- the concatenated detections are bit-identical to it (tests/test_gpu_shard.py).
+        T_total = T * world
+        seg0, seg1 = dist_utils.shard_clip(T_total, rank, world)
+        assert seg1 - seg0 == T
+        lo, hi = max(0, seg0 - 2), min(T_total, seg1 + 2)
+
+        def synth(first, n):
+            return data.darken_and_add_noise(data.synth_clean_clip(n, args.height, args.width, seed=100, first=first), seed=200, first=first)
+        head_n = min(3, T_total)
+        u8 = torch.cat([synth(0, head_n), synth(lo, hi - lo)], 0).to(torch.uint8).to(dev)
+        allf, img_shape, pad_shape = data.preprocess_clip_device(u8, replicate_ends=0)          # gain from frame 0 of the CLIP
+        head, local = allf[:head_n], allf[head_n:]
+        clip = local[[min(max(t, 0), T_total - 1) - lo for t in range(seg0 - 2, seg1 + 2)]].contiguous()
+        calib_window = head[[0, 0, 0, min(1, head_n - 1), min(2, head_n - 1)]].contiguous()
+        del allf, local, u8
+    else:
+        # each rank gets its own clip (clips shard across ranks; a video's frames stay on one device)
+        T_total, seg0 = T, 0
+        clean = data.synth_clean_clip(T, args.height, args.width, seed=100 + rank)
+        dark = data.darken_and_add_noise(clean, seed=200 + rank)
+        # Brighten -> Normalize -> Pad on the device kernel (llv_brighten_normalize_pad_u8), outside the timed region as in the
+        # reference's benchmark (data loading excluded)
+        clip, img_shape, pad_shape = data.preprocess_clip_device(dark.to(torch.uint8).to(dev))
+        calib_window = None
     hp, wp = pad_shape[0], pad_shape[1]
 
     def make_plan(cls=engine.EnhanceDetectPlan):
@@ -568,8 +599,13 @@ def main():
                    use_graph=not args.no_graph)
     # one pass with the raw seeded weights, then give the head trained-detector-like statistics so that a
     # few thousand candidates pass score_thr and NMS has real work ("busy" variant)
-    plan = make_plan()
-    plan.den.frames.copy_(clip[:B + 4])
+    if calib_window is not None:
+        plan = engine.EnhanceDetectPlan(cleaner.state_dict(), det.state_dict(), NUM_CLASSES, 1, hp, wp, dev,
+                                        detector_kwargs=dict(test_cfg=dict(det.bbox_head.test_cfg), img_shapes=[img_shape]), use_graph=False)
+        plan.den.frames.copy_(calib_window)
+    else:
+        plan = make_plan()
+        plan.den.frames.copy_(clip[:B + 4])
     plan.plan.run()
     torch.cuda.synchronize()
     calibrate_head_on_device(det, plan.det, target_cls_mean=-6.0, target_cls_std=1.3)
@@ -606,6 +642,31 @@ def main():
     if args.pipeline:
         plan.flush()
     n_det = sum(len(d) for d, _ in plan.results())
+    # frame-sharded clip: one untimed pass over the rank's whole segment, window by window, then the only exchange of the path, the
+    # gather of the per-frame detections to rank 0 in frame order (multi_gpu_test's collect step, mmtrack/apis/test.py:117-122)
+    frames_gathered = None
+    if frame_sharded and not args.pipeline:
+        per_frame, done = [], 0
+        starts = list(range(0, T - B + 1, B))
+        if starts[-1] + B < T:
+            starts.append(T - B)
+        for t0_ in starts:
+            plan.step(clip, t0_)
+            res = plan.results()
+            for n_ in range(B):
+                if t0_ + n_ >= done:
+                    per_frame.append((res[n_][0].numpy().copy(), res[n_][1].numpy().copy()))
+            done = t0_ + B
+        assert len(per_frame) == T
+        try:
+            allres = dist_utils.collect_result_dicts({'bbox_results': per_frame})
+            frames_gathered = len(allres['bbox_results']) if rank == 0 else None
+        except Exception as e:                          # the timed number stands on its own; report the failed gather instead of dying
+            allres, frames_gathered = None, f'gather failed: {type(e).__name__}: {e}'
+        if rank == 0 and args.dump_results and allres is not None:
+            import numpy as np
+            np.savez(args.dump_results, **{f'dets_{i}': d for i, (d, _) in enumerate(allres['bbox_results'])},
+                     **{f'labels_{i}': l for i, (_, l) in enumerate(allres['bbox_results'])})
     trips = {'throughput': ops.guard_trips()}            # capacity guards of decode / NMS that fired so far (0 = consistent inputs)
     last = plan.p[plan._i & 1] if args.pipeline else plan
     # batch-1 latency mode (the reference's per-frame protocol: 3 temp1 + 1 temp2 DenBlocks per frame)
@@ -719,7 +780,10 @@ def main():
                 'algorithmic_gflop_per_frame': round(flops_step / B / 1e9, 1),
                 'candidates_above_score_thr': n_cand_thr, 'detections_last_step': n_det,
                 'postprocess_guard_trips': ops.guard_trips(), 'postprocess_guard_trips_after_phase': trips,
-                'parallelism': f'clip-sharded x{world}, no data-path collective',
+                'parallelism': (f'one clip of {T_total} frames sharded by frame: {world} contiguous segment(s) of {T} frames + 2+2 halo frames, '
+                                f'no data-path collective (results gathered to rank 0 after the timed region)') if frame_sharded
+                               else f'clip-sharded x{world} (every rank its own clip), no data-path collective',
+                'frames_gathered_on_rank0': frames_gathered,
             },
         }
         # ---- roofline of the dominant kernel: the conv kernel with the largest share of the step's time. Every launch

@@ -11,8 +11,9 @@ import math
 import torch
 
 
-def synth_clean_clip(t, h, w, seed=0, device='cpu'):
-    """Smooth content + moving rectangles, uint8-valued BGR frames (t, h, w, 3) as float32."""
+def synth_clean_clip(t, h, w, seed=0, device='cpu', first=0):
+    """Smooth content + moving rectangles, uint8-valued BGR frames (t, h, w, 3) as float32. `first`: the frames are frames
+    first .. first+t-1 of the clip the seed defines (a rank of a frame-sharded run synthesises only its segment and halo)."""
     g = torch.Generator().manual_seed(seed)
     base = torch.rand(1, 3, h // 16 + 2, w // 16 + 2, generator=g)
     bg = torch.nn.functional.interpolate(base, size=(h, w), mode='bicubic', align_corners=False).clamp(0, 1)[0]
@@ -24,16 +25,20 @@ def synth_clean_clip(t, h, w, seed=0, device='cpu'):
     col = torch.rand(nrect, 3, generator=g) * 255
     for i in range(t):
         for r in range(nrect):
-            cy, cx = (pos[r] + vel[r] * i) % 1.0
+            cy, cx = (pos[r] + vel[r] * (first + i)) % 1.0
             y0, x0 = int(cy * h), int(cx * w)
             y1, x1 = min(h, y0 + int(size[r, 0] * h)), min(w, x0 + int(size[r, 1] * w))
             frames[i, :, y0:y1, x0:x1] = col[r].view(3, 1, 1)
     return frames.permute(0, 2, 3, 1).round().clamp(0, 255).contiguous().to(device)
 
 
-def darken_and_add_noise(frames, mean_level=0.1, ratio=0.5, seed=0):
+def darken_and_add_noise(frames, mean_level=0.1, ratio=0.5, seed=0, first=None):
     """Scale to a dark exposure (mean ~ mean_level*255) and add the reference's noise model (add_noise.py:26-52):
-    per RGGB channel Poisson gain a*ratio, Gaussian variance b*ratio, row noise variance c*ratio^3."""
+    per RGGB channel Poisson gain a*ratio, Gaussian variance b*ratio, row noise variance c*ratio^3.
+    first = k: the frames are frames k, k+1, .. of a longer clip and each is processed on its own (exposure from its own mean, noise
+    from a generator seeded by (seed, frame index)), so that any rank of a frame-sharded run produces the same pixels for a frame."""
+    if first is not None:
+        return torch.cat([darken_and_add_noise(frames[i:i + 1], mean_level, ratio, seed * 1000003 + first + i) for i in range(frames.shape[0])], 0)
     g = torch.Generator(device='cpu').manual_seed(seed)
     t, h, w, _ = frames.shape
     x = frames.float().cpu()

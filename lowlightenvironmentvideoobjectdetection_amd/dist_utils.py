@@ -27,6 +27,36 @@ def shard_videos(video_lengths, rank, world):
     return list(range(first, first + count))
 
 
+def shard_clip(num_frames, rank, world, align=1):
+    """Frames [start, stop) of ONE clip that `rank` owns: `world` contiguous segments whose boundaries are multiples of `align`
+    (the key-frame interval / sampling stride, so that a segment starts where the one-rank run itself rebuilds its state), sizes as
+    even as np.array_split makes them (the rule DistributedVideoSampler applies to videos, distributed_video_sampler.py:35-41,
+    applied to blocks of `align` frames). A rank may get an empty segment when the clip has fewer blocks than ranks."""
+    assert num_frames >= 0 and world >= 1 and 0 <= rank < world and align >= 1
+    blocks = (num_frames + align - 1) // align
+    base, extra = divmod(blocks, world)
+    b0 = rank * base + min(rank, extra)
+    b1 = b0 + base + (1 if rank < extra else 0)
+    return min(b0 * align, num_frames), min(b1 * align, num_frames)
+
+
+def collect_result_dicts(result_part):
+    """multi_gpu_test's collect step for the dict-of-lists the video detectors return (apis/test.py:100-122,125-173): the parts are
+    concatenated key by key in rank order (= frame order for contiguous segments). One all_gather_object; rank 0 gets the dict."""
+    rank, world = get_dist_info()
+    if world == 1:
+        return {k: list(v) for k, v in result_part.items()}
+    parts = [None] * world
+    dist.all_gather_object(parts, {k: list(v) for k, v in result_part.items()})
+    if rank != 0:
+        return None
+    out = {}
+    for p in parts:
+        for k, v in p.items():
+            out.setdefault(k, []).extend(v)
+    return out
+
+
 def collect_results(result_part, size):
     """multi_gpu_test's collect step (mmtracking/mmtrack/apis/test.py:125-173) as one all_gather_object."""
     rank, world = get_dist_info()

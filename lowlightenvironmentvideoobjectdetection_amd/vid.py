@@ -106,6 +106,12 @@ class BaseVideoDetector(PlannedModule):
     def aug_test(self, imgs, img_metas, **kwargs):
         raise NotImplementedError('test-time augmentation is outside the hot path')
 
+    def reset_video(self):
+        """Forget the current video (what frame_id == 0 does inside simple_test): the per-video memo and any carried streaming
+        state. apis.single_gpu_test calls it before a clip segment, whose first frame need not be frame 0."""
+        self.memo = None
+        self._stream_state = None
+
 
 @MODELS.register_module()
 class FastDVDnetDetect(BaseVideoDetector):
@@ -557,9 +563,15 @@ class FGFA(BaseVideoDetector):
                 raise LlvError('frame 0 of a video needs ref_img (fgfa.py:224-230,234-246)')
             refs = refs_of(ref_img)
             nr = refs.shape[0]
-            st = stages(nr, [1, nr])
-            pyr = st.extract(refs)
-            self.memo = dict(img=refs, nr=nr, feats=[pyr.level(l).clone() for l in range(len(pyr.level_hw))])
+            st = stages(nr, [1])
+            # one frame per launch set, the way every later reference enters the window: a frame's features then never depend on
+            # which other frames shared its launches (tile / split-K choices follow the launch size), so a clip segment that starts
+            # mid-video (apis.sharded_clip_test) rebuilds bit for bit the window the one-rank run has slid to
+            per = []
+            for i in range(nr):
+                pyr = st.extract(refs[i:i + 1])
+                per.append([pyr.level(l).clone() for l in range(len(pyr.level_hw))])
+            self.memo = dict(img=refs, nr=nr, feats=[torch.cat([p[l] for p in per], 0) for l in range(len(per[0]))])
             if fixed:                     # the key frame is one of the references (fgfa.py:243-246)
                 assert 0 <= num_left < nr
                 x_levels = [f[num_left:num_left + 1] for f in self.memo['feats']]
@@ -568,17 +580,17 @@ class FGFA(BaseVideoDetector):
             assert ref_img is not None
             new = refs_of(ref_img)
             k = new.shape[0]
-            st = stages(self.memo['nr'], [1, self.memo['nr']])
-            stn = st if k == 1 else stages(self.memo['nr'], [k])
-            pyr = stn.extract(new)
-            for l in range(len(pyr.level_hw)):
-                self.memo['feats'][l] = torch.cat((self.memo['feats'][l], pyr.level(l)), 0)[k:].contiguous()
+            st = stages(self.memo['nr'], [1])
+            for i in range(k):
+                pyr = st.extract(new[i:i + 1])
+                for l in range(len(pyr.level_hw)):
+                    self.memo['feats'][l] = torch.cat((self.memo['feats'][l], pyr.level(l)), 0)[1:].contiguous()
             self.memo['img'] = torch.cat((self.memo['img'], new), 0)[k:].contiguous()
             x_levels = [f[num_left:num_left + 1] for f in self.memo['feats']]
         elif fixed:
             assert ref_img is None        # fgfa.py:258-260
         nr = self.memo['nr']
-        st = stages(nr, [1, nr])
+        st = stages(nr, [1])
         n_slots, key_slot = (nr, num_left) if fixed else (nr + 1, 0)
         agg_plan, stack = self._plan(('agg', h, w, n_slots, key_slot, dev), lambda: self._agg_plan(st, n_slots, key_slot, img.device))
         if x_levels is None:
