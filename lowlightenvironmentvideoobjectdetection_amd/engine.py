@@ -18,7 +18,7 @@ import numpy as np
 import torch
 
 from . import ops
-from ._lib import (CONV_ACT_FIRST, CONV_LEAKY, CONV_OUT_F32, CONV_PIXSHUF, CONV_RELU, CONV_RES_ADD, CONV_RES_RSUB, CONV_RES_UPS, LlvError, lib)
+from ._lib import (CONV_ACT_FIRST, CONV_LEAKY, CONV_OUT_F32, CONV_PIXSHUF, CONV_RELU, CONV_RES_ADD, CONV_RES_RSUB, CONV_RES_UPS, LlvError, check, lib)
 
 BN_EPS = 1e-5
 # direct (halo-in-LDS) 3x3 kernel for the FastDVDnet layers: on by default; LLV_HALO=0 falls back to implicit GEMM
@@ -141,6 +141,10 @@ class Builder:
         self._ws = None              # one split-K workspace shared by all launches of the plan (they run in order)
         self._ws_descs = []
         self.tape = []               # every conv launch in order (training: the backward pass walks it in reverse)
+        # kernel selection as if the launch had this many images (None: its own batch). The planner follows the launch size (tile
+        # family, split K on launches that cannot fill the chip), and tile / split decide the order a pixel's sum is accumulated
+        # in; two launches of different batch whose results must agree bit for bit select for the same batch (FastDVDnetPlan)
+        self.select_batch = None
         self.window_descs = []       # fused-CvBlock descriptors that read the clip window directly (FastDVDnetPlan.bind_clip)
 
     def buf(self, *shape, dtype=torch.float16):
@@ -153,6 +157,13 @@ class Builder:
         pc.to(self.dev)
         d = ops.make_conv_desc(pc, xs, y, batch, segs, x_ld, y_ld, res, res_ld, flags, res_hw, tile, 0, y_group_stride,
                                act_slope, ps_out)
+        if self.select_batch is not None and self.select_batch != batch and tile == 0:
+            d.batch = self.select_batch
+            t_, k_ = C.c_int(0), C.c_int(0)
+            check(lib().llv_conv2d_plan(C.byref(d), C.byref(t_), C.byref(k_)), 'llv_conv2d_plan')
+            d.batch = batch
+            if t_.value > 0:          # -1: the register-staged halo kernel, which has no variants
+                d.tile, d.k_splits = t_.value, k_.value
         m = sum(batch * s[2] * s[3] for s in segs)
         flops = 2.0 * m * pc.true_macs_per_pixel
         nbytes = 2.0 * (sum(batch * s[0] * s[1] for s in segs) * pc.cin * pc.groups + m * pc.cout * pc.groups) + \
@@ -612,7 +623,12 @@ class FastDVDnetPlan:
         self.out = out if out is not None else b.buf(batch, height, width, 8)
         p1, p2 = prefix + 'temp1.', prefix + 'temp2.'
         srcs = [self.frames[s:s + n1] for s in range(3)]
+        # the first stage runs on batch + 2 windows here and on `batch` new ones in the streaming step (enable_stream), whose results
+        # are carried from step to step next to these: both select their kernels for `batch` images, so a first-stage result has the
+        # same bits whichever step computed it and a frame's output does not depend on the frames processed before it
+        b.select_batch = batch
         _denblock(b, sd, p1, srcs, n1, 'temp1', self.mid)
+        b.select_batch = None
         srcs2 = [self.mid[s:s + batch] for s in range(3)]
         _denblock(b, sd, p2, srcs2, batch, 'temp2', self.out)
         self._sd, self._p1, self.plan_stream = sd, p1, None

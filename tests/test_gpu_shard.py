@@ -14,7 +14,7 @@ from helpers import calibrate_cls, img_meta, randomize, retinanet_cfg, smooth_im
 
 pytestmark = pytest.mark.gpu
 
-NCLS, H, W = 4, 64, 96
+NCLS, H, W = 4, 128, 192
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 
 
