@@ -1763,6 +1763,19 @@ __global__ __launch_bounds__(256) void convpair_kernel(const ConvKArgs a, const 
 // LDS (bytes): patch[2] | w0[2] | halo | w1     InputCvBlock 2x7168 + 2x7168 + 22528 + 19456 = 70656
 //                                               OutputCvBlock 27648 + 19456 + 22528 + 10240 = 79872   (2 per CU)
 // ------------------------------------------------------------------------------------------------
+// Diagnostic build only (tools/cp2_probe.py compiles this file with -DLLV_CP2_STAMPS into its own library): s_memtime stamps of the
+// phases of the first 8 tiles of the first 64 workgroups. In the product build the macro is empty and no stamp executes.
+#ifdef LLV_CP2_STAMPS
+__device__ unsigned long long g_cp2_stamps[64 * 8 * 16];
+#define CP2_STAMP(K)                                                                                                   \
+    do {                                                                                                               \
+        if (tid == 0 && blockIdx.x < 64 && stamp_tile < 8)                                                             \
+            g_cp2_stamps[(blockIdx.x * 8 + stamp_tile) * 16 + (K)] = __builtin_amdgcn_s_memtime();                      \
+    } while (0)
+#else
+#define CP2_STAMP(K) do {} while (0)
+#endif
+
 static __device__ unsigned int g_conv_guard_trips = 0u;   // clamps of the sliding-window offset word (llv_guard_trips sums it in)
 
 struct Pair2Args {
@@ -1944,14 +1957,37 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a_in,
     // bias (+ ReLU) only, as the InputCvBlock's second conv is: the bias rides in the accumulator, ReLU is applied to the rounded
     // halves, and no pixel is located before the staging (the tap kernel's lean epilogue)
     const bool lean = CK0 == 8 && !(a.flags & ~LLV_CONV_RELU) && a.y_gstride == 0;   // compiled out of the OutputCvBlock instantiation (residual subtract)
+    // OutputCvBlock: the residual (in1 of `in1 - x`) of the tile's pixels is requested together with the tile's patch and kept in
+    // registers until the epilogue, instead of one exposed global-load latency per accumulator row there
+    const bool pre_res = CK0 == 32 && (a.flags & (LLV_CONV_RES_ADD | LLV_CONV_RES_RSUB)) != 0 &&
+                         !(a.flags & (LLV_CONV_PIXSHUF | LLV_CONV_ACT_FIRST | LLV_CONV_RES_UPS)) && fch * 4 < a.cout;
+    f16x4 rres[TM];
+    auto load_res = [&](const Tile& t) __attribute__((always_inline)) {
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int prow = (2 * wave + (j >> 1)) * 32 + (j & 1) * 16 + frow;
+            const int oy = t.ty0 + (prow >> 5), ox = t.tx0 + (prow & 31);
+            const f16x4 z4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+            rres[j] = z4;
+            if (pre_res && oy < H && ox < W)
+                rres[j] = *reinterpret_cast<const f16x4*>(a.res + (long)(a.seg_yoff[0] + t.n * H * W + oy * W + ox) * a.res_ld + fch * 4);
+        }
+    };
+    // first-conv bias of the group that runs next (constant for one group: loaded once)
+    float4 nb0 = *reinterpret_cast<const float4*>(pre.bias + fch * 4);
+    float4 nb1 = *reinterpret_cast<const float4*>(pre.bias + 16 + fch * 4);
     int v = blockIdx.x;
     Tile cur = tile_of(v);
     set_pvo(cur);
     issue_w1(0);
     issue_patch(0, 0);
     issue_w0(0, 0);
+    load_res(cur);
+    int stamp_tile = 0;
+    (void)stamp_tile;
 #pragma unroll 1
     for (;;) {
+    CP2_STAMP(0);
     const int tx0 = cur.tx0, ty0 = cur.ty0, n = cur.n;
     const int vn = v + gridDim.x;
     const bool has_next = vn < h.nblk;
@@ -1964,14 +2000,19 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a_in,
 #pragma unroll
         for (int j = 0; j < TM; ++j)
             acc[i][j] = lean ? (f32x4){bias4[i].x, bias4[i].y, bias4[i].z, bias4[i].w} : (f32x4){0.f, 0.f, 0.f, 0.f};
+    f16x4 rcur[TM];
 #pragma unroll 1
     for (int g = 0; g < G; ++g) {
         const int pb = g & (NPB - 1);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                     // patch/w0 of group g landed; halo and w1 are free (B of g-1 done)
+        CP2_STAMP(1 + 4 * g);
         if (g > 0) issue_w1(g);
-        const float4 b0 = *reinterpret_cast<const float4*>(pre.bias + g * 32 + fch * 4);
-        const float4 b1 = *reinterpret_cast<const float4*>(pre.bias + g * 32 + 16 + fch * 4);
+        const float4 b0 = nb0, b1 = nb1;                     // landed with the group's operands (requested a group ago)
+        if (g == G - 1) {
+#pragma unroll
+            for (int j = 0; j < TM; ++j) rcur[j] = rres[j];  // this tile's residual; rres is re-requested for the next tile below
+        }
         // ---- stage A: first conv on the halo tile. The weight fragments are the same for every M-tile: registers.
         const unsigned char* sP = smem + O_PATCH + pb * PATCH_PIECES * 1024;
         const unsigned char* sW0 = smem + O_W0 + pb * W0_PIECES * 1024;
@@ -1981,34 +2022,56 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a_in,
             a0[ks] = *reinterpret_cast<const f16x8*>(sW0 + ks * 2048 + wa);
             a1[ks] = *reinterpret_cast<const f16x8*>(sW0 + ks * 2048 + 1024 + wa);
         }
+        // One flat stream of (M-tile, k-step) steps, two MFMAs each, with the pixel fragment of step s + PD requested before the
+        // MFMAs of step s (a ring of PD + 1 registers): the compiler's own order was read -> lgkmcnt(0) -> 2 MFMAs, i.e. one exposed
+        // LDS latency per 32 MFMA cycles (the first conv ran at a quarter of the MFMA rate). Every wave walks MTW M-tiles; where
+        // 4 * it + wave runs past the last one the addresses are clamped and nothing is written (the barrier behind this stage
+        // waits for the slowest wave anyway).
+        {
+            constexpr int SA = MTW * NKS0, PD = 3;
+            auto lda = [&](int st) __attribute__((always_inline)) {
+                const int it = st / NKS0, ks = st % NKS0;
+                if (CK0 == 8) return *reinterpret_cast<const f16x8*>(sP + pa[it][ks]);
+                return *reinterpret_cast<const f16x8*>(sP + pa[it][ks % 3] + (ks / 3) * PROWB);
+            };
+            f16x8 ring[PD + 1];
 #pragma unroll
-        for (int it = 0; it < MTW; ++it) {
-            if (wave + 4 * it < NMT) {
-                f32x4 c0 = {b0.x, b0.y, b0.z, b0.w}, c1 = {b1.x, b1.y, b1.z, b1.w};   // bias rides in the accumulator
+            for (int st = 0; st < PD; ++st) ring[st] = lda(st);
+            f32x4 c0 = {b0.x, b0.y, b0.z, b0.w}, c1 = {b1.x, b1.y, b1.z, b1.w};      // bias rides in the accumulator
 #pragma unroll
-                for (int ks = 0; ks < NKS0; ++ks) {
-                    f16x8 bf;
-                    if (CK0 == 8) bf = *reinterpret_cast<const f16x8*>(sP + pa[it][ks]);
-                    else bf = *reinterpret_cast<const f16x8*>(sP + pa[it][ks % 3] + (ks / 3) * PROWB);
-                    c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[ks], bf, c0, 0, 0, 0);
-                    c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], bf, c1, 0, 0, 0);
-                }
-                // ReLU on the rounded halves (max commutes with the monotone rounding); zero outside the image
-                // (= the second conv's zero padding), which only workgroups on the image border can see
-                f16x4 o0 = {(_Float16)c0[0], (_Float16)c0[1], (_Float16)c0[2], (_Float16)c0[3]};
-                f16x4 o1 = {(_Float16)c1[0], (_Float16)c1[1], (_Float16)c1[2], (_Float16)c1[3]};
-                const f16x4 z4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
-                o0 = __builtin_elementwise_max(o0, z4);
-                o1 = __builtin_elementwise_max(o1, z4);
-                if (border && !((inside >> it) & 1u)) { o0 = z4; o1 = z4; }
-                if (hw[it] >= 0) {
-                    *reinterpret_cast<f16x4*>(smem + O_HALO + hw[it]) = o0;          // channels 4*fch .. (16-B slot fch>>1)
-                    *reinterpret_cast<f16x4*>(smem + O_HALO + (hw[it] ^ 32)) = o1;   // channels 16 + 4*fch .. (slot 2 + (fch>>1))
+            for (int st = 0; st < SA; ++st) {
+                const int it = st / NKS0, ks = st % NKS0;
+                if (st + PD < SA) ring[(st + PD) % (PD + 1)] = lda(st + PD);
+                c0 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a0[ks], ring[st % (PD + 1)], c0, 0, 0, 0);
+                c1 = __builtin_amdgcn_mfma_f32_16x16x32_f16(a1[ks], ring[st % (PD + 1)], c1, 0, 0, 0);
+                if (st + PD < SA) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+                if (ks == NKS0 - 1) {
+                    // ReLU on the rounded halves (max commutes with the monotone rounding); zero outside the image
+                    // (= the second conv's zero padding), which only workgroups on the image border can see
+                    f16x4 o0 = {(_Float16)c0[0], (_Float16)c0[1], (_Float16)c0[2], (_Float16)c0[3]};
+                    f16x4 o1 = {(_Float16)c1[0], (_Float16)c1[1], (_Float16)c1[2], (_Float16)c1[3]};
+                    const f16x4 z4 = {(_Float16)0.f, (_Float16)0.f, (_Float16)0.f, (_Float16)0.f};
+                    o0 = __builtin_elementwise_max(o0, z4);
+                    o1 = __builtin_elementwise_max(o1, z4);
+                    if (border && !((inside >> it) & 1u)) { o0 = z4; o1 = z4; }
+                    if (hw[it] >= 0) {
+                        *reinterpret_cast<f16x4*>(smem + O_HALO + hw[it]) = o0;          // channels 4*fch .. (16-B slot fch>>1)
+                        *reinterpret_cast<f16x4*>(smem + O_HALO + (hw[it] ^ 32)) = o1;   // channels 16 + 4*fch .. (slot 2 + (fch>>1))
+                    }
+                    c0 = (f32x4){b0.x, b0.y, b0.z, b0.w};
+                    c1 = (f32x4){b1.x, b1.y, b1.z, b1.w};
                 }
             }
         }
+        CP2_STAMP(2 + 4 * g);
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
         __syncthreads();                                     // halo complete, w1 of group g landed, patch/w0 buffers of g-1 free
+        if (G > 1) {
+            const int gn = g + 1 < G ? g + 1 : 0;
+            nb0 = *reinterpret_cast<const float4*>(pre.bias + gn * 32 + fch * 4);
+            nb1 = *reinterpret_cast<const float4*>(pre.bias + gn * 32 + 16 + fch * 4);
+        }
         if (g + 1 < G) {
             issue_patch(g + 1, (g + 1) & (NPB - 1));
             issue_w0(g + 1, (g + 1) & (NPB - 1));
@@ -2018,25 +2081,50 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a_in,
             set_pvo(nxt);
             issue_patch(0, 0);
             if (G > 1) issue_w0(0, 0);
+            load_res(nxt);
         }
+        CP2_STAMP(3 + 4 * g);
         // ---- stage B: second conv, chunk g
         const unsigned char* sH = smem + O_HALO;
         const unsigned char* sW1 = smem + O_W1;
+        {
+            // tap t + 1's fragments are requested before tap t's MFMAs (two register sets), one read per MFMA
+            f16x8 af[2][TN2], bf[2][TM];
+#define CP2_LOADB(SET, TP)                                                                                            \
+    _Pragma("unroll") for (int j = 0; j < TM; ++j)                                                                    \
+        bf[SET][j] = *reinterpret_cast<const f16x8*>(sH + hb[j][(TP) % 3] + ((TP) / 3) * ROWB);                       \
+    _Pragma("unroll") for (int i = 0; i < TN2; ++i)                                                                   \
+        af[SET][i] = *reinterpret_cast<const f16x8*>(sW1 + (TP) * (BN2 * 64) + i * 1024 + wa);
+            CP2_LOADB(0, 0)
 #pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            f16x8 af[TN2], bf[TM];
+            for (int t = 0; t < 9; ++t) {
+                if (t < 8) { CP2_LOADB((t + 1) & 1, t + 1) }
 #pragma unroll
-            for (int j = 0; j < TM; ++j) bf[j] = *reinterpret_cast<const f16x8*>(sH + hb[j][t % 3] + (t / 3) * ROWB);
+                for (int i = 0; i < TN2; ++i)
 #pragma unroll
-            for (int i = 0; i < TN2; ++i) af[i] = *reinterpret_cast<const f16x8*>(sW1 + t * (BN2 * 64) + i * 1024 + wa);
+                    for (int j = 0; j < TM; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[t & 1][i], bf[t & 1][j], acc[i][j], 0, 0, 0);
+                if (t < 8) {
+                    constexpr int NR = TN2 + TM, NM = TN2 * TM, NI = NR < NM ? NR : NM;
 #pragma unroll
-            for (int i = 0; i < TN2; ++i)
-#pragma unroll
-                for (int j = 0; j < TM; ++j)
-                    acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf[j], acc[i][j], 0, 0, 0);
+                    for (int k = 0; k < NI; ++k) {
+                        __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+                        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+                    }
+                    if (NR > NM) __builtin_amdgcn_sched_group_barrier(0x100, NR - NM, 0);
+                    if (NM > NR) __builtin_amdgcn_sched_group_barrier(0x008, NM - NR, 0);
+                }
+            }
+#undef CP2_LOADB
         }
+        CP2_STAMP(4 + 4 * g);
     }
-    __syncthreads();         // every wave is done with the patch / weight buffers and the halo
+    // Barriers from here to the end of the tile order LDS accesses only: s_waitcnt lgkmcnt(0) + s_barrier. __syncthreads() also emits
+    // vmcnt(0), which here would wait for the NEXT tile's patch (requested before the last second conv so that it lands during this
+    // epilogue) and for the output stores.
+#define CP2_LDS_BARRIER() asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory")
+    CP2_LDS_BARRIER();       // every wave is done with the patch / weight buffers and the halo
+    CP2_STAMP(13);
 
     // the next tile's second-conv weights can only follow this tile's last second conv; with one group (OutputCvBlock) both
     // weight images simply stay resident in LDS across tiles
@@ -2067,7 +2155,8 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a_in,
                 *reinterpret_cast<f16x4*>(tile + prow * TS + i * 16 + fch * 4) = o4;
             }
         }
-        __syncthreads();
+        CP2_LDS_BARRIER();
+        CP2_STAMP(14);
         constexpr int CPR = BN2 / 8;
         const int cc = tid % CPR, co = cc * 8;
         if (co < a.cout) {
@@ -2083,6 +2172,8 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a_in,
                 else *reinterpret_cast<uint2*>(dst) = make_uint2(val.x, val.y);
             }
         }
+        CP2_STAMP(15);
+        ++stamp_tile;
         if (!has_next) break;
         v = vn;
         cur = nxt;
@@ -2097,17 +2188,31 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a_in,
         for (int i = 0; i < TN2; ++i) {
             const int col = i * 16 + fch * 4;
             float vv[4] = {acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]};
-            if (ok && col < a.cout) epi_compute_b(a, ec, col, vv, bias4[i]);
+            if (pre_res && i == 0) {                         // the same arithmetic as epi_compute_b, residual from the registers
+                if (ok) {
+                    vv[0] += bias4[0].x; vv[1] += bias4[0].y; vv[2] += bias4[0].z; vv[3] += bias4[0].w;
+#pragma unroll
+                    for (int e = 0; e < 4; ++e) vv[e] = (a.flags & LLV_CONV_RES_RSUB) ? (float)rcur[j][e] - vv[e] : vv[e] + (float)rcur[j][e];
+                    if (a.flags & (LLV_CONV_RELU | LLV_CONV_LEAKY)) {
+#pragma unroll
+                        for (int e = 0; e < 4; ++e) vv[e] = act_fn(a, vv[e]);
+                    }
+                }
+            } else if (ok && col < a.cout) epi_compute_b(a, ec, col, vv, bias4[i]);
             const f16x4 o4 = {(_Float16)vv[0], (_Float16)vv[1], (_Float16)vv[2], (_Float16)vv[3]};
             *reinterpret_cast<f16x4*>(tile + prow * TS + col) = o4;
         }
     }
-    __syncthreads();
+    CP2_LDS_BARRIER();
+    CP2_STAMP(14);
     staged_store_loc<BN2, 256>(a, tile, 0, 0, loc);
+    CP2_STAMP(15);
+    ++stamp_tile;
     if (!has_next) break;
     v = vn;
     cur = nxt;
     }   // tile loop (the next iteration's first barrier orders this tile's staged reads before the next halo writes)
+#undef CP2_LDS_BARRIER
 }
 
 template <int BN>
@@ -2246,6 +2351,18 @@ int pick_tile(int co, long m, int groups) {
 }
 
 }  // namespace
+
+#ifdef LLV_CP2_STAMPS
+extern "C" int llv_dbg_cp2_stamps(unsigned long long* host, int reset) {
+    if (hipDeviceSynchronize() != hipSuccess) return LLV_E_LAUNCH;
+    if (host && hipMemcpyFromSymbol(host, HIP_SYMBOL(g_cp2_stamps), sizeof(unsigned long long) * 64 * 8 * 16) != hipSuccess) return LLV_E_LAUNCH;
+    if (reset) {
+        static unsigned long long zeros[64 * 8 * 16];
+        if (hipMemcpyToSymbol(HIP_SYMBOL(g_cp2_stamps), zeros, sizeof(zeros)) != hipSuccess) return LLV_E_LAUNCH;
+    }
+    return LLV_OK;
+}
+#endif
 
 // clamps of the sliding-window offset word since the last reset (summed into llv_guard_trips, decode.hip)
 unsigned int llv_conv_guard_trips_(int reset) {
