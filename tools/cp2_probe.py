@@ -12,7 +12,7 @@ ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 from lowlightenvironmentvideoobjectdetection_amd import _lib  # noqa: E402
 
-probe = os.path.join(ROOT, 'tools', '_build', 'libllv_cp2probe.so')
+probe = os.environ.get('CP2_LIB') or os.path.join(ROOT, 'tools', '_build', 'libllv_cp2probe.so')
 use_probe = os.path.exists(probe) and os.environ.get('CP2_NO_STAMPS', '0') != '1'
 if use_probe:
     _lib.LIB_PATH = probe
@@ -39,7 +39,7 @@ for r in rows:
         print(f'{r[0]:18s} {r[1] * 1e3:9.1f} us  {r[2] / max(r[1], 1e-9) / 1e9:8.1f} TFLOP/s  ({plan.plan.kernel_of.get(r[0])})')
 tot = sum(r[1] for r in rows)
 print(f'FastDVDnet plan ({n} frames): {tot:.3f} ms, fused CvBlocks {sum(r[1] for r in rows if "cv" in r[0]):.3f} ms')
-if not use_probe:
+if not use_probe or os.environ.get('CP2_LIB'):
     sys.exit(0)
 fn = lib().llv_dbg_cp2_stamps
 fn.restype, fn.argtypes = C.c_int, [C.c_void_p, C.c_int]
