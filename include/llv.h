@@ -326,6 +326,19 @@ int llv_embed_aggregate(const void* x_embed, const void* ref_embed, const void* 
 int llv_embed_aggregate_ring(const void* embed, const void* feat, void* out, int n_slots, int key_slot, int64_t hw,
                              int c, int embed_ld, int feat_ld, int out_ld, void* stream);
 
+/* Backward of the two temporal ops (training of the flow / aggregation video detectors, mmtracking/mmtrack/models/vid/dff.py:49-182,
+ * fgfa.py:52-194, llvod.py:45-154), what torch autograd derives for embed_aggregator.py:70-81 and flow.py:4-41.
+ * llv_embed_aggregate_bwd (ring form: embed / feat [n_slots][hw][c], the key frame is slot key_slot): grad_out [hw][c] fp16;
+ *   d_embed [n_slots][hw][c] and d_feat [n_slots][hw][c] are fp16 buffers the gradients are ADDED to (slot key_slot of d_feat is
+ *   not touched: the key frame's features reach the output only through its embedding).
+ * llv_flow_warp_bwd: gradient with respect to the warped features only (the flow network is frozen on this path): dy fp16 NHWC
+ *   (n,h,w,c) with ld, flow as in llv_flow_warp, dx fp32 [n][h][w][c] accumulated with atomics (zero it first);
+ *   llv_add_f32_to_f16 then adds it into an fp16 gradient buffer [rows][ld]. */
+int llv_embed_aggregate_bwd(const void* embed, const void* feat, const void* grad_out, void* d_embed, void* d_feat, int n_slots,
+                            int key_slot, int64_t hw, int c, int embed_ld, int feat_ld, int gout_ld, void* stream);
+int llv_flow_warp_bwd(const void* dy, const float* flow, float* dx, int n, int h, int w, int c, int ld, int hf, int wf, void* stream);
+int llv_add_f32_to_f16(const float* src, void* dst, int64_t rows, int c, int ld, void* stream);
+
 /* FlowNetSimple.prepare_imgs (flownet_simple.py:149-190) for image pairs: x (n,6,h,w) NCHW fp32 normalised images ->
  * y (n, ho, wo, 8) NHWC fp16: v = x*scale[c] + shift[c] (de-normalise, /255, -flow mean folded by the caller), zero for
  * rows >= img_h / cols >= img_w, bilinear resize (align_corners=False) by scale_factor = wo/w; channels 6,7 zero. */

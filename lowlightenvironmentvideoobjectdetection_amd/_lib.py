@@ -154,6 +154,9 @@ SIGNATURES = {
     'llv_nms': (_I, [_P, _P, _I, _F, _P, _P, _P, _Z, _P]),
     'llv_embed_aggregate': (_I, [_P, _P, _P, _P, _I, _L, _I, _I, _I, _I, _P]),
     'llv_embed_aggregate_ring': (_I, [_P, _P, _P, _I, _I, _L, _I, _I, _I, _I, _P]),
+    'llv_embed_aggregate_bwd': (_I, [_P, _P, _P, _P, _P, _I, _I, _L, _I, _I, _I, _I, _P]),
+    'llv_flow_warp_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'llv_add_f32_to_f16': (_I, [_P, _P, _L, _I, _I, _P]),
     'llv_flow_prepare': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P, _P, _F, _P]),
     'llv_bilinear_resize_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P]),
     'llv_flow_warp': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),

@@ -211,6 +211,143 @@ __global__ void flow_warp_kernel(const _Float16* __restrict__ x, const float* __
     }
 }
 
+// Backward of the EmbedAggregator tail (ring form: the key frame is slot key_slot, the references are the other slots). One wave per
+// pixel. With e_n = embed slot n, k = e_key, c_n = <e_n, k> / (|e_n| |k|), w = softmax_n(c), out = sum_n w_n f_n and g = d loss / d out:
+//   d f_n = w_n g;   d w_n = <g, f_n>;   d c_n = w_n (d w_n - sum_m w_m d w_m);
+//   d e_n = d c_n (k / |k| - c_n e_n / |e_n|) / |e_n|;   d k = sum_n d c_n (e_n / |e_n| - c_n k / |k|) / |k|.
+// All three gradients are ADDED to fp16 buffers (the training graph's gradient twins accumulate over consumers).
+__global__ void embed_aggregate_bwd_kernel(const _Float16* __restrict__ emb, const _Float16* __restrict__ feat,
+                                           const _Float16* __restrict__ gout, _Float16* __restrict__ d_emb,
+                                           _Float16* __restrict__ d_feat, int n_slots, int key_slot, long hw, int c, int embed_ld,
+                                           int feat_ld, int gout_ld) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    extern __shared__ float sw[];                            // [waves per block][3 * n_slots]: cosine, |e_n|, d c_n
+    float* cs = sw + (threadIdx.x >> 6) * 3 * n_slots;
+    float* rn = cs + n_slots;
+    float* dc = rn + n_slots;
+    for (long p = wave; p < hw; p += nwaves) {
+        const _Float16* kp = emb + ((long)key_slot * hw + p) * embed_ld;
+        float kk = 0.f;
+        for (int ch = lane * 8; ch < c; ch += 512) {
+            const f16x8 v = *reinterpret_cast<const f16x8*>(kp + ch);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) kk += (float)v[e] * (float)v[e];
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) kk += __shfl_xor(kk, o);
+        const float kn = sqrtf(kk);
+        float mx = -INFINITY;
+        for (int n = 0; n < n_slots; ++n) {
+            if (n == key_slot) continue;
+            float rr = 0.f, rx = 0.f, gf = 0.f;
+            for (int ch = lane * 8; ch < c; ch += 512) {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(emb + ((long)n * hw + p) * embed_ld + ch);
+                const f16x8 u = *reinterpret_cast<const f16x8*>(kp + ch);
+                const f16x8 f = *reinterpret_cast<const f16x8*>(feat + ((long)n * hw + p) * feat_ld + ch);
+                const f16x8 g = *reinterpret_cast<const f16x8*>(gout + p * gout_ld + ch);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    rr += (float)v[e] * (float)v[e];
+                    rx += (float)v[e] * (float)u[e];
+                    gf += (float)g[e] * (float)f[e];
+                }
+            }
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) { rr += __shfl_xor(rr, o); rx += __shfl_xor(rx, o); gf += __shfl_xor(gf, o); }
+            const float r = sqrtf(rr), cv = rx / (r * kn);
+            if (lane == 0) { cs[n] = cv; rn[n] = r; dc[n] = gf; }         // dc holds d w_n until the softmax below
+            mx = fmaxf(mx, cv);
+        }
+        __builtin_amdgcn_wave_barrier();
+        float den = 0.f, s = 0.f;
+        for (int n = 0; n < n_slots; ++n)
+            if (n != key_slot) den += expf(cs[n] - mx);
+        for (int n = 0; n < n_slots; ++n)
+            if (n != key_slot) s += expf(cs[n] - mx) / den * dc[n];
+        __builtin_amdgcn_wave_barrier();
+        for (int ch = lane * 8; ch < c; ch += 512) {
+            const f16x8 u = *reinterpret_cast<const f16x8*>(kp + ch);
+            const f16x8 g = *reinterpret_cast<const f16x8*>(gout + p * gout_ld + ch);
+            float dk[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+            for (int n = 0; n < n_slots; ++n) {
+                if (n == key_slot) continue;
+                const float wn = expf(cs[n] - mx) / den;
+                const float dcn = wn * (dc[n] - s);
+                const float ir = 1.f / rn[n], ik = 1.f / kn;
+                const f16x8 v = *reinterpret_cast<const f16x8*>(emb + ((long)n * hw + p) * embed_ld + ch);
+                _Float16* de = d_emb + ((long)n * hw + p) * embed_ld + ch;
+                _Float16* df = d_feat + ((long)n * hw + p) * feat_ld + ch;
+                f16x8 oe = *reinterpret_cast<const f16x8*>(de), of = *reinterpret_cast<const f16x8*>(df);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) {
+                    const float vn = (float)v[e] * ir, un = (float)u[e] * ik;
+                    oe[e] = (_Float16)((float)oe[e] + dcn * (un - cs[n] * vn) * ir);
+                    of[e] = (_Float16)((float)of[e] + wn * (float)g[e]);
+                    dk[e] += dcn * (vn - cs[n] * un) * ik;
+                }
+                *reinterpret_cast<f16x8*>(de) = oe;
+                *reinterpret_cast<f16x8*>(df) = of;
+            }
+            _Float16* dkp = d_emb + ((long)key_slot * hw + p) * embed_ld + ch;
+            f16x8 ok = *reinterpret_cast<const f16x8*>(dkp);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) ok[e] = (_Float16)((float)ok[e] + dk[e]);
+            *reinterpret_cast<f16x8*>(dkp) = ok;
+        }
+        __builtin_amdgcn_wave_barrier();
+    }
+}
+
+// Backward of flow_warp_feats with respect to the warped features: every output pixel's gradient is scattered to the (up to) four
+// input pixels it was interpolated from, with the forward kernel's weights (same coordinate arithmetic, operation by operation).
+// One thread per (pixel, channel), channels fastest: a wave-instruction's atomics cover 64 consecutive floats of one input pixel.
+// dx is fp32 [n][h][w][c] (zeroed by the caller); llv_add_f32_to_f16 folds it into the fp16 gradient buffer afterwards.
+__global__ void flow_warp_bwd_kernel(const _Float16* __restrict__ dy, const float* __restrict__ flow, float* __restrict__ dx,
+                                     int nb, int h, int w, int c, int ld, int hf, int wf, float rscale_h, float rscale_w, float mul) {
+    const long total = (long)nb * h * w * c;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
+        const int ch = (int)(i % c);
+        unsigned p = i / c;
+        const int ox = (int)(p % w); p /= w;
+        const int oy = (int)(p % h);
+        const int n = (int)(p / h);
+        const float g = (float)dy[(((long)n * h + oy) * w + ox) * ld + ch];
+        if (g == 0.f) continue;
+        const float sy = ((float)oy + 0.5f) * rscale_h - 0.5f;
+        const float sx = ((float)ox + 0.5f) * rscale_w - 0.5f;
+        const float* fu = flow + ((long)n * 2 + 0) * hf * wf;
+        const float* fv = flow + ((long)n * 2 + 1) * hf * wf;
+        const float u = bilerp_flow(fu, hf, wf, sy, sx) * mul;
+        const float v = bilerp_flow(fv, hf, wf, sy, sx) * mul;
+        const float gx = ((float)ox + u) / (float)w * 2.f - 1.f;
+        const float gy = ((float)oy + v) / (float)h * 2.f - 1.f;
+        float fx = (gx + 1.f) * 0.5f * (float)(w - 1);
+        float fy = (gy + 1.f) * 0.5f * (float)(h - 1);
+        fx = fminf(fmaxf(fx, 0.f), (float)(w - 1));
+        fy = fminf(fmaxf(fy, 0.f), (float)(h - 1));
+        const int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
+        const int x1 = x0 + 1, y1 = y0 + 1;
+        const float lx = fx - (float)x0, ly = fy - (float)y0;
+        float* xb = dx + (long)n * h * w * c + ch;
+        auto tap = [&](int yy, int xx, float wt) {
+            if ((unsigned)yy < (unsigned)h && (unsigned)xx < (unsigned)w && wt != 0.f) atomicAdd(xb + ((long)yy * w + xx) * c, wt * g);
+        };
+        tap(y0, x0, (1.f - lx) * (1.f - ly)); tap(y0, x1, lx * (1.f - ly)); tap(y1, x0, (1.f - lx) * ly); tap(y1, x1, lx * ly);
+    }
+}
+
+__global__ void add_f32_to_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long rows, int c, int ld) {
+    const long total = rows * c;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c;
+        const int ch = (int)(i - r * c);
+        _Float16* d = dst + r * ld + ch;
+        *d = (_Float16)((float)*d + src[i]);
+    }
+}
+
 // bilinear sample of plane f (h x w) at PyTorch's align_corners=False source coordinate of output (oy, ox)
 __device__ __forceinline__ float bilerp_plane(const float* f, int h, int w, float sy, float sx) {
     sy = sy < 0.f ? 0.f : sy;
@@ -475,6 +612,43 @@ extern "C" int llv_embed_aggregate_ring(const void* embed, const void* feat, voi
     hipLaunchKernelGGL(embed_aggregate_kernel, dim3((int)blocks), dim3(256), 4 * n_slots * sizeof(float), (hipStream_t)stream,
                        (const _Float16*)embed, (const _Float16*)embed, (const _Float16*)feat, (_Float16*)out, n_slots, (long)hw,
                        c, embed_ld, feat_ld, out_ld, key_slot);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_embed_aggregate_bwd(const void* embed, const void* feat, const void* grad_out, void* d_embed, void* d_feat,
+                                       int n_slots, int key_slot, int64_t hw, int c, int embed_ld, int feat_ld, int gout_ld,
+                                       void* stream) {
+    if (!embed || !feat || !grad_out || !d_embed || !d_feat || n_slots < 2 || n_slots > 256 || key_slot < 0 || key_slot >= n_slots ||
+        hw < 1 || c < 8 || (c & 7))
+        return LLV_E_BADARG;
+    if ((embed_ld & 7) || (feat_ld & 7) || (gout_ld & 7) || embed_ld < c || feat_ld < c || gout_ld < c) return LLV_E_BADARG;
+    long blocks = ((long)hw + 3) / 4;
+    if (blocks > 256L * 8) blocks = 256L * 8;
+    hipLaunchKernelGGL(embed_aggregate_bwd_kernel, dim3((int)blocks), dim3(256), 4 * 3 * n_slots * sizeof(float), (hipStream_t)stream,
+                       (const _Float16*)embed, (const _Float16*)feat, (const _Float16*)grad_out, (_Float16*)d_embed, (_Float16*)d_feat,
+                       n_slots, key_slot, (long)hw, c, embed_ld, feat_ld, gout_ld);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_flow_warp_bwd(const void* dy, const float* flow, float* dx, int n, int h, int w, int c, int ld, int hf, int wf,
+                                 void* stream) {
+    if (!dy || !flow || !dx || n < 1 || h < 1 || w < 1 || c < 1 || ld < c || hf < 1 || wf < 1) return LLV_E_BADARG;
+    const float s = (float)w / (float)wf;
+    if ((int)floor((double)hf * (double)s) != h || (int)floor((double)wf * (double)s) != w) return LLV_E_BADARG;
+    const float rs = 1.f / s;
+    const long total = (long)n * h * w * c;
+    if (total >= (1L << 31)) return LLV_E_UNSUPPORTED;
+    hipLaunchKernelGGL(flow_warp_bwd_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, (const _Float16*)dy, flow, dx,
+                       n, h, w, c, ld, hf, wf, rs, rs, s);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_add_f32_to_f16(const float* src, void* dst, int64_t rows, int c, int ld, void* stream) {
+    if (rows < 0 || c < 1 || ld < c) return LLV_E_BADARG;
+    if (rows == 0) return LLV_OK;
+    if (!src || !dst) return LLV_E_BADARG;
+    hipLaunchKernelGGL(add_f32_to_f16_kernel, dim3(grid_for(rows * c)), dim3(kBlock), 0, (hipStream_t)stream, src, (_Float16*)dst,
+                       (long)rows, c, ld);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 

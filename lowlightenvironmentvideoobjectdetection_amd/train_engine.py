@@ -36,12 +36,7 @@ class TrainGraph:
 
     def __init__(self, det, batch: int, height: int, width: int, device, loss_scale: float = 512.0, frozen_prefixes=None):
         head, neck, bb = det.bbox_head, det.neck, det.backbone
-        self.det, self.device, self.batch, self.loss_scale = det, device, batch, float(loss_scale)
-        self.params: Dict[str, torch.Tensor] = dict(det.named_parameters())
-        self.buffers: Dict[str, torch.Tensor] = dict(det.named_buffers())
-        for t in list(self.params.values()) + list(self.buffers.values()):
-            if t.device.type != 'cuda':
-                raise LlvError('training runs on the MI355X: move the detector to the GPU first (det.cuda()); no CPU fallback')
+        self._init_common(det, dict(det.named_parameters()), dict(det.named_buffers()), device, batch, loss_scale)
         b = engine.Builder(device)
         self.builder = b
         sd = engine._cpu_sd(det.state_dict())
@@ -51,12 +46,28 @@ class TrainGraph:
                                         neck.relu_before_extra_convs, p='neck.')
         self.cls_buf, self.reg_buf = engine.build_retina_head(b, sd, self.pyramid, head.stacked_convs, True, p='bbox_head.',
                                                               pingpong=False)
-        self.plan = b.plan
-        self.tape = b.tape
         # frozen part: frozen_stages of the backbone (stem + layer1 .. layerK), resnet.py:573-590
         if frozen_prefixes is None:
             fs = getattr(bb, 'frozen_stages', -1)
             frozen_prefixes = (['stem.'] if fs >= 0 else []) + [f'backbone.layer{i}.' for i in range(1, fs + 1)]
+        self._finish(b, frozen_prefixes)
+
+    def _init_common(self, det, params, buffers, device, batch, loss_scale):
+        self.det, self.device, self.batch, self.loss_scale = det, device, batch, float(loss_scale)
+        self.params: Dict[str, torch.Tensor] = params
+        self.buffers: Dict[str, torch.Tensor] = buffers
+        for t in list(self.params.values()) + list(self.buffers.values()):
+            if t.device.type != 'cuda':
+                raise LlvError('training runs on the MI355X: move the detector to the GPU first (det.cuda()); no CPU fallback')
+
+    def _finish(self, b, frozen_prefixes):
+        """Everything the backward pass needs, from the builder's tape. Besides convolution launches the tape may hold CUSTOM
+        entries (dict(name, custom=True, xs=[input buffers], y=output buffer, bwd=callable(graph, op))): parameter-free ops between
+        the convolutions (feature warp, temporal aggregation) whose forward launches already sit in the plan and whose backward is
+        the callable, which ADDS into the gradient twins of its inputs (self.gview)."""
+        device = self.device
+        self.plan = b.plan
+        self.tape = b.tape
         self.frozen_prefixes = tuple(frozen_prefixes)
         bases = {}
         for t in b.plan.keep:
@@ -66,9 +77,12 @@ class TrainGraph:
         # which tensors need a gradient
         req = set()
         for op in self.tape:
-            op['frozen'] = op['name'].startswith(self.frozen_prefixes)
-            if op['pc'].parts is None:
-                raise LlvError(f"{op['name']}: launch has no parameter provenance (training needs PackedConv.parts)")
+            if op.get('custom'):
+                op['frozen'], op['need_dx'], op['res'] = True, False, None
+            else:
+                op['frozen'] = bool(self.frozen_prefixes) and op['name'].startswith(self.frozen_prefixes)
+                if op['pc'].parts is None:
+                    raise LlvError(f"{op['name']}: launch has no parameter provenance (training needs PackedConv.parts)")
             inp = any(_sptr(x) in req for x in op['xs']) or (op['res'] is not None and _sptr(op['res']) in req)
             if not op['frozen'] or inp:
                 req.add(_sptr(op['y']))
@@ -86,6 +100,8 @@ class TrainGraph:
                     self.grads[p] = torch.zeros_like(base)
         # per-launch backward state
         for op in self.tape:
+            if op.get('custom'):
+                continue
             pc = op['pc']
             if not op['frozen']:
                 op['dw'] = torch.zeros(pc.groups, pc.w_rows, pc.k_pad, dtype=torch.float32, device=device)
@@ -202,6 +218,9 @@ class TrainGraph:
         for op in ops_rev:
             yp = _sptr(op['y'])
             if yp not in self.req:
+                continue
+            if op.get('custom'):
+                op['bwd'](self, op)
                 continue
             pc, flags = op['pc'], op['flags']
             gy_base = self.grads[yp]

@@ -283,9 +283,24 @@ class LLVOD(BaseVideoDetector):
             if isinstance(m, PlannedModule):
                 m.invalidate_plans()
 
-    def forward_train(self, img, img_metas, **kwargs):
-        raise LlvError('LLVOD.forward_train has no runnable reference: llvod.py:91 calls general_clean_noise_pairs, which the module never '
-                       'imports (NameError in the reference itself); not built (DESIGN.md, scope table)')
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, ref_img, ref_img_metas=None, ref_gt_bboxes=None, ref_gt_labels=None,
+                      gt_bboxes_ignore=None, **kwargs):
+        """llvod.py:45-154 for a dense-head detector: the key frame is put in the middle of its references (:87-88), every frame goes
+        through backbone + FPN, per level `aggregator(feat[key], feat[others])` (:107-112), then bbox_head.forward_train (:148-150).
+        The reference's body also (a) adds synthetic noise (general_clean_noise_pairs, :91: applied here when train_cfg['add_noise']
+        is true, on un-normalised frames as the reference's data pipeline delivers them) and (b) regresses the noisy frames' features
+        onto a `cleaner`'s (:93-94,114-118), which needs a backbone returning two feature sets and exists only with the authors'
+        DarkResNet: without a cleaner (`with_cleaner` false) that term is absent there too."""
+        from . import vid_train
+        self._check_input(img)
+        assert len(img) == 1, 'video detector only support 1 batch size per gpu for now.'
+        index = ref_img.shape[1] // 2
+        all_imgs = torch.cat((ref_img[0][:index], img, ref_img[0][index:]), dim=0)
+        if (self.train_cfg or {}).get('add_noise', False):
+            from .core.add_noise import general_clean_noise_pairs
+            all_imgs, _ = general_clean_noise_pairs(all_imgs, constant=[0.5, 0.5])
+        return vid_train.video_forward_train(self, 'llvod', all_imgs.float().contiguous(), None, index, img_metas, gt_bboxes, gt_labels,
+                                             gt_bboxes_ignore)
 
     def _make_plan(self, h, w, device):
         from .aggregators import embed_packed_convs
@@ -443,8 +458,22 @@ class DFF(BaseVideoDetector):
             if isinstance(m, PlannedModule):
                 m.invalidate_plans()
 
-    def forward_train(self, img, img_metas, **kwargs):
-        raise LlvError('DFF.forward_train is not built: it needs backward kernels for llv_flow_warp and FlowNetSimple (DESIGN.md section 8)')
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, ref_img, ref_img_metas=None, ref_gt_bboxes=None, ref_gt_labels=None,
+                      gt_bboxes_ignore=None, **kwargs):
+        """dff.py:49-182, single-stage branch: flow = motion(cat(img, ref)); the REFERENCE frame's pyramid is warped to the key frame
+        (or used as it is for still-image data, :143-144) and fed to bbox_head.forward_train with the key frame's ground truth.
+        The flow network is used frozen (vid_train.require_frozen_motion)."""
+        from . import vid_train
+        self._check_input(img)
+        assert len(img) == 1, 'Dff video detectors only support 1 batch size per gpu for now.'
+        vid_train.require_frozen_motion(self, 'DFF')
+        is_video_data = img_metas[0].get('is_video_data', True)
+        ref = ref_img[:, 0].float().contiguous()
+        flow = None
+        if is_video_data:
+            with torch.no_grad():
+                flow = self.motion(torch.cat((img.float(), ref), dim=1), img_metas)
+        return vid_train.video_forward_train(self, 'dff', ref, flow, 0, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, warp=is_video_data)
 
     def simple_test(self, img, img_metas, ref_img=None, ref_img_metas=None, rescale=False, **kwargs):
         self._check_input(img)
@@ -507,9 +536,26 @@ class FGFA(BaseVideoDetector):
             if isinstance(m, PlannedModule):
                 m.invalidate_plans()
 
-    def forward_train(self, img, img_metas, **kwargs):
-        raise LlvError('FGFA.forward_train is not built: it needs backward kernels for llv_flow_warp, llv_embed_aggregate and FlowNetSimple '
-                       '(DESIGN.md section 8)')
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, ref_img, ref_img_metas=None, ref_gt_bboxes=None, ref_gt_labels=None,
+                      gt_bboxes_ignore=None, **kwargs):
+        """fgfa.py:52-194, single-stage branch: flows = motion(cat(img, ref_i)) for every reference, all frames through backbone + FPN,
+        per level `aggregator(feat[img], flow_warp_feats(feat[refs], flows))` (:155-160), bbox_head.forward_train. The authors' noise
+        injection (:141-147) is applied when train_cfg['add_noise'] is true. The flow network is used frozen."""
+        from . import vid_train
+        self._check_input(img)
+        assert len(img) == 1, 'fgfa video detectors only support 1 batch size per gpu for now.'
+        vid_train.require_frozen_motion(self, 'FGFA')
+        refs = ref_img[0].float()
+        img = img.float()
+        if (self.train_cfg or {}).get('add_noise', False):
+            from .core.add_noise import general_clean_noise_pairs
+            noise, _ = general_clean_noise_pairs(torch.cat([img, refs], dim=0), constant=[0.5, 0.5])
+            img, refs = noise[[0]], noise[1:]
+        nr = refs.shape[0]
+        with torch.no_grad():
+            flows = self.motion(torch.cat((img.repeat(nr, 1, 1, 1), refs), dim=1), img_metas)
+        all_imgs = torch.cat((img, refs), dim=0).contiguous()
+        return vid_train.video_forward_train(self, 'fgfa', all_imgs, flows, 0, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore)
 
     def _agg_plan(self, st, n_slots, key_slot, device):
         """Embedding convs over the n_slots frames of every level in one multi-segment launch + the tail per level.
