@@ -245,3 +245,29 @@ class InsertResNet(ResNet):
         ops.pack_input(x.float().contiguous(), 8, out=x_in)
         plan.run()
         return tuple(ops.unpack_output(f, f.shape[-1], owner=plan) for f in feats)
+
+
+@BACKBONES.register_module()
+class ResNetH(ResNet):
+    """mmtracking/mmtrack/models/backbones/resnet_H.py:123-426 ("ResNet backbone for Dark Denoising Network"), the one A..H experiment
+    fork a config names (configs/vid/llvod/done/llvod_selsa_tra_rh50_l34*.py). It is InsertResNet's ResLayer with the plugin switch
+    renamed: a stage with insert_plugins[i] ends in `build_aggregator(plugins_cfg['type'], **plugins_cfg['cfg'])` (resnet_H.py:94-95) --
+    but `plugins_cfg` is a ResLayer argument that ResNetH never passes (it hands `plugins=` to the blocks instead, :204-217), so with any
+    insert_plugins entry true (the default, and what both configs set) the reference's constructor fails with
+    `TypeError: 'NoneType' object is not subscriptable`. Kept constructor-compatible: that case raises the same TypeError, saying why;
+    with every entry false it is mmdet's ResNet on the conv engine (depth 50 / 101 only, :129-132), parameter names unchanged. The working
+    form of the same idea is InsertResNet (insert_tag / insert_cfg)."""
+
+    def __init__(self, depth, insert_plugins=(True, True, True, True), plugins=None, num_stages=4, **kwargs):
+        if depth not in (50, 101):
+            raise KeyError(f'invalid depth {depth} for resnet')
+        assert len(insert_plugins) == num_stages
+        if any(insert_plugins):
+            raise TypeError("'NoneType' object is not subscriptable (ResNetH: resnet_H.py:94-95 builds the stage plugin from `plugins_cfg`, "
+                            'which ResNetH never passes to its ResLayer -- the reference cannot construct this backbone with insert_plugins '
+                            'set either; use InsertResNet(insert_tag=..., insert_cfg=...) for a ResNet with denoising plugins)')
+        if plugins is not None:
+            raise NotImplementedError('mmdet block plugins (context / non-local blocks) are outside the hot path')
+        super().__init__(depth, num_stages=num_stages, **kwargs)
+        self.insert_plugins = tuple(insert_plugins)
+        self.feat_dim = 4 * self.base_channels * 2 ** (self.num_stages - 1)          # resnet_H.py:226-227
