@@ -405,6 +405,24 @@ int llv_add_f16(const void* a, const void* b, void* y, int64_t rows, int c, int 
 int llv_roi_align(const void* feat, const float* rois, void* out, int n, int h, int w, int c, int ld, int k, int ph, int pw,
                   float spatial_scale, int sampling_ratio, int aligned, int out_f32, void* stream);
 
+/* ---- SELSA RoI head: selsa_aggregator.py:29-73, selsa_bbox_head.py:60-84, bbox_head.py:270-371.
+ * The matrix products run on llv_conv2d_nhwc_fwd (fully connected layer = 1x1 / 7x7-valid convolution over the RoI batch; the attention
+ * of an aggregator = two grouped 1x1 convolutions, one group per attention block, whose weights are the packed reference rows).
+ * llv_selsa_pack_kv: rows [row0, row0 + rows) of the packed weights from src (rows, blocks*d) fp16 (row stride src_ld):
+ *   transposed == 0: dst [blocks][dst_rows][dst_kpad], dst[g][row0 + r][k] = src[r][g*d + k]   (scores = x_embed . ref_embed^T)
+ *   transposed != 0: dst [blocks][dst_rows][dst_kpad], dst[g][k][row0 + r] = src[r][g*d + k]   (x_new = weights . ref_new)
+ * llv_selsa_softmax: scores fp32 [n_rows][blocks][m_ld] -> weights fp16, same shape: softmax(scale * s) over the valid reference rows
+ *   [0, m_static + min(*live_count, m_live_max)) (live_count NULL: all m_live_max), 0 elsewhere.
+ * llv_softmax_rows_masked: y[r] = softmax(x[r][0..c)) for r < *count (count NULL: every row), 0 for the padding rows behind.
+ * llv_dets_to_rois: rois[i] = (batch_index, dets[i][0..3]) for i < *count, zeros behind (max_rows rows); boxes4 (may be NULL) gets the
+ *   same boxes as [max_rows][4] (the `rois[:, 1:]` of bbox_head.py:340 for llv_delta2bbox). */
+int llv_selsa_pack_kv(const void* src, void* dst, int rows, int row0, int blocks, int d, int src_ld, int dst_rows, int dst_kpad, int transposed,
+                      void* stream);
+int llv_selsa_softmax(const float* scores, void* weights, int64_t n_rows, int blocks, int m_ld, int m_static, int m_live_max,
+                      const int32_t* live_count, float scale, void* stream);
+int llv_softmax_rows_masked(const float* x, float* y, int n, int c, int x_ld, int y_ld, const int32_t* count, void* stream);
+int llv_dets_to_rois(const float* dets, const int32_t* count, float* rois, float* boxes4, int max_rows, int batch_index, void* stream);
+
 /* ---- TemporalRoIAlign (the RoI extractor of the authors' own model: mmtracking/configs/vid/llvod/llvod_fastdvdnet_darkfarm.py:49-59,
  * mmtracking/mmtrack/models/roi_heads/roi_extractors/temporal_roi_align.py). Its two dense products run on llv_conv2d_nhwc_fwd (the
  * cosine similarity maps as a 1x1 convolution of the normalised reference maps with the normalised RoI points as weights, fp32 out;

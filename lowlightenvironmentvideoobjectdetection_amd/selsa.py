@@ -11,27 +11,77 @@ What is native here: RoI features through `llv_roi_align`, detections through `l
 boxes. The fully connected layers and the attention of the aggregator are plain GEMMs and run as torch (rocBLAS / hipBLASLt) calls on
 the device (fp16 operands, fp32 accumulation: `_lin`); the element-wise decode is torch on the device. No CPU path: CPU inputs raise. Training (`forward_train`, sampling,
 losses) is not built."""
+import ctypes as C
+
 import numpy as np
 import torch
 import torch.nn as nn
 import torch.nn.functional as F
 
 from . import ops
-from ._lib import LlvError
+from ._lib import CONV_OUT_F32, LlvError, check, lib
 from .core.bbox import bbox2result
 from .registry import AGGREGATORS, HEADS, ROI_EXTRACTORS, build, build_aggregator
 
 
-def _lin(fc, x):
-    """fc(x) as a library GEMM with fp16 operands and fp32 accumulation (the arithmetic type of the rest of the path: fp16 storage, fp32
-    accumulate); the fp16 copy of the weight is kept on the layer until the weight changes. Returns fp32."""
+def linear_pc(fc, roi_hw=None):
+    """The packed weights of a fully connected layer as the convolution engine reads them: a 1x1 convolution over rows, or -- for the
+    first shared fc, whose input is the flattened (C, ph, pw) RoI map -- a ph x pw "valid" convolution over the NHWC RoI features
+    (the K index c*ph*pw + y*pw + x of the Linear weight is exactly conv weight [out][c][y][x]). Kept on the layer until weight or
+    bias change."""
     w = fc.weight
-    key = (w.data_ptr(), w._version, str(w.device), None if fc.bias is None else (fc.bias.data_ptr(), fc.bias._version))
-    if getattr(fc, '_llv_half_key', None) != key:
-        fc._llv_half = (w.detach().half(), fc.bias.detach().half() if fc.bias is not None else None)
-        fc._llv_half_key = key
-    wh, bh = fc._llv_half
-    return F.linear(x.half(), wh, bh).float()
+    key = (w.data_ptr(), w._version, str(w.device), None if fc.bias is None else (fc.bias.data_ptr(), fc.bias._version), roi_hw)
+    if getattr(fc, '_llv_pc_key', None) != key:
+        wt = w.detach().float().cpu()
+        if roi_hw is None:
+            wt = wt.view(wt.shape[0], wt.shape[1], 1, 1)
+        else:
+            wt = wt.view(wt.shape[0], wt.shape[1] // (roi_hw[0] * roi_hw[1]), roi_hw[0], roi_hw[1])
+        fc._llv_pc = ops.pack_conv(wt, None if fc.bias is None else fc.bias.detach().float().cpu(), 1, 0).to(w.device)
+        fc._llv_pc_key = key
+    return fc._llv_pc
+
+
+def _lin(fc, x):
+    """fc(x) on the in-tree implicit-GEMM kernel (fp16 operands, fp32 accumulation, fp32 out: the arithmetic type of the rest of the
+    path): x (rows, K) -> (rows, out) fp32."""
+    pc = linear_pc(fc)
+    n, k = x.shape
+    x16 = x.to(torch.float16).contiguous().view(1, n, 1, k)
+    if k % 8:
+        raise LlvError('fully connected layer: the input width must be a multiple of 8')
+    y = ops.conv2d(x16, pc, flags=CONV_OUT_F32)
+    return y.view(n, -1)[:, :fc.out_features]
+
+
+def selsa_attention(x_embed, ref_embed, ref_new, num_blocks):
+    """softmax(x_embed_b . ref_embed_b^T / sqrt(d)) . ref_new_b for every attention block b (selsa_aggregator.py:44-71) on the
+    convolution engine: two grouped 1x1 convolutions whose weights are the packed reference rows (llv_selsa_pack_kv) around
+    llv_selsa_softmax. x_embed (N, C), ref_embed / ref_new (M, C) -> (N, C) fp16."""
+    L = lib()
+    n, c = x_embed.shape
+    m = ref_embed.shape[0]
+    nb, d = num_blocks, c // num_blocks
+    if c % num_blocks or d % 8:
+        raise LlvError(f'SelsaAggregator: {c} channels in {num_blocks} attention blocks (block width must be a multiple of 8)')
+    dev = x_embed.device
+    m_pad = ops.round_up(m, 32)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    xe = x_embed.to(torch.float16).contiguous()
+    re, rn = ref_embed.to(torch.float16).contiguous(), ref_new.to(torch.float16).contiguous()
+    kp = ops.round_up(d, 32)
+    kw = torch.zeros((nb, m_pad, kp), device=dev, dtype=torch.float16)
+    vw = torch.zeros((nb, ops.round_up(d, 16), m_pad), device=dev, dtype=torch.float16)
+    check(L.llv_selsa_pack_kv(re.data_ptr(), kw.data_ptr(), m, 0, nb, d, c, m_pad, kp, 0, st), 'llv_selsa_pack_kv')
+    check(L.llv_selsa_pack_kv(rn.data_ptr(), vw.data_ptr(), m, 0, nb, d, c, vw.shape[1], m_pad, 1, st), 'llv_selsa_pack_kv')
+    pck = ops.PackedConv(w=kw, bias=torch.zeros(nb * m_pad, device=dev), cin=d, cout=m_pad, w_rows=m_pad, k_pad=kp,
+                         kh=1, kw=1, stride=1, pad=0, groups=nb, true_macs_per_pixel=m * c)
+    pcv = ops.PackedConv(w=vw, bias=torch.zeros(nb * d, device=dev), cin=m_pad, cout=d, w_rows=vw.shape[1], k_pad=m_pad, kh=1, kw=1, stride=1,
+                         pad=0, groups=nb, true_macs_per_pixel=m * c)
+    s = ops.conv2d(xe.view(1, n, 1, c), pck, flags=CONV_OUT_F32)                        # (1, n, 1, nb * m_pad) fp32
+    p = torch.empty((1, n, 1, nb * m_pad), device=dev, dtype=torch.float16)
+    check(L.llv_selsa_softmax(s.data_ptr(), p.data_ptr(), n, nb, m_pad, m, 0, None, 1.0 / d ** 0.5, st), 'llv_selsa_softmax')
+    return ops.conv2d(p, pcv).view(n, c)
 
 
 def _gpu(*ts):
@@ -60,12 +110,8 @@ class SelsaAggregator(nn.Module):
         _gpu(x, ref_x)
         n, m, nb = x.shape[0], ref_x.shape[0], self.num_attention_blocks
         r_embed, r_new = self.ref_side(ref_x) if ref_side is None else ref_side
-        x_embed = _lin(self.fc_embed, x).view(n, nb, -1).permute(1, 0, 2)
-        ref_embed = r_embed.view(m, nb, -1).permute(1, 2, 0)
-        weights = (torch.bmm(x_embed, ref_embed) / (x_embed.shape[-1] ** 0.5)).softmax(dim=2)
-        ref_new = r_new.view(m, nb, -1).permute(1, 0, 2)
-        x_new = torch.bmm(weights, ref_new).permute(1, 0, 2).contiguous()
-        return _lin(self.fc, x_new.view(n, -1))
+        x_new = selsa_attention(_lin(self.fc_embed, x), r_embed, r_new, nb)
+        return _lin(self.fc, x_new)
 
 
 @HEADS.register_module()
