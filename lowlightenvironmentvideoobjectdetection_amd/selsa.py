@@ -369,6 +369,34 @@ class SELSA(BaseVideoDetector):
             self.init_module('detector', pretrain['detector'])
 
     cache_static_refs = True      # memo mode: keep the memo frames' proposals / RoI features / reference branch for the video (simple_test)
+    use_key_plan = True           # memo mode, frames after frame 0: the whole step as one launch list / HIP graph (selsa_plan.SelsaKeyPlan)
+
+    def _key_plan_step(self, img, img_metas, ref_img, proposals, rescale):
+        """Frames 1.. of a video in memo mode (frame_stride < 1, nothing new to reference): one graph replay. Frame 0 (and every
+        case the plan does not cover) goes through the module-level path below, which also fills the memo the plan is built from."""
+        from . import selsa_plan
+        meta = img_metas[0]
+        if not (self.use_key_plan and self.cache_static_refs and proposals is None and ref_img is None and self.memo is not None
+                and meta.get('frame_stride', -1) < 1 and meta.get('frame_id', -1) > 0 and img.shape[0] == 1):
+            return None
+        cache = self.memo.get('roi_cache') if isinstance(self.memo, dict) else None
+        if not cache or 'ref_branch' not in cache or not selsa_plan.eligible(self):
+            return None
+        branch = cache['ref_branch']
+        n, c, h, w = img.shape
+        rows = tuple(int(t[1].shape[0]) for t in branch)
+        shape = tuple(int(v) for v in meta['img_shape'])
+        sfk = tuple(float(v) for v in np.asarray(meta.get('scale_factor', 1.0), dtype=np.float32).reshape(-1))
+        key = ('key_plan', h, w, rows, shape, sfk, bool(rescale), str(img.device))
+        plan = self._plans.get(key)
+        if plan is None:
+            plan = self._plans[key] = selsa_plan.SelsaKeyPlan(self, h, w, img.device, branch, meta, rescale)
+            self.memo['key_plan_static'] = id(branch)
+        elif self.memo.get('key_plan_static') != id(branch):        # a new video on a cached plan: its reference rows
+            plan.set_static(branch)
+            self.memo['key_plan_static'] = id(branch)
+        dets, labels = plan.run(img)
+        return dict(bbox_results=bbox2result(dets, labels, self.detector.roi_head.bbox_head.num_classes))
 
     def forward_train(self, *a, **k):
         raise LlvError('SELSA.forward_train: the two-stage training path is not built')
@@ -411,6 +439,9 @@ class SELSA(BaseVideoDetector):
     def simple_test(self, img, img_metas, ref_img=None, ref_img_metas=None, proposals=None, ref_proposals=None, rescale=False):
         """selsa.py:260-330. Returns {'bbox_results': list[num_classes] of (k, 5) arrays}."""
         self._check_input(img)
+        fast = self._key_plan_step(img, img_metas, ref_img, proposals, rescale)
+        if fast is not None:
+            return fast
         if ref_img is not None:
             ref_img = ref_img[0]
         if ref_img_metas is not None:

@@ -424,6 +424,7 @@ def test_selsa_memo_caches_equal_recomputing_every_frame(dev):
         model.detector.roi_head.bbox_head.fc_reg.weight.mul_(0.3)
     plain = copy.deepcopy(model)
     plain.cache_static_refs = False
+    model.use_key_plan = False              # this test is about the caches of the module-level path; the launch plan has its own below
     model, plain = model.to(dev).eval(), plain.to(dev).eval()
     H, W, NREF = 128, 192, 2
     frames = smooth_image(NREF + 3, H, W, seed=75)
@@ -445,3 +446,68 @@ def test_selsa_memo_caches_equal_recomputing_every_frame(dev):
             if len(a):
                 assert np.abs(a - b).max() < 2e-3, np.abs(a - b).max()
     assert n_tot >= 60
+
+
+@pytest.mark.gpu
+def test_selsa_key_plan_equals_module_level_path(dev):
+    """selsa_plan.SelsaKeyPlan (frames after frame 0 in memo mode: the whole step as one captured launch list of fixed shapes, padding
+    rows masked on the device) against the module-level path on the same frames. Between the fully connected layers the plan keeps fp16
+    (the module path hands fp32 across module boundaries and rounds at the next layer's input), so logits differ in the 4th digit:
+    >= 90 % of the module path's detections are reproduced with IoU > 0.9 and |score difference| < 0.03, and the plan's proposals are
+    exactly the module path's."""
+    import copy
+    import lowlightenvironmentvideoobjectdetection_amd.models as M
+    from helpers import match_detections, randomize, smooth_image
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    model = M.build_model(_selsa_cfg())
+    randomize(model.detector.backbone, seed=81)
+    randomize(model.detector.neck, seed=82)
+    randomize(model.detector.rpn_head, seed=83)
+    g = torch.Generator().manual_seed(84)
+    with torch.no_grad():
+        model.detector.rpn_head.rpn_cls.bias.add_(-1.0)
+        model.detector.rpn_head.rpn_reg.weight.mul_(0.3)
+        for n, p in model.detector.roi_head.named_parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * ((1.5 / p.shape[1]) ** 0.5 if p.dim() == 2 else 0.1))
+        model.detector.roi_head.bbox_head.fc_reg.weight.mul_(0.3)
+    eager = copy.deepcopy(model)
+    eager.use_key_plan = False
+    model, eager = model.to(dev).eval(), eager.to(dev).eval()
+    H, W, NREF = 128, 192, 2
+    frames = smooth_image(NREF + 4, H, W, seed=85)
+    outs = []
+    for m in (model, eager):
+        res = []
+        for t in range(4):
+            meta = dict(img_meta(H, W), frame_id=t, num_left_ref_imgs=-1, frame_stride=-1)
+            kw = dict(ref_img=[frames[:NREF].unsqueeze(0).to(dev)], ref_img_metas=[[[img_meta(H, W)] * NREF]]) if t == 0 else {}
+            with torch.no_grad():
+                res.append(m(return_loss=False, img=[frames[NREF + t:NREF + t + 1].to(dev)], img_metas=[[meta]], **kw)['bbox_results'])
+        outs.append(res)
+    plans = [v for k, v in model._plans.items() if isinstance(k, tuple) and k and k[0] == 'key_plan']
+    assert len(plans) == 1 and plans[0]._graph is not None, 'frames 1..3 went through the captured plan'
+    assert ops.guard_trips() == 0
+    def same_rows(ra, rb, px=0.5, sc=0.03):
+        """fraction of rb's rows (per class) that ra holds too: every corner within px, score within sc. (IoU is no use here: random
+        heads put many boxes on the image border, where clipping leaves them with zero area.)"""
+        hit = tot = 0
+        for a, b in zip(ra, rb):
+            tot += len(b)
+            if len(a) and len(b):
+                d = np.abs(a[:, None, :4] - b[None, :, :4]).max(-1)
+                ok = (d < px) & (np.abs(a[:, None, 4] - b[None, :, 4]) < sc)
+                hit += int(ok.any(0).sum())
+        return hit / max(tot, 1), tot
+    tot = 0
+    for t, (ra, rb) in enumerate(zip(*outs)):
+        frac, n = same_rows(ra, rb)
+        tot += n
+        assert n >= 10 and frac >= (1.0 if t == 0 else 0.9), (t, frac, n)
+    assert tot >= 60
+    # the plan's proposals (RPN convs -> decode -> NMS inside the graph) are the module path's, row for row
+    cnt = int(plans[0].count.item())
+    last = frames[NREF + 3:NREF + 4].to(dev)
+    with torch.no_grad():
+        want = eager.detector.rpn_head.simple_test_rpn(eager.detector.extract_feat(last), [img_meta(H, W)])[0]
+    got = plans[0].rpn_post.nb.dets[:cnt]
+    assert got.shape == want.shape and torch.allclose(got, want, atol=1e-4)
