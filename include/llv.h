@@ -404,6 +404,10 @@ int llv_add_f16(const void* a, const void* b, void* y, int64_t rows, int c, int 
  * x1, y1, x2, y2); out (k,ph,pw,c) NHWC fp16, or fp32 with out_f32. sampling_ratio 0 = adaptive (ceil(bin size)). */
 int llv_roi_align(const void* feat, const float* rois, void* out, int n, int h, int w, int c, int ld, int k, int ph, int pw,
                   float spatial_scale, int sampling_ratio, int aligned, int out_f32, void* stream);
+/* Its backward with respect to the feature map (two-stage training, selsa_roi_head.py:94-111 -> mmcv roi_align backward): grad_out
+ * (k,ph,pw,c) fp32 NHWC -> dfeat (n,h,w,c) fp32, accumulated with atomics (the caller zeroes it). */
+int llv_roi_align_bwd(const float* grad_out, const float* rois, float* dfeat, int n, int h, int w, int c, int k, int ph, int pw,
+                      float spatial_scale, int sampling_ratio, int aligned, void* stream);
 
 /* ---- SELSA RoI head: selsa_aggregator.py:29-73, selsa_bbox_head.py:60-84, bbox_head.py:270-371.
  * The matrix products run on llv_conv2d_nhwc_fwd (fully connected layer = 1x1 / 7x7-valid convolution over the RoI batch; the attention

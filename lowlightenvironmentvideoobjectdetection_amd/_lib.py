@@ -180,6 +180,7 @@ SIGNATURES = {
     'llv_selsa_softmax': (_I, [_P, _P, _L, _I, _I, _I, _I, _P, _F, _P]),
     'llv_softmax_rows_masked': (_I, [_P, _P, _I, _I, _I, _I, _P, _P]),
     'llv_dets_to_rois': (_I, [_P, _P, _P, _P, _I, _I, _P]),
+    'llv_roi_align_bwd': (_I, [_P, _P, _P] + [_I] * 7 + [_F, _I, _I, _P]),
     'llv_l2norm_rows_f16': (_I, [_P, _I, _P, _L, _I, _L, _L, _P, _P]),
     'llv_msra_top2_gather': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'llv_troi_attention_fuse': (_I, [_P, _P, _P, _I, _L, _I, _I, _P]),

@@ -87,7 +87,7 @@ def dgrad_weight(weight: torch.Tensor, stride: int, pad: int, cin_pad: int) -> T
 # ----------------------------------------------------------------------------------------------
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, cin_pad: int, cout: int, w_rows: int, k_pad: int,
                kh: int, kw: int, stride: int, pad: int, groups: int, batch: int, seg: tuple, x_ld: int, dy_ld: int,
-               db: Optional[torch.Tensor] = None):
+               db: Optional[torch.Tensor] = None, dilation: int = 1):
     """Accumulate the weight gradient of one segment into dw (fp32 [groups][w_rows][k_pad]) and, if given, the bias
     gradient into db (fp32 [groups*cout]). seg = (h, w, ho, wo, x_pixel_off, dy_pixel_off)."""
     d = ConvDesc()
@@ -96,6 +96,7 @@ def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, cin_pad: 
     d.x_ld = x_ld
     d.cin, d.cout, d.w_rows, d.k_pad = cin_pad, cout, w_rows, k_pad
     d.kh, d.kw, d.stride, d.pad, d.groups, d.batch = kh, kw, stride, pad, groups, batch
+    d.dilation = dilation
     d.seg_h[0], d.seg_w[0], d.seg_ho[0], d.seg_wo[0], d.seg_xoff[0], d.seg_yoff[0] = seg
     check(lib().llv_conv2d_nhwc_wgrad(C.byref(d), dy.data_ptr(), dy_ld, dw.data_ptr(), db.data_ptr() if db is not None else None,
                                       _stream()), 'llv_conv2d_nhwc_wgrad')
@@ -138,6 +139,7 @@ def conv_dgrad(dy: torch.Tensor, pcd: ops.PackedConv, dx: torch.Tensor, batch: i
     f.stride = 2 if s2 else 1
     f.cin = pcd.cout // 4 if s2 else pcd.cout
     f.groups, f.batch = pcd.groups, batch
+    f.dilation = pcd.dilation
     for s, (h, w, ho, wo, xo, yo) in enumerate(segs):
         f.seg_h[s], f.seg_w[s], f.seg_ho[s], f.seg_wo[s], f.seg_xoff[s], f.seg_yoff[s] = h, w, ho, wo, xo, yo
     # split-K workspace of the underlying forward launch, if the planner wants one

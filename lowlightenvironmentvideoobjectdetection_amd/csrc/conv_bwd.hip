@@ -48,6 +48,7 @@ struct WgArgs {
     int x_ld, dy_ld;
     int cin, cout, k_pad, w_rows;
     int kh, kw, stride, pad, groups;
+    int dil;                   // dilation of the forward conv (>= 1): tap (r, q) reads input (y*stride - pad + r*dil, ...)
     int H, W, Ho, Wo;
     int xoff, yoff;             // pixel offsets of image 0 in x / dy
     int m_total, m_per_split;
@@ -125,7 +126,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
 #pragma unroll
         for (int i = 0; i < PBW; ++i) {
             if (wave + 4 * i < PB) {
-                const int iy = xoy[i] * a.stride - a.pad + tr, ix = xox[i] * a.stride - a.pad + tq;
+                const int iy = xoy[i] * a.stride - a.pad + tr * a.dil, ix = xox[i] * a.stride - a.pad + tq * a.dil;
                 int v = (int)a.x_bytes;
                 if (xrow[i] < left && xc[i] >= 0 && (unsigned)iy < (unsigned)a.H && (unsigned)ix < (unsigned)a.W)
                     v = (a.xoff + (xn[i] * a.H + iy) * a.W + ix) * a.x_ld * 2 + xc[i];
@@ -441,6 +442,7 @@ extern "C" int llv_conv2d_nhwc_wgrad(const llv_conv_desc* d, const void* dy, int
     a.x = (const _Float16*)d->x[0]; a.dy = (const _Float16*)dy; a.dw = dw; a.db = db;
     a.x_ld = d->x_ld; a.dy_ld = dy_ld; a.cin = d->cin; a.cout = d->cout; a.k_pad = d->k_pad; a.w_rows = d->w_rows;
     a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.groups = d->groups;
+    a.dil = d->dilation > 1 ? d->dilation : 1;
     a.H = d->seg_h[0]; a.W = d->seg_w[0]; a.Ho = d->seg_ho[0]; a.Wo = d->seg_wo[0];
     a.xoff = (int)d->seg_xoff[0]; a.yoff = (int)d->seg_yoff[0];
     a.m_total = (int)m; a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
@@ -546,7 +548,9 @@ extern "C" int llv_conv2d_nhwc_dgrad(const llv_conv_desc* fwd, const void* w_dgr
     if (fwd->stride != 1 && fwd->stride != 2) return LLV_E_UNSUPPORTED;
     const bool s2 = fwd->stride == 2;
     if (s2 && fwd->n_seg != 1) return LLV_E_UNSUPPORTED;
+    if (s2 && fwd->dilation > 1) return LLV_E_UNSUPPORTED;        // dilated stride-2 convs do not occur (DC5 dilates stride-1 stages)
     llv_conv_desc d = {};
+    d.dilation = fwd->dilation > 1 ? fwd->dilation : 0;          // the flipped filter keeps the forward conv's dilation
     d.x[0] = dy; d.w = w_dgrad; d.bias = zero_bias; d.y = dx;
     d.res = accumulate ? dx : nullptr;
     d.n_src = 1; d.x_ld = dy_ld; d.y_ld = dx_ld; d.res_ld = accumulate ? dx_ld : 0;

@@ -305,7 +305,63 @@ __global__ __launch_bounds__(256) void roi_align_kernel(const _Float16* __restri
     }
 }
 
+
+// Backward of RoIAlign with respect to the feature map (mmcv roi_align_backward_cuda_kernel: every bilinear sample's gradient
+// g / count goes to its four neighbours with the forward weights). One thread per (output bin, channel), channels fastest, so the
+// atomics of a wave-instruction hit 64 consecutive floats of one map pixel. dfeat fp32 [n][h][w][c], accumulated (zero it first).
+__global__ __launch_bounds__(256) void roi_align_bwd_kernel(const float* __restrict__ gout, const float* __restrict__ rois,
+                                                           float* __restrict__ dfeat, int n, int h, int w, int c, int ph, int pw, float scale,
+                                                           int grid, int aligned, unsigned total) {
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const unsigned ch = t % (unsigned)c;
+        unsigned p = t / (unsigned)c;
+        const unsigned ox = p % (unsigned)pw; p /= (unsigned)pw;
+        const unsigned oy = p % (unsigned)ph;
+        const unsigned r = p / (unsigned)ph;
+        const float* roi = rois + (long)r * 5;
+        const int b = (int)roi[0];
+        if (b < 0 || b >= n) continue;
+        const float off = aligned ? 0.5f : 0.f;
+        const float x1 = roi[1] * scale - off, y1 = roi[2] * scale - off, x2 = roi[3] * scale - off, y2 = roi[4] * scale - off;
+        float rw = x2 - x1, rh = y2 - y1;
+        if (!aligned) { rw = fmaxf(rw, 1.f); rh = fmaxf(rh, 1.f); }
+        const float bw = rw / (float)pw, bh = rh / (float)ph;
+        const int gh = grid > 0 ? grid : (int)ceilf(rh / (float)ph), gw = grid > 0 ? grid : (int)ceilf(rw / (float)pw);
+        const float g = gout[t] / fmaxf((float)(gh * gw), 1.f);
+        if (g == 0.f) continue;
+        float* fb = dfeat + (long)b * h * w * c + ch;
+        for (int iy = 0; iy < gh; ++iy) {
+            const float y = y1 + (float)oy * bh + ((float)iy + 0.5f) * bh / (float)gh;
+            for (int ix = 0; ix < gw; ++ix) {
+                const float x = x1 + (float)ox * bw + ((float)ix + 0.5f) * bw / (float)gw;
+                if (y < -1.f || y > (float)h || x < -1.f || x > (float)w) continue;
+                float yy = y <= 0.f ? 0.f : y, xx = x <= 0.f ? 0.f : x;
+                int yl = (int)yy, xl = (int)xx, yh, xh;
+                if (yl >= h - 1) { yh = yl = h - 1; yy = (float)yl; } else yh = yl + 1;
+                if (xl >= w - 1) { xh = xl = w - 1; xx = (float)xl; } else xh = xl + 1;
+                const float ly = yy - (float)yl, lx = xx - (float)xl, hy = 1.f - ly, hx = 1.f - lx;
+                atomicAdd(fb + ((long)yl * w + xl) * c, g * hy * hx);
+                atomicAdd(fb + ((long)yl * w + xh) * c, g * hy * lx);
+                atomicAdd(fb + ((long)yh * w + xl) * c, g * ly * hx);
+                atomicAdd(fb + ((long)yh * w + xh) * c, g * ly * lx);
+            }
+        }
+    }
+}
+
 }  // namespace
+
+extern "C" int llv_roi_align_bwd(const float* grad_out, const float* rois, float* dfeat, int n, int h, int w, int c, int k, int ph, int pw,
+                                 float spatial_scale, int sampling_ratio, int aligned, void* stream) {
+    if (n <= 0 || h <= 0 || w <= 0 || c <= 0 || k < 0 || ph <= 0 || pw <= 0 || !(spatial_scale > 0.f) || sampling_ratio < 0) return LLV_E_BADARG;
+    if (k == 0) return LLV_OK;
+    if (!grad_out || !rois || !dfeat) return LLV_E_BADARG;
+    const long total = (long)k * ph * pw * c;
+    if (total >= (1L << 31)) return LLV_E_UNSUPPORTED;
+    hipLaunchKernelGGL(roi_align_bwd_kernel, dim3(grid_of(total)), dim3(256), 0, (hipStream_t)stream, grad_out, rois, dfeat, n, h, w, c, ph, pw,
+                       spatial_scale, sampling_ratio, aligned, (unsigned)total);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
 
 extern "C" int llv_roi_align(const void* feat, const float* rois, void* out, int n, int h, int w, int c, int ld, int k, int ph, int pw,
                              float spatial_scale, int sampling_ratio, int aligned, int out_f32, void* stream) {

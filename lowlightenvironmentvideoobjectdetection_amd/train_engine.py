@@ -111,12 +111,17 @@ class TrainGraph:
                 assert len(op['xs']) == 1 and pc.n_src == 1, 'multi-source launches are not on the training path'
                 dyc = self._dy_ld(op) // pc.groups
                 KH, KW, pd, _, _ = B.dgrad_geometry(pc.kh, pc.kw, pc.stride, pc.pad)
+                dil = max(int(pc.dilation), 1)
+                if dil > 1:                  # dilated stride-1 conv (the DC5 stage): the flipped filter keeps the dilation
+                    if pc.stride != 1:
+                        raise LlvError(f"{op['name']}: data gradient of a dilated stride-{pc.stride} conv is not built")
+                    pd = dil * (pc.kh - 1) - pc.pad
                 rows = pc.cin * (4 if pc.stride == 2 else 1)
                 w_rows, k_pad = ops.round_up(rows, 16), ops.round_up(KH * KW * dyc, 32)
                 op['pcd'] = ops.PackedConv(w=torch.zeros(pc.groups, w_rows, k_pad, dtype=torch.float16, device=device),
                                            bias=torch.zeros(pc.groups * rows, dtype=torch.float32, device=device), cin=dyc, cout=rows,
                                            w_rows=w_rows, k_pad=k_pad, kh=KH, kw=KW, stride=1, pad=pd, groups=pc.groups,
-                                           true_macs_per_pixel=0)
+                                           true_macs_per_pixel=0, dilation=dil)
                 op['dflags'] = CONV_PIXSHUF if pc.stride == 2 else 0
         self.trainable = self._trainable_keys()
 
@@ -242,7 +247,7 @@ class TrainGraph:
                 for (h, w, ho, wo, xo, yo) in op['segs']:
                     B.conv_wgrad(op['xs'][0], gy, op['dw'], cin_pad=pc.cin, cout=pc.cout,
                                  w_rows=pc.w_rows, k_pad=pc.k_pad, kh=pc.kh, kw=pc.kw, stride=pc.stride, pad=pc.pad, groups=pc.groups,
-                                 batch=op['batch'], seg=(h, w, ho, wo, xo, yo), x_ld=op['x_ld'], dy_ld=dy_ld, db=op['db'])
+                                 batch=op['batch'], seg=(h, w, ho, wo, xo, yo), x_ld=op['x_ld'], dy_ld=dy_ld, db=op['db'], dilation=max(int(pc.dilation), 1))
             if op['need_dx']:
                 gx = self.gview(op['xs'][0])
                 if op['dflags'] & CONV_PIXSHUF:

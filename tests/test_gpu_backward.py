@@ -134,3 +134,29 @@ def test_relu_bias_upsample_sgd(dev):
         opt.step()
         B.sgd_momentum(wd, (gr * 512).to(dev), md, 0.01, 0.9, 1e-4, 1.0 / 512, step == 0)
     assert _rel(wd.cpu(), p.detach()) < 1e-6
+
+
+@pytest.mark.parametrize('cfg', [(2, 64, 64, 14, 19, 2), (1, 128, 96, 9, 12, 2), (1, 64, 64, 11, 13, 3)])
+def test_dilated_conv_backward_matches_autograd(dev, cfg):
+    """3x3 / stride 1 / padding = dilation (the conv2 of a DC5 stage, resnet.py:151-167 with dilations (1, 1, 1, 2)): weight gradient
+    (llv_conv_desc.dilation read by the wgrad kernel's tap addressing) and data gradient (the flipped filter on the forward kernel with
+    the same dilation and padding dil*(k-1) - pad)."""
+    from lowlightenvironmentvideoobjectdetection_amd import backward as B, ops
+    n, cin, cout, h, w, dil = cfg
+    g = torch.Generator().manual_seed(7)
+    x = torch.randn(n, cin, h, w, generator=g).half().float().requires_grad_()
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / (cin * 9) ** 0.5).half().float().requires_grad_()
+    y = F.conv2d(x, wt, None, 1, dil, dil)
+    assert y.shape[2:] == x.shape[2:]
+    dy = torch.randn(y.shape, generator=g).half().float()
+    y.backward(dy)
+    w_rows, k_pad = ops.round_up(cout, 16), ops.round_up(9 * cin, 32)
+    dw = torch.zeros(1, w_rows, k_pad, dtype=torch.float32, device=dev)
+    B.conv_wgrad(_nhwc(x.detach()).half().to(dev), _nhwc(dy).half().to(dev), dw, cin_pad=cin, cout=cout, w_rows=w_rows, k_pad=k_pad, kh=3, kw=3,
+                 stride=1, pad=dil, groups=1, batch=n, seg=(h, w, h, w, 0, 0), x_ld=cin, dy_ld=cout, dilation=dil)
+    assert _rel(B.unpack_wgrad(dw[0].cpu(), cout, cin, 3, 3, cin), wt.grad) < 2e-3
+    wd, KH, KW, pd, flags = B.dgrad_weight(wt.detach(), 1, 1, cin)                    # flipped, in/out-transposed filter (geometry for pad 1)
+    pcd = ops.pack_conv(wd, None, 1, dil * 2 - dil, cout_store=wd.shape[0], dilation=dil).to(dev)
+    dx = torch.zeros(n, h, w, cin, dtype=torch.float16, device=dev)
+    B.conv_dgrad(_nhwc(dy).half().to(dev), pcd, dx, n, [(h, w, h, w, 0, 0)], cout, cin, flags, accumulate=False)
+    assert _rel(dx.float().cpu().permute(0, 3, 1, 2), x.grad) < 3e-3
