@@ -44,6 +44,11 @@ class SamplingResult:
             self.pos_gt_bboxes = gt_bboxes[self.pos_assigned_gt_inds, :]
         self.pos_gt_labels = assign_result.labels[pos_inds] if assign_result.labels is not None else None
 
+    @property
+    def bboxes(self):
+        """sampling_result.py:63-65"""
+        return torch.cat([self.pos_bboxes, self.neg_bboxes])
+
 
 @BBOX_ASSIGNERS.register_module()
 class MaxIoUAssigner(object):

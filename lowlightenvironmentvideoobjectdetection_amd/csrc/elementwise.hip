@@ -556,6 +556,72 @@ extern "C" int llv_maxpool3x3s2_nhwc(const void* x, void* y, int batch, int h, i
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
+// Backward of nn.MaxPool2d(3, 2, 1): dx[n, iy, ix, c] += sum over the (at most four) windows that contain (iy, ix) of dy[window] where
+// (iy, ix) is the window's arg-max. Gather form (one thread per 8 input channels, no atomics). ATen's rule for ties (post-ReLU maps
+// are full of equal zeros): the FIRST maximum in (dy, dx) scan order takes the gradient (`val > maxval` while scanning).
+__global__ void maxpool3x3s2_bwd_kernel(const _Float16* __restrict__ x, const _Float16* __restrict__ dy, _Float16* __restrict__ dx,
+                                        int batch, int h, int w, int c8, int ho, int wo, int x_ld, int dy_ld, int dx_ld) {
+    const long total = (long)batch * h * w * c8;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
+        const int cv = (int)(i % c8);
+        unsigned p = i / c8;
+        const int ix = (int)(p % w); p /= w;
+        const int iy = (int)(p % h);
+        const int n = (int)(p / h);
+        const f16x8 me = *reinterpret_cast<const f16x8*>(x + (((long)n * h + iy) * w + ix) * x_ld + cv * 8);
+        float acc[8];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+        // windows (oy, ox) with oy*2-1 <= iy <= oy*2+1
+        const int oy0 = iy / 2, oy1 = (iy + 1) / 2, ox0 = ix / 2, ox1 = (ix + 1) / 2;
+        for (int oy = oy0; oy <= oy1; ++oy) {
+            if (oy >= ho) continue;
+            for (int ox = ox0; ox <= ox1; ++ox) {
+                if (ox >= wo) continue;
+                // is (iy, ix) the first maximum of this window?  earlier positions must be strictly smaller, later ones not larger
+                bool win[8];
+#pragma unroll
+                for (int e = 0; e < 8; ++e) win[e] = true;
+                const int my = iy - (oy * 2 - 1), mx = ix - (ox * 2 - 1);
+#pragma unroll
+                for (int ky = 0; ky < 3; ++ky) {
+                    const int yy = oy * 2 - 1 + ky;
+                    if ((unsigned)yy >= (unsigned)h) continue;
+#pragma unroll
+                    for (int kx = 0; kx < 3; ++kx) {
+                        const int xx = ox * 2 - 1 + kx;
+                        if ((unsigned)xx >= (unsigned)w || (ky == my && kx == mx)) continue;
+                        const f16x8 v = *reinterpret_cast<const f16x8*>(x + (((long)n * h + yy) * w + xx) * x_ld + cv * 8);
+                        const bool earlier = ky < my || (ky == my && kx < mx);
+#pragma unroll
+                        for (int e = 0; e < 8; ++e) win[e] = win[e] && (earlier ? (v[e] < me[e]) : !(v[e] > me[e]));
+                    }
+                }
+                const f16x8 g = *reinterpret_cast<const f16x8*>(dy + (((long)n * ho + oy) * wo + ox) * dy_ld + cv * 8);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += win[e] ? (float)g[e] : 0.f;
+            }
+        }
+        _Float16* d = dx + (((long)n * h + iy) * w + ix) * dx_ld + cv * 8;
+        f16x8 o = *reinterpret_cast<const f16x8*>(d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)((float)o[e] + acc[e]);
+        *reinterpret_cast<f16x8*>(d) = o;
+    }
+}
+
+extern "C" int llv_maxpool3x3s2_nhwc_bwd(const void* x, const void* dy, void* dx, int batch, int h, int w, int c, int x_ld, int dy_ld, int dx_ld,
+                                         void* stream) {
+    if (!x || !dy || !dx || batch < 1 || h < 1 || w < 1 || c < 8 || (c & 7) || x_ld < c || dy_ld < c || dx_ld < c || ((x_ld | dy_ld | dx_ld) & 7))
+        return LLV_E_BADARG;
+    const int ho = (h + 2 - 3) / 2 + 1, wo = (w + 2 - 3) / 2 + 1;
+    const long total = (long)batch * h * w * (c / 8);
+    if (total >= (1L << 31)) return LLV_E_UNSUPPORTED;
+    hipLaunchKernelGGL(maxpool3x3s2_bwd_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, (const _Float16*)x, (const _Float16*)dy,
+                       (_Float16*)dx, batch, h, w, c / 8, ho, wo, x_ld, dy_ld, dx_ld);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
 extern "C" int llv_pack_nchw_f32_to_nhwc_f16(const float* x, void* y, int batch, int c, int h, int w, int c_pad,
                                              const float* scale, const float* shift, void* stream) {
     if (!x || !y || batch < 1 || c < 1 || h < 1 || w < 1 || c_pad < c || (c_pad & 7)) return LLV_E_BADARG;

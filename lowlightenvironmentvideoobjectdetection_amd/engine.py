@@ -227,7 +227,17 @@ class Builder:
         out = self.buf(n, (h - 1) // 2 + 1, (w - 1) // 2 + 1, c)
         self.plan.add(name, lib().llv_maxpool3x3s2_nhwc, (C.c_void_p(x.data_ptr()), C.c_void_p(out.data_ptr()), n, h, w, c),
                       0.0, 2.0 * (x.numel() + out.numel()))
+        # training tape: a parameter-free op between convolutions (train_engine.TrainGraph._finish); only walked when the stem trains
+        self.tape.append(dict(name=name, custom=True, xs=[x], y=out, bwd=_maxpool_bwd))
         return out
+
+
+def _maxpool_bwd(g, op):
+    x, y = op['xs'][0], op['y']
+    gx, gy = g.gview(x), g.gview(y)
+    n, h, w, c = x.shape
+    check(lib().llv_maxpool3x3s2_nhwc_bwd(ops._ptr(x), ops._ptr(gy), ops._ptr(gx), n, h, w, c, x.shape[-1], gy.shape[-1], gx.shape[-1],
+                                          C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'llv_maxpool3x3s2_nhwc_bwd')
 
 
 # ------------------------------------------------------------------------------------------------

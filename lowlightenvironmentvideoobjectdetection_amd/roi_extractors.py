@@ -25,12 +25,15 @@ class RoIAlign(nn.Module):
         self.spatial_scale, self.sampling_ratio, self.aligned = float(spatial_scale), int(sampling_ratio), bool(aligned)
 
     def forward(self, feat, rois):
-        """feat (N, C, H, W) fp32 on the GPU, rois (k, 5) -> (k, C, ph, pw) fp32."""
+        """feat (N, C, H, W) fp32 on the GPU, rois (k, 5) -> (k, C, ph, pw) fp32. Differentiable with respect to `feat` (training
+        of the two-stage heads: llv_roi_align_bwd); the RoIs carry no gradient, as in mmcv."""
         if not feat.is_cuda:
             raise LlvError('RoIAlign runs on an MI355X only (llv_roi_align)')
         c = feat.shape[1]
         if c % 8:
             raise LlvError('RoIAlign: channel count must be a multiple of 8')
+        if feat.requires_grad and torch.is_grad_enabled():
+            return _RoIAlignFn.apply(feat, rois.detach().float().contiguous(), self.output_size, self.spatial_scale, self.sampling_ratio, self.aligned)
         return self.forward_nhwc(feat, rois).permute(0, 3, 1, 2).contiguous()
 
     def forward_nhwc(self, feat, rois):
@@ -42,6 +45,29 @@ class RoIAlign(nn.Module):
             raise LlvError('RoIAlign: channel count must be a multiple of 8')
         x = ops.pack_input(feat.float().contiguous(), c)
         return ops.roi_align(x, rois.float(), self.output_size, self.spatial_scale, self.sampling_ratio, self.aligned, out_f32=True)
+
+
+class _RoIAlignFn(torch.autograd.Function):
+    """mmcv RoIAlignFunction (forward llv_roi_align on the fp16 NHWC copy of the map, backward llv_roi_align_bwd: fp32 atomics)."""
+
+    @staticmethod
+    def forward(ctx, feat, rois, output_size, spatial_scale, sampling_ratio, aligned):
+        n, c, h, w = feat.shape
+        x = ops.pack_input(feat.detach().float().contiguous(), c)
+        out = ops.roi_align(x, rois, output_size, spatial_scale, sampling_ratio, aligned, out_f32=True)        # (k, ph, pw, c)
+        ctx.save_for_backward(rois)
+        ctx.geom = (n, c, h, w, output_size, spatial_scale, sampling_ratio, aligned)
+        return out.permute(0, 3, 1, 2).contiguous()
+
+    @staticmethod
+    def backward(ctx, grad):
+        (rois,) = ctx.saved_tensors
+        n, c, h, w, (ph, pw), scale, ratio, aligned = ctx.geom
+        g = grad.float().permute(0, 2, 3, 1).contiguous()
+        dfeat = torch.zeros((n, h, w, c), device=grad.device, dtype=torch.float32)
+        check(lib().llv_roi_align_bwd(g.data_ptr(), rois.data_ptr(), dfeat.data_ptr(), n, h, w, c, rois.shape[0], ph, pw, float(scale), int(ratio),
+                                      1 if aligned else 0, _stream()), 'llv_roi_align_bwd')
+        return dfeat.permute(0, 3, 1, 2).contiguous(), None, None, None, None, None
 
 
 @ROI_EXTRACTORS.register_module()
@@ -166,9 +192,42 @@ class TemporalRoIAlign(SingleRoIExtractor, PlannedModule):
                                             _stream()), 'llv_troi_attention_fuse')
         return out
 
+    def forward_autograd(self, feats, rois, ref_feats):
+        """temporal_roi_align.py:46-207 for training: RoIAlign through llv_roi_align / llv_roi_align_bwd, the similarity search, the
+        embed convolution over 7x7 maps and the attention as torch's differentiable ops on the device (a few thousand RoI points:
+        the gradient reaches the key map through RoIAlign, the reference maps through the gathered pixels and the cosines)."""
+        import torch.nn.functional as F
+        ph, pw = self.roi_layers[0].output_size
+        roi_feats = self.roi_layers[0](feats[0], rois)                                # (k, C, ph, pw)
+        k, c = roi_feats.shape[:2]
+        ref = ref_feats[-1]
+        img_n, _, h, w = ref.shape
+        re = (roi_feats / roi_feats.norm(p=2, dim=1, keepdim=True)).permute(0, 2, 3, 1).reshape(-1, c)
+        fe = (ref / ref.norm(p=2, dim=1, keepdim=True)).permute(1, 0, 2, 3).reshape(c, -1)
+        cos = re.mm(fe).view(-1, img_n, h * w)
+        values, indices = cos.topk(k=self.num_most_similar_points, dim=2, largest=True)
+        weights = values.softmax(dim=2)
+        ref_r = ref.permute(2, 3, 0, 1).reshape(-1, img_n, c)
+        picked = [(ref_r[indices[:, i], i, :] * weights[:, i].unsqueeze(-1)).sum(dim=1) for i in range(img_n)]
+        ref_roi = torch.stack(picked, 0).view(img_n, k, ph, pw, c).permute(0, 1, 4, 2, 3)
+        x = torch.cat((roi_feats.unsqueeze(0), ref_roi), dim=0)                       # (1 + img_n, k, C, ph, pw)
+        nb = self.num_temporal_attention_blocks
+        if nb <= 0:
+            return x.mean(dim=0)
+        n = x.shape[0]
+        conv = self.embed_network.conv
+        e = F.conv2d(x.reshape(n * k, c, ph, pw), conv.weight, conv.bias, 1, 1)
+        ce = e.shape[1]
+        e = e.view(n, k, nb, -1, ph, pw)
+        a = torch.sum(e * e[[0]], dim=3, keepdim=True) / (float(ce / nb) ** 0.5)
+        a = a.expand(-1, -1, -1, int(ce / nb), -1, -1).contiguous().view(n, k, ce, ph, pw).softmax(dim=0)
+        return (x * a).sum(dim=0)
+
     def forward(self, feats, rois, roi_scale_factor=None, ref_feats=None):
         if ref_feats is None:          # proposals of the reference images: plain RoIAlign (temporal_roi_align.py:184-187)
             return SingleRoIExtractor.forward(self, feats, rois, roi_scale_factor)
+        if torch.is_grad_enabled() and len(feats) == 1 and rois.size(0) > 0 and (feats[0].requires_grad or ref_feats[-1].requires_grad):
+            return self.forward_autograd(feats, rois, ref_feats)
         if len(feats) != 1:
             raise LlvError('TemporalRoIAlign with ref_feats: one feature level (featmap_strides of the SELSA configs: [16])')
         # roi_scale_factor: with one level the reference returns before its roi_rescale (single_level_roi_extractor.py:73-76), so

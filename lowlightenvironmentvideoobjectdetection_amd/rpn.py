@@ -98,8 +98,27 @@ class RPNHead(AnchorHead):
             reg.append(ops.conv2d(t, pc_reg, flags=CONV_OUT_F32)[..., :nreg].permute(0, 3, 1, 2).contiguous())
         return cls, reg
 
-    def loss(self, *a, **k):
-        raise LlvError('RPNHead.loss: the two-stage training path is not built')
+    def loss(self, cls_scores, bbox_preds, gt_bboxes, img_metas, gt_bboxes_ignore=None):
+        """rpn_head.py:49-80: AnchorHead.loss without class labels (every matched anchor is class 0 = foreground), keys renamed."""
+        from .training import anchor_head_loss
+        losses = anchor_head_loss(self, cls_scores, bbox_preds, gt_bboxes, None, img_metas, gt_bboxes_ignore)
+        if losses is None:
+            raise LlvError('RPNHead.loss: no valid anchors inside the image')
+        return dict(loss_rpn_cls=losses['loss_cls'], loss_rpn_bbox=losses['loss_bbox'])
+
+    def forward_train(self, x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=None, proposal_cfg=None, outs=None, **kwargs):
+        """base_dense_head.py:23-59: (losses, proposal_list). `outs` = (cls_scores, bbox_preds) as the detector's training graph
+        produced them (two_stage_train.TwoStageBody: the RPN's three convolutions are launches of that graph, which is what carries
+        the gradient into their weights); without them this module could only offer constants, so it refuses."""
+        if outs is None:
+            raise LlvError('RPNHead.forward_train: pass outs=(cls_scores, bbox_preds) from the training graph '
+                           '(SELSA.forward_train does); a module-level call would not reach the conv weights')
+        losses = self.loss(*outs, gt_bboxes, img_metas, gt_bboxes_ignore=gt_bboxes_ignore)
+        if proposal_cfg is None:
+            return losses
+        with torch.no_grad():
+            proposal_list = self.get_bboxes([t.detach() for t in outs[0]], [t.detach() for t in outs[1]], img_metas, cfg=proposal_cfg)
+        return losses, proposal_list
 
     def get_bboxes(self, cls_scores, bbox_preds, img_metas, cfg=None, rescale=False, with_nms=True):
         """rpn_head.py:88-234. Returns list[N] of (k, 5) proposals (x1, y1, x2, y2, score) on the GPU, best first."""

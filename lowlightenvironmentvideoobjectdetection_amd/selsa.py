@@ -10,7 +10,7 @@ constructors and parameter names:
 What is native here: RoI features through `llv_roi_align`, detections through `llv_multiclass_nms_batched_ex` with class-specific
 boxes. The fully connected layers and the attention of the aggregator are plain GEMMs and run as torch (rocBLAS / hipBLASLt) calls on
 the device (fp16 operands, fp32 accumulation: `_lin`); the element-wise decode is torch on the device. No CPU path: CPU inputs raise. Training (`forward_train`, sampling,
-losses) is not built."""
+losses): two_stage_train.py."""
 import ctypes as C
 
 import numpy as np
@@ -105,9 +105,22 @@ class SelsaAggregator(nn.Module):
         key frame, so a caller may keep them for reference frames that stay in the memo (SelsaBBoxHead.ref_branch)."""
         return _lin(self.ref_fc_embed, ref_x), _lin(self.ref_fc, ref_x)
 
+    def forward_autograd(self, x, ref_x):
+        """The same arithmetic with torch's differentiable ops (fp32 library GEMMs on the device): the training path, where autograd
+        has to reach the four fully connected layers and both inputs (selsa_aggregator.py:29-73 as written)."""
+        n, m, nb = x.shape[0], ref_x.shape[0], self.num_attention_blocks
+        x_embed = self.fc_embed(x).view(n, nb, -1).permute(1, 0, 2)
+        ref_embed = self.ref_fc_embed(ref_x).view(m, nb, -1).permute(1, 2, 0)
+        weights = (torch.bmm(x_embed, ref_embed) / (x_embed.shape[-1] ** 0.5)).softmax(dim=2)
+        ref_new = self.ref_fc(ref_x).view(m, nb, -1).permute(1, 0, 2)
+        x_new = torch.bmm(weights, ref_new).permute(1, 0, 2).contiguous()
+        return self.fc(x_new.view(n, -1))
+
     def forward(self, x, ref_x, ref_side=None):
         """x [N, C] key-frame proposal features, ref_x [M, C] reference ones -> [N, C] (selsa_aggregator.py:29-73)."""
         _gpu(x, ref_x)
+        if torch.is_grad_enabled() and ref_side is None and (x.requires_grad or ref_x.requires_grad or any(p.requires_grad for p in self.parameters())):
+            return self.forward_autograd(x, ref_x)
         n, m, nb = x.shape[0], ref_x.shape[0], self.num_attention_blocks
         r_embed, r_new = self.ref_side(ref_x) if ref_side is None else ref_side
         x_new = selsa_attention(_lin(self.fc_embed, x), r_embed, r_new, nb)
@@ -139,6 +152,13 @@ class SelsaBBoxHead(nn.Module):
         self.fc_cls = nn.Linear(fc_out_channels, num_classes + 1)
         self.fc_reg = nn.Linear(fc_out_channels, 4 if reg_class_agnostic else 4 * num_classes)
         self.aggregator = nn.ModuleList([build_aggregator(aggregator) for _ in range(num_shared_fcs)])
+        from .registry import LOSSES
+        self.reg_decoded_bbox = reg_decoded_bbox
+        if reg_decoded_bbox:
+            raise NotImplementedError('SelsaBBoxHead: reg_decoded_bbox (IoU losses on decoded boxes) is not on this path')
+        # bbox_head.py:28-36 defaults
+        self.loss_cls = build(dict(loss_cls or dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0)), LOSSES)
+        self.loss_bbox = build(dict(loss_bbox or dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0)), LOSSES)
 
     def init_weights(self):                      # bbox_head.py:93-101, convfc_bbox_head.py:119-127
         nn.init.normal_(self.fc_cls.weight, 0, 0.01); nn.init.constant_(self.fc_cls.bias, 0)
@@ -163,10 +183,73 @@ class SelsaBBoxHead(nn.Module):
     def cat_branches(a, b):
         return [tuple(torch.cat((u, v), 0) for u, v in zip(la, lb)) for la, lb in zip(a, b)]
 
+    def forward_autograd(self, x, ref_x):
+        """selsa_bbox_head.py:60-84 with torch's differentiable ops (training): both RoI feature sets carry gradient back to the
+        feature maps through RoIAlign's backward."""
+        x, ref_x = x.flatten(1), ref_x.flatten(1)
+        for i, fc in enumerate(self.shared_fcs):
+            x = fc(x)
+            ref_x = fc(ref_x)
+            x = x + self.aggregator[i].forward_autograd(x, ref_x)
+            ref_x = F.relu(ref_x)
+            x = F.relu(x)
+        return self.fc_cls(x), self.fc_reg(x)
+
+    def _get_target_single(self, pos_bboxes, neg_bboxes, pos_gt_bboxes, pos_gt_labels, cfg):
+        """bbox_head.py:103-150"""
+        from .training import _bbox2delta
+        num_pos, num_neg = pos_bboxes.size(0), neg_bboxes.size(0)
+        num_samples = num_pos + num_neg
+        labels = pos_bboxes.new_full((num_samples,), self.num_classes, dtype=torch.long)
+        label_weights = pos_bboxes.new_zeros(num_samples)
+        bbox_targets = pos_bboxes.new_zeros(num_samples, 4)
+        bbox_weights = pos_bboxes.new_zeros(num_samples, 4)
+        if num_pos > 0:
+            labels[:num_pos] = pos_gt_labels
+            pw = cfg['pos_weight'] if isinstance(cfg, dict) else cfg.pos_weight
+            label_weights[:num_pos] = 1.0 if pw <= 0 else pw
+            bbox_targets[:num_pos, :] = _bbox2delta(pos_bboxes, pos_gt_bboxes, self.bbox_coder.means, self.bbox_coder.stds)
+            bbox_weights[:num_pos, :] = 1
+        if num_neg > 0:
+            label_weights[-num_neg:] = 1.0
+        return labels, label_weights, bbox_targets, bbox_weights
+
+    def get_targets(self, sampling_results, gt_bboxes, gt_labels, rcnn_train_cfg, concat=True):
+        """bbox_head.py:152-207"""
+        outs = [self._get_target_single(r.pos_bboxes, r.neg_bboxes, r.pos_gt_bboxes, r.pos_gt_labels, rcnn_train_cfg) for r in sampling_results]
+        cols = list(zip(*outs))
+        if concat:
+            return tuple(torch.cat(c, 0) for c in cols)
+        return tuple(list(c) for c in cols)
+
+    def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights, reduction_override=None):
+        """bbox_head.py:209-268: softmax cross entropy over all sampled RoIs (llv_softmax_ce), box loss over the positives' own class."""
+        from .losses import accuracy
+        losses = dict()
+        if cls_score is not None:
+            avg_factor = max(torch.sum(label_weights > 0).float().item(), 1.)
+            if cls_score.numel() > 0:
+                losses['loss_cls'] = self.loss_cls(cls_score, labels, label_weights, avg_factor=avg_factor, reduction_override=reduction_override)
+                losses['acc'] = accuracy(cls_score, labels)
+        if bbox_pred is not None:
+            pos_inds = (labels >= 0) & (labels < self.num_classes)
+            if pos_inds.any():
+                if self.reg_class_agnostic:
+                    pos_bbox_pred = bbox_pred.view(bbox_pred.size(0), 4)[pos_inds]
+                else:
+                    pos_bbox_pred = bbox_pred.view(bbox_pred.size(0), -1, 4)[pos_inds, labels[pos_inds]]
+                losses['loss_bbox'] = self.loss_bbox(pos_bbox_pred, bbox_targets[pos_inds], bbox_weights[pos_inds], avg_factor=bbox_targets.size(0),
+                                                     reduction_override=reduction_override)
+            else:
+                losses['loss_bbox'] = bbox_pred[pos_inds].sum()
+        return losses
+
     def forward(self, x, ref_x, ref_branch=None):
         """x [N, C, H, W] key-frame RoI features, ref_x [M, C, H, W] (or None with a precomputed `ref_branch` over the same M rows)
         -> (cls_score [N, classes+1], bbox_pred [N, 4*classes])."""
         _gpu(x, ref_x)
+        if torch.is_grad_enabled() and ref_branch is None and ref_x is not None and (x.requires_grad or ref_x.requires_grad):
+            return self.forward_autograd(x, ref_x)
         if ref_branch is None:
             ref_branch = self.ref_branch(ref_x)
         x = x.flatten(1)
@@ -217,6 +300,11 @@ class SelsaRoIHead(nn.Module):
         self.bbox_roi_extractor = build(bbox_roi_extractor, ROI_EXTRACTORS)
         self.bbox_head = build(bbox_head, HEADS)
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
+        self.bbox_assigner = self.bbox_sampler = None
+        if train_cfg:                                    # base_roi_head.py init_assigner_sampler (standard_roi_head.py:18-25)
+            from .registry import build_assigner, build_sampler
+            self.bbox_assigner = build_assigner(train_cfg['assigner'])
+            self.bbox_sampler = build_sampler(train_cfg['sampler'], context=self)
 
     with_bbox, with_mask = True, False
 
@@ -248,8 +336,33 @@ class SelsaRoIHead(nn.Module):
             cls_score, bbox_pred = self.bbox_head(bbox_feats, ref_bbox_feats)
         return dict(cls_score=cls_score, bbox_pred=bbox_pred, bbox_feats=bbox_feats)
 
-    def forward_train(self, *a, **k):
-        raise LlvError('SelsaRoIHead.forward_train: the two-stage training path is not built')
+    def forward_train(self, x, ref_x, img_metas, proposal_list, ref_proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None):
+        """selsa_roi_head.py:10-72: assign + sample the key frame's proposals, then _bbox_forward_train. x / ref_x: tuples of NCHW fp32
+        feature maps that carry gradient (two_stage_train.TwoStageBody's outputs); the RoIs do not."""
+        if self.bbox_assigner is None:
+            raise LlvError('SelsaRoIHead.forward_train needs train_cfg (assigner, sampler, pos_weight)')
+        num_imgs = len(img_metas)
+        if gt_bboxes_ignore is None:
+            gt_bboxes_ignore = [None for _ in range(num_imgs)]
+        sampling_results = []
+        for i in range(num_imgs):
+            props = proposal_list[i].detach()
+            assign_result = self.bbox_assigner.assign(props[:, :4].contiguous(), gt_bboxes[i], gt_bboxes_ignore[i], gt_labels[i])
+            sampling_results.append(self.bbox_sampler.sample(assign_result, props, gt_bboxes[i], gt_labels[i]))
+        losses = dict()
+        bbox_results = self._bbox_forward_train(x, ref_x, sampling_results, ref_proposal_list, gt_bboxes, gt_labels)
+        losses.update(bbox_results['loss_bbox'])
+        return losses
+
+    def _bbox_forward_train(self, x, ref_x, sampling_results, ref_proposal_list, gt_bboxes, gt_labels):
+        """selsa_roi_head.py:94-111"""
+        rois = bbox2roi([res.bboxes for res in sampling_results])
+        ref_rois = bbox2roi([p.detach() for p in ref_proposal_list])
+        bbox_results = self._bbox_forward(x, ref_x, rois, ref_rois)
+        bbox_targets = self.bbox_head.get_targets(sampling_results, gt_bboxes, gt_labels, self.train_cfg)
+        loss_bbox = self.bbox_head.loss(bbox_results['cls_score'], bbox_results['bbox_pred'], rois, *bbox_targets)
+        bbox_results.update(loss_bbox=loss_bbox)
+        return bbox_results
 
     def simple_test_bboxes(self, x, ref_x, proposals, ref_proposals, img_metas, rcnn_test_cfg, rescale=False, static_refs=0, cache=None):
         """selsa_roi_head.py:134-187."""
@@ -326,7 +439,8 @@ class TwoStageDetector(BaseDetector):
         return self.neck(x)
 
     def forward_train(self, *a, **k):
-        raise LlvError('two-stage training is not built')
+        raise LlvError('the two-stage detector is trained through the SELSA video detectors here (SELSA / SelsaFastDVDnetDetect.forward_train: '
+                       'key + reference frames); a single-image Faster R-CNN step is outside SURVEY section 8')
 
     def simple_test(self, img, img_metas, proposals=None, rescale=False):
         raise LlvError('the two-stage detector is driven by the SELSA video detector here (key + reference frames)')
@@ -398,8 +512,14 @@ class SELSA(BaseVideoDetector):
         dets, labels = plan.run(img)
         return dict(bbox_results=bbox2result(dets, labels, self.detector.roi_head.bbox_head.num_classes))
 
-    def forward_train(self, *a, **k):
-        raise LlvError('SELSA.forward_train: the two-stage training path is not built')
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, ref_img, ref_img_metas, ref_gt_bboxes=None, ref_gt_labels=None,
+                      gt_instance_ids=None, gt_bboxes_ignore=None, gt_masks=None, proposals=None, ref_gt_instance_ids=None,
+                      ref_gt_bboxes_ignore=None, ref_gt_masks=None, ref_proposals=None, **kwargs):
+        """selsa.py:47-170 (two_stage_train.selsa_forward_train: every convolution on the conv engine's training graph, RoIAlign
+        forward / backward kernels, the RoI head's GEMMs under autograd)."""
+        from .two_stage_train import selsa_forward_train
+        return selsa_forward_train(self, img, img_metas, gt_bboxes, gt_labels, ref_img, ref_img_metas, ref_gt_bboxes, ref_gt_labels,
+                                   gt_bboxes_ignore=gt_bboxes_ignore, proposals=proposals, ref_proposals=ref_proposals)
 
     def extract_feats(self, img, img_metas, ref_img, ref_img_metas):
         """selsa.py:172-258."""
@@ -512,8 +632,13 @@ class SelsaFastDVDnetDetect(BaseVideoDetector):
         super().invalidate_plans()
         self.memo = None
 
-    def forward_train(self, *a, **k):
-        raise LlvError('SelsaFastDVDnetDetect.forward_train: the two-stage training path is not built')
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, ref_img, ref_img_metas, ref_gt_bboxes=None, ref_gt_labels=None,
+                      gt_instance_ids=None, gt_bboxes_ignore=None, gt_masks=None, proposals=None, ref_gt_instance_ids=None,
+                      ref_gt_bboxes_ignore=None, ref_gt_masks=None, ref_proposals=None, **kwargs):
+        """selsa_fastdvd_darkfarm.py:65-227 (two_stage_train.selsa_fastdvd_forward_train; the cleaner is frozen)."""
+        from .two_stage_train import selsa_fastdvd_forward_train
+        return selsa_fastdvd_forward_train(self, img, img_metas, gt_bboxes, gt_labels, ref_img, ref_img_metas, ref_gt_bboxes, ref_gt_labels,
+                                           gt_bboxes_ignore=gt_bboxes_ignore, proposals=proposals, ref_proposals=ref_proposals)
 
     def denoise_cyclic(self, noise_imgs):
         """noise_imgs (5, 3, H, W) fp32 on the GPU -> (5, 3, H, W): frame i denoised from the stack of frames (i-2 .. i+2) mod 5

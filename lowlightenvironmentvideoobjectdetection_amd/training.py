@@ -58,8 +58,16 @@ def get_targets_single(head, flat_anchors, valid_flags, gt_bboxes, gt_labels, im
     gt_inds, _ = ops.iou_assign(gt_bboxes, flat_anchors, inside, a.pos_iou_thr, a.neg_iou_thr, a.min_pos_iou,
                                 a.match_low_quality, a.gt_max_assign_all)
     n = flat_anchors.shape[0]
-    pos_inds = torch.nonzero(gt_inds > 0, as_tuple=False).squeeze(-1)
-    neg_inds = torch.nonzero(gt_inds == 0, as_tuple=False).squeeze(-1)
+    sampler = getattr(head, 'sampler', None)
+    if head.sampling and sampler is not None and type(sampler).__name__ != 'PseudoSampler':
+        # anchor_head.py:217-219 with a real sampler (the RPN: RandomSampler(num=256, pos_fraction=0.5, add_gt_as_proposals=False)):
+        # anchors outside the image carry gt_inds == -1 and are neither positives nor negatives
+        from .core.assign import AssignResult
+        sr = sampler.sample(AssignResult(gt_bboxes.shape[0], gt_inds, None, None), flat_anchors, gt_bboxes)
+        pos_inds, neg_inds = sr.pos_inds, sr.neg_inds
+    else:
+        pos_inds = torch.nonzero(gt_inds > 0, as_tuple=False).squeeze(-1)
+        neg_inds = torch.nonzero(gt_inds == 0, as_tuple=False).squeeze(-1)
     bbox_targets = torch.zeros_like(flat_anchors)
     bbox_weights = torch.zeros_like(flat_anchors)
     labels = flat_anchors.new_full((n,), head.num_classes, dtype=torch.long)
