@@ -505,6 +505,9 @@ def main():
                     help="infer mode, N > 1 ranks: 'frames' (default) = ONE clip of clip-frames * N frames cut into N contiguous segments, "
                          "each rank its segment + 2+2 halo frames (north_star: clips shard by frame); 'clips' = every rank its own "
                          'clip of clip-frames frames (whole-video sharding, the reference\'s DistributedVideoSampler unit)')
+    ap.add_argument('--dump-launches', default=None,
+                    help='write the timed plan\'s launch list (step name, device kernel, algorithmic flops / bytes) as JSON: '
+                         'tools/traffic_from_pmc.py attributes the PMC bytes of every dispatch to its step with it')
     ap.add_argument('--dump-results', default=None,
                     help="write the detections of every frame of the clip, gathered on rank 0 in frame order, to this .npz ('frames' sharding)")
     args = ap.parse_args()
@@ -616,6 +619,11 @@ def main():
     else:
         plan.prepare(clip, zero_copy=not args.copy_window)      # the window is read in place: no copy inside or in front of the graph
     n_windows = T - B + 1
+    if args.dump_launches and rank == 0:
+        pl = plan.plan if hasattr(plan, 'plan') else None
+        if pl is not None:
+            with open(args.dump_launches, 'w') as f:
+                json.dump([dict(name=n, kernel=pl.kernel_of.get(n, ''), flops=fl, bytes=nb) for (n, _, _, fl, nb) in pl.steps], f, indent=0)
 
     def run_steps(k, start=0):
         for s in range(k):
@@ -792,6 +800,9 @@ def main():
         if not args.no_kernel_timing:
             timed = plan.plan.run_timed(iters=5)
             kof = plan.plan.kernel_of
+            if args.dump_launches:
+                with open(args.dump_launches, 'w') as f:
+                    json.dump([dict(name=n, kernel=kof.get(n, ''), flops=fl, bytes=nb, ms=ms) for (n, ms, fl, nb) in timed], f, indent=0)
             per = {}
             for (n, ms, fl, nb) in timed:
                 if fl <= 0:

@@ -1167,9 +1167,25 @@ __global__ __launch_bounds__(256) void conv3x3_halo_kernel(const ConvKArgs a, co
 //         2 weight buffers (BN x 64 B); everything issued in step s has landed before step s+1 starts (vmcnt(0)).
 // Weights are the ordinary [row][k_pad] packing with k = tap*Cin + c (same buffer the implicit GEMM reads).
 // ------------------------------------------------------------------------------------------------
+// Dispatch order of the tap kernels: the grid is one-dimensional in (spatial tile, n-tile); hardware deals workgroup L to XCD L & 7.
+// Every XCD walks ITS contiguous run of spatial tiles with the n-tiles of one spatial tile next to each other (n fastest), so the
+// workgroups that read the same halo run at the same time behind the same L2. With n-tiles in blockIdx.y the second n-tile of a
+// spatial tile started a whole grid later and re-read the input from HBM (measured per launch, profiles/r03a_traffic.txt: UpBlock
+// convs 2.2x / 3.1x, retina_cls 4.8x the algorithmic bytes). The grid is padded to 8 * ceil(nblk / 8) * ntn; the (< 8 * ntn)
+// workgroups without a tile return at once.
+__device__ __forceinline__ bool tap_dispatch(int lin, int nblk, int ntn, int& bid, int& tile_n) {
+    const int q = nblk >> 3, r = nblk & 7, xcd = lin & 7, idx = lin >> 3;
+    tile_n = idx % ntn;
+    const int sl = idx / ntn;
+    if (sl >= (xcd < r ? q + 1 : q)) return false;
+    bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + sl;
+    return true;
+}
+static inline unsigned tap_grid_x(int nblk, int ntn) { return 8u * (unsigned)((nblk + 7) / 8) * (unsigned)ntn; }
+
 struct TapArgs {
     int tiles_x[LLV_MAX_SEG], tiles_y[LLV_MAX_SEG], blk0[LLV_MAX_SEG + 1];
-    int nblk, n_chunks;
+    int nblk, n_chunks, ntn;     // ntn = n-tiles (output-channel tiles) per group
     unsigned x_bytes, w_bytes;   // sizes of the source tensors / weight buffer (buffer-resource bounds, < 2 GiB)
 };
 
@@ -1213,12 +1229,8 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
     __shared__ __attribute__((aligned(16))) unsigned char smem[SMEM];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-    int bid = blockIdx.x;
-    {
-        const int nblk = h.nblk;
-        const int q = nblk >> 3, r = nblk & 7, xcd = bid & 7, idx = bid >> 3;
-        bid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + idx;
-    }
+    int bid, tile_n;
+    if (!tap_dispatch(blockIdx.x, h.nblk, h.ntn, bid, tile_n)) return;
     int seg = 0;
 #pragma unroll
     for (int s = 1; s < LLV_MAX_SEG; ++s)
@@ -1229,7 +1241,6 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
     const int t1 = local / h.tiles_x[seg];
     const int ty0 = (t1 % h.tiles_y[seg]) * HALO_TH;
     const int n = t1 / h.tiles_y[seg];
-    const int tile_n = blockIdx.y;
     const int g = blockIdx.z;                                // group: input channels [g*Cin, ..), its own weight block
     const int img_base = a.seg_xoff[seg] + n * H * W;        // pixel index of this image's (0, 0)
 
@@ -2250,6 +2261,7 @@ static void fill_tap(const llv_conv_desc* d, TapArgs& h) {
     }
     h.blk0[LLV_MAX_SEG] = blk;
     h.nblk = blk;
+    h.ntn = 1;
     h.n_chunks = d->cin / 32;
     h.x_bytes = (unsigned)tap_x_bytes(d);
     h.w_bytes = (unsigned)((size_t)d->w_rows * d->k_pad * 2);
@@ -2260,7 +2272,8 @@ int launch_tap(ConvKArgs& k, const llv_conv_desc* d, hipStream_t st) {
     TapArgs h;
     fill_tap(d, h);
     k.k_splits = 1;
-    dim3 grid(h.nblk, (d->cout + BN - 1) / BN, d->groups);
+    h.ntn = (d->cout + BN - 1) / BN;
+    dim3 grid(tap_grid_x(h.nblk, h.ntn), 1, d->groups);
     if (d->n_src > 1) hipLaunchKernelGGL((conv3x3_tap_kernel<BN, R, true>), grid, dim3(256), 0, st, k, h);
     else hipLaunchKernelGGL((conv3x3_tap_kernel<BN, R, false>), grid, dim3(256), 0, st, k, h);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
