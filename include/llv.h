@@ -379,6 +379,31 @@ int llv_iou_assign(const float* gt, int k, const float* anchors, const uint8_t* 
                    int gt_max_assign_all, int64_t* assigned_gt_inds, float* max_overlaps, void* workspace,
                    size_t workspace_bytes, void* stream);
 
+/* The dense head's loss in one pass (AnchorHead.loss with FocalLoss + L1Loss / SmoothL1Loss and PseudoSampler:
+ * mmdetection/mmdet/models/dense_heads/anchor_head.py:175-271,375-493, losses/focal_loss.py:160-181, smooth_l1_loss.py:8-45,
+ * core/bbox/coder/delta_xywh_bbox_coder.py:88-130). cls / reg: the fp32 logit / delta buffers of all levels, pixel-major (level l of
+ * image n starts at row level_off[l] + n * level_h[l] * level_w[l]; anchor a of a pixel owns cls columns [a*C, (a+1)*C) and reg
+ * columns [4a, 4a+4)). gt_inds (batch, anchors_per_image): llv_iou_assign's output per image in mmdet's anchor order (level-major,
+ * then y, x, a; level_anchor0[l] = first anchor of level l). Outputs: losses[0..L) = loss_cls per level, losses[L..2L) = loss_bbox per
+ * level (already * loss_weight / avg_factor); dcls / dreg (fp16, written, not added) = d(sum of all terms)/d(logit) * grad_scale;
+ * avg_factor (device scalar) = sum over images of max(#positives, 1). sums: 2L floats of scratch. beta = 0: L1, > 0: smooth L1. */
+typedef struct llv_retina_loss_desc {
+    const float* cls; const float* reg;
+    void* dcls; void* dreg;
+    int cls_ld, reg_ld, dcls_ld, dreg_ld;
+    int batch, n_levels, num_anchors, num_classes;
+    int level_h[LLV_MAX_SEG], level_w[LLV_MAX_SEG];
+    int64_t level_off[LLV_MAX_SEG], level_anchor0[LLV_MAX_SEG];
+    int64_t anchors_per_image;
+    const float* anchors;
+    const int64_t* gt_inds;
+    const float* gt_boxes; const int64_t* gt_labels; int max_gt;
+    float gamma, alpha, cls_weight, reg_weight, beta, pos_weight, grad_scale;
+    float means[4], stds[4];
+    float* sums; float* avg_factor; float* losses;
+} llv_retina_loss_desc;
+int llv_retina_loss(const llv_retina_loss_desc* desc, void* stream);
+
 /* Modulated deformable convolution, column step (ModulatedDCNPack.forward, denoising_aggregator.py:103-111 ->
  * mmcv.ops.modulated_deform_conv2d): x (n,h,w,x_ld) NHWC fp16 (c channels used, c % 8 == 0, (c/deform_groups) % 8 == 0);
  * om (n,ho,wo,om_ld) fp32 = the raw conv_offset output: channels [0, 2*dg*K) offsets, (g*K + k)*2 = dy, +1 = dx; channels
@@ -580,6 +605,25 @@ int llv_fold_bias(const float* b, const float* gamma, const float* beta, const f
 int llv_unpack_wgrad(const float* dw, const float* db, const float* w, const float* gamma, const float* mean, const float* var,
                      float eps, float* gw, float* ggamma, float* gbeta, float* gbias, int cout, int cin, int kh, int kw,
                      int cpad, int k_pad, void* stream);
+
+/* The three bookkeeping launches above over tables of jobs that live in DEVICE memory (one launch per table, blockIdx.y = job): the
+ * fields of a job are the arguments of the single-job entry point of the same name. blocks_per_job: workgroups of 256 threads each
+ * job is given (it loops; size it for the largest job). Pointers inside the jobs are device pointers the caller keeps valid. */
+typedef struct llv_pack_job {
+    const float* w; const float* gamma; const float* var; float eps; void* dst;
+    int cout, cin, kh, kw, cpad, k_pad, row0, mode, pad, KH, KW, padp, rows;
+} llv_pack_job;
+typedef struct llv_fold_job {
+    const float* b; const float* gamma; const float* beta; const float* mean; const float* var; float eps; float* out; int n;
+} llv_fold_job;
+typedef struct llv_unpack_job {
+    const float* dw; const float* db; const float* w; const float* gamma; const float* mean; const float* var; float eps;
+    float* gw; float* ggamma; float* gbeta; float* gbias;
+    int cout, cin, kh, kw, cpad, k_pad;
+} llv_unpack_job;
+int llv_pack_conv_weights_batched(const llv_pack_job* jobs, int n_jobs, int blocks_per_job, void* stream);
+int llv_fold_bias_batched(const llv_fold_job* jobs, int n_jobs, int blocks_per_job, void* stream);
+int llv_unpack_wgrad_batched(const llv_unpack_job* jobs, int n_jobs, int blocks_per_job, void* stream);
 
 /* dx (+)= data gradient of the convolution described by `fwd` (its x/w/y pointers are not read; geometry, groups, batch and
  * segments are). w_dgrad: filter packed by llv_pack_conv_weights mode 1 (stride 1) or 2 (stride 2) with wd_rows x wd_k_pad,

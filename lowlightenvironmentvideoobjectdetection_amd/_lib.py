@@ -57,6 +57,40 @@ class BottleneckDesc(C.Structure):
                 ('x_ld', C.c_int32), ('y_ld', C.c_int32)]
 
 
+class PackJob(C.Structure):
+    """llv_pack_job"""
+    _fields_ = [('w', C.c_void_p), ('gamma', C.c_void_p), ('var', C.c_void_p), ('eps', C.c_float), ('dst', C.c_void_p)] + \
+               [(n, C.c_int32) for n in ('cout', 'cin', 'kh', 'kw', 'cpad', 'k_pad', 'row0', 'mode', 'pad', 'KH', 'KW', 'padp', 'rows')]
+
+
+class FoldJob(C.Structure):
+    """llv_fold_job"""
+    _fields_ = [('b', C.c_void_p), ('gamma', C.c_void_p), ('beta', C.c_void_p), ('mean', C.c_void_p), ('var', C.c_void_p), ('eps', C.c_float),
+                ('out', C.c_void_p), ('n', C.c_int32)]
+
+
+class UnpackJob(C.Structure):
+    """llv_unpack_job"""
+    _fields_ = [('dw', C.c_void_p), ('db', C.c_void_p), ('w', C.c_void_p), ('gamma', C.c_void_p), ('mean', C.c_void_p), ('var', C.c_void_p),
+                ('eps', C.c_float), ('gw', C.c_void_p), ('ggamma', C.c_void_p), ('gbeta', C.c_void_p), ('gbias', C.c_void_p)] + \
+               [(n, C.c_int32) for n in ('cout', 'cin', 'kh', 'kw', 'cpad', 'k_pad')]
+
+
+class RetinaLossDesc(C.Structure):
+    """llv_retina_loss_desc (include/llv.h)."""
+    _fields_ = [('cls', C.c_void_p), ('reg', C.c_void_p), ('dcls', C.c_void_p), ('dreg', C.c_void_p),
+                ('cls_ld', C.c_int32), ('reg_ld', C.c_int32), ('dcls_ld', C.c_int32), ('dreg_ld', C.c_int32),
+                ('batch', C.c_int32), ('n_levels', C.c_int32), ('num_anchors', C.c_int32), ('num_classes', C.c_int32),
+                ('level_h', C.c_int32 * LLV_MAX_SEG), ('level_w', C.c_int32 * LLV_MAX_SEG),
+                ('level_off', C.c_int64 * LLV_MAX_SEG), ('level_anchor0', C.c_int64 * LLV_MAX_SEG),
+                ('anchors_per_image', C.c_int64),
+                ('anchors', C.c_void_p), ('gt_inds', C.c_void_p), ('gt_boxes', C.c_void_p), ('gt_labels', C.c_void_p), ('max_gt', C.c_int32),
+                ('gamma', C.c_float), ('alpha', C.c_float), ('cls_weight', C.c_float), ('reg_weight', C.c_float), ('beta', C.c_float),
+                ('pos_weight', C.c_float), ('grad_scale', C.c_float),
+                ('means', C.c_float * 4), ('stds', C.c_float * 4),
+                ('sums', C.c_void_p), ('avg_factor', C.c_void_p), ('losses', C.c_void_p)]
+
+
 class ConvDesc(C.Structure):
     _fields_ = [
         ('x', C.c_void_p * LLV_MAX_SRC),
@@ -197,6 +231,10 @@ SIGNATURES = {
     'llv_bias_grad': (_I, [_P, _L, _I, _I, _P, _P]),
     'llv_upsample_add_bwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'llv_sgd_momentum': (_I, [_P, _P, _P, _L, _F, _F, _F, _F, _I, _P]),
+    'llv_retina_loss': (_I, [_P, _P]),
+    'llv_pack_conv_weights_batched': (_I, [_P, _I, _I, _P]),
+    'llv_fold_bias_batched': (_I, [_P, _I, _I, _P]),
+    'llv_unpack_wgrad_batched': (_I, [_P, _I, _I, _P]),
 }
 
 _lib = None

@@ -158,17 +158,90 @@ def _p(t):
     return t.data_ptr() if t is not None else None
 
 
+class JobRecorder:
+    """While active, pack_weights / fold_bias / unpack_wgrad_device record their arguments as jobs instead of launching: the
+    training graph replays its bookkeeping once under a recorder and from then on launches each table with ONE call
+    (llv_*_batched). The recorded pointers are those of the live parameter / buffer / gradient tensors: `signature` lets the owner
+    notice when one of them moved (load_state_dict into new storage, TrainStep's flat buffers) and record again."""
+    active = None
+
+    def __init__(self):
+        self.pack, self.fold, self.unpack, self.tensors = [], [], [], []
+
+    def __enter__(self):
+        assert JobRecorder.active is None
+        JobRecorder.active = self
+        return self
+
+    def __exit__(self, *exc):
+        JobRecorder.active = None
+
+    def note(self, *ts):
+        self.tensors += [t for t in ts if t is not None]
+
+    def signature(self):
+        return tuple(t.data_ptr() for t in self.tensors)
+
+
+class JobTables:
+    """Device copies of a recorder's job lists + their launches."""
+
+    def __init__(self, rec: JobRecorder, device):
+        import ctypes as C
+        import numpy as np
+        self.rec = rec
+        self.sig = rec.signature()
+
+        def table(jobs, ty):
+            if not jobs:
+                return None
+            arr = (ty * len(jobs))(*jobs)
+            return torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(device)
+        from ._lib import FoldJob, PackJob, UnpackJob
+        self.n = (len(rec.pack), len(rec.fold), len(rec.unpack))
+        self.t_pack, self.t_fold, self.t_unpack = table(rec.pack, PackJob), table(rec.fold, FoldJob), table(rec.unpack, UnpackJob)
+        self.b_pack = max([1] + [min(512, ((j.cout * j.kh * j.kw * j.cpad if j.mode == 0 else j.rows * j.KH * j.KW * j.cout) + 255) // 256)
+                                 for j in rec.pack])
+        self.b_fold = max([1] + [min(64, (j.n + 255) // 256) for j in rec.fold])
+        self.b_unpack = max([1] + [j.cout for j in rec.unpack])
+
+    def valid(self):
+        return self.sig == self.rec.signature()
+
+    def launch(self):
+        L, st = lib(), _stream()
+        if self.t_pack is not None:
+            check(L.llv_pack_conv_weights_batched(self.t_pack.data_ptr(), self.n[0], self.b_pack, st), 'llv_pack_conv_weights_batched')
+        if self.t_fold is not None:
+            check(L.llv_fold_bias_batched(self.t_fold.data_ptr(), self.n[1], self.b_fold, st), 'llv_fold_bias_batched')
+        if self.t_unpack is not None:
+            check(L.llv_unpack_wgrad_batched(self.t_unpack.data_ptr(), self.n[2], self.b_unpack, st), 'llv_unpack_wgrad_batched')
+
+
 def pack_weights(w: torch.Tensor, gamma, var, eps: float, dst: torch.Tensor, *, cpad: int, k_pad: int, row0: int, mode: int,
                  pad: int = 0, KH: int = 1, KW: int = 1, padp: int = 0, rows: int = 1):
     """llv_pack_conv_weights: (Cout,Cin,kh,kw) fp32 parameter (+ eval-mode BN scale) -> one block of a packed fp16 weight
     tensor (dst = the group's [w_rows][k_pad] matrix). mode 0 forward, 1 / 2 data gradient of a stride-1 / stride-2 conv."""
     cout, cin, kh, kw = w.shape
     assert w.is_contiguous() and w.dtype == torch.float32 and dst.dtype == torch.float16
+    rec = JobRecorder.active
+    if rec is not None:
+        from ._lib import PackJob
+        rec.pack.append(PackJob(w.data_ptr(), _p(gamma), _p(var), float(eps), dst.data_ptr(), cout, cin, kh, kw, cpad, k_pad, row0, mode, pad, KH, KW,
+                                padp, rows))
+        rec.note(w, gamma, var, dst)
+        return
     check(lib().llv_pack_conv_weights(w.data_ptr(), _p(gamma), _p(var), float(eps), dst.data_ptr(), cout, cin, kh, kw, cpad, k_pad,
                                       row0, mode, pad, KH, KW, padp, rows, _stream()), 'llv_pack_conv_weights')
 
 
 def fold_bias(b, gamma, beta, mean, var, eps: float, out: torch.Tensor):
+    rec = JobRecorder.active
+    if rec is not None:
+        from ._lib import FoldJob
+        rec.fold.append(FoldJob(_p(b), _p(gamma), _p(beta), _p(mean), _p(var), float(eps), out.data_ptr(), out.numel()))
+        rec.note(b, gamma, beta, mean, var, out)
+        return
     check(lib().llv_fold_bias(_p(b), _p(gamma), _p(beta), _p(mean), _p(var), float(eps), out.data_ptr(), out.numel(), _stream()),
           'llv_fold_bias')
 
@@ -177,5 +250,12 @@ def unpack_wgrad_device(dw: torch.Tensor, db, w: torch.Tensor, gamma, mean, var,
                         cpad: int, k_pad: int):
     """llv_unpack_wgrad: rows of the packed fp32 gradient (dw: first row of the part) -> parameter gradients."""
     cout, cin, kh, kw = w.shape
+    rec = JobRecorder.active
+    if rec is not None:
+        from ._lib import UnpackJob
+        rec.unpack.append(UnpackJob(dw.data_ptr(), _p(db), w.data_ptr(), _p(gamma), _p(mean), _p(var), float(eps), _p(gw), _p(ggamma), _p(gbeta),
+                                    _p(gbias), cout, cin, kh, kw, cpad, k_pad))
+        rec.note(dw, db, w, gamma, mean, var, gw, ggamma, gbeta, gbias)
+        return
     check(lib().llv_unpack_wgrad(dw.data_ptr(), _p(db), w.data_ptr(), _p(gamma), _p(mean), _p(var), float(eps), _p(gw), _p(ggamma),
                                  _p(gbeta), _p(gbias), cout, cin, kh, kw, cpad, k_pad, _stream()), 'llv_unpack_wgrad')

@@ -335,9 +335,7 @@ struct PackArgs {
     int cout, cin, kh, kw, cpad, k_pad, row0, mode, pad, KH, KW, padp, rows;
 };
 
-__global__ void pack_weights_kernel(const PackArgs a) {
-    const long total = a.mode == 0 ? (long)a.cout * a.kh * a.kw * a.cpad : (long)a.rows * a.KH * a.KW * a.cout;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+__device__ __forceinline__ void pack_one(const PackArgs& a, long idx) {
         if (a.mode == 0) {
             const int i = (int)(idx % a.cpad);
             long t = idx / a.cpad;
@@ -373,6 +371,10 @@ __global__ void pack_weights_kernel(const PackArgs a) {
             a.dst[(long)row * a.k_pad + (dy * a.KW + dx) * a.cpad + a.row0 + o] = (_Float16)v;
         }
     }
+
+__global__ void pack_weights_kernel(const PackArgs a) {
+    const long total = a.mode == 0 ? (long)a.cout * a.kh * a.kw * a.cpad : (long)a.rows * a.KH * a.KW * a.cout;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) pack_one(a, idx);
 }
 
 // folded bias: out[o] = beta[o] + ((b ? b[o] : 0) - mean[o]) * s[o]   (or plain b / 0 without BN)
@@ -395,8 +397,7 @@ struct UnpackArgs {
     int cin, kh, kw, cpad, k_pad;
 };
 
-__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const UnpackArgs a) {
-    const int o = blockIdx.x;
+__device__ __forceinline__ void unpack_one(const UnpackArgs& a, int o) {
     const int n = a.cin * a.kh * a.kw;
     float inv = 1.f, s = 1.f;
     if (a.gamma) { inv = rsqrtf(a.var[o] + a.eps); s = a.gamma[o] * inv; }
@@ -423,6 +424,33 @@ __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const UnpackArgs a) {
         if (a.gbeta) a.gbeta[o] = d;
         if (a.gbias) a.gbias[o] = d * s;
     }
+    __syncthreads();
+}
+
+__global__ __launch_bounds__(256) void unpack_wgrad_kernel(const UnpackArgs a) { unpack_one(a, blockIdx.x); }
+// ---- the same three bookkeeping kernels over a TABLE of jobs in device memory (blockIdx.y = job): a training step re-packs ~120
+// parameter tensors and unpacks ~60 gradients, each a few microseconds of work behind a launch of its own; one launch per table
+// instead (round 3: 250 launches per step -> 3 + one per all-reduce bucket).
+__global__ void pack_weights_batched_kernel(const llv_pack_job* __restrict__ jobs) {
+    const llv_pack_job j = jobs[blockIdx.y];
+    const PackArgs a{j.w, j.gamma, j.var, j.eps, (_Float16*)j.dst, j.cout, j.cin, j.kh, j.kw, j.cpad, j.k_pad, j.row0, j.mode, j.pad, j.KH, j.KW,
+                     j.padp, j.rows};
+    const long total = a.mode == 0 ? (long)a.cout * a.kh * a.kw * a.cpad : (long)a.rows * a.KH * a.KW * a.cout;
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) pack_one(a, idx);
+}
+
+__global__ void fold_bias_batched_kernel(const llv_fold_job* __restrict__ jobs) {
+    const llv_fold_job j = jobs[blockIdx.y];
+    for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < j.n; o += gridDim.x * blockDim.x) {
+        const float bv = j.b ? j.b[o] : 0.f;
+        j.out[o] = j.gamma ? j.beta[o] + (bv - j.mean[o]) * j.gamma[o] * rsqrtf(j.var[o] + j.eps) : bv;
+    }
+}
+
+__global__ __launch_bounds__(256) void unpack_wgrad_batched_kernel(const llv_unpack_job* __restrict__ jobs) {
+    const llv_unpack_job j = jobs[blockIdx.y];
+    const UnpackArgs a{j.dw, j.db, j.w, j.gamma, j.mean, j.var, j.eps, j.gw, j.ggamma, j.gbeta, j.gbias, j.cin, j.kh, j.kw, j.cpad, j.k_pad};
+    for (int o = blockIdx.x; o < j.cout; o += gridDim.x) unpack_one(a, o);      // workgroup-uniform loop: the barriers inside are safe
 }
 
 }  // namespace
@@ -569,4 +597,22 @@ extern "C" int llv_conv2d_nhwc_dgrad(const llv_conv_desc* fwd, const void* w_dgr
     if (s2) { d.ps_out_h = fwd->seg_h[0]; d.ps_out_w = fwd->seg_w[0]; }
     d.workspace = workspace; d.workspace_bytes = workspace_bytes;
     return llv_conv2d_nhwc_fwd(&d, stream);
+}
+
+extern "C" int llv_pack_conv_weights_batched(const llv_pack_job* jobs, int n_jobs, int blocks_per_job, void* stream) {
+    if (!jobs || n_jobs < 1 || n_jobs > 65535 || blocks_per_job < 1) return LLV_E_BADARG;
+    hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(blocks_per_job > 4096 ? 4096 : blocks_per_job, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_fold_bias_batched(const llv_fold_job* jobs, int n_jobs, int blocks_per_job, void* stream) {
+    if (!jobs || n_jobs < 1 || n_jobs > 65535 || blocks_per_job < 1) return LLV_E_BADARG;
+    hipLaunchKernelGGL(fold_bias_batched_kernel, dim3(blocks_per_job > 64 ? 64 : blocks_per_job, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_unpack_wgrad_batched(const llv_unpack_job* jobs, int n_jobs, int blocks_per_job, void* stream) {
+    if (!jobs || n_jobs < 1 || n_jobs > 65535 || blocks_per_job < 1) return LLV_E_BADARG;
+    hipLaunchKernelGGL(unpack_wgrad_batched_kernel, dim3(blocks_per_job > 2048 ? 2048 : blocks_per_job, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }

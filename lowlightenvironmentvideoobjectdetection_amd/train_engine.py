@@ -17,6 +17,8 @@ op to torch: `loss.backward()` fills `param.grad` of the module, so the referenc
 unchanged; `TrainStep.step_fused()` is the all-device path `bench.py --mode train` measures.
 """
 import ctypes as C
+from collections import OrderedDict
+from collections.abc import Mapping
 from typing import Dict, List
 
 import torch
@@ -88,24 +90,37 @@ class TrainGraph:
                 req.add(_sptr(op['y']))
         self.req = req
         # gradient buffers (fp16), one per activation buffer that needs one; fp32 logits get padded fp16 twins
+        # (one fp16 arena, so that zero_act_grads is one fill instead of one per buffer)
         self.grads: Dict[int, torch.Tensor] = {}
+        shapes = {}
         for op in self.tape:
             p = _sptr(op['y'])
-            if p in req and p not in self.grads:
+            if p in req and p not in shapes:
                 base = bases[p]
-                if base.dtype == torch.float32:
-                    c = base.shape[-1]
-                    self.grads[p] = torch.zeros(base.shape[:-1] + (ops.round_up(c, 8),), dtype=torch.float16, device=device)
-                else:
-                    self.grads[p] = torch.zeros_like(base)
+                shapes[p] = base.shape[:-1] + (ops.round_up(base.shape[-1], 8),) if base.dtype == torch.float32 else tuple(base.shape)
+        sizes = {p: ops.round_up(int(torch.Size(sh).numel()), 64) for p, sh in shapes.items()}
+        self._grad_arena = torch.zeros(sum(sizes.values()), dtype=torch.float16, device=device)
+        o = 0
+        for p, sh in shapes.items():
+            self.grads[p] = self._grad_arena[o:o + int(torch.Size(sh).numel())].view(sh)
+            o += sizes[p]
         # per-launch backward state
+        live = [op for op in self.tape if not op.get('custom') and not op['frozen']]
+        wsz = [ops.round_up(op['pc'].groups * op['pc'].w_rows * op['pc'].k_pad, 64) + ops.round_up(op['pc'].groups * op['pc'].cout, 64) for op in live]
+        self._wgrad_arena = torch.zeros(sum(wsz), dtype=torch.float32, device=device)        # every dW / db: zero_param_grads is one fill
+        o = 0
+        for op, n in zip(live, wsz):
+            pc = op['pc']
+            nw = pc.groups * pc.w_rows * pc.k_pad
+            op['dw'] = self._wgrad_arena[o:o + nw].view(pc.groups, pc.w_rows, pc.k_pad)
+            o2 = o + ops.round_up(nw, 64)
+            op['db'] = self._wgrad_arena[o2:o2 + pc.groups * pc.cout]
+            o += n
+        self._tables = {}
         for op in self.tape:
             if op.get('custom'):
                 continue
             pc = op['pc']
-            if not op['frozen']:
-                op['dw'] = torch.zeros(pc.groups, pc.w_rows, pc.k_pad, dtype=torch.float32, device=device)
-                op['db'] = torch.zeros(pc.groups * pc.cout, dtype=torch.float32, device=device)
             op['need_dx'] = any(_sptr(x) in req for x in op['xs'])
             if op['need_dx']:
                 assert len(op['xs']) == 1 and pc.n_src == 1, 'multi-source launches are not on the training path'
@@ -135,7 +150,7 @@ class TrainGraph:
         if base.dtype == torch.float32:
             assert t.shape == base.shape
             return g
-        return g.as_strided(t.shape, t.stride(), t.storage_offset() - base.storage_offset())
+        return g.as_strided(t.shape, t.stride(), g.storage_offset() + t.storage_offset() - base.storage_offset())
 
     def _trainable_keys(self) -> List[str]:
         keys = []
@@ -170,9 +185,27 @@ class TrainGraph:
         gk, bk, mk, vk = q['bn']
         return self.params[gk].detach(), self.params[bk].detach(), self.buffers[mk], self.buffers[vk]
 
+    def _sig(self):
+        return tuple(t.data_ptr() for t in self.params.values()) + tuple(t.data_ptr() for t in self.buffers.values())
+
+    def _batched(self, key, record, extra_sig=()):
+        """Run `record()` (a sequence of B.pack_weights / fold_bias / unpack_wgrad_device calls) as job tables: recorded once, then one
+        launch per table for as long as no parameter, buffer or destination tensor has moved."""
+        sig = self._sig() + tuple(extra_sig)
+        tab = self._tables.get(key)
+        if tab is None or tab.sig != sig:
+            with B.JobRecorder() as rec:
+                record()
+            tab = self._tables[key] = B.JobTables(rec, self.device)
+            tab.sig = sig
+        tab.launch()
+
     def repack(self):
         """Write the current parameter values into every trainable launch's packed weights (+ its dgrad filter):
-        llv_pack_conv_weights / llv_fold_bias, two or three small launches per parameter tensor."""
+        llv_pack_conv_weights / llv_fold_bias over job tables (two launches; round 2 issued two or three per parameter tensor)."""
+        self._batched('repack', self._repack_each)
+
+    def _repack_each(self):
         for op in self.tape:
             if op['frozen'] and not op['need_dx']:
                 continue
@@ -207,8 +240,7 @@ class TrainGraph:
         self.backward_ops(list(reversed(self.tape)), on_op_done)
 
     def zero_act_grads(self):
-        for g in self.grads.values():
-            g.zero_()
+        self._grad_arena.zero_()
 
     def set_logit_grads(self, dcls, dreg):
         gc, gr = self.grads[_sptr(self.cls_buf)], self.grads[_sptr(self.reg_buf)]
@@ -266,10 +298,18 @@ class TrainGraph:
         return flat[off:off + n]
 
     def zero_param_grads(self):
-        for op in self.tape:
-            if not op['frozen']:
-                op['dw'].zero_()
-                op['db'].zero_()
+        self._wgrad_arena.zero_()
+
+    def param_grads_batched(self, ops_list, dst: Dict[str, torch.Tensor]):
+        """param_grads for a list of launches as ONE llv_unpack_wgrad_batched call (`dst` must name a tensor for every parameter)."""
+        live = [op for op in ops_list if not op.get('custom') and not op['frozen']]
+        if not live:
+            return
+
+        def record():
+            for op in live:
+                self.param_grads(only_op=op, dst=dst)
+        self._batched(('unpack',) + tuple(id(op) for op in live), record, extra_sig=tuple(t.data_ptr() for t in dst.values()))
 
     def param_grads(self, only_op=None, dst: Dict[str, torch.Tensor] = None) -> Dict[str, torch.Tensor]:
         """Module-parameter gradients (fp32, still multiplied by loss_scale) from the packed dW / db of every launch
@@ -366,6 +406,36 @@ def plan_buckets(keys_per_op, slices, limit):
     return out
 
 
+class LazyLogVars(Mapping):
+    """BaseDetector._parse_losses' log_vars (base.py:226-261: per key the sum of the per-level means, 'loss' = sum of the keys with
+    'loss' in the name, averaged over the ranks) as a read-on-demand mapping: the values stay on the device until somebody looks, so
+    a training loop that logs every n-th step does not stall the other n - 1."""
+
+    def __init__(self, vec, world):
+        self._vec, self._world, self._vals = vec, world, None
+
+    def _resolve(self):
+        if self._vals is None:
+            v = self._vec
+            if self._world > 1:
+                v = v.clone()
+                dist.all_reduce(v.div_(self._world))
+            v = v.tolist()
+            nl = len(v) // 2
+            lc, lb = float(sum(v[:nl])), float(sum(v[nl:]))
+            self._vals = OrderedDict(loss_cls=lc, loss_bbox=lb, loss=lc + lb)
+        return self._vals
+
+    def __getitem__(self, k):
+        return self._resolve()[k]
+
+    def __iter__(self):
+        return iter(self._resolve())
+
+    def __len__(self):
+        return 3
+
+
 class TrainStep:
     """All-device training step: forward, loss, backward, gradient all-reduce over the ranks (RCCL when the process
     group is nccl), fused SGD on one flat fp32 parameter buffer. The parameters of `det` become views of that buffer.
@@ -375,9 +445,10 @@ class TrainStep:
     parameter gradient has been written, overlapping the collective (xGMI) with the remaining convolution kernels."""
 
     def __init__(self, det, batch, height, width, device, lr=0.01, momentum=0.9, weight_decay=1e-4, loss_scale=512.0,
-                 bucket_mb=25.0, use_graph=True):
+                 bucket_mb=25.0, use_graph=True, fused_loss=True):
         self.det, self.device = det, device
         self.use_graph, self._g_fwd = use_graph, None
+        self.fused_loss, self._fused = fused_loss, None       # training.FusedHeadLoss where the head's losses allow it
         self.graph = TrainGraph(det, batch, height, width, device, loss_scale)
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         g = self.graph
@@ -439,7 +510,8 @@ class TrainStep:
             ops_k = self._segs[k][0]
             if k == 0:
                 g.zero_param_grads()
-            g.backward_ops(ops_k, lambda op: g.param_grads(only_op=op, dst=self.gviews))
+            g.backward_ops(ops_k, None)
+            g.param_grads_batched(ops_k, self.gviews)
 
         # warm-up on a side stream (lazy initialisation, split-K workspaces), then capture
         s = torch.cuda.Stream()
@@ -475,17 +547,27 @@ class TrainStep:
         else:
             g.repack()
             cls, reg = g.forward(img)
-        lc = [t.detach().requires_grad_() for t in cls]
-        lr_ = [t.detach().requires_grad_() for t in reg]
-        losses = anchor_head_loss(head, [t.permute(0, 3, 1, 2) for t in lc], [t.permute(0, 3, 1, 2) for t in lr_],
-                                  gt_bboxes, gt_labels, img_metas)
-        if losses is None:
-            raise LlvError('no valid anchors inside the image')
-        total = sum(sum(v) if isinstance(v, list) else v for k, v in losses.items() if 'loss' in k)
-        total.backward()
+        from .training import FusedHeadLoss
+        if self.fused_loss and self._fused is None and FusedHeadLoss.eligible(head):
+            self._fused = FusedHeadLoss(g, head, self.device)
         self._works = []
-        g.zero_act_grads()
-        g.set_logit_grads([t.grad for t in lc], [t.grad for t in lr_])
+        if self.fused_loss and self._fused is not None:
+            # device-only loss: no element-wise torch launches, no host synchronisation before the backward graphs are queued
+            g.zero_act_grads()
+            vec = self._fused.run(gt_bboxes, gt_labels, img_metas)
+            nl = vec.shape[0] // 2
+            losses = dict(loss_cls=[vec[i] for i in range(nl)], loss_bbox=[vec[nl + i] for i in range(nl)])
+        else:
+            lc = [t.detach().requires_grad_() for t in cls]
+            lr_ = [t.detach().requires_grad_() for t in reg]
+            losses = anchor_head_loss(head, [t.permute(0, 3, 1, 2) for t in lc], [t.permute(0, 3, 1, 2) for t in lr_],
+                                      gt_bboxes, gt_labels, img_metas)
+            if losses is None:
+                raise LlvError('no valid anchors inside the image')
+            total = sum(sum(v) if isinstance(v, list) else v for k, v in losses.items() if 'loss' in k)
+            total.backward()
+            g.zero_act_grads()
+            g.set_logit_grads([t.grad for t in lc], [t.grad for t in lr_])
         if self.use_graph:
             for k, (ops_k, buckets) in enumerate(self._segs):
                 self._g_bwd[k].replay()
@@ -501,6 +583,8 @@ class TrainStep:
         B.sgd_momentum(self.flat_w, self.flat_g, self.flat_m, self.lr, self.momentum, self.weight_decay,
                        1.0 / (g.loss_scale * world), self.steps_done == 0)
         self.steps_done += 1
+        if self.fused_loss and self._fused is not None:
+            return dict(loss=vec.sum(), log_vars=LazyLogVars(vec.clone(), world), num_samples=len(img_metas))
         loss, log_vars = self.det._parse_losses({k: [x.detach() for x in v] if isinstance(v, list) else v.detach() for k, v in losses.items()})
         return dict(loss=loss, log_vars=log_vars, num_samples=len(img_metas))
 

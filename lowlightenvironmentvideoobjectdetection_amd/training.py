@@ -11,7 +11,7 @@ SingleStageDetector.forward_train goes through it (single_stage_forward_train be
 import torch
 
 from . import ops
-from ._lib import LlvError
+from ._lib import LlvError, check, lib
 from .core.anchor import anchor_inside_flags, images_to_levels
 
 
@@ -124,6 +124,118 @@ def anchor_head_loss(head, cls_scores, bbox_preds, gt_bboxes, gt_labels, img_met
             reg = _delta2bbox(anc.reshape(-1, 4), reg, head.bbox_coder.means, head.bbox_coder.stds)
         losses_bbox.append(head.loss_bbox(reg, bt.reshape(-1, 4), bw.reshape(-1, 4), avg_factor=num_total_samples))
     return dict(loss_cls=losses_cls, loss_bbox=losses_bbox)
+
+
+class FusedHeadLoss:
+    """AnchorHead.loss for the training step WITHOUT a host round trip (train_engine.TrainStep): per image llv_iou_assign over the
+    cached flat anchors, then llv_retina_loss -- labels / weights / box targets, FocalLoss and L1 (SmoothL1) terms, their derivatives
+    written straight into the fp16 gradient twins of the logit buffers (times loss_weight / avg_factor * loss_scale), avg_factor counted
+    on the device. Same arithmetic as anchor_head_loss above (tests/test_gpu_train.py compares the two); what it replaces is the
+    ~350 element-wise launches and the four host synchronisations of the module-level path."""
+
+    @staticmethod
+    def eligible(head):
+        lc, lb, a = head.loss_cls, head.loss_bbox, getattr(head, 'assigner', None)
+        return (type(lc).__name__ == 'FocalLoss' and getattr(lc, 'use_sigmoid', False) and lc.reduction == 'mean'
+                and type(lb).__name__ in ('L1Loss', 'SmoothL1Loss') and lb.reduction == 'mean' and not head.reg_decoded_bbox
+                and not head.sampling and type(a).__name__ == 'MaxIoUAssigner' and a.ignore_iof_thr <= 0 and head.train_cfg is not None)
+
+    def __init__(self, graph, head, device):
+        import ctypes as C
+        from ._lib import RetinaLossDesc
+        self.graph, self.head, self.device = graph, head, device
+        pyr = graph.pyramid
+        hw = [tuple(int(v) for v in x) for x in pyr.level_hw]
+        assert len(hw) == head.anchor_generator.num_levels
+        A = head.num_anchors
+        self.flat_anchors = torch.cat(head.anchor_generator.grid_anchors(hw, device)).float().contiguous()
+        self.a_total = self.flat_anchors.shape[0]
+        self.hw, self.batch = hw, graph.batch
+        n = graph.batch
+        self.gt_inds = torch.zeros((n, self.a_total), dtype=torch.int64, device=device)
+        self.max_ov = torch.zeros((self.a_total,), dtype=torch.float32, device=device)
+        self.max_gt = 0
+        self._grow(64)
+        self.scratch = torch.zeros(2 * len(hw) * 2 + 4, dtype=torch.float32, device=device)     # sums | losses | avg_factor
+        L = len(hw)
+        self.losses = self.scratch[2 * L:4 * L]
+        self.avg_factor = self.scratch[4 * L:4 * L + 1]
+        gc, gr = graph.grads[_sptr(graph.cls_buf)], graph.grads[_sptr(graph.reg_buf)]
+        d = RetinaLossDesc()
+        d.cls, d.reg, d.dcls, d.dreg = graph.cls_buf.data_ptr(), graph.reg_buf.data_ptr(), gc.data_ptr(), gr.data_ptr()
+        d.cls_ld, d.reg_ld, d.dcls_ld, d.dreg_ld = graph.cls_buf.shape[-1], graph.reg_buf.shape[-1], gc.shape[-1], gr.shape[-1]
+        d.batch, d.n_levels, d.num_anchors, d.num_classes = n, L, A, head.cls_out_channels
+        a0 = 0
+        for i, (h, w) in enumerate(hw):
+            d.level_h[i], d.level_w[i], d.level_off[i], d.level_anchor0[i] = h, w, int(pyr.level_off[i]), a0
+            a0 += h * w * A
+        d.anchors_per_image = self.a_total
+        d.anchors, d.gt_inds = self.flat_anchors.data_ptr(), self.gt_inds.data_ptr()
+        lc, lb, tc = head.loss_cls, head.loss_bbox, head.train_cfg
+        d.gamma, d.alpha, d.cls_weight, d.reg_weight = lc.gamma, lc.alpha, lc.loss_weight, lb.loss_weight
+        d.beta = float(getattr(lb, 'beta', 0.0)) if type(lb).__name__ == 'SmoothL1Loss' else 0.0
+        d.pos_weight, d.grad_scale = float(tc['pos_weight']), graph.loss_scale
+        for i in range(4):
+            d.means[i], d.stds[i] = float(head.bbox_coder.means[i]), float(head.bbox_coder.stds[i])
+        d.sums, d.avg_factor, d.losses = self.scratch.data_ptr(), self.avg_factor.data_ptr(), self.losses.data_ptr()
+        self.desc = d
+        self._set_gt_ptrs()
+        self._inside = {}
+        wsb = lib().llv_iou_assign_workspace_bytes(4096, self.a_total)
+        self.ws = torch.empty((max(wsb, 256),), device=device, dtype=torch.uint8)
+        self.wsb = wsb
+
+    def _grow(self, k):
+        self.max_gt = k
+        self.gt_boxes = torch.zeros((self.batch, k, 4), dtype=torch.float32, device=self.device)
+        self.gt_labels = torch.zeros((self.batch, k), dtype=torch.int64, device=self.device)
+
+    def _set_gt_ptrs(self):
+        self.desc.gt_boxes, self.desc.gt_labels, self.desc.max_gt = self.gt_boxes.data_ptr(), self.gt_labels.data_ptr(), self.max_gt
+
+    def inside_flags(self, meta):
+        """valid_flags & anchor_inside_flags of one image geometry (anchor_head.py:145-173, 206-211), cached; raises when no anchor
+        lies inside (the module-level path returns None there)."""
+        tc = self.head.train_cfg
+        key = (tuple(meta['img_shape'][:2]), tuple(meta['pad_shape'][:2]), tc['allowed_border'])
+        if key not in self._inside:
+            flags = torch.cat(self.head.anchor_generator.valid_flags(self.hw, meta['pad_shape'], self.device))
+            inside = anchor_inside_flags(self.flat_anchors, flags, meta['img_shape'][:2], tc['allowed_border'])
+            if not bool(inside.any()):
+                raise LlvError('no valid anchors inside the image')
+            self._inside[key] = inside.to(torch.uint8).contiguous()
+        return self._inside[key]
+
+    def run(self, gt_bboxes, gt_labels, img_metas):
+        """-> (2 * levels,) fp32 device tensor: loss_cls per level, then loss_bbox per level. The gradient twins of the logits hold
+        d(total loss)/d(logit) * loss_scale afterwards."""
+        L, a, st = lib(), self.head.assigner, _stream()
+        k_max = max(int(b.shape[0]) for b in gt_bboxes)
+        if k_max > self.max_gt:
+            self._grow(max(k_max, 2 * self.max_gt))
+            self._set_gt_ptrs()
+        for n, (gb, gl, meta) in enumerate(zip(gt_bboxes, gt_labels, img_metas)):
+            k = int(gb.shape[0])
+            if k > 4096:
+                raise LlvError('more than 4096 ground-truth boxes in one image')
+            if k:
+                self.gt_boxes[n, :k].copy_(gb, non_blocking=True)
+                self.gt_labels[n, :k].copy_(gl, non_blocking=True)
+            check(L.llv_iou_assign(ops._ptr(self.gt_boxes[n]), k, ops._ptr(self.flat_anchors), ops._ptr(self.inside_flags(meta)), self.a_total,
+                                   a.pos_iou_thr, a.neg_iou_thr, a.min_pos_iou, int(a.match_low_quality), int(a.gt_max_assign_all),
+                                   ops._ptr(self.gt_inds[n]), ops._ptr(self.max_ov), ops._ptr(self.ws), self.wsb, st), 'llv_iou_assign')
+        import ctypes as C
+        check(L.llv_retina_loss(C.byref(self.desc), st), 'llv_retina_loss')
+        return self.losses
+
+
+def _stream():
+    import ctypes as C
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def _sptr(t):
+    return t.untyped_storage().data_ptr()
 
 
 def single_stage_forward_train(det, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None):
