@@ -386,7 +386,7 @@ int llv_iou_assign(const float* gt, int k, const float* anchors, const uint8_t* 
  * columns [4a, 4a+4)). gt_inds (batch, anchors_per_image): llv_iou_assign's output per image in mmdet's anchor order (level-major,
  * then y, x, a; level_anchor0[l] = first anchor of level l). Outputs: losses[0..L) = loss_cls per level, losses[L..2L) = loss_bbox per
  * level (already * loss_weight / avg_factor); dcls / dreg (fp16, written, not added) = d(sum of all terms)/d(logit) * grad_scale;
- * avg_factor (device scalar) = sum over images of max(#positives, 1). sums: 2L floats of scratch. beta = 0: L1, > 0: smooth L1. */
+ * avg_factor (device scalar) = sum over images of max(#positives, 1). sums: 2L floats of scratch, zero on the first call. beta = 0: L1, > 0: smooth L1. */
 typedef struct llv_retina_loss_desc {
     const float* cls; const float* reg;
     void* dcls; void* dreg;
@@ -401,6 +401,7 @@ typedef struct llv_retina_loss_desc {
     float gamma, alpha, cls_weight, reg_weight, beta, pos_weight, grad_scale;
     float means[4], stds[4];
     float* sums; float* avg_factor; float* losses;
+    int* counts;     /* `batch` ints of scratch, ZERO on the first call (every call leaves them and `sums` zero again) */
 } llv_retina_loss_desc;
 int llv_retina_loss(const llv_retina_loss_desc* desc, void* stream);
 

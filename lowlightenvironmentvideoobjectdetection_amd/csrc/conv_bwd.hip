@@ -335,10 +335,11 @@ struct PackArgs {
     int cout, cin, kh, kw, cpad, k_pad, row0, mode, pad, KH, KW, padp, rows;
 };
 
-__device__ __forceinline__ void pack_one(const PackArgs& a, long idx) {
+// (element counts are below 2^31: host check; 32-bit divisions)
+__device__ __forceinline__ void pack_one(const PackArgs& a, unsigned idx) {
         if (a.mode == 0) {
             const int i = (int)(idx % a.cpad);
-            long t = idx / a.cpad;
+            unsigned t = idx / a.cpad;
             const int q = (int)(t % a.kw); t /= a.kw;
             const int r = (int)(t % a.kh);
             const int o = (int)(t / a.kh);
@@ -350,7 +351,7 @@ __device__ __forceinline__ void pack_one(const PackArgs& a, long idx) {
             a.dst[(long)(a.row0 + o) * a.k_pad + (r * a.kw + q) * a.cpad + i] = (_Float16)v;
         } else {
             const int o = (int)(idx % a.cout);
-            long t = idx / a.cout;
+            unsigned t = idx / a.cout;
             const int dx = (int)(t % a.KW); t /= a.KW;
             const int dy = (int)(t % a.KH);
             const int row = (int)(t / a.KH);
@@ -374,7 +375,7 @@ __device__ __forceinline__ void pack_one(const PackArgs& a, long idx) {
 
 __global__ void pack_weights_kernel(const PackArgs a) {
     const long total = a.mode == 0 ? (long)a.cout * a.kh * a.kw * a.cpad : (long)a.rows * a.KH * a.KW * a.cout;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) pack_one(a, idx);
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) pack_one(a, (unsigned)idx);
 }
 
 // folded bias: out[o] = beta[o] + ((b ? b[o] : 0) - mean[o]) * s[o]   (or plain b / 0 without BN)
@@ -436,7 +437,7 @@ __global__ void pack_weights_batched_kernel(const llv_pack_job* __restrict__ job
     const PackArgs a{j.w, j.gamma, j.var, j.eps, (_Float16*)j.dst, j.cout, j.cin, j.kh, j.kw, j.cpad, j.k_pad, j.row0, j.mode, j.pad, j.KH, j.KW,
                      j.padp, j.rows};
     const long total = a.mode == 0 ? (long)a.cout * a.kh * a.kw * a.cpad : (long)a.rows * a.KH * a.KW * a.cout;
-    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) pack_one(a, idx);
+    for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) pack_one(a, (unsigned)idx);
 }
 
 __global__ void fold_bias_batched_kernel(const llv_fold_job* __restrict__ jobs) {
@@ -542,6 +543,7 @@ extern "C" int llv_pack_conv_weights(const float* w, const float* gamma, const f
     if (mode != 0 && (KH < 1 || KW < 1 || rows < 1 || cpad < row0 + cout || k_pad < KH * KW * cpad)) return LLV_E_BADARG;
     PackArgs a{w, gamma, var, eps, (_Float16*)dst, cout, cin, kh, kw, cpad, k_pad, row0, mode, pad, KH, KW, padp, rows};
     const long total = mode == 0 ? (long)cout * kh * kw * cpad : (long)rows * KH * KW * cout;
+    if (total >= (1L << 31)) return LLV_E_UNSUPPORTED;
     long grid = (total + 255) / 256;
     grid = grid > 4096 ? 4096 : grid;
     hipLaunchKernelGGL(pack_weights_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, a);

@@ -222,46 +222,38 @@ __global__ void softmax_ce_bwd_kernel(const float* __restrict__ x, const int64_t
 // per-level sums (fp32 atomics, one per workgroup), the derivatives -- times loss_weight / avg_factor * grad_scale -- straight into
 // the fp16 gradient twins of the logit buffers the backward pass starts from. avg_factor = sum over images of max(#positives, 1)
 // (anchor_head.py:468-470) is read from device memory (retina_count_pos_kernel): no host round trip anywhere in the step.
-__global__ void retina_count_pos_kernel(const int64_t* __restrict__ gt_inds, int batch, long a_total, float* __restrict__ avg_factor,
-                                        float* __restrict__ sums, int n_sums) {
-    // one workgroup: per-image positive counts -> sum of max(count, 1); zeroes the loss sums
-    __shared__ int red[256];
-    float tot = 0.f;
-    for (int n = 0; n < batch; ++n) {
-        int c = 0;
-        for (long i = threadIdx.x; i < a_total; i += blockDim.x) c += gt_inds[(long)n * a_total + i] > 0 ? 1 : 0;
-        red[threadIdx.x] = c;
-        __syncthreads();
-        for (int st = 128; st > 0; st >>= 1) {
-            if ((int)threadIdx.x < st) red[threadIdx.x] += red[threadIdx.x + st];
-            __syncthreads();
-        }
-        tot += (float)(red[0] > 1 ? red[0] : 1);
-        __syncthreads();
-    }
-    if (threadIdx.x == 0) *avg_factor = tot;
-    for (int i = threadIdx.x; i < n_sums; i += blockDim.x) sums[i] = 0.f;
+__global__ void retina_count_pos_kernel(const int64_t* __restrict__ gt_inds, long a_total, int* __restrict__ counts) {
+    // blockIdx.y = image; every workgroup counts a grid-stride slice and adds it to the image's counter (zero on entry: the finish
+    // kernel of the previous call leaves it so, the first call finds the allocation's zeros)
+    const int n = blockIdx.y;
+    int c = 0;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < a_total; i += (long)gridDim.x * blockDim.x)
+        c += gt_inds[(long)n * a_total + i] > 0 ? 1 : 0;
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    if ((threadIdx.x & 63) == 0 && c) atomicAdd(&counts[n], c);
 }
 
-__global__ __launch_bounds__(256) void retina_loss_kernel(const llv_retina_loss_desc d) {
+__global__ __launch_bounds__(256) void retina_loss_kernel(const llv_retina_loss_desc d, const int* __restrict__ counts) {
     const int l = blockIdx.y;
-    const int A = d.num_anchors, C = d.num_classes, AC = A * C;
-    const long hw = (long)d.level_h[l] * d.level_w[l];
-    const long total = (long)d.batch * hw * AC;
+    const unsigned A = d.num_anchors, C = d.num_classes, AC = A * C;
+    const unsigned hw = (unsigned)d.level_h[l] * d.level_w[l];
+    const unsigned total = (unsigned)d.batch * hw * AC;          // < 2^31 (host check)
     const long a_total = d.anchors_per_image;
-    const float inv_avg = 1.f / *d.avg_factor;
+    float avg = 0.f;
+    for (int n = 0; n < d.batch; ++n) avg += (float)(counts[n] > 1 ? counts[n] : 1);
+    const float inv_avg = 1.f / avg;
     const float gs_cls = d.cls_weight * inv_avg * d.grad_scale, gs_reg = d.reg_weight * inv_avg * d.grad_scale;
+    const bool g2 = d.gamma == 2.f;
     _Float16* const dcls = reinterpret_cast<_Float16*>(d.dcls);
     _Float16* const dreg = reinterpret_cast<_Float16*>(d.dreg);
     float lc = 0.f, lb = 0.f;
-    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
-        const int ch = (int)(i % AC);
-        const long pn = i / AC;                                  // pixel of the level's (batch, h, w) block
-        const int n = (int)(pn / hw);
-        const long pix = pn - (long)n * hw;
-        const int a = ch / C, cls = ch - a * C;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < total; i += gridDim.x * blockDim.x) {
+        const unsigned pn = i / AC, ch = i - pn * AC;            // pixel of the level's (batch, h, w) block, channel
+        const unsigned n = pn / hw, pix = pn - n * hw;
+        const unsigned a = ch / C, cls = ch - a * C;
         const long row = d.level_off[l] + pn;                    // row of the pixel-major buffers
-        const long aidx = d.level_anchor0[l] + pix * A + a;      // anchor index inside the image (mmdet order)
+        const long aidx = d.level_anchor0[l] + (long)pix * A + a;      // anchor index inside the image (mmdet order)
         const int64_t gi = d.gt_inds[(long)n * a_total + aidx];
         // labels / weights: positives carry their gt's class, negatives the background class C, ignored anchors weight 0
         const int64_t label = gi > 0 ? d.gt_labels[(long)n * d.max_gt + (gi - 1)] : (int64_t)C;
@@ -273,11 +265,13 @@ __global__ __launch_bounds__(256) void retina_loss_kernel(const llv_retina_loss_
         const float log_p = -(fmaxf(-xi, 0.f) + sp), log_1mp = -(fmaxf(xi, 0.f) + sp);
         float loss, grad;
         if (pos) {
-            loss = -d.alpha * (powf(1.f - p, d.gamma) * log_p);
-            grad = -d.alpha * (powf(1.f - p, d.gamma) * (1.f - p - d.gamma * p * log_p));
+            const float m = g2 ? (1.f - p) * (1.f - p) : powf(1.f - p, d.gamma);
+            loss = -d.alpha * (m * log_p);
+            grad = -d.alpha * (m * (1.f - p - d.gamma * p * log_p));
         } else {
-            loss = -(1.f - d.alpha) * (powf(p, d.gamma) * log_1mp);
-            grad = -(1.f - d.alpha) * (powf(p, d.gamma) * (d.gamma * (1.f - p) * log_1mp - p));
+            const float m = g2 ? p * p : powf(p, d.gamma);
+            loss = -(1.f - d.alpha) * (m * log_1mp);
+            grad = -(1.f - d.alpha) * (m * (d.gamma * (1.f - p) * log_1mp - p));
         }
         lc += loss * w;
         dcls[row * d.dcls_ld + ch] = (_Float16)(grad * w * gs_cls);
@@ -325,11 +319,17 @@ __global__ __launch_bounds__(256) void retina_loss_kernel(const llv_retina_loss_
     }
 }
 
-// sums -> losses: [2][n_levels] * loss_weight / avg_factor
-__global__ void retina_loss_finish_kernel(const float* __restrict__ sums, const float* __restrict__ avg_factor, float* __restrict__ out,
-                                          int n_levels, float cls_weight, float reg_weight) {
+// sums -> losses: [2][n_levels] * loss_weight / avg_factor; leaves sums and counters zero for the next call
+__global__ void retina_loss_finish_kernel(float* __restrict__ sums, int* __restrict__ counts, int batch, float* __restrict__ avg_factor,
+                                          float* __restrict__ out, int n_levels, float cls_weight, float reg_weight) {
+    float avg = 0.f;
+    for (int n = 0; n < batch; ++n) avg += (float)(counts[n] > 1 ? counts[n] : 1);
     const int i = threadIdx.x;
-    if (i < 2 * n_levels) out[i] = sums[i] * (i < n_levels ? cls_weight : reg_weight) / *avg_factor;
+    if (i < 2 * n_levels) out[i] = sums[i] * (i < n_levels ? cls_weight : reg_weight) / avg;
+    __syncthreads();
+    if (i < 2 * n_levels) sums[i] = 0.f;
+    if (i < batch) counts[i] = 0;
+    if (i == 0) *avg_factor = avg;
 }
 
 }  // namespace
@@ -419,9 +419,10 @@ extern "C" int llv_iou_assign(const float* gt, int k, const float* anchors, cons
 }
 
 extern "C" int llv_retina_loss(const llv_retina_loss_desc* d, void* stream) {
-    if (!d || !d->cls || !d->reg || !d->dcls || !d->dreg || !d->anchors || !d->gt_inds || !d->sums || !d->avg_factor || !d->losses)
+    if (!d || !d->cls || !d->reg || !d->dcls || !d->dreg || !d->anchors || !d->gt_inds || !d->sums || !d->avg_factor || !d->losses || !d->counts)
         return LLV_E_BADARG;
-    if (d->batch < 1 || d->n_levels < 1 || d->n_levels > LLV_MAX_SEG || d->num_anchors < 1 || d->num_classes < 1 || d->max_gt < 0) return LLV_E_BADARG;
+    if (d->batch < 1 || d->batch > 64 || d->n_levels < 1 || d->n_levels > LLV_MAX_SEG || d->num_anchors < 1 || d->num_classes < 1 || d->max_gt < 0)
+        return LLV_E_BADARG;
     if (d->max_gt > 0 && (!d->gt_boxes || !d->gt_labels)) return LLV_E_BADARG;
     const int AC = d->num_anchors * d->num_classes;
     if (d->cls_ld < AC || d->dcls_ld < AC || d->reg_ld < 4 * d->num_anchors || d->dreg_ld < 4 * d->num_anchors) return LLV_E_BADARG;
@@ -434,12 +435,15 @@ extern "C" int llv_retina_loss(const llv_retina_loss_desc* d, void* stream) {
         max_work = work > max_work ? work : max_work;
     }
     if (a_sum != d->anchors_per_image) return LLV_E_BADARG;
+    if (max_work >= (1L << 31)) return LLV_E_UNSUPPORTED;        // the kernel indexes a level's logits with 32-bit arithmetic
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(retina_count_pos_kernel, dim3(1), dim3(256), 0, st, d->gt_inds, d->batch, (long)d->anchors_per_image, d->avg_factor,
-                       d->sums, 2 * d->n_levels);
+    long gc = (a_sum + 255) / 256;
+    gc = gc > 64 ? 64 : gc;
+    hipLaunchKernelGGL(retina_count_pos_kernel, dim3((int)gc, d->batch), dim3(256), 0, st, d->gt_inds, (long)d->anchors_per_image, d->counts);
     long gx = (max_work + 255) / 256;
-    gx = gx > 1024 ? 1024 : gx;
-    hipLaunchKernelGGL(retina_loss_kernel, dim3((int)gx, d->n_levels), dim3(256), 0, st, *d);
-    hipLaunchKernelGGL(retina_loss_finish_kernel, dim3(1), dim3(64), 0, st, d->sums, d->avg_factor, d->losses, d->n_levels, d->cls_weight, d->reg_weight);
+    gx = gx > 2048 ? 2048 : gx;
+    hipLaunchKernelGGL(retina_loss_kernel, dim3((int)gx, d->n_levels), dim3(256), 0, st, *d, (const int*)d->counts);
+    hipLaunchKernelGGL(retina_loss_finish_kernel, dim3(1), dim3(64), 0, st, d->sums, d->counts, d->batch, d->avg_factor, d->losses, d->n_levels,
+                       d->cls_weight, d->reg_weight);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }

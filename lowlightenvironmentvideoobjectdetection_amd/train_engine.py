@@ -16,7 +16,9 @@ gradients accumulate in fp32. The autograd bridge (`DetectorFunction`) makes the
 op to torch: `loss.backward()` fills `param.grad` of the module, so the reference's runner / OptimizerHook / DDP work
 unchanged; `TrainStep.step_fused()` is the all-device path `bench.py --mode train` measures.
 """
+import contextlib
 import ctypes as C
+import os
 from collections import OrderedDict
 from collections.abc import Mapping
 from typing import Dict, List
@@ -251,18 +253,25 @@ class TrainGraph:
             gc[o:o + n, :dcls[i].shape[-1]] = (dcls[i].reshape(n, -1) * self.loss_scale).to(torch.float16)
             gr[o:o + n, :dreg[i].shape[-1]] = (dreg[i].reshape(n, -1) * self.loss_scale).to(torch.float16)
 
-    def backward_ops(self, ops_rev, on_op_done=None):
+    def backward_ops(self, ops_rev, on_op_done=None, phase='all'):
+        """phase 'data': everything but the weight gradients (ReLU masks, residual / top-down routing, data gradients); 'weight': the
+        weight gradients alone. A launch's dW depends only on its input activation and on dY as the data phase left it, nothing later
+        in the pass writes that dY again, and dW is not read before the unpack -- so TrainStep replays the weight phase of one
+        all-reduce bucket on a second stream beside the data phase of the next (single-image launches that each fill part of the chip)."""
         for op in ops_rev:
             yp = _sptr(op['y'])
             if yp not in self.req:
                 continue
             if op.get('custom'):
-                op['bwd'](self, op)
+                if phase != 'weight':
+                    op['bwd'](self, op)
                 continue
             pc, flags = op['pc'], op['flags']
             gy_base = self.grads[yp]
             gy = self.gview(op['y'])
             dy_ld = gy_base.shape[-1]
+            if phase == 'weight':
+                flags = 0                                        # masks and routing belong to the data phase
             # rows of y this launch wrote: per segment (batch*ho*wo rows at y offset)
             if flags & CONV_RELU:
                 for (h, w, ho, wo, xo, yo) in op['segs']:
@@ -275,11 +284,13 @@ class TrainGraph:
                     B.upsample_add_bwd(gy, gres, accumulate=True)
                 else:
                     B.relu_bwd(gres, None, gres, dy2=gy)
-            if not op['frozen']:
+            if not op['frozen'] and phase != 'data':
                 for (h, w, ho, wo, xo, yo) in op['segs']:
                     B.conv_wgrad(op['xs'][0], gy, op['dw'], cin_pad=pc.cin, cout=pc.cout,
                                  w_rows=pc.w_rows, k_pad=pc.k_pad, kh=pc.kh, kw=pc.kw, stride=pc.stride, pad=pc.pad, groups=pc.groups,
                                  batch=op['batch'], seg=(h, w, ho, wo, xo, yo), x_ld=op['x_ld'], dy_ld=dy_ld, db=op['db'], dilation=max(int(pc.dilation), 1))
+            if phase == 'weight':
+                continue
             if op['need_dx']:
                 gx = self.gview(op['xs'][0])
                 if op['dflags'] & CONV_PIXSHUF:
@@ -449,6 +460,7 @@ class TrainStep:
         self.det, self.device = det, device
         self.use_graph, self._g_fwd = use_graph, None
         self.fused_loss, self._fused = fused_loss, None       # training.FusedHeadLoss where the head's losses allow it
+        self._wstream = torch.cuda.Stream(device=device) if os.environ.get('LLV_WGRAD_STREAM', '1') != '0' else None
         self.graph = TrainGraph(det, batch, height, width, device, loss_scale)
         self.lr, self.momentum, self.weight_decay = lr, momentum, weight_decay
         g = self.graph
@@ -506,32 +518,36 @@ class TrainStep:
             ops.pack_input(self.img_static, 8, out=g.x_in)
             g.plan.run()
 
-        def seg_fn(k):
-            ops_k = self._segs[k][0]
+        def seg_data(k):
+            g.backward_ops(self._segs[k][0], None, phase='data')
+
+        def seg_weight(k):
             if k == 0:
                 g.zero_param_grads()
-            g.backward_ops(ops_k, None)
-            g.param_grads_batched(ops_k, self.gviews)
+            g.backward_ops(self._segs[k][0], None, phase='weight')
+            g.param_grads_batched(self._segs[k][0], self.gviews)
 
-        # warm-up on a side stream (lazy initialisation, split-K workspaces), then capture
+        # warm-up on a side stream (lazy initialisation, split-K workspaces, job tables), then capture
         s = torch.cuda.Stream()
         s.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(s):
             fwd()
             g.zero_act_grads()
             for k in range(len(segs)):
-                seg_fn(k)
+                seg_data(k)
+                seg_weight(k)
         torch.cuda.current_stream().wait_stream(s)
         torch.cuda.synchronize()
         self._g_fwd = torch.cuda.CUDAGraph()
         with torch.cuda.graph(self._g_fwd):
             fwd()
-        self._g_bwd = []
+        self._g_bwd, self._g_wgt = [], []
         for k in range(len(segs)):
-            gk = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(gk):
-                seg_fn(k)
-            self._g_bwd.append(gk)
+            for fn, lst in ((seg_data, self._g_bwd), (seg_weight, self._g_wgt)):
+                gk = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(gk):
+                    fn(k)
+                lst.append(gk)
 
     def step_fused(self, img, img_metas, gt_bboxes, gt_labels):
         from .training import anchor_head_loss
@@ -569,11 +585,20 @@ class TrainStep:
             g.zero_act_grads()
             g.set_logit_grads([t.grad for t in lc], [t.grad for t in lr_])
         if self.use_graph:
+            # per all-reduce bucket: the data phase on this stream, its weight phase (+ unpack + the bucket's all-reduce) on the side
+            # stream beside the NEXT bucket's data phase
+            main, side = torch.cuda.current_stream(), self._wstream
             for k, (ops_k, buckets) in enumerate(self._segs):
                 self._g_bwd[k].replay()
-                if self._dist():
-                    for (a, b) in buckets:
-                        self._works.append(dist.all_reduce(self.flat_g[a:b], async_op=True))
+                if side is not None:
+                    side.wait_stream(main)
+                with torch.cuda.stream(side) if side is not None else contextlib.nullcontext():
+                    self._g_wgt[k].replay()
+                    if self._dist():
+                        for (a, b) in buckets:
+                            self._works.append(dist.all_reduce(self.flat_g[a:b], async_op=True))
+            if side is not None:
+                main.wait_stream(side)
         else:
             g.zero_param_grads()
             g.backward_ops(list(reversed(g.tape)), self._op_done)

@@ -178,6 +178,8 @@ class FusedHeadLoss:
         for i in range(4):
             d.means[i], d.stds[i] = float(head.bbox_coder.means[i]), float(head.bbox_coder.stds[i])
         d.sums, d.avg_factor, d.losses = self.scratch.data_ptr(), self.avg_factor.data_ptr(), self.losses.data_ptr()
+        self.counts = torch.zeros(max(n, 1), dtype=torch.int32, device=device)
+        d.counts = self.counts.data_ptr()
         self.desc = d
         self._set_gt_ptrs()
         self._inside = {}
