@@ -272,7 +272,14 @@ def build_resnet(b: Builder, sd, x, depth=50, strides=(1, 2, 2, 2), style='pytor
             stride = strides[i] if j == 0 else 1
             dil = dilations[i]                               # resnet.py:151-167: conv2 padding = dilation (DC5 stages)
             identity = x
-            if (q + 'downsample.0.weight') in sd:          # res_layer.py:36-58: conv1x1(stride) + BN
+            # conv3 and a stride-1 downsample conv over as many channels as conv2 writes are ONE 1x1 convolution over the two
+            # tensors side by side (K = [conv2 out | block input], weights [W3' | Wd'] with both BatchNorms folded, biases added):
+            # the (4 x MID)-channel identity tensor is neither written nor read back. Inference plans only (fuse_blocks): the training
+            # tape keeps a launch per parameter tensor. R-50's layer1.0 (64 | 64 channels at 184 x 320): 403 -> 160 us at 16 frames.
+            kcat = (kind == 'bottleneck' and fuse_blocks and (q + 'downsample.0.weight') in sd and stride == 1 and
+                    sd[q + 'downsample.0.weight'].shape[1] == sd[q + 'conv3.weight'].shape[1] and x.shape[-1] == sd[q + 'conv3.weight'].shape[1]
+                    and sd[q + 'conv3.weight'].shape[1] % 32 == 0 and _os.environ.get('LLV_KCAT', '1') != '0')
+            if (q + 'downsample.0.weight') in sd and not kcat:          # res_layer.py:36-58: conv1x1(stride) + BN
                 identity = b.conv(q + 'downsample', x, ops.pack_conv(sd[q + 'downsample.0.weight'], None, stride, 0,
                                                                      bn=_bn(sd, q + 'downsample.1'), eps=BN_EPS))
             if kind == 'bottleneck' and fuse_blocks and identity is x and stride == 1 and dil == 1 and \
@@ -287,8 +294,20 @@ def build_resnet(b: Builder, sd, x, depth=50, strides=(1, 2, 2, 2), style='pytor
                                                          eps=BN_EPS), CONV_RELU)
                 o = b.conv(q + 'conv2', o, ops.pack_conv(sd[q + 'conv2.weight'], None, s2, dil, bn=_bn(sd, q + 'bn2'),
                                                          eps=BN_EPS, dilation=dil), CONV_RELU)
-                x = b.conv(q + 'conv3', o, ops.pack_conv(sd[q + 'conv3.weight'], None, 1, 0, bn=_bn(sd, q + 'bn3'),
-                                                         eps=BN_EPS), CONV_RELU | CONV_RES_ADD, res=identity)
+                if kcat:
+                    def fold(wk, bnk):
+                        w = sd[wk].detach().double().cpu()
+                        gamma, beta, mean, var = [t.detach().double().cpu() for t in _bn(sd, bnk)]
+                        sc = gamma / torch.sqrt(var + BN_EPS)
+                        return w * sc.view(-1, 1, 1, 1), beta - mean * sc
+                    w3, b3 = fold(q + 'conv3.weight', q + 'bn3')
+                    wd, bd = fold(q + 'downsample.0.weight', q + 'downsample.1')
+                    pcc = ops.pack_conv(torch.cat([w3, wd], 1).float(), (b3 + bd).float(), 1, 0, n_src=2)
+                    pcc.true_macs_per_pixel = w3.shape[0] * (w3.shape[1] + wd.shape[1])
+                    x = b.conv(q + 'conv3+downsample', [o, x], pcc, CONV_RELU)
+                else:
+                    x = b.conv(q + 'conv3', o, ops.pack_conv(sd[q + 'conv3.weight'], None, 1, 0, bn=_bn(sd, q + 'bn3'),
+                                                             eps=BN_EPS), CONV_RELU | CONV_RES_ADD, res=identity)
             else:
                 o = b.conv(q + 'conv1', x, ops.pack_conv(sd[q + 'conv1.weight'], None, stride, dil,
                                                          bn=_bn(sd, q + 'bn1'), eps=BN_EPS, dilation=dil), CONV_RELU)
