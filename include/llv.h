@@ -528,6 +528,13 @@ int llv_coco_match(const double* dets, const int* det_off, const double* gts, co
  * memory. Inside a captured graph it is a kernel node, not a memcpy node. */
 int llv_copy_d2d(void* dst, const void* src, size_t bytes, void* stream);
 
+/* One frame of the ConvLSTM inside DarkResNet's DenoisingBlock (mmtracking/mmtrack/models/backbones/dark_resnet.py:226-246,267-269):
+ * gates (rows, gates_ld >= 4p) fp16 = conv2([x_t | h_{t-1}]) with the channels in i | f | o | g order, every gate through a sigmoid;
+ * c (rows, p) fp32 is the cell state, updated in place (c = f*c + i*g); h (rows, h_ld) fp16 = o * tanh(c) is the next frame's recurrent
+ * input; act (rows, act_ld) fp16 = relu(h * scale + shift) is the block's norm2 + ReLU (eval-mode BatchNorm as a per-channel affine). */
+int llv_convlstm_gate(const void* gates, float* c, const float* scale, const float* shift, void* h, void* act, int64_t rows, int p,
+                      int gates_ld, int h_ld, int act_ld, void* stream);
+
 /* bbox2result's device-to-host step (mmdetection/mmdet/core/bbox/transforms.py:99-116) as one kernel: the NMS outputs of `batch`
  * images (dets [batch][max_num][5] fp32, labels [batch][max_num] int64, count [batch] int32) -> rows [batch][max_num][6] fp32
  * (x1, y1, x2, y2, score, label) and count_out [batch] int32; rows / count_out may be device-mapped pinned host memory, which

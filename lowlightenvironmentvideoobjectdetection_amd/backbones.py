@@ -64,6 +64,34 @@ class Bottleneck(nn.Module):
     norm3 = property(lambda self: self.bn3)
 
 
+class DenoisingBlock(nn.Module):
+    """mmtracking/mmtrack/models/backbones/dark_resnet.py:15-285: a Bottleneck whose 3x3 conv is the gate convolution of a ConvLSTM
+    that runs along the batch (the frames of a clip): conv2 maps [x_t | h_{t-1}] (2 * planes) to the four gates (4 * planes, weights
+    shared by all frames, :119-130), norm2 / conv3 see the hidden state (planes channels). Parameter container; the launches are built
+    by engine._denoising_block."""
+    expansion = 4
+
+    def __init__(self, inplanes, planes, seqs=4, stride=1, dilation=1, downsample=None, style='pytorch', with_cp=False, conv_cfg=None,
+                 norm_cfg=dict(type='BN'), dcn=None, plugins=None):
+        super().__init__()
+        assert style in ['pytorch', 'caffe']
+        if dcn is not None or plugins is not None:
+            raise NotImplementedError('dcn / plugins are outside the hot path')
+        self.inplanes, self.planes, self.seqs, self.stride, self.dilation, self.style = inplanes, planes, seqs, stride, dilation, style
+        s1, s2 = (1, stride) if style == 'pytorch' else (stride, 1)
+        self.conv1 = nn.Conv2d(inplanes, planes, 1, stride=s1, bias=False)
+        self.bn1 = _norm(norm_cfg, planes)
+        self.conv2 = nn.Conv2d(planes * 2, planes * 4, 3, stride=s2, padding=dilation, dilation=dilation, bias=False)
+        self.bn2 = _norm(norm_cfg, planes)
+        self.conv3 = nn.Conv2d(planes, planes * self.expansion, 1, bias=False)
+        self.bn3 = _norm(norm_cfg, planes * self.expansion)
+        self.downsample = downsample
+
+    norm1 = property(lambda self: self.bn1)
+    norm2 = property(lambda self: self.bn2)
+    norm3 = property(lambda self: self.bn3)
+
+
 class ResLayer(nn.Sequential):
     """res_layer.py:5-103 (downsample_first=True, no avg_down)."""
 
@@ -176,9 +204,14 @@ class ResNet(PlannedModule):
                     m.eval()
         return self
 
+    dark_stages = ()
+
     def plan_kwargs(self):
-        return dict(depth=self.depth, strides=self.strides, style=self.style, out_indices=self.out_indices,
-                    num_stages=self.num_stages, dilations=tuple(self.dilations))
+        kw = dict(depth=self.depth, strides=self.strides, style=self.style, out_indices=self.out_indices,
+                  num_stages=self.num_stages, dilations=tuple(self.dilations))
+        if self.dark_stages:
+            kw['dark_stages'] = tuple(self.dark_stages)
+        return kw
 
     def forward(self, x):
         """NCHW fp32 image on the GPU -> tuple of NCHW fp32 stage outputs (BN uses running statistics)."""
@@ -271,3 +304,32 @@ class ResNetH(ResNet):
         super().__init__(depth, num_stages=num_stages, **kwargs)
         self.insert_plugins = tuple(insert_plugins)
         self.feat_dim = 4 * self.base_channels * 2 ** (self.num_stages - 1)          # resnet_H.py:226-227
+
+
+@BACKBONES.register_module()
+class DarkResNet(ResNet):
+    """mmtracking/mmtrack/models/backbones/dark_resnet.py:386-709 ("ResNet backbone for Dark Denoising Network"): ResNet-50 whose
+    SECOND stage, or ResNet-101 whose FIRST stage, is made of DenoisingBlocks (arch_settings :392-395) -- Bottlenecks whose 3x3 conv is
+    a ConvLSTM along the frames of the batch. Same constructor; `seqs` is accepted and, as in the reference, never reaches the blocks
+    (:455 tests `isinstance(block[0], DenoisingBlock)` on the CLASS, which is false, so the stage is built by the plain ResLayer with
+    the block's default seqs=4, which the block's forward does not read either). Parameter names as the reference's
+    (`layer2.0.conv2.weight` of shape (4P, 2P, 3, 3), ...). zero_init_residual does not touch the DenoisingBlocks (:676-681 list
+    Bottleneck and BasicBlock only)."""
+    dark_arch = {50: (1,), 101: (0,)}
+
+    def __init__(self, depth, seqs=4, **kwargs):
+        if depth not in self.dark_arch:
+            raise KeyError(f'invalid depth {depth} for resnet')
+        super().__init__(depth, **kwargs)
+        self.seqs = seqs
+        self.dark_stages = tuple(i for i in self.dark_arch[depth] if i < self.num_stages)
+        inplanes = self.stem_channels
+        for i, num_blocks in enumerate(self.stage_blocks):
+            planes = self.base_channels * 2 ** i
+            if i in self.dark_stages:
+                layer = ResLayer(block=DenoisingBlock, inplanes=inplanes, planes=planes, num_blocks=num_blocks, stride=self.strides[i],
+                                 dilation=self.dilations[i], style=self.style, norm_cfg=self.norm_cfg)
+                setattr(self, f'layer{i + 1}', layer)
+            inplanes = planes * 4
+        self._freeze_stages()
+        self.block_expansion = 4

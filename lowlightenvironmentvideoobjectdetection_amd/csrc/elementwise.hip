@@ -622,6 +622,50 @@ extern "C" int llv_maxpool3x3s2_nhwc_bwd(const void* x, const void* dy, void* dx
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
+// The ConvLSTM update of DarkResNet's DenoisingBlock (mmtracking/mmtrack/models/backbones/dark_resnet.py:226-246) for one frame:
+// gates (rows, 4P) fp16 = conv2([x_t | h_{t-1}]) split along channels into i | f | o | g, ALL FOUR through a sigmoid (the reference
+// applies sigmoid to g as well, :240); c <- f * c + i * g (fp32 state, in place), h = o * tanh(c). Two outputs: h (fp16, the next
+// frame's recurrent input) and act = relu(h * scale + shift) (fp16: norm2 + ReLU of the block, :267-269, eval-mode BN as an affine).
+__global__ void convlstm_gate_kernel(const _Float16* __restrict__ gates, float* __restrict__ c, const float* __restrict__ scale,
+                                     const float* __restrict__ shift, _Float16* __restrict__ h, _Float16* __restrict__ act, long rows, int p8,
+                                     int gates_ld, int h_ld, int act_ld) {
+    const long total = rows * p8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / p8;
+        const int cv = (int)(i - r * p8) * 8;
+        const int P = p8 * 8;
+        const _Float16* gr = gates + r * gates_ld + cv;
+        const f16x8 gi = *reinterpret_cast<const f16x8*>(gr), gf = *reinterpret_cast<const f16x8*>(gr + P);
+        const f16x8 go = *reinterpret_cast<const f16x8*>(gr + 2 * P), gg = *reinterpret_cast<const f16x8*>(gr + 3 * P);
+        float* cr = c + r * P + cv;
+        f16x8 ho, ao;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float si = 1.f / (1.f + expf(-(float)gi[e])), sf = 1.f / (1.f + expf(-(float)gf[e]));
+            const float so = 1.f / (1.f + expf(-(float)go[e])), sg = 1.f / (1.f + expf(-(float)gg[e]));
+            const float cn = sf * cr[e] + si * sg;
+            cr[e] = cn;
+            const float hv = so * tanhf(cn);
+            ho[e] = (_Float16)hv;
+            const float a = hv * scale[cv + e] + shift[cv + e];
+            ao[e] = (_Float16)(a > 0.f ? a : 0.f);
+        }
+        *reinterpret_cast<f16x8*>(h + r * h_ld + cv) = ho;
+        *reinterpret_cast<f16x8*>(act + r * act_ld + cv) = ao;
+    }
+}
+
+extern "C" int llv_convlstm_gate(const void* gates, float* c, const float* scale, const float* shift, void* h, void* act, int64_t rows, int p,
+                                 int gates_ld, int h_ld, int act_ld, void* stream) {
+    if (!gates || !c || !scale || !shift || !h || !act || rows < 1 || p < 8 || (p & 7) || gates_ld < 4 * p || h_ld < p || act_ld < p ||
+        ((gates_ld | h_ld | act_ld) & 7))
+        return LLV_E_BADARG;
+    const long total = rows * (p / 8);
+    hipLaunchKernelGGL(convlstm_gate_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, (const _Float16*)gates, c, scale, shift,
+                       (_Float16*)h, (_Float16*)act, (long)rows, p / 8, gates_ld, h_ld, act_ld);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
 extern "C" int llv_pack_nchw_f32_to_nhwc_f16(const float* x, void* y, int batch, int c, int h, int w, int c_pad,
                                              const float* scale, const float* shift, void* stream) {
     if (!x || !y || batch < 1 || c < 1 || h < 1 || w < 1 || c_pad < c || (c_pad & 7)) return LLV_E_BADARG;

@@ -255,7 +255,7 @@ def _cpu_sd(sd):
 
 
 def build_resnet(b: Builder, sd, x, depth=50, strides=(1, 2, 2, 2), style='pytorch', out_indices=(0, 1, 2, 3), p='',
-                 num_stages=4, after_stage=None, dilations=(1, 1, 1, 1), fuse_blocks=False):
+                 num_stages=4, after_stage=None, dilations=(1, 1, 1, 1), fuse_blocks=False, dark_stages=()):
     """x: (N,H,W,8) fp16 NHWC normalised image (3 real channels). Returns the out_indices stage outputs.
     resnet.py:622-640 with every BatchNorm folded (norm_eval, running stats) and ReLU / identity-add fused
     into the producing conv's epilogue. fuse_blocks (inference plans only: the training tape needs every activation) runs
@@ -276,18 +276,20 @@ def build_resnet(b: Builder, sd, x, depth=50, strides=(1, 2, 2, 2), style='pytor
             # tensors side by side (K = [conv2 out | block input], weights [W3' | Wd'] with both BatchNorms folded, biases added):
             # the (4 x MID)-channel identity tensor is neither written nor read back. Inference plans only (fuse_blocks): the training
             # tape keeps a launch per parameter tensor. R-50's layer1.0 (64 | 64 channels at 184 x 320): 403 -> 160 us at 16 frames.
-            kcat = (kind == 'bottleneck' and fuse_blocks and (q + 'downsample.0.weight') in sd and stride == 1 and
+            kcat = (kind == 'bottleneck' and fuse_blocks and i not in dark_stages and (q + 'downsample.0.weight') in sd and stride == 1 and
                     sd[q + 'downsample.0.weight'].shape[1] == sd[q + 'conv3.weight'].shape[1] and x.shape[-1] == sd[q + 'conv3.weight'].shape[1]
                     and sd[q + 'conv3.weight'].shape[1] % 32 == 0 and _os.environ.get('LLV_KCAT', '1') != '0')
             if (q + 'downsample.0.weight') in sd and not kcat:          # res_layer.py:36-58: conv1x1(stride) + BN
                 identity = b.conv(q + 'downsample', x, ops.pack_conv(sd[q + 'downsample.0.weight'], None, stride, 0,
                                                                      bn=_bn(sd, q + 'downsample.1'), eps=BN_EPS))
-            if kind == 'bottleneck' and fuse_blocks and identity is x and stride == 1 and dil == 1 and \
+            if kind == 'bottleneck' and fuse_blocks and i not in dark_stages and identity is x and stride == 1 and dil == 1 and \
                     sd[q + 'conv1.weight'].shape[0] in (64, 128) and x.shape[-1] == 4 * sd[q + 'conv1.weight'].shape[0]:
                 x = b.bottleneck(q + 'fused', x,
                                  ops.pack_conv(sd[q + 'conv1.weight'], None, 1, 0, bn=_bn(sd, q + 'bn1'), eps=BN_EPS),
                                  ops.pack_conv(sd[q + 'conv2.weight'], None, 1, 1, bn=_bn(sd, q + 'bn2'), eps=BN_EPS),
                                  ops.pack_conv(sd[q + 'conv3.weight'], None, 1, 0, bn=_bn(sd, q + 'bn3'), eps=BN_EPS))
+            elif kind == 'bottleneck' and i in dark_stages:
+                x = _denoising_block(b, sd, q, x, identity, stride, dil, style)
             elif kind == 'bottleneck':
                 s1, s2 = (1, stride) if style == 'pytorch' else (stride, 1)          # resnet.py:151-156
                 o = b.conv(q + 'conv1', x, ops.pack_conv(sd[q + 'conv1.weight'], None, s1, 0, bn=_bn(sd, q + 'bn1'),
@@ -319,6 +321,43 @@ def build_resnet(b: Builder, sd, x, depth=50, strides=(1, 2, 2, 2), style='pytor
             if i == j:
                 feats.append(x)
     return feats
+
+
+def _denoising_block(b: Builder, sd, q, x, identity, stride, dil, style):
+    """DarkResNet's DenoisingBlock (mmtracking/mmtrack/models/backbones/dark_resnet.py:226-285): conv1 + BN + ReLU over all frames, then a
+    ConvLSTM along the BATCH (= the frames of the clip, in order): per frame conv2 over [x_t | h_{t-1}] (a two-source launch, 2P -> 4P
+    channels, no BatchNorm in between) and llv_convlstm_gate (c, h; norm2 + ReLU of h as its second output), then conv3 + BN + identity +
+    ReLU over all frames. h_0 = c_0 = 0 at every call (:230-231). With the stride on conv2 (style 'pytorch') and more than one frame the
+    reference's torch.cat([x, h_cur]) (:233) meets two resolutions and raises; so does this."""
+    L = lib()
+    s1, s2 = (1, stride) if style == 'pytorch' else (stride, 1)
+    planes = sd[q + 'conv1.weight'].shape[0]
+    if planes % 32:
+        raise LlvError('DenoisingBlock: planes must be a multiple of 32 (a 32-channel chunk of the two-source conv lies in one source)')
+    t1 = b.conv(q + 'conv1', x, ops.pack_conv(sd[q + 'conv1.weight'], None, s1, 0, bn=_bn(sd, q + 'bn1'), eps=BN_EPS), CONV_RELU)
+    n, h1, w1, _ = t1.shape
+    if s2 != 1 and n > 1:
+        raise LlvError(f'{q}: DenoisingBlock with stride {s2} on conv2 and {n} frames: the hidden state of frame 0 has the strided size, frame '
+                       "1's input has not (dark_resnet.py:233 raises 'Sizes of tensors must match' there); use style='caffe' or stride 1")
+    pc2 = ops.pack_conv(sd[q + 'conv2.weight'], None, s2, dil, n_src=2, dilation=dil)
+    ho, wo = ops.conv_out_size(h1, w1, pc2)
+    h_all, act = b.buf(n, ho, wo, planes), b.buf(n, ho, wo, planes)
+    h0 = b.buf(1, h1, w1, planes)                                  # zeros, never written
+    gates = b.buf(1, ho, wo, 4 * planes)
+    c = b.buf(ho * wo, planes, dtype=torch.float32)
+    czero = b.buf(ho * wo, planes, dtype=torch.float32)
+    gamma, beta, mean, var = [t.detach().double().cpu() for t in _bn(sd, q + 'bn2')]
+    sc = gamma / torch.sqrt(var + BN_EPS)
+    scale, shift = sc.float().to(b.dev), (beta - mean * sc).float().to(b.dev)
+    b.plan.keep += [scale, shift]
+    b.plan.add(q + 'lstm.zero_c', L.llv_copy_d2d, (ops._ptr(c), ops._ptr(czero), C.c_size_t(c.numel() * 4)), 0.0, 8.0 * c.numel())
+    for t in range(n):
+        b.conv(f'{q}conv2.t{t}', [t1[t:t + 1], h0 if t == 0 else h_all[t - 1:t]], pc2, 0, out=gates)
+        b.plan.add(f'{q}lstm.t{t}', L.llv_convlstm_gate, (ops._ptr(gates), ops._ptr(c), ops._ptr(scale), ops._ptr(shift), ops._ptr(h_all[t:t + 1]),
+                                                        ops._ptr(act[t:t + 1]), ho * wo, planes, 4 * planes, planes, planes),
+                   0.0, 2.0 * ho * wo * planes * 8)
+    return b.conv(q + 'conv3', act, ops.pack_conv(sd[q + 'conv3.weight'], None, 1, 0, bn=_bn(sd, q + 'bn3'), eps=BN_EPS),
+                  CONV_RELU | CONV_RES_ADD, res=identity)
 
 
 class Pyramid:

@@ -27,10 +27,11 @@ def _bn(x, sd, p, eps=1e-5):
 
 
 def resnet_forward(sd, x, depth=50, out_indices=(0, 1, 2, 3), strides=(1, 2, 2, 2), style='pytorch', prefix='backbone.',
-                   after_stage=None, dilations=(1, 1, 1, 1)):
+                   after_stage=None, dilations=(1, 1, 1, 1), dark_stages=(), num_stages=4):
     """after_stage(i, num_blocks, x) -> x: the plugin InsertResNet appends to stage i
     (mmtracking/mmtrack/models/backbones/insert_resnet.py:93-97); an out index may repeat (:410-415)."""
     kind, blocks = ARCH[depth]
+    blocks = blocks[:num_stages]
     p = prefix
     x = F.conv2d(x, sd[p + 'conv1.weight'], None, 2, 3)          # resnet.py:559-566 (7x7/s2, bias=False)
     x = F.relu(_bn(x, sd, p + 'bn1'))
@@ -42,7 +43,24 @@ def resnet_forward(sd, x, depth=50, out_indices=(0, 1, 2, 3), strides=(1, 2, 2, 
             stride = strides[i] if b == 0 else 1
             dil = dilations[i]                         # resnet.py:151-167: conv2 (Bottleneck) / conv1 (BasicBlock) padding = dilation
             identity = x
-            if kind == 'bottleneck':
+            if kind == 'bottleneck' and i in dark_stages:
+                # DenoisingBlock of DarkResNet (mmtracking/mmtrack/models/backbones/dark_resnet.py:226-285): the 3x3 conv is the gate
+                # convolution of a ConvLSTM along the batch; all four gates through a sigmoid (:237-240); h_0 = c_0 = 0
+                s1, s2 = (1, stride) if style == 'pytorch' else (stride, 1)
+                out = F.relu(_bn(F.conv2d(x, sd[q + 'conv1.weight'], None, s1, 0), sd, q + 'bn1'))
+                hs, h_cur, c_cur = [], None, None
+                for t in range(out.shape[0]):
+                    xt = out[t:t + 1]
+                    if h_cur is None:
+                        h_cur, c_cur = torch.zeros_like(xt), torch.zeros_like(xt)
+                    cc = F.conv2d(torch.cat([xt, h_cur], dim=1), sd[q + 'conv2.weight'], None, s2, dil, dil)
+                    ci, cf, co, cg = torch.split(cc, xt.shape[1], dim=1)
+                    c_cur = torch.sigmoid(cf) * c_cur + torch.sigmoid(ci) * torch.sigmoid(cg)
+                    h_cur = torch.sigmoid(co) * torch.tanh(c_cur)
+                    hs.append(h_cur)
+                out = F.relu(_bn(torch.cat(hs, 0), sd, q + 'bn2'))
+                out = _bn(F.conv2d(out, sd[q + 'conv3.weight'], None, 1, 0), sd, q + 'bn3')
+            elif kind == 'bottleneck':
                 s1, s2 = (1, stride) if style == 'pytorch' else (stride, 1)    # resnet.py:151-156
                 out = F.relu(_bn(F.conv2d(x, sd[q + 'conv1.weight'], None, s1, 0), sd, q + 'bn1'))
                 out = F.relu(_bn(F.conv2d(out, sd[q + 'conv2.weight'], None, s2, dil, dil), sd, q + 'bn2'))
