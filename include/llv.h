@@ -630,6 +630,9 @@ typedef struct llv_unpack_job {
     int cout, cin, kh, kw, cpad, k_pad;
 } llv_unpack_job;
 int llv_pack_conv_weights_batched(const llv_pack_job* jobs, int n_jobs, int blocks_per_job, void* stream);
+/* jobs of mode 1 / 2 only (data-gradient filters), moved as 32 x 32 x taps tiles through LDS; the destination must have been zero
+ * when first packed (positions no tap maps to are not written). Same result as llv_pack_conv_weights_batched on the same jobs. */
+int llv_pack_dgrad_weights_batched(const llv_pack_job* jobs, int n_jobs, int blocks_per_job, void* stream);
 int llv_fold_bias_batched(const llv_fold_job* jobs, int n_jobs, int blocks_per_job, void* stream);
 int llv_unpack_wgrad_batched(const llv_unpack_job* jobs, int n_jobs, int blocks_per_job, void* stream);
 

@@ -235,6 +235,7 @@ SIGNATURES = {
     'llv_convlstm_gate': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
     'llv_pack_conv_weights_batched': (_I, [_P, _I, _I, _P]),
     'llv_fold_bias_batched': (_I, [_P, _I, _I, _P]),
+    'llv_pack_dgrad_weights_batched': (_I, [_P, _I, _I, _P]),
     'llv_unpack_wgrad_batched': (_I, [_P, _I, _I, _P]),
 }
 

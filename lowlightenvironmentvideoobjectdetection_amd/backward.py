@@ -198,10 +198,13 @@ class JobTables:
             arr = (ty * len(jobs))(*jobs)
             return torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(device)
         from ._lib import FoldJob, PackJob, UnpackJob
-        self.n = (len(rec.pack), len(rec.fold), len(rec.unpack))
-        self.t_pack, self.t_fold, self.t_unpack = table(rec.pack, PackJob), table(rec.fold, FoldJob), table(rec.unpack, UnpackJob)
-        self.b_pack = max([1] + [min(512, ((j.cout * j.kh * j.kw * j.cpad if j.mode == 0 else j.rows * j.KH * j.KW * j.cout) + 255) // 256)
-                                 for j in rec.pack])
+        fwd = [j for j in rec.pack if j.mode == 0]
+        dgr = [j for j in rec.pack if j.mode != 0]                # transposes: the LDS-tiled kernel
+        self.n = (len(fwd), len(rec.fold), len(rec.unpack), len(dgr))
+        self.t_pack, self.t_fold, self.t_unpack = table(fwd, PackJob), table(rec.fold, FoldJob), table(rec.unpack, UnpackJob)
+        self.t_dgrad = table(dgr, PackJob)
+        self.b_pack = max([1] + [min(512, (j.cout * j.kh * j.kw * j.cpad + 255) // 256) for j in fwd])
+        self.b_dgrad = max([1] + [((j.cout + 31) // 32) * ((j.cin + 31) // 32) for j in dgr])
         self.b_fold = max([1] + [min(64, (j.n + 255) // 256) for j in rec.fold])
         self.b_unpack = max([1] + [j.cout for j in rec.unpack])
 
@@ -212,6 +215,8 @@ class JobTables:
         L, st = lib(), _stream()
         if self.t_pack is not None:
             check(L.llv_pack_conv_weights_batched(self.t_pack.data_ptr(), self.n[0], self.b_pack, st), 'llv_pack_conv_weights_batched')
+        if self.t_dgrad is not None:
+            check(L.llv_pack_dgrad_weights_batched(self.t_dgrad.data_ptr(), self.n[3], self.b_dgrad, st), 'llv_pack_dgrad_weights_batched')
         if self.t_fold is not None:
             check(L.llv_fold_bias_batched(self.t_fold.data_ptr(), self.n[1], self.b_fold, st), 'llv_fold_bias_batched')
         if self.t_unpack is not None:

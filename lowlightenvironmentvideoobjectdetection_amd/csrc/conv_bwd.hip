@@ -70,7 +70,11 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
     constexpr int PA = BCO / 16, PB = BCI / 16;              // 1-KiB pieces per k-step
     constexpr int PAW = (PA + 3) / 4, PBW = (PB + 3) / 4;
     constexpr int RPA = 1024 / RBA, RPB = 1024 / RBB;        // pixel rows per piece
-    __shared__ __attribute__((aligned(16))) unsigned char smem[2 * STAGE];
+    // three k-steps in LDS: the loop body is 16 (128 x 128) or 4 (64 x 64) MFMAs per wave, far shorter than a DMA round trip, and a
+    // single-image launch has ~8-30 k-steps per workgroup -- with two buffers every step exposed most of that latency (round 3:
+    // counted waits, step ks + 2 requested while ks computes)
+    constexpr int NST = 3;
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE];
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave & 1, wc = wave >> 1;
@@ -171,12 +175,19 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
         return lo;
     };
 
+    // every wave issues the same number of DMA instructions per step when PA and PB are multiples of 4 (both tile shapes: 8 + 8 or
+    // 4 + 4 pieces), so "at most one step's worth outstanding" is a compile-time count
+    constexpr int PER_STEP = PAW + PBW;
+    static_assert(PA % 4 == 0 && PB % 4 == 0, "equal DMA counts per wave");
     issue(0, 0);
+    if (nk > 1) issue(1, 1);
+    int cur = 0;
     for (int ks = 0; ks < nk; ++ks) {
-        const int cur = ks & 1;
-        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-        __syncthreads();
-        if (ks + 1 < nk) issue(ks + 1, cur ^ 1);
+        if (ks + 1 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STEP) : "memory");      // step ks has landed, ks + 1 may be in flight
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // ... for every wave, and everyone is done reading buffer (ks - 1) % 3
+                                                             // (__syncthreads() would drain the DMA queue: it emits vmcnt(0))
+        if (ks + 2 < nk) issue(ks + 2, cur >= 1 ? cur - 1 : NST - 1);      // (ks + 2) % 3 == (ks - 1) % 3
         const unsigned char* sA = smem + cur * STAGE;
         const unsigned char* sB = sA + 32 * RBA;
         f16x8 af[TMO], bf[TNI];
@@ -201,6 +212,7 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
 #pragma unroll
             for (int i = 0; i < TMO; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], ones, accb[i], 0, 0, 0);
         }
+        cur = cur + 1 == NST ? 0 : cur + 1;
     }
     if (do_bias && (lane & 15) == 0) {        // every column of D holds the same row sum: take column 0
 #pragma unroll
@@ -440,6 +452,58 @@ __global__ void pack_weights_batched_kernel(const llv_pack_job* __restrict__ job
     for (long idx = blockIdx.x * (long)blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) pack_one(a, (unsigned)idx);
 }
 
+// The data-gradient filters (modes 1 / 2: input channel i becomes the ROW, output channel o runs along K) are a transpose of the
+// parameter tensor: in the element-wise kernel above consecutive threads read addresses cin*kh*kw floats apart (one cache line per
+// lane, 2.3 GB of line traffic for the 36 M parameters of the trainable part: ~300 us of every step). Here a workgroup moves a
+// 32 (o) x 32 (i) x all-taps tile through LDS: the reads are whole contiguous runs of 32*kh*kw floats per o, the writes 64-byte runs
+// of 32 consecutive o per (row, tap). Same values to the same places; positions no source tap maps to keep the zeros they were
+// allocated with (the element-wise kernel rewrites those zeros every time).
+constexpr int PT = 32, PT_TAPS = 9;
+__global__ __launch_bounds__(256) void pack_dgrad_tiled_kernel(const llv_pack_job* __restrict__ jobs) {
+    const llv_pack_job j = jobs[blockIdx.y];
+    __shared__ _Float16 tile[PT_TAPS][PT][PT + 2];
+    const int T = j.kh * j.kw;
+    const int tiles_i = (j.cin + PT - 1) / PT, tiles_o = (j.cout + PT - 1) / PT;
+    _Float16* const dst = (_Float16*)j.dst;
+    for (int tl = blockIdx.x; tl < tiles_i * tiles_o; tl += gridDim.x) {
+        const int o0 = (tl / tiles_i) * PT, i0 = (tl % tiles_i) * PT;
+        const int ni = j.cin - i0 < PT ? j.cin - i0 : PT, no = j.cout - o0 < PT ? j.cout - o0 : PT;
+        for (int t0 = 0; t0 < T; t0 += PT_TAPS) {
+            const int nt = T - t0 < PT_TAPS ? T - t0 : PT_TAPS;
+            __syncthreads();
+            // read: for each o a run of ni * T floats (the taps of ni consecutive input channels); take taps [t0, t0 + nt)
+            const int run = ni * T;
+            for (int e = threadIdx.x; e < no * run; e += blockDim.x) {
+                const int o = e / run, rem = e - o * run;
+                const int i = rem / T, t = rem - i * T;
+                if (t < t0 || t >= t0 + nt) continue;
+                float v = j.w[((long)(o0 + o) * j.cin + i0) * T + rem];
+                if (j.gamma) v *= j.gamma[o0 + o] * rsqrtf(j.var[o0 + o] + j.eps);
+                tile[t - t0][i][o] = (_Float16)v;
+            }
+            __syncthreads();
+            for (int e = threadIdx.x; e < nt * ni * PT; e += blockDim.x) {
+                const int o = e & (PT - 1), ti = e >> 5;
+                const int i = ti % ni, t = t0 + ti / ni;
+                if (o >= no) continue;
+                const int r = t / j.kw, q = t - r * j.kw;
+                long at;
+                if (j.mode == 1) {
+                    const int dy = j.kh - 1 - r, dx = j.kw - 1 - q;
+                    at = (long)(i0 + i) * j.k_pad + (dy * j.KW + dx) * j.cpad;
+                } else {
+                    // r = py + pad - 2 (dy - padp): the phase is the parity of r - pad, the window row follows
+                    const int py = (r - j.pad) & 1, px = (q - j.pad) & 1;
+                    const int dy = (py + j.pad - r) / 2 + j.padp, dx = (px + j.pad - q) / 2 + j.padp;
+                    if ((unsigned)dy >= (unsigned)j.KH || (unsigned)dx >= (unsigned)j.KW) continue;
+                    at = (long)(((i0 + i) << 2) + py * 2 + px) * j.k_pad + (dy * j.KW + dx) * j.cpad;
+                }
+                dst[at + j.row0 + o0 + o] = tile[t - t0][i][o];
+            }
+        }
+    }
+}
+
 __global__ void fold_bias_batched_kernel(const llv_fold_job* __restrict__ jobs) {
     const llv_fold_job j = jobs[blockIdx.y];
     for (int o = blockIdx.x * blockDim.x + threadIdx.x; o < j.n; o += gridDim.x * blockDim.x) {
@@ -604,6 +668,12 @@ extern "C" int llv_conv2d_nhwc_dgrad(const llv_conv_desc* fwd, const void* w_dgr
 extern "C" int llv_pack_conv_weights_batched(const llv_pack_job* jobs, int n_jobs, int blocks_per_job, void* stream) {
     if (!jobs || n_jobs < 1 || n_jobs > 65535 || blocks_per_job < 1) return LLV_E_BADARG;
     hipLaunchKernelGGL(pack_weights_batched_kernel, dim3(blocks_per_job > 4096 ? 4096 : blocks_per_job, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_pack_dgrad_weights_batched(const llv_pack_job* jobs, int n_jobs, int blocks_per_job, void* stream) {
+    if (!jobs || n_jobs < 1 || n_jobs > 65535 || blocks_per_job < 1) return LLV_E_BADARG;
+    hipLaunchKernelGGL(pack_dgrad_tiled_kernel, dim3(blocks_per_job > 1024 ? 1024 : blocks_per_job, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 

@@ -112,8 +112,10 @@ class SelsaKeyPlan:
             x_new = b.conv(f'head.agg{i}.values', pwt, pcv)                    # (1, P, 1, F)
             # relu(x_pre + fc(x_new)) = the residual + ReLU epilogue of the aggregator's last fc (selsa_bbox_head.py:78-80)
             x = b.conv(f'head.agg{i}.fc', x_new.view(P, 1, 1, Fc), linear_pc(ag.fc), CONV_RELU | CONV_RES_ADD, res=x_pre.view(P, 1, 1, Fc))
-            if i + 1 < nf:                     # the reference chain's input to the next fc: relu(r_pre) -- the same fc with a ReLU epilogue
-                r = b.conv(f'head.fc{i}.ref_relu', r, pc, CONV_RELU)
+            if i + 1 < nf:                     # the reference chain's input to the next fc: relu(r_pre), element-wise on the rows already there
+                r = b.buf(*r_pre.shape)        # (y * (y > 0) = llv_relu_bwd with dy = y; bit-identical to the fc's ReLU epilogue, whose
+                b.plan.add(f'head.fc{i}.ref_relu', L.llv_relu_bwd,          # re-run of the 12544-wide first fc cost 73 us per frame)
+                           (ops._ptr(r_pre), None, ops._ptr(r_pre), ops._ptr(r), C.c_int64(r_pre.numel())), 0.0, 4.0 * r_pre.numel())
         ncl = head.num_classes
         cls_l = b.conv('head.fc_cls', x, linear_pc(head.fc_cls), CONV_OUT_F32)                  # (P, 1, 1, >= ncl + 1) fp32
         reg_l = b.conv('head.fc_reg', x, linear_pc(head.fc_reg), CONV_OUT_F32)                  # (P, 1, 1, 4 * ncl)
