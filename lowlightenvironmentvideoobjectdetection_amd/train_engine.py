@@ -420,18 +420,21 @@ def plan_buckets(keys_per_op, slices, limit):
 class LazyLogVars(Mapping):
     """BaseDetector._parse_losses' log_vars (base.py:226-261: per key the sum of the per-level means, 'loss' = sum of the keys with
     'loss' in the name, averaged over the ranks) as a read-on-demand mapping: the values stay on the device until somebody looks, so
-    a training loop that logs every n-th step does not stall the other n - 1."""
+    a training loop that logs every n-th step does not stall the other n - 1 (the all-reduce itself is queued by every rank at once)."""
 
     def __init__(self, vec, world):
-        self._vec, self._world, self._vals = vec, world, None
+        # the average over the ranks is a collective: it is issued HERE, by every rank, asynchronously (a rank that never looks at its
+        # values must still take part -- reading them lazily on rank 0 alone would hang the other ranks' next collective)
+        self._vec, self._world, self._vals, self._work = vec, world, None, None
+        if world > 1:
+            self._vec = vec.div(world)
+            self._work = dist.all_reduce(self._vec, async_op=True)
 
     def _resolve(self):
         if self._vals is None:
-            v = self._vec
-            if self._world > 1:
-                v = v.clone()
-                dist.all_reduce(v.div_(self._world))
-            v = v.tolist()
+            if self._work is not None:
+                self._work.wait()
+            v = self._vec.tolist()
             nl = len(v) // 2
             lc, lb = float(sum(v[:nl])), float(sum(v[nl:]))
             self._vals = OrderedDict(loss_cls=lc, loss_bbox=lb, loss=lc + lb)

@@ -231,8 +231,10 @@ def _ddp_worker(rank, world, port, q):
     img = torch.roll(img, shifts=5 * rank, dims=3)                        # different data per rank
     ts = TE.TrainStep(det, 2, img.shape[2], img.shape[3], dev, lr=2e-5, bucket_mb=0.5)
     out = None
-    for _ in range(2):
+    for it in range(3):
         out = ts.step_fused(img.to(dev), metas, [b.to(dev) for b in gtb], [l.to(dev) for l in gtl])
+        if it == 0 and rank == 0:
+            float(out['log_vars']['loss'])          # ONE rank looks at its values (bench.py's pattern): must not be a lone collective
     flat = ts.flat_w.detach().clone()
     gathered = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(gathered, flat)
