@@ -566,6 +566,17 @@ int llv_upsample2x_nhwc(const void* src, void* dst, int n, int h, int w, int c, 
  * boxes [n][h*w*A][4] (xyxy), conf [n][h*w*A] = sigmoid(attr 4). anchors_wh: A (w, h) pairs (host floats). */
 int llv_yolo_decode(const float* pred, int n, int h, int w, int num_anchors, int num_attrib, int ld, int stride,
                     const float* anchors_wh, float* boxes, float* conf, void* stream);
+
+/* YOLOV3Head._get_bboxes between the per-anchor decode and the NMS (yolo_head.py:281-335) for one level of `batch` images: the nms_pre
+ * anchors with the highest objectness (torch.topk order: best first; all n anchors in anchor order when n <= nms_pre or nms_pre <= 0),
+ * their boxes (divided by inv_scale[img][0..4) when given: the rescale of :316-318), objectness and class scores sigmoid(logit) -- zero
+ * for rows whose objectness is below conf_thr (:320-327) -- written to rows [out_row0, out_row0 + m) of the per-image candidate lists
+ * out_boxes [batch][n_total][4], out_conf [batch][n_total], out_scores [batch][n_total][num_classes]. pred / boxes / conf as for
+ * llv_yolo_decode. workspace: llv_yolo_select_workspace_bytes(batch, n). */
+size_t llv_yolo_select_workspace_bytes(int batch, int n);
+int llv_yolo_select(const float* pred, const float* boxes, const float* conf, int batch, int n, int num_anchors, int num_attrib,
+                    int num_classes, int ld, int nms_pre, float conf_thr, const float* inv_scale, int64_t out_row0, int64_t n_total,
+                    float* out_boxes, float* out_conf, float* out_scores, void* workspace, size_t workspace_bytes, void* stream);
 /* llv_multiclass_nms_batched with multiclass_nms's score_factors (bbox_nms.py:55-62): the threshold test uses the raw score,
  * the ranking / reported score is score * score_factors[i] (YOLOv3: objectness). score_factors [batch][n], may be NULL. */
 int llv_multiclass_nms_batched_sf(const float* boxes, const float* scores, const float* score_factors, int batch, int n,

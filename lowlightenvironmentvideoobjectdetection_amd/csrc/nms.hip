@@ -479,3 +479,99 @@ unsigned int llv_nms_guard_trips_(int reset) {
     }
     return v;
 }
+
+// ------------------------------------------------------------------------------------------------
+// YOLOV3Head._get_bboxes between the per-anchor decode and the NMS (yolo_head.py:281-335), one workgroup per (level, image):
+// the nms_pre anchors with the highest objectness (conf.topk(nms_pre), :283-292) by an 8-pass radix select over (conf, index) keys and a
+// bitonic sort of the selected ones (torch.topk returns them best first), then the gather of their boxes, objectness and class
+// scores = sigmoid(class logits) into the concatenated candidate lists the NMS reads, with the conf_thr rule (:320-327: a row whose
+// objectness is below conf_thr is dropped == all its class scores are zero) and the rescale by scale_factor (:316-318) folded in.
+// A level with at most nms_pre anchors keeps them all, in anchor order.
+// ------------------------------------------------------------------------------------------------
+namespace {
+
+struct YoloSelArgs {
+    const float* pred;      // [batch][h*w][ld] fp32, channel a*na + attr
+    const float* boxes;     // [batch][n][4] (llv_yolo_decode)
+    const float* conf;      // [batch][n]
+    int n, A, na, nc, ld, m;            // n = h*w*A anchors of the level, m = min(nms_pre, n) kept
+    long out0;              // first row of this level in the candidate lists
+    long n_total;           // rows of the candidate lists per image
+    float* out_boxes; float* out_conf; float* out_scores;
+    uint64_t* keys;         // workspace: [batch][n]
+    float conf_thr;
+    const float* inv_scale; // [batch][4] or null
+};
+
+__global__ __launch_bounds__(1024) void yolo_select_kernel(const YoloSelArgs a) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    const int img = blockIdx.x, tid = threadIdx.x;
+    const int mp = llv::next_pow2(a.m);
+    uint64_t* sel = reinterpret_cast<uint64_t*>(sm);                       // [mp]
+    unsigned* hist = reinterpret_cast<unsigned*>(sel + mp);                // [256]
+    uint64_t* sh = reinterpret_cast<uint64_t*>(hist + 256);                // [2]
+    const float* conf = a.conf + (long)img * a.n;
+    const bool all = a.m >= a.n;
+    if (!all) {
+        uint64_t* keys = a.keys + (long)img * a.n;
+        for (int i = tid; i < a.n; i += blockDim.x) keys[i] = llv::make_key(conf[i], (uint32_t)i);
+        __syncthreads();
+        llv::block_select_top(keys, a.n, a.m, sel, hist, sh);
+        for (int i = a.m + tid; i < mp; i += blockDim.x) sel[i] = 0;
+        __syncthreads();
+        llv::bitonic_sort_desc(sel, mp);
+    }
+    const float* boxes = a.boxes + (long)img * a.n * 4;
+    const float* pred = a.pred + (long)img * (a.n / a.A) * a.ld;
+    float* ob = a.out_boxes + ((long)img * a.n_total + a.out0) * 4;
+    float* oc = a.out_conf + (long)img * a.n_total + a.out0;
+    float* os = a.out_scores + ((long)img * a.n_total + a.out0) * a.nc;
+    float4 inv = make_float4(1.f, 1.f, 1.f, 1.f);
+    if (a.inv_scale) inv = reinterpret_cast<const float4*>(a.inv_scale)[img];
+    // boxes + objectness: one thread per kept row; class scores: one thread per (row, class)
+    for (int j = tid; j < a.m; j += blockDim.x) {
+        int idx = all ? j : (int)llv::key_index(sel[j]);
+        if ((unsigned)idx >= (unsigned)a.n) { LLV_GUARD_TRIP(); idx = 0; }
+        const float4 b = reinterpret_cast<const float4*>(boxes)[idx];
+        reinterpret_cast<float4*>(ob)[j] = a.inv_scale ? make_float4(b.x / inv.x, b.y / inv.y, b.z / inv.z, b.w / inv.w) : b;
+        oc[j] = conf[idx];
+    }
+    const int total = a.m * a.nc;
+    for (int e = tid; e < total; e += blockDim.x) {
+        const int j = e / a.nc, c = e - j * a.nc;
+        int idx = all ? j : (int)llv::key_index(sel[j]);
+        if ((unsigned)idx >= (unsigned)a.n) idx = 0;
+        const int cell = idx / a.A, an = idx - cell * a.A;
+        const float x = pred[(long)cell * a.ld + an * a.na + 5 + c];
+        const float sc = 1.f / (1.f + expf(-x));
+        os[(long)j * a.nc + c] = (a.conf_thr > 0.f && !(conf[idx] >= a.conf_thr)) ? 0.f : sc;
+    }
+}
+
+}  // namespace
+
+extern "C" size_t llv_yolo_select_workspace_bytes(int batch, int n) { return batch > 0 && n > 0 ? (size_t)batch * n * 8 : 0; }
+
+extern "C" int llv_yolo_select(const float* pred, const float* boxes, const float* conf, int batch, int n, int num_anchors, int num_attrib,
+                               int num_classes, int ld, int nms_pre, float conf_thr, const float* inv_scale, int64_t out_row0, int64_t n_total,
+                               float* out_boxes, float* out_conf, float* out_scores, void* workspace, size_t workspace_bytes, void* stream) {
+    if (!pred || !boxes || !conf || !out_boxes || !out_conf || !out_scores || batch < 1 || n < 1 || num_anchors < 1 || n % num_anchors) return LLV_E_BADARG;
+    if (num_attrib < 5 + num_classes || num_classes < 1 || ld < num_anchors * num_attrib || out_row0 < 0) return LLV_E_BADARG;
+    const int m = (nms_pre > 0 && nms_pre < n) ? nms_pre : n;
+    if (out_row0 + m > n_total) return LLV_E_BADARG;
+    YoloSelArgs a{pred, boxes, conf, n, num_anchors, num_attrib, num_classes, ld, m, (long)out_row0, (long)n_total, out_boxes, out_conf, out_scores,
+                  (uint64_t*)workspace, conf_thr, inv_scale};
+    size_t lds = 0;
+    if (m < n) {
+        if (!workspace || workspace_bytes < llv_yolo_select_workspace_bytes(batch, n)) return LLV_E_WORKSPACE;
+        int mp = 1;
+        while (mp < m) mp <<= 1;
+        lds = (size_t)mp * 8 + 256 * 4 + 16;
+        if (lds > kLdsLimit) return LLV_E_UNSUPPORTED;
+        if (lds > 48 * 1024 &&
+            hipFuncSetAttribute((const void*)yolo_select_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, (int)kLdsLimit) != hipSuccess)
+            return LLV_E_LAUNCH;
+    }
+    hipLaunchKernelGGL(yolo_select_kernel, dim3(batch), dim3(1024), lds, (hipStream_t)stream, a);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}

@@ -435,24 +435,30 @@ def _yolo_select_nms(head, pred, boxes_l, conf_l, A, na, bs, img_metas, rescale,
     nc = head.num_classes
     device = pred[0].device
     nms_pre = cfg.get('nms_pre', -1)
-    bl, sl, cl = [], [], []
-    for i, pm in enumerate(pred):
-        conf, box = conf_l[i], boxes_l[i]
-        pmf = pm.view(bs, -1, pm.shape[-1])[..., :A * na].reshape(bs, -1, na)
-        if nms_pre > 0 and conf.shape[1] > nms_pre:
-            _, ti = conf.topk(nms_pre)
-            bi = torch.arange(bs, device=conf.device).view(-1, 1).expand_as(ti)
-            box, conf, pmf = box[bi, ti, :], conf[bi, ti], pmf[bi, ti, :]
-        bl.append(box); cl.append(conf); sl.append(torch.sigmoid(pmf[..., 5:]))
-    boxes, scores, confs = torch.cat(bl, 1).contiguous(), torch.cat(sl, 1), torch.cat(cl, 1).contiguous()
-    if rescale and img_metas is not None:
-        sf = torch.tensor(np.stack([np.asarray(m['scale_factor'], dtype=np.float32).reshape(-1)[:4] * np.ones(4, np.float32)
-                                    for m in img_metas]), device=boxes.device)
-        boxes = (boxes / sf.unsqueeze(1)).contiguous()
     thr = cfg.get('conf_thr', -1)
-    if thr > 0:       # dropping a row == making all its class scores fail the score threshold
-        scores = scores * confs.ge(thr).unsqueeze(-1)
-    scores = scores.contiguous()
+    # per level: llv_yolo_select (radix-select top-k on objectness, gather, sigmoid of the class logits, conf_thr, rescale) straight into
+    # the concatenated candidate lists; buffers kept between calls
+    ns = [int(c.shape[1]) for c in conf_l]
+    ms = [min(nms_pre, n_) if nms_pre > 0 else n_ for n_ in ns]
+    n_total = sum(ms)
+    key = (bs, tuple(ns), tuple(ms), nc)
+    sel = getattr(cache, '_sel', None)
+    if sel is None or sel[0] != key:
+        wsb = max(int(lib().llv_yolo_select_workspace_bytes(bs, n_)) for n_ in ns)
+        sel = (key, torch.zeros(bs, n_total, 4, device=device), torch.zeros(bs, n_total, device=device), torch.zeros(bs, n_total, nc, device=device),
+               torch.empty(max(wsb, 256), dtype=torch.uint8, device=device), torch.ones(bs, 4, device=device))
+        cache._sel = sel
+    _, boxes, confs, scores, sws, inv = sel
+    use_sf = bool(rescale and img_metas is not None)
+    if use_sf:
+        inv.copy_(torch.tensor(np.stack([np.asarray(m['scale_factor'], dtype=np.float32).reshape(-1)[:4] * np.ones(4, np.float32) for m in img_metas])))
+    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    row0 = 0
+    for i, pm in enumerate(pred):
+        check(lib().llv_yolo_select(pm.data_ptr(), boxes_l[i].data_ptr(), conf_l[i].data_ptr(), bs, ns[i], A, na, nc, pm.shape[-1], int(nms_pre),
+                                    float(thr), inv.data_ptr() if use_sf else None, row0, n_total, boxes.data_ptr(), confs.data_ptr(), scores.data_ptr(),
+                                    sws.data_ptr(), sws.numel(), stream), 'llv_yolo_select')
+        row0 += ms[i]
     n = boxes.shape[1]
     nms_cfg = cfg['nms']
     iou_thr = nms_cfg.get('iou_threshold', nms_cfg.get('iou_thr'))
@@ -463,7 +469,6 @@ def _yolo_select_nms(head, pred, boxes_l, conf_l, A, na, bs, img_metas, rescale,
                       torch.zeros(bs, max_num, 5, device=device), torch.zeros(bs, max_num, dtype=torch.int64, device=device),
                       torch.zeros(bs, dtype=torch.int32, device=device), torch.zeros(bs, max_num, dtype=torch.int32, device=device))
     _, ws, dets, labels, count, keep = cache._nms
-    stream = C.c_void_p(torch.cuda.current_stream().cuda_stream)
     check(lib().llv_multiclass_nms_batched_sf(boxes.data_ptr(), scores.data_ptr(), confs.data_ptr(), bs, n, nc, nc, cfg['score_thr'],
                                               iou_thr, max_num, dets.data_ptr(), labels.data_ptr(), count.data_ptr(),
                                               keep.data_ptr(), ws.data_ptr(), ws.numel(), stream), 'llv_multiclass_nms_batched_sf')
