@@ -830,7 +830,12 @@ def main():
                 # the same kernel against the memory roof (its 32/64-channel layers have fewer FLOP per byte than the machine's ridge):
                 # algorithmic bytes per launch / average launch duration, peak 8 TB/s
                 'hbm_view': {'achieved': round(dnb / (dms * 1e-3) / 1e9, 1), 'peak': 8000.0, 'unit': 'GB/s',
-                             'frac': round(dnb / (dms * 1e-3) / 1e9 / 8000.0, 4)},
+                             'frac': round(dnb / (dms * 1e-3) / 1e9 / 8000.0, 4),
+                             # the same with the bytes the PMC counters saw (profiles/traffic.json; FETCH_SIZE x2 + WRITE_SIZE per launch)
+                             'counter_bytes_per_launch': _profiled_traffic(B, dom),
+                             'counter_gbps': (round(_profiled_traffic(B, dom) * dn / (dms * 1e-3) / 1e9, 1)
+                                              if _profiled_traffic(B, dom) else None),
+                             'counter_over_algorithmic': (round(_profiled_traffic(B, dom) * dn / dnb, 3) if _profiled_traffic(B, dom) else None)},
                 'all_conv_kernels': {'achieved': round(conv_fl / (conv_ms * 1e-3) / 1e12, 2),
                                      'frac': round(conv_fl / (conv_ms * 1e-3) / 1e12 / peak, 4),
                                      'launches_per_step': len(convs), 'ms_per_step': round(conv_ms, 4)},
