@@ -659,6 +659,12 @@ int llv_conv2d_nhwc_dgrad(const llv_conv_desc* fwd, const void* w_dgrad, const f
 /* dx = (dy [+ dy2]) * (y > 0); dy2 and y may be NULL (then: plain sum / plain copy). n fp16 elements, multiple of 8.
  * torch autograd of F.relu(x [+ identity]) (resnet.py:292-296). */
 int llv_relu_bwd(const void* dy, const void* dy2, const void* y, void* dx, int64_t n, void* stream);
+/* Backward of a LeakyReLU epilogue (Darknet / YOLOV3Neck ConvModules), with the residual of a ResBlock (y = res + act(v), darknet.py:50-57)
+ * when res != NULL: gres += dy (when gres != NULL), then dy *= (y - res > 0 ? 1 : slope) in place. `rows` rows of c halfs, own pitches. */
+int llv_act_bwd(void* dy, const void* y, const void* res, void* gres, int64_t rows, int c, int dy_ld, int y_ld, int res_ld, int gres_ld,
+                float slope, void* stream);
+/* Backward of llv_upsample2x_nhwc: gsrc[n][y][x][c] += the four fine pixels of gdst (n, 2h, 2w, gdst_ld). */
+int llv_upsample2x_nhwc_bwd(const void* gdst, void* gsrc, int n, int h, int w, int c, int gdst_ld, int gsrc_ld, void* stream);
 
 /* out[c] += sum_p dy[p][c]  (fp32 atomics; dy fp16 [m][ld]): the bias / BN-shift gradient of a conv */
 int llv_bias_grad(const void* dy, int64_t m, int c, int ld, float* out, void* stream);

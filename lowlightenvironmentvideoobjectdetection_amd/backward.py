@@ -109,6 +109,22 @@ def relu_bwd(dy: torch.Tensor, y: Optional[torch.Tensor], dx: torch.Tensor, dy2:
                              dx.data_ptr(), n, _stream()), 'llv_relu_bwd')
 
 
+def act_bwd(dy: torch.Tensor, y: torch.Tensor, res: Optional[torch.Tensor], gres: Optional[torch.Tensor], slope: float):
+    """llv_act_bwd over (..., C) fp16 tensors whose last-but-one stride is their row pitch: gres += dy; dy *= (y - res > 0 ? 1 : slope)."""
+    c = y.shape[-1]
+    rows = y.numel() // c
+    ld = lambda t: t.stride(-2) if t.dim() > 1 else c
+    check(lib().llv_act_bwd(dy.data_ptr(), y.data_ptr(), _p(res), _p(gres), rows, c, ld(dy), ld(y), ld(res) if res is not None else 0,
+                            ld(gres) if gres is not None else 0, float(slope), _stream()), 'llv_act_bwd')
+
+
+def upsample2x_bwd(gdst: torch.Tensor, gsrc: torch.Tensor):
+    """gsrc (n, h, w, c) += the four fine pixels of gdst (n, 2h, 2w, c) (views with their own row pitch allowed)."""
+    n, h, w, c = gsrc.shape
+    check(lib().llv_upsample2x_nhwc_bwd(gdst.data_ptr(), gsrc.data_ptr(), n, h, w, c, gdst.stride(-2), gsrc.stride(-2), _stream()),
+          'llv_upsample2x_nhwc_bwd')
+
+
 def bias_grad(dy: torch.Tensor, m: int, c: int, ld: int, out: torch.Tensor):
     check(lib().llv_bias_grad(dy.data_ptr(), m, c, ld, out.data_ptr(), _stream()), 'llv_bias_grad')
 

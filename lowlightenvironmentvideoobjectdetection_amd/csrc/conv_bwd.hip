@@ -441,6 +441,62 @@ __device__ __forceinline__ void unpack_one(const UnpackArgs& a, int o) {
 }
 
 __global__ __launch_bounds__(256) void unpack_wgrad_kernel(const UnpackArgs a) { unpack_one(a, blockIdx.x); }
+// Backward of a LeakyReLU epilogue, with the residual of Darknet's ResBlock (y = res + act(v), LLV_CONV_ACT_FIRST) when there is one:
+// gres += dy, then dy *= (act(v) > 0 ? 1 : slope) in place, where act(v) = y (- res). Rows of c halfs with their own pitches.
+__global__ void act_bwd_kernel(_Float16* __restrict__ dy, const _Float16* __restrict__ y, const _Float16* __restrict__ res,
+                               _Float16* __restrict__ gres, long rows, int c8, int dy_ld, int y_ld, int res_ld, int gres_ld, float slope) {
+    const long total = rows * c8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / c8;
+        const int cv = (int)(i - r * c8) * 8;
+        f16x8 g = *reinterpret_cast<const f16x8*>(dy + r * dy_ld + cv);
+        const f16x8 yv = *reinterpret_cast<const f16x8*>(y + r * y_ld + cv);
+        f16x8 rv;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) rv[e] = (_Float16)0.f;
+        if (res) rv = *reinterpret_cast<const f16x8*>(res + r * res_ld + cv);
+        if (gres) {
+            f16x8 gr = *reinterpret_cast<const f16x8*>(gres + r * gres_ld + cv);
+#pragma unroll
+            for (int e = 0; e < 8; ++e) gr[e] = (_Float16)((float)gr[e] + (float)g[e]);
+            *reinterpret_cast<f16x8*>(gres + r * gres_ld + cv) = gr;
+        }
+#pragma unroll
+        for (int e = 0; e < 8; ++e) g[e] = ((float)yv[e] - (float)rv[e]) > 0.f ? g[e] : (_Float16)((float)g[e] * slope);
+        *reinterpret_cast<f16x8*>(dy + r * dy_ld + cv) = g;
+    }
+}
+
+// Backward of llv_upsample2x_nhwc (nearest, x2): gsrc[n][y][x][c] += sum over the four fine pixels of gdst[n][2y+dy][2x+dx][c]
+__global__ void upsample2x_bwd_kernel(const _Float16* __restrict__ gdst, _Float16* __restrict__ gsrc, int n, int h, int w, int c8, int gdst_ld,
+                                      int gsrc_ld) {
+    const long total = (long)n * h * w * c8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const int cv = (int)(i % c8) * 8;
+        long p = i / c8;
+        const int x = (int)(p % w); p /= w;
+        const int y = (int)(p % h);
+        const int b = (int)(p / h);
+        float acc[8];
+        _Float16* d = gsrc + (((long)b * h + y) * w + x) * gsrc_ld + cv;
+        const f16x8 cur = *reinterpret_cast<const f16x8*>(d);
+#pragma unroll
+        for (int e = 0; e < 8; ++e) acc[e] = (float)cur[e];
+#pragma unroll
+        for (int dy = 0; dy < 2; ++dy)
+#pragma unroll
+            for (int dx = 0; dx < 2; ++dx) {
+                const f16x8 v = *reinterpret_cast<const f16x8*>(gdst + (((long)b * 2 * h + 2 * y + dy) * (2 * w) + 2 * x + dx) * gdst_ld + cv);
+#pragma unroll
+                for (int e = 0; e < 8; ++e) acc[e] += (float)v[e];
+            }
+        f16x8 o;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) o[e] = (_Float16)acc[e];
+        *reinterpret_cast<f16x8*>(d) = o;
+    }
+}
+
 // ---- the same three bookkeeping kernels over a TABLE of jobs in device memory (blockIdx.y = job): a training step re-packs ~120
 // parameter tensors and unpacks ~60 gradients, each a few microseconds of work behind a launch of its own; one launch per table
 // instead (round 3: 250 launches per step -> 3 + one per all-reduce bucket).
@@ -686,5 +742,28 @@ extern "C" int llv_fold_bias_batched(const llv_fold_job* jobs, int n_jobs, int b
 extern "C" int llv_unpack_wgrad_batched(const llv_unpack_job* jobs, int n_jobs, int blocks_per_job, void* stream) {
     if (!jobs || n_jobs < 1 || n_jobs > 65535 || blocks_per_job < 1) return LLV_E_BADARG;
     hipLaunchKernelGGL(unpack_wgrad_batched_kernel, dim3(blocks_per_job > 2048 ? 2048 : blocks_per_job, n_jobs), dim3(256), 0, (hipStream_t)stream, jobs);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_act_bwd(void* dy, const void* y, const void* res, void* gres, int64_t rows, int c, int dy_ld, int y_ld, int res_ld, int gres_ld,
+                           float slope, void* stream) {
+    if (!dy || !y || rows < 0 || c < 8 || (c & 7) || dy_ld < c || y_ld < c || ((dy_ld | y_ld) & 7)) return LLV_E_BADARG;
+    if ((res && (res_ld < c || (res_ld & 7))) || (gres && (gres_ld < c || (gres_ld & 7)))) return LLV_E_BADARG;
+    if (rows == 0) return LLV_OK;
+    const long total = rows * (c / 8);
+    long grid = (total + 255) / 256;
+    grid = grid > 8192 ? 8192 : grid;
+    hipLaunchKernelGGL(act_bwd_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (_Float16*)dy, (const _Float16*)y, (const _Float16*)res,
+                       (_Float16*)gres, (long)rows, c / 8, dy_ld, y_ld, res_ld, gres_ld, slope);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_upsample2x_nhwc_bwd(const void* gdst, void* gsrc, int n, int h, int w, int c, int gdst_ld, int gsrc_ld, void* stream) {
+    if (!gdst || !gsrc || n < 1 || h < 1 || w < 1 || c < 8 || (c & 7) || gdst_ld < c || gsrc_ld < c || ((gdst_ld | gsrc_ld) & 7)) return LLV_E_BADARG;
+    const long total = (long)n * h * w * (c / 8);
+    long grid = (total + 255) / 256;
+    grid = grid > 8192 ? 8192 : grid;
+    hipLaunchKernelGGL(upsample2x_bwd_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)gdst, (_Float16*)gsrc, n, h, w,
+                       c / 8, gdst_ld, gsrc_ld);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }

@@ -182,7 +182,7 @@ class Builder:
         self.plan.keep += [pc, pc.w, pc.bias, d] + list(xs) + [y] + ([res] if res is not None else [])
         self.plan.add(name, self._fn_conv, (C.byref(d),), flops, nbytes, kernel=ops.conv_kernel_name(d))
         self.tape.append(dict(name=name, pc=pc, xs=list(xs), y=y, batch=batch, segs=list(segs), x_ld=x_ld, y_ld=y_ld, res=res,
-                              res_ld=res_ld, flags=flags, res_hw=res_hw, desc=d))
+                              res_ld=res_ld, flags=flags, res_hw=res_hw, desc=d, act_slope=act_slope))
         return d
 
     def conv(self, name, x, pc: ops.PackedConv, flags=0, res=None, out=None, tile=0):

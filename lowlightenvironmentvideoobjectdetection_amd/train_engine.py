@@ -28,7 +28,7 @@ import torch.distributed as dist
 
 from . import backward as B
 from . import engine, ops
-from ._lib import LlvError, CONV_RELU, CONV_RES_ADD, CONV_RES_UPS, CONV_PIXSHUF, CONV_OUT_F32
+from ._lib import LlvError, CONV_ACT_FIRST, CONV_LEAKY, CONV_RELU, CONV_RES_ADD, CONV_RES_UPS, CONV_PIXSHUF, CONV_OUT_F32
 
 
 def _sptr(t: torch.Tensor) -> int:
@@ -278,7 +278,15 @@ class TrainGraph:
                     n = op['batch'] * ho * wo
                     yv, gv = self._rows(op['y'], yo, n), self._rows(gy, yo, n)
                     B.relu_bwd(gv, yv, gv)
-            if (flags & CONV_RES_ADD) and op['res'] is not None and _sptr(op['res']) in self.req:
+            if flags & CONV_LEAKY:
+                # LeakyReLU epilogue (Darknet / YOLOV3Neck ConvModules); with LLV_CONV_ACT_FIRST the residual joins AFTER the activation
+                # (ResBlock: y = res + act(v)): the residual takes dY as it is, the conv's own dY gets the activation's slope
+                res = op['res'] if (flags & CONV_RES_ADD) else None
+                if res is not None and not (flags & CONV_ACT_FIRST):
+                    raise LlvError(f"{op['name']}: backward of LeakyReLU(v + res) is not built (ResBlocks add after the activation)")
+                gres = self.gview(res) if res is not None and _sptr(res) in self.req else None
+                B.act_bwd(gy, op['y'], res, gres, op.get('act_slope', 0.0))
+            elif (flags & CONV_RES_ADD) and op['res'] is not None and _sptr(op['res']) in self.req:
                 gres = self.gview(op['res'])
                 if flags & CONV_RES_UPS:
                     B.upsample_add_bwd(gy, gres, accumulate=True)

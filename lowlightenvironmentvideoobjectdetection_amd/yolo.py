@@ -340,6 +340,96 @@ def _cm(b, sd, name, p, x, stride=1, pad=0, res=None, out=None, y_ld=None):
     return out
 
 
+def _concat_bwd(g, op):
+    """Backward of the neck's torch.cat((upsampled, backbone stage), 1) (yolo_neck.py:123-124) in the training graph: the upsampled part
+    goes back through the 2x nearest upsampling (sum of the four fine pixels), the stage's part is added to the stage's gradient."""
+    from . import backward as B
+    tmp, xf = op['xs']
+    cat = op['y']
+    gcat = g.gview(cat)
+    oc = tmp.shape[-1]
+    if train_engine_sptr(tmp) in g.req:
+        B.upsample2x_bwd(gcat[..., :oc], g.gview(tmp))
+    if train_engine_sptr(xf) in g.req:
+        gx = g.gview(xf)
+        n, h, w, c = xf.shape
+        check(lib().llv_add_f16(gx.data_ptr(), gcat[..., oc:].data_ptr(), gx.data_ptr(), n * h * w, c, gx.stride(-2), gcat.stride(-2), gx.stride(-2),
+                                C.c_void_p(torch.cuda.current_stream().cuda_stream)), 'llv_add_f16')
+
+
+def train_engine_sptr(t):
+    return t.untyped_storage().data_ptr()
+
+
+def build_yolo_body(b, sd, bb, neck, head, x_in, train=False):
+    """Darknet -> YOLOV3Neck -> head convs on the builder; returns (per-level fp32 NHWC prediction maps, their (h, w)).
+    Inference (train=False): the backbone stages the neck concatenates write straight into the concat buffer's upper channels and the
+    upsampling into its lower ones. train=True: every conv writes a buffer of its own and the concatenation is an explicit pair of
+    launches with a CUSTOM tape entry (the backward pass wants one gradient buffer per activation: train_engine.TrainGraph)."""
+    layers, channels = ARCH[bb.depth]
+    ns = neck.num_scales
+    out_idx = list(bb.out_indices)
+    assert len(out_idx) == ns
+    feats = {}
+    x = _cm(b, sd, 'backbone.conv1', 'backbone.conv1', x_in, 1, 1)
+    for i, nres in enumerate(layers):
+        q = f'backbone.conv_res_block{i + 1}'
+        x = _cm(b, sd, q + '.conv', q + '.conv', x, 2, 1)
+        for r in range(nres):
+            y = _cm(b, sd, f'{q}.res{r}.conv1', f'{q}.res{r}.conv1', x, 1, 0)
+            last = r == nres - 1 and (i + 1) in out_idx and out_idx.index(i + 1) < ns - 1
+            if last and not train:
+                # concat buffer of the neck level that consumes this stage: [upsampled out_c | this stage's in_c]
+                lvl = ns - 1 - out_idx.index(i + 1)          # feats are reversed inside the neck
+                oc = neck.out_channels[lvl]
+                n_, h_, w_, c_ = x.shape
+                cat = b.buf(n_, h_, w_, oc + c_)
+                dst = cat[..., oc:]
+                x = _cm(b, sd, f'{q}.res{r}.conv2', f'{q}.res{r}.conv2', y, 1, 1, res=x, out=dst, y_ld=oc + c_)
+                feats[i + 1] = (x, cat)
+            else:
+                x = _cm(b, sd, f'{q}.res{r}.conv2', f'{q}.res{r}.conv2', y, 1, 1, res=x)
+        if (i + 1) in out_idx and (i + 1) not in feats:
+            feats[i + 1] = (x, None)
+
+    # neck (yolo_neck.py:110-131)
+    def detect(xin, p, tag):
+        t = _cm(b, sd, tag + '.conv1', p + 'conv1', xin, 1, 0)
+        t = _cm(b, sd, tag + '.conv2', p + 'conv2', t, 1, 1)
+        t = _cm(b, sd, tag + '.conv3', p + 'conv3', t, 1, 0)
+        t = _cm(b, sd, tag + '.conv4', p + 'conv4', t, 1, 1)
+        return _cm(b, sd, tag + '.conv5', p + 'conv5', t, 1, 0)
+    ordered = [feats[k] for k in out_idx]
+    out = detect(ordered[-1][0], 'neck.detect1.', 'neck.detect1')
+    outs = [out]
+    for i, (xf, cat) in enumerate(reversed(ordered[:-1])):
+        tmp = _cm(b, sd, f'neck.conv{i + 1}', f'neck.conv{i + 1}', out, 1, 0)
+        n_, h_, w_, c_ = tmp.shape
+        if cat is None:                          # training graph: the concat buffer is filled by two launches of its own
+            cx = xf.shape[-1]
+            cat = b.buf(n_, 2 * h_, 2 * w_, c_ + cx)
+            zero = b.buf(*xf.shape)
+            b.plan.add(f'neck.cat{i + 1}', lib().llv_add_f16,
+                       (C.c_void_p(xf.data_ptr()), C.c_void_p(zero.data_ptr()), C.c_void_p(cat[..., c_:].data_ptr()), xf.numel() // cx, cx, cx, cx,
+                        c_ + cx), 0.0, 4.0 * xf.numel())
+        b.plan.add(f'neck.upsample{i + 1}', lib().llv_upsample2x_nhwc,
+                   (C.c_void_p(tmp.data_ptr()), C.c_void_p(cat.data_ptr()), n_, h_, w_, c_, c_, cat.shape[-1]), 0.0,
+                   2.0 * tmp.numel() * 5)
+        b.plan.keep += [tmp, cat]
+        if train:
+            b.tape.append(dict(name=f'neck.cat{i + 1}', custom=True, xs=[tmp, xf], y=cat, bwd=_concat_bwd))
+        out = detect(cat, f'neck.detect{i + 2}.', f'neck.detect{i + 2}')
+        outs.append(out)
+    # head (yolo_head.py:150-170): bridge 3x3 + 1x1 prediction (fp32 logits)
+    pred, level_hw = [], []
+    for i, f in enumerate(outs):
+        t = _cm(b, sd, f'head.bridge{i}', f'bbox_head.convs_bridge.{i}', f, 1, 1)
+        pc = ops.pack_conv(sd[f'bbox_head.convs_pred.{i}.weight'], sd[f'bbox_head.convs_pred.{i}.bias'], 1, 0)
+        pred.append(b.conv(f'head.pred{i}', t, pc, CONV_OUT_F32))
+        level_hw.append((t.shape[1], t.shape[2]))
+    return pred, level_hw
+
+
 class YoloPlan:
     """Whole YOLOv3 inference plan for a fixed (batch, H, W): Darknet-53 -> neck -> head convs -> decode; results() runs
     the selection + NMS."""
@@ -352,59 +442,8 @@ class YoloPlan:
         self.builder, self.plan, self.batch, self.head, self.device = b, b.plan, batch, head, device
         sd = engine._cpu_sd(det.state_dict())
         self.x_in = b.buf(batch, height, width, 8)
-        layers, channels = ARCH[bb.depth]
-        ns = neck.num_scales
-        # the stages the neck concatenates with an upsampled map write straight into the concat buffer's upper channels
-        out_idx = list(bb.out_indices)
-        assert len(out_idx) == ns
-        feats = {}
-        x = _cm(b, sd, 'backbone.conv1', 'backbone.conv1', self.x_in, 1, 1)
-        for i, nres in enumerate(layers):
-            q = f'backbone.conv_res_block{i + 1}'
-            x = _cm(b, sd, q + '.conv', q + '.conv', x, 2, 1)
-            for r in range(nres):
-                y = _cm(b, sd, f'{q}.res{r}.conv1', f'{q}.res{r}.conv1', x, 1, 0)
-                last = r == nres - 1 and (i + 1) in out_idx and out_idx.index(i + 1) < ns - 1
-                if last:
-                    # concat buffer of the neck level that consumes this stage: [upsampled out_c | this stage's in_c]
-                    lvl = ns - 1 - out_idx.index(i + 1)          # feats are reversed inside the neck
-                    oc = neck.out_channels[lvl]
-                    n_, h_, w_, c_ = x.shape
-                    cat = b.buf(n_, h_, w_, oc + c_)
-                    dst = cat[..., oc:]
-                    x = _cm(b, sd, f'{q}.res{r}.conv2', f'{q}.res{r}.conv2', y, 1, 1, res=x, out=dst, y_ld=oc + c_)
-                    feats[i + 1] = (x, cat)
-                else:
-                    x = _cm(b, sd, f'{q}.res{r}.conv2', f'{q}.res{r}.conv2', y, 1, 1, res=x)
-            if (i + 1) in out_idx and (i + 1) not in feats:
-                feats[i + 1] = (x, None)
-        # neck (yolo_neck.py:110-131)
-        def detect(xin, p, tag):
-            t = _cm(b, sd, tag + '.conv1', p + 'conv1', xin, 1, 0)
-            t = _cm(b, sd, tag + '.conv2', p + 'conv2', t, 1, 1)
-            t = _cm(b, sd, tag + '.conv3', p + 'conv3', t, 1, 0)
-            t = _cm(b, sd, tag + '.conv4', p + 'conv4', t, 1, 1)
-            return _cm(b, sd, tag + '.conv5', p + 'conv5', t, 1, 0)
-        ordered = [feats[k] for k in out_idx]
-        out = detect(ordered[-1][0], 'neck.detect1.', 'neck.detect1')
-        outs = [out]
-        for i, (xf, cat) in enumerate(reversed(ordered[:-1])):
-            tmp = _cm(b, sd, f'neck.conv{i + 1}', f'neck.conv{i + 1}', out, 1, 0)
-            n_, h_, w_, c_ = tmp.shape
-            b.plan.add(f'neck.upsample{i + 1}', lib().llv_upsample2x_nhwc,
-                       (C.c_void_p(tmp.data_ptr()), C.c_void_p(cat.data_ptr()), n_, h_, w_, c_, c_, cat.shape[-1]), 0.0,
-                       2.0 * tmp.numel() * 5)
-            b.plan.keep += [tmp, cat]
-            out = detect(cat, f'neck.detect{i + 2}.', f'neck.detect{i + 2}')
-            outs.append(out)
-        # head (yolo_head.py:150-170): bridge 3x3 + 1x1 prediction (fp32 logits)
-        self.pred, self.level_hw = [], []
+        self.pred, self.level_hw = build_yolo_body(b, sd, bb, neck, head, self.x_in)
         self.A, self.na = head.num_anchors, head.num_attrib
-        for i, f in enumerate(outs):
-            t = _cm(b, sd, f'head.bridge{i}', f'bbox_head.convs_bridge.{i}', f, 1, 1)
-            pc = ops.pack_conv(sd[f'bbox_head.convs_pred.{i}.weight'], sd[f'bbox_head.convs_pred.{i}.bias'], 1, 0)
-            self.pred.append(b.conv(f'head.pred{i}', t, pc, CONV_OUT_F32))
-            self.level_hw.append((t.shape[1], t.shape[2]))
         # decode every anchor of every level (llv_yolo_decode)
         self.boxes, self.conf, self._wh = [], [], []
         for i, pm in enumerate(self.pred):
@@ -496,5 +535,8 @@ class YOLOV3(SingleStageDetector):
     def extract_feat(self, img):
         raise LlvError('YOLOV3.extract_feat: use simple_test (the plan keeps the features on the device)')
 
-    def forward_train(self, *a, **k):
-        raise LlvError('YOLOV3 training is not built on this path (config #5 is an inference stand-in)')
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None):
+        """single_stage.py:68-96 for YOLOv3: Darknet, YOLOV3Neck and the head convs as one training graph on the device
+        (yolo_train.YoloTrainGraph), YOLOV3Head.loss on its prediction maps."""
+        from .yolo_train import yolo_forward_train
+        return yolo_forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore)

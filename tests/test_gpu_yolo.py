@@ -170,3 +170,87 @@ def test_yolo_select_kernel_vs_torch_topk(dev, bs, h, w, nms_pre, thr, rescale):
     assert torch.equal(oc[:, 5:], rc) and (oc[:, :5] == 0).all()
     assert torch.allclose(ob[:, 5:], rb, rtol=1e-6, atol=0)
     assert torch.allclose(osc[:, 5:], rs, rtol=2e-6, atol=1e-7)
+
+
+def test_yolov3_forward_train_matches_oracle(dev):
+    """YOLOV3.forward_train (single_stage.py:68-96): Darknet-53 + YOLOV3Neck + head convs as one training graph on the device (LeakyReLU
+    and add-after-activation ResBlock backward, upsample + concat backward, eval-mode BN with trainable affine), YOLOV3Head.loss on its
+    prediction maps -- the four loss terms and d(loss)/d(parameter) of all ~220 trainable tensors against autograd over the fp32 oracle
+    (oracle/yolo.py). 75 conv layers deep in fp16: loss terms 3 %, gradients 10 % of each tensor's scale (20 % for tensors whose whole
+    gradient is below 1e-4 of the largest)."""
+    import lowlightenvironmentvideoobjectdetection_amd.models as M
+    from oracle import yolo as OY
+    nc = 4
+    cfg = _cfg(nc)
+    cfg['bbox_head'].update(loss_cls=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0, reduction='sum'),
+                            loss_conf=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=1.0, reduction='sum'),
+                            loss_xy=dict(type='CrossEntropyLoss', use_sigmoid=True, loss_weight=2.0, reduction='sum'),
+                            loss_wh=dict(type='MSELoss', loss_weight=2.0, reduction='sum'))
+    cfg['train_cfg'] = dict(assigner=dict(type='GridAssigner', pos_iou_thr=0.5, neg_iou_thr=0.5, min_pos_iou=0))
+    det = M.build_detector(cfg)
+    randomize(det, seed=21)
+    with torch.no_grad():
+        for m in det.bbox_head.convs_pred:
+            m.weight.mul_(0.2)
+            m.bias.zero_()
+    H, W = 256, 384
+    img = smooth_image(2, H, W, seed=22)
+    gtb = [torch.tensor([[10., 20., 190., 200.], [200., 30., 380., 220.], [104., 34., 250., 190.]]), torch.tensor([[5., 5., 160., 140.], [1., 60., 290., 226.]])]
+    gtl = [torch.tensor([0, 3, 1]), torch.tensor([2, 2])]
+    sd = {k: v.detach().clone().float() for k, v in det.state_dict().items()}
+    names = [n for n, p in det.named_parameters() if p.requires_grad]
+    for n in names:
+        sd[n].requires_grad_(True)
+    maps = OY.yolo_head_forward(sd, OY.yolo_neck_forward(sd, OY.darknet_forward(sd, img)))
+    ref = OY.yolo_loss(maps, gtb, gtl, BASE_SIZES, [32, 16, 8], nc)
+    sum(sum(v) for v in ref.values()).backward()
+    ref_g = {n: sd[n].grad for n in names}
+    det = det.to(dev).train()
+    metas = [dict(img_shape=(H, W, 3), pad_shape=(H, W, 3), scale_factor=1.0)] * 2
+    out = det(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in gtb], gt_labels=[l.to(dev) for l in gtl], return_loss=True)
+    for k in ref:
+        a, r = float(sum(out[k])), float(sum(ref[k]))
+        print(k, a, r)
+        assert abs(a - r) <= 3e-2 * max(1.0, abs(r)), (k, a, r)
+    sum(sum(v) for v in out.values()).backward()
+    params = dict(det.named_parameters())
+    top = max(v.abs().max().item() for v in ref_g.values() if v is not None)
+    errs = []
+    for k, r in ref_g.items():
+        g = params[k].grad
+        assert (g is None) == (r is None), k
+        if r is None:
+            continue
+        scale = r.abs().max().item()
+        if scale < 1e-7 * top:
+            continue
+        errs.append(((g.float().cpu() - r).abs().max().item() / scale, k, scale))
+    errs.sort(reverse=True)
+    print('largest relative gradient errors:', [(round(e, 3), k, round(sc, 5)) for e, k, sc in errs[:8]])
+    for e, k, sc in errs:
+        assert e < (1.5e-1 if sc > 1e-4 * top else 2.5e-1), (k, e, sc)
+    assert len(errs) > 200, len(errs)
+    assert sum(1 for e, _, _ in errs if e < 5e-2) >= 0.95 * len(errs)          # all but a handful within 5 %
+    # the tensors with the largest differences sit behind the 8 x 12-pixel level (192 pixels per gradient sum; a LeakyReLU whose fp16 input
+    # has the other sign than the oracle's changes that element's contribution tenfold). Independent check on the DEVICE alone: the
+    # directional derivative along sign(grad) by central differences of the loss against <grad, sign(grad)>
+    def total_loss():
+        with torch.no_grad():
+            o = det(img=img.to(dev), img_metas=metas, gt_bboxes=[b.to(dev) for b in gtb], gt_labels=[l.to(dev) for l in gtl], return_loss=True)
+            return float(sum(sum(v) for v in o.values()))
+    for k in ('bbox_head.convs_bridge.0.conv.weight', 'backbone.conv_res_block5.conv.conv.weight', 'neck.detect2.conv1.conv.weight'):
+        p_, g_ = params[k], params[k].grad.float()
+        u = torch.sign(g_)
+        eps = 4e-4 * p_.detach().abs().mean().item()
+        with torch.no_grad():
+            p_.add_(eps * u)
+        det.invalidate_plans() if hasattr(det, 'invalidate_plans') else None
+        lp = total_loss()
+        with torch.no_grad():
+            p_.sub_(2 * eps * u)
+        lm = total_loss()
+        with torch.no_grad():
+            p_.add_(eps * u)
+        fd, an = (lp - lm) / (2 * eps), float((g_ * u).sum())
+        print(k, 'finite difference', fd, 'analytic', an)
+        assert abs(fd - an) <= 0.1 * abs(an), (k, fd, an)
