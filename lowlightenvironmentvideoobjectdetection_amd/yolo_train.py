@@ -69,6 +69,8 @@ def yolo_forward_train(det, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_igno
     if img.device.type != 'cuda':
         raise LlvError('forward_train runs on the MI355X (conv forward/backward kernels); no CPU fallback')
     n, _, h, w = img.shape
+    if len(gt_bboxes) != n or len(gt_labels) != n or len(img_metas) != n:
+        raise LlvError(f'YOLOV3.forward_train: {n} images, {len(gt_bboxes)} gt_bboxes, {len(gt_labels)} gt_labels, {len(img_metas)} img_metas')
     for k in [k for k in det._plans if not (isinstance(k, tuple) and k and k[0] == 'train')]:      # inference plans hold packed copies
         del det._plans[k]
     graph = det._plan(('train', n, h, w, str(img.device)), lambda: YoloTrainGraph(det, n, h, w, img.device))
