@@ -340,6 +340,13 @@ int llv_embed_aggregate_ring(const void* embed, const void* feat, void* out, int
 int llv_embed_aggregate_bwd(const void* embed, const void* feat, const void* grad_out, void* d_embed, void* d_feat, int n_slots,
                             int key_slot, int64_t hw, int c, int embed_ld, int feat_ld, int gout_ld, void* stream);
 int llv_flow_warp_bwd(const void* dy, const float* flow, float* dx, int n, int h, int w, int c, int ld, int hf, int wf, void* stream);
+/* The OTHER gradient of the warp: d(loss)/d(flow) (n, 2, hf, wf) fp32, ADDED (grid gradient of grid_sample -- zero where the sample was
+ * clamped to the border -- through grid = (x + u) / W * 2 - 1 and the bilinear resize of the flow field; flow.py:4-41). dy (n, h, w, dy_ld)
+ * fp16 = gradient of the warped map, x (n, h, w, x_ld) fp16 = the map that was warped. */
+int llv_flow_warp_bwd_flow(const void* dy, const void* x, const float* flow, float* dflow, int n, int h, int w, int c, int dy_ld, int x_ld,
+                           int hf, int wf, void* stream);
+/* Backward of llv_bilinear_resize_f32 (same arguments): dx (nc, h, w) += resize^T (dy (nc, ho, wo)) * mul. */
+int llv_bilinear_resize_f32_bwd(const float* dy, float* dx, int nc, int h, int w, int ho, int wo, float scale_factor, float mul, void* stream);
 int llv_add_f32_to_f16(const float* src, void* dst, int64_t rows, int c, int ld, void* stream);
 
 /* FlowNetSimple.prepare_imgs (flownet_simple.py:149-190) for image pairs: x (n,6,h,w) NCHW fp32 normalised images ->

@@ -234,6 +234,8 @@ SIGNATURES = {
     'llv_upsample_add_bwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'llv_sgd_momentum': (_I, [_P, _P, _P, _L, _F, _F, _F, _F, _I, _P]),
     'llv_retina_loss': (_I, [_P, _P]),
+    'llv_flow_warp_bwd_flow': (_I, [_P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
+    'llv_bilinear_resize_f32_bwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _F, _F, _P]),
     'llv_yolo_select_workspace_bytes': (_Z, [_I, _I]),
     'llv_yolo_select': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _L, _L, _P, _P, _P, _P, _Z, _P]),
     'llv_convlstm_gate': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),

@@ -338,6 +338,104 @@ __global__ void flow_warp_bwd_kernel(const _Float16* __restrict__ dy, const floa
     }
 }
 
+// d(loss)/d(flow) of flow_warp_feats (mmtracking/mmtrack/core/motion/flow.py:4-41): the grid gradient of grid_sample (bilinear, border
+// padding, align_corners=True) chained through grid = (x + u) / W * 2 - 1 and the bilinear resize of the flow field (x scale factor).
+// One wavefront per output pixel (n, oy, ox): the lanes split the channels, d out_c / d fx = (1 - ly)(X01 - X00) + ly (X11 - X10) (and the
+// same in y) are summed over the channels against dY, times d fx / d u = (w - 1) / w * mul -- zero where the sample was clamped to the
+// border, as ATen's clip_coordinates_set_grad has it -- and scattered with the resize's four weights into dflow (fp32 atomics).
+__global__ void flow_warp_bwd_flow_kernel(const _Float16* __restrict__ dy, const _Float16* __restrict__ x, const float* __restrict__ flow,
+                                          float* __restrict__ dflow, int nb, int h, int w, int c, int dy_ld, int x_ld, int hf, int wf,
+                                          float rscale, float mul) {
+    const int lane = threadIdx.x & 63;
+    const long wave = (blockIdx.x * (long)blockDim.x + threadIdx.x) >> 6;
+    const long nwaves = ((long)gridDim.x * blockDim.x) >> 6;
+    const long total = (long)nb * h * w;
+    for (long p = wave; p < total; p += nwaves) {
+        const int ox = (int)(p % w);
+        const long t = p / w;
+        const int oy = (int)(t % h);
+        const int n = (int)(t / h);
+        float sy = ((float)oy + 0.5f) * rscale - 0.5f, sx = ((float)ox + 0.5f) * rscale - 0.5f;
+        const float* fu = flow + ((long)n * 2 + 0) * hf * wf;
+        const float* fv = flow + ((long)n * 2 + 1) * hf * wf;
+        const float u = bilerp_flow(fu, hf, wf, sy, sx) * mul;
+        const float v = bilerp_flow(fv, hf, wf, sy, sx) * mul;
+        const float rx = (((float)ox + u) / (float)w * 2.f - 1.f + 1.f) * 0.5f * (float)(w - 1);
+        const float ry = (((float)oy + v) / (float)h * 2.f - 1.f + 1.f) * 0.5f * (float)(h - 1);
+        const bool inx = rx > 0.f && rx < (float)(w - 1), iny = ry > 0.f && ry < (float)(h - 1);
+        const float fx = fminf(fmaxf(rx, 0.f), (float)(w - 1)), fy = fminf(fmaxf(ry, 0.f), (float)(h - 1));
+        const int x0 = (int)floorf(fx), y0 = (int)floorf(fy);
+        const int x1 = x0 + 1, y1 = y0 + 1;
+        const float lx = fx - (float)x0, ly = fy - (float)y0;
+        const bool x1ok = x1 < w, y1ok = y1 < h;
+        const _Float16* xb = x + (long)n * h * w * x_ld;
+        const _Float16* g = dy + (((long)n * h + oy) * w + ox) * dy_ld;
+        float gx = 0.f, gy = 0.f;
+        for (int ch = lane; ch < c; ch += 64) {
+            const float d = (float)g[ch];
+            const float v00 = (float)xb[((long)y0 * w + x0) * x_ld + ch];
+            const float v01 = x1ok ? (float)xb[((long)y0 * w + x1) * x_ld + ch] : 0.f;
+            const float v10 = y1ok ? (float)xb[((long)y1 * w + x0) * x_ld + ch] : 0.f;
+            const float v11 = (x1ok && y1ok) ? (float)xb[((long)y1 * w + x1) * x_ld + ch] : 0.f;
+            gx += d * ((1.f - ly) * (v01 - v00) + ly * (v11 - v10));
+            gy += d * ((1.f - lx) * (v10 - v00) + lx * (v11 - v01));
+        }
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) {
+            gx += __shfl_xor(gx, o);
+            gy += __shfl_xor(gy, o);
+        }
+        if (lane == 0) {
+            const float du = inx ? gx * (float)(w - 1) / (float)w * mul : 0.f;
+            const float dv = iny ? gy * (float)(h - 1) / (float)h * mul : 0.f;
+            // the transpose of bilerp_flow at (sy, sx)
+            sy = sy < 0.f ? 0.f : sy;
+            sx = sx < 0.f ? 0.f : sx;
+            int fy0 = (int)sy, fx0 = (int)sx;
+            fy0 = fy0 < hf - 1 ? fy0 : hf - 1;
+            fx0 = fx0 < wf - 1 ? fx0 : wf - 1;
+            const int fy1 = fy0 < hf - 1 ? fy0 + 1 : fy0, fx1 = fx0 < wf - 1 ? fx0 + 1 : fx0;
+            const float wy = sy - (float)fy0, wx = sx - (float)fx0;
+            float* du_p = dflow + ((long)n * 2 + 0) * hf * wf;
+            float* dv_p = dflow + ((long)n * 2 + 1) * hf * wf;
+            const float w00 = (1.f - wy) * (1.f - wx), w01 = (1.f - wy) * wx, w10 = wy * (1.f - wx), w11 = wy * wx;
+            if (du != 0.f) {
+                atomicAdd(du_p + fy0 * wf + fx0, w00 * du); atomicAdd(du_p + fy0 * wf + fx1, w01 * du);
+                atomicAdd(du_p + fy1 * wf + fx0, w10 * du); atomicAdd(du_p + fy1 * wf + fx1, w11 * du);
+            }
+            if (dv != 0.f) {
+                atomicAdd(dv_p + fy0 * wf + fx0, w00 * dv); atomicAdd(dv_p + fy0 * wf + fx1, w01 * dv);
+                atomicAdd(dv_p + fy1 * wf + fx0, w10 * dv); atomicAdd(dv_p + fy1 * wf + fx1, w11 * dv);
+            }
+        }
+    }
+}
+
+// Backward of llv_bilinear_resize_f32: dx (nc, h, w) += the transpose of the resize applied to dy (nc, ho, wo) * mul (fp32 atomics)
+__global__ void bilinear_resize_bwd_kernel(const float* __restrict__ dy, float* __restrict__ dx, int nc, int h, int w, int ho, int wo,
+                                           float rscale, float mul) {
+    const long total = (long)nc * ho * wo;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
+        const int ox = (int)(i % wo);
+        const unsigned t = i / wo;
+        const int oy = (int)(t % ho);
+        const unsigned p = t / ho;
+        const float g = dy[i] * mul;
+        if (g == 0.f) continue;
+        float sy = ((float)oy + 0.5f) * rscale - 0.5f, sx = ((float)ox + 0.5f) * rscale - 0.5f;
+        sy = sy < 0.f ? 0.f : sy;
+        sx = sx < 0.f ? 0.f : sx;
+        int y0 = (int)sy, x0 = (int)sx;
+        y0 = y0 < h - 1 ? y0 : h - 1;
+        x0 = x0 < w - 1 ? x0 : w - 1;
+        const int y1 = y0 < h - 1 ? y0 + 1 : y0, x1 = x0 < w - 1 ? x0 + 1 : x0;
+        const float ly = sy - (float)y0, lx = sx - (float)x0;
+        float* d = dx + (long)p * h * w;
+        atomicAdd(d + y0 * w + x0, (1.f - ly) * (1.f - lx) * g); atomicAdd(d + y0 * w + x1, (1.f - ly) * lx * g);
+        atomicAdd(d + y1 * w + x0, ly * (1.f - lx) * g); atomicAdd(d + y1 * w + x1, ly * lx * g);
+    }
+}
+
 __global__ void add_f32_to_f16_kernel(const float* __restrict__ src, _Float16* __restrict__ dst, long rows, int c, int ld) {
     const long total = rows * c;
     for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
@@ -759,6 +857,30 @@ extern "C" int llv_add_f32_to_f16(const float* src, void* dst, int64_t rows, int
     if (!src || !dst) return LLV_E_BADARG;
     hipLaunchKernelGGL(add_f32_to_f16_kernel, dim3(grid_for(rows * c)), dim3(kBlock), 0, (hipStream_t)stream, src, (_Float16*)dst,
                        (long)rows, c, ld);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_flow_warp_bwd_flow(const void* dy, const void* x, const float* flow, float* dflow, int n, int h, int w, int c, int dy_ld,
+                                      int x_ld, int hf, int wf, void* stream) {
+    if (!dy || !x || !flow || !dflow || n < 1 || h < 1 || w < 1 || c < 1 || dy_ld < c || x_ld < c || hf < 1 || wf < 1) return LLV_E_BADARG;
+    const float s = (float)w / (float)wf;
+    if ((int)floor((double)hf * (double)s) != h || (int)floor((double)wf * (double)s) != w) return LLV_E_BADARG;
+    const long waves = (long)n * h * w;
+    long grid = (waves + 3) / 4;                                 // four wavefronts per workgroup
+    grid = grid > 256L * 16 ? 256L * 16 : grid;
+    hipLaunchKernelGGL(flow_warp_bwd_flow_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)dy, (const _Float16*)x, flow,
+                       dflow, n, h, w, c, dy_ld, x_ld, hf, wf, 1.f / s, s);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_bilinear_resize_f32_bwd(const float* dy, float* dx, int nc, int h, int w, int ho, int wo, float scale_factor, float mul,
+                                           void* stream) {
+    if (!dy || !dx || nc < 1 || h < 1 || w < 1 || ho < 1 || wo < 1 || !(scale_factor > 0.f)) return LLV_E_BADARG;
+    if ((int)floor((double)h * (double)scale_factor) != ho || (int)floor((double)w * (double)scale_factor) != wo) return LLV_E_BADARG;
+    const long total = (long)nc * ho * wo;
+    if (total >= (1L << 31)) return LLV_E_UNSUPPORTED;
+    hipLaunchKernelGGL(bilinear_resize_bwd_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, dy, dx, nc, h, w, ho, wo,
+                       1.f / scale_factor, mul);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 

@@ -211,3 +211,44 @@ def test_motion_must_be_frozen_and_noise_restatement(dev):
     assert torch.allclose(clean, (rgb - mean) / std, atol=1e-4)
     raw_noise = noise * std + mean
     assert abs((raw_noise.mean() / (0.5 * rgb).mean()).item() - 1.0) < 0.25 and raw_noise.min().item() >= -1e-3 and raw_noise.max().item() <= 255.001
+
+
+@pytest.mark.parametrize('n,c,h,w,hf,wf', [(1, 8, 16, 24, 128, 192), (2, 40, 8, 12, 128, 192), (2, 256, 4, 6, 64, 96)])
+def test_flow_warp_flow_gradient_vs_autograd(dev, n, c, h, w, hf, wf):
+    """llv_flow_warp_bwd_flow: d(loss)/d(flow) of flow_warp_feats (grid gradient of grid_sample with border padding, through the /W, /H grid
+    and the bilinear resize of the flow) against torch autograd over the oracle; gradients are ADDED."""
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    from lowlightenvironmentvideoobjectdetection_amd._lib import check, lib
+    from oracle.temporal import flow_warp_feats
+    g = torch.Generator().manual_seed(n * 7 + c)
+    x = torch.randn(n, c, h, w, generator=g).half()
+    flow = torch.randn(n, 2, hf, wf, generator=g) * 12.0           # a few feature pixels; some samples clamp at the border
+    dy = torch.randn(n, c, h, w, generator=g).half()
+    fr = flow.clone().requires_grad_(True)
+    (flow_warp_feats(x.float(), fr) * dy.float()).sum().backward()
+    xd = x.permute(0, 2, 3, 1).contiguous().to(dev)
+    dyd = dy.permute(0, 2, 3, 1).contiguous().to(dev)
+    df = torch.zeros(n, 2, hf, wf, dtype=torch.float32, device=dev)
+    for _ in range(2):
+        check(lib().llv_flow_warp_bwd_flow(ops._ptr(dyd), ops._ptr(xd), ops._ptr(flow.to(dev)), ops._ptr(df), n, h, w, c, c, c, hf, wf, _stream()),
+              'llv_flow_warp_bwd_flow')
+    got = df.cpu() / 2
+    scale = fr.grad.abs().max().item()
+    assert scale > 0 and (got - fr.grad).abs().max().item() < 2e-3 * scale, ((got - fr.grad).abs().max().item(), scale)
+
+
+@pytest.mark.parametrize('nc,h,w,sf', [(4, 8, 12, 8.0), (2, 5, 7, 2.0), (3, 16, 24, 0.5)])
+def test_bilinear_resize_backward_vs_autograd(dev, nc, h, w, sf):
+    import torch.nn.functional as F
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    from lowlightenvironmentvideoobjectdetection_amd._lib import check, lib
+    g = torch.Generator().manual_seed(nc)
+    x = torch.randn(1, nc, h, w, generator=g).requires_grad_(True)
+    y = F.interpolate(x, scale_factor=sf, mode='bilinear', align_corners=False) * 3.5
+    dy = torch.randn(y.shape, generator=g)
+    (y * dy).sum().backward()
+    ho, wo = y.shape[2:]
+    dx = torch.zeros(nc, h, w, device=dev)
+    check(lib().llv_bilinear_resize_f32_bwd(ops._ptr(dy[0].contiguous().to(dev)), ops._ptr(dx), nc, h, w, ho, wo, sf, 3.5, _stream()),
+          'llv_bilinear_resize_f32_bwd')
+    assert (dx.cpu() - x.grad[0]).abs().max().item() < 1e-4 * x.grad.abs().max().item()
