@@ -462,17 +462,15 @@ class DFF(BaseVideoDetector):
                       gt_bboxes_ignore=None, **kwargs):
         """dff.py:49-182, single-stage branch: flow = motion(cat(img, ref)); the REFERENCE frame's pyramid is warped to the key frame
         (or used as it is for still-image data, :143-144) and fed to bbox_head.forward_train with the key frame's ground truth.
-        The flow network is used frozen (vid_train.require_frozen_motion)."""
+        The flow network trains with the detector unless it is frozen (vid_train.motion_flow)."""
         from . import vid_train
         self._check_input(img)
         assert len(img) == 1, 'Dff video detectors only support 1 batch size per gpu for now.'
-        vid_train.require_frozen_motion(self, 'DFF')
         is_video_data = img_metas[0].get('is_video_data', True)
         ref = ref_img[:, 0].float().contiguous()
         flow = None
         if is_video_data:
-            with torch.no_grad():
-                flow = self.motion(torch.cat((img.float(), ref), dim=1), img_metas)
+            flow = vid_train.motion_flow(self, torch.cat((img.float(), ref), dim=1), img_metas)
         return vid_train.video_forward_train(self, 'dff', ref, flow, 0, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, warp=is_video_data)
 
     def simple_test(self, img, img_metas, ref_img=None, ref_img_metas=None, rescale=False, **kwargs):
@@ -540,11 +538,10 @@ class FGFA(BaseVideoDetector):
                       gt_bboxes_ignore=None, **kwargs):
         """fgfa.py:52-194, single-stage branch: flows = motion(cat(img, ref_i)) for every reference, all frames through backbone + FPN,
         per level `aggregator(feat[img], flow_warp_feats(feat[refs], flows))` (:155-160), bbox_head.forward_train. The authors' noise
-        injection (:141-147) is applied when train_cfg['add_noise'] is true. The flow network is used frozen."""
+        injection (:141-147) is applied when train_cfg['add_noise'] is true. The flow network trains too unless it is frozen."""
         from . import vid_train
         self._check_input(img)
         assert len(img) == 1, 'fgfa video detectors only support 1 batch size per gpu for now.'
-        vid_train.require_frozen_motion(self, 'FGFA')
         refs = ref_img[0].float()
         img = img.float()
         if (self.train_cfg or {}).get('add_noise', False):
@@ -552,8 +549,7 @@ class FGFA(BaseVideoDetector):
             noise, _ = general_clean_noise_pairs(torch.cat([img, refs], dim=0), constant=[0.5, 0.5])
             img, refs = noise[[0]], noise[1:]
         nr = refs.shape[0]
-        with torch.no_grad():
-            flows = self.motion(torch.cat((img.repeat(nr, 1, 1, 1), refs), dim=1), img_metas)
+        flows = vid_train.motion_flow(self, torch.cat((img.repeat(nr, 1, 1, 1), refs), dim=1), img_metas)
         all_imgs = torch.cat((img, refs), dim=0).contiguous()
         return vid_train.video_forward_train(self, 'fgfa', all_imgs, flows, 0, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore)
 

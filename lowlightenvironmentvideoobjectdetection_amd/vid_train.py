@@ -11,9 +11,9 @@ for a dense-head detector, each followed by bbox_head.forward_train(x, ...) (Anc
                                                    llv_flow_warp / _bwd             llv_embed_aggregate_ring / _bwd
 
 and one autograd Function around it, so the returned losses support .backward() and fill param.grad of detector AND aggregator
-exactly as the reference's module tree does. The flow network is NOT trained on this path: the gradient with respect to the flow
-field (grid_sample's grid gradient -> bilinear-resize backward -> FlowNetSimple's LeakyReLU / transposed-conv tape) is not built, so
-`motion` must be frozen (frozen_modules=['motion'], the constructor argument the reference provides, base.py:39-54).
+exactly as the reference's module tree does. The flow network trains too unless it is frozen (frozen_modules=['motion'], base.py:39-54):
+the warp's backward also yields d(loss)/d(flow) (llv_flow_warp_bwd_flow: grid_sample's grid gradient through the /W, /H grid and the
+bilinear resize), which flow_train.FlowNetTrainGraph carries through FlowNetSimple's convolutions and transposed convolutions.
 
 The authors' forward_train of FGFA / LLVOD first passes the frames through general_clean_noise_pairs (random Poisson / Gaussian /
 row noise; core/utils/add_noise.py:13-52 -- the import is commented out in fgfa.py:8 / llvod.py:6, so the reference raises
@@ -103,6 +103,7 @@ class VideoTrainGraph(train_engine.TrainGraph):
         frozen = (['stem.'] if fs >= 0 else []) + [f'detector.backbone.layer{i}.' for i in range(1, fs + 1)]
         self._finish(b, frozen)
         self._dx32 = {}
+        self.want_dflow, self.dflow = False, None
 
     # ---- the flow field (an input of every step, not a parameter)
     def set_flow(self, flow):
@@ -144,6 +145,11 @@ class VideoTrainGraph(train_engine.TrainGraph):
             check(L.llv_flow_warp_bwd(ops._ptr(gyl[first:]), ops._ptr(g.flow), ops._ptr(dx), n, hh, ww, cc, gyl.shape[-1],
                                       g.flow.shape[2], g.flow.shape[3], _stream()), 'llv_flow_warp_bwd')
             check(L.llv_add_f32_to_f16(ops._ptr(dx), ops._ptr(gxl[first:]), n * hh * ww, cc, gxl.shape[-1], _stream()), 'llv_add_f32_to_f16')
+            if g.want_dflow:                              # the flow network trains too: d(loss)/d(flow) of this level (llv_flow_warp_bwd_flow)
+                if g.dflow is None or g.dflow.shape != g.flow.shape:
+                    g.dflow = torch.zeros_like(g.flow)
+                check(L.llv_flow_warp_bwd_flow(ops._ptr(gyl[first:]), ops._ptr(src), ops._ptr(g.flow), ops._ptr(g.dflow), n, hh, ww, cc, gyl.shape[-1],
+                                               src.shape[-1], g.flow.shape[2], g.flow.shape[3], _stream()), 'llv_flow_warp_bwd_flow')
 
     @staticmethod
     def _aggregate_bwd(g, op):
@@ -180,10 +186,14 @@ class VideoFunction(torch.autograd.Function):
         g = ctx.graph
         n = ctx.n_levels
         g.zero_param_grads()
+        g.want_dflow = bool(ctx.needs_input_grad[2]) and g.flow is not None
+        if g.want_dflow and g.dflow is not None:
+            g.dflow.zero_()
         g.backward([x.contiguous() for x in grads[:n]], [x.contiguous() for x in grads[n:]])
         pg = g.param_grads()
         inv = 1.0 / g.loss_scale
-        return (None, None, None) + tuple((pg[k] * inv) if k in pg else None for k in g.trainable)
+        dflow = (g.dflow * inv) if (g.want_dflow and g.dflow is not None) else None
+        return (None, None, dflow) + tuple((pg[k] * inv) if k in pg else None for k in g.trainable)
 
 
 def video_forward_train(model, mode, frames, flow, key_slot, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, warp=True):
@@ -214,7 +224,11 @@ def video_forward_train(model, mode, frames, flow, key_slot, img_metas, gt_bboxe
     return losses
 
 
-def require_frozen_motion(model, who):
+def motion_flow(model, pairs, img_metas):
+    """flow = motion(pairs): under no_grad when the flow network is frozen (frozen_modules=['motion']), otherwise through
+    flow_train.flownet_train_forward (FlowNetSimple on the training tape; the warp's backward then also returns d(loss)/d(flow))."""
     if any(p.requires_grad for p in model.motion.parameters()):
-        raise LlvError(f"{who}.forward_train: freeze the flow network (frozen_modules=['motion']); the gradient with respect to the flow "
-                       f'field (grid gradient of the warp, FlowNetSimple backward) is not built')
+        from .flow_train import flownet_train_forward
+        return flownet_train_forward(model.motion, pairs, img_metas)
+    with torch.no_grad():
+        return model.motion(pairs, img_metas)

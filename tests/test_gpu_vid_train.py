@@ -192,15 +192,11 @@ def test_video_forward_train_matches_oracle(dev, kind, nr):
     print(f'{kind}: loss {total.item():.4f} vs {ref_loss:.4f}; {checked} tensors, worst relative gradient error {worst:.3f}')
 
 
-def test_motion_must_be_frozen_and_noise_restatement(dev):
+def test_noise_restatement(dev):
     import lowlightenvironmentvideoobjectdetection_amd.models as M
     from lowlightenvironmentvideoobjectdetection_amd._lib import LlvError
     from lowlightenvironmentvideoobjectdetection_amd.core.add_noise import general_clean_noise_pairs
-    model = M.build_model(dict(type='DFF', detector=_cfg_det(), motion=dict(type='FlowNetSimple', img_scale_factor=0.5))).to(dev)
-    img, refs, meta, gtb, gtl = _data(1, seed=5)
-    with pytest.raises(LlvError, match='freeze the flow network'):
-        model(img=img.to(dev), img_metas=[meta], gt_bboxes=gtb, gt_labels=gtl, ref_img=refs.unsqueeze(0).to(dev), ref_img_metas=[[meta]],
-              ref_gt_bboxes=None, ref_gt_labels=None, return_loss=True)
+    # (an unfrozen flow network trains: test_dff_trains_the_flow_network_too below)
     # general_clean_noise_pairs (add_noise.py:13-75) on the device: the clean output is the normalised RGB frame (BGR-ordered mean / std, as
     # the reference has it), the noisy one scatters around `am` times it with the model's variance
     frames = torch.rand(2, 3, 32, 48, device=dev) * 200 + 20
@@ -252,3 +248,138 @@ def test_bilinear_resize_backward_vs_autograd(dev, nc, h, w, sf):
     check(lib().llv_bilinear_resize_f32_bwd(ops._ptr(dy[0].contiguous().to(dev)), ops._ptr(dx), nc, h, w, ho, wo, sf, 3.5, _stream()),
           'llv_bilinear_resize_f32_bwd')
     assert (dx.cpu() - x.grad[0]).abs().max().item() < 1e-4 * x.grad.abs().max().item()
+
+
+def _flownet(seed):
+    import lowlightenvironmentvideoobjectdetection_amd.models as M
+    m = M.build_motion(dict(type='FlowNetSimple', img_scale_factor=0.5))
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in m.named_parameters():
+            if p.dim() == 4:
+                fan = p.shape[1] * p.shape[2] * p.shape[3] if 'deconv' not in name and 'upsample_flow' not in name else p.shape[0] * 4
+                p.copy_(torch.randn(p.shape, generator=g) * (1.6 / fan) ** 0.5)
+            else:
+                p.copy_(torch.randn(p.shape, generator=g) * 0.05)
+            if name.startswith('predict_flow'):
+                p.mul_(0.3)
+    return m
+
+
+def test_flownet_training_graph_vs_oracle(dev):
+    """flow_train.FlowNetTrainGraph: FlowNetSimple's flow and d(<flow, R>)/d(parameter) of all 33 tensors (9 convs with LeakyReLU, 5
+    predict_flow convs, 4 + 4 transposed convs run as data gradients of 4x4 / stride-2 convs, the three-way concatenations, the final
+    bilinear x8) against autograd over oracle/flownet.py."""
+    from lowlightenvironmentvideoobjectdetection_amd.flow_train import flownet_train_forward
+    from oracle.flownet import flownet_forward
+    m = _flownet(3)
+    Hh, Ww = 128, 256
+    base = smooth_image(2, Hh, Ww, seed=5)
+    pairs = torch.cat([base, torch.roll(base, shifts=(2, -3), dims=(2, 3))], 1)
+    meta = dict(img_shape=(Hh, Ww, 3), pad_shape=(Hh, Ww, 3), img_norm_cfg=dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True))
+    sd = {k: v.detach().clone().float().requires_grad_(True) for k, v in m.state_dict().items()}
+    ref = flownet_forward(sd, pairs, meta, 0.5, 5.0)
+    R = torch.randn(ref.shape, generator=torch.Generator().manual_seed(9))
+    (ref * R).sum().backward()
+    m = m.to(dev).train()
+    flow = flownet_train_forward(m, pairs.to(dev), [meta])
+    assert flow.shape == ref.shape
+    assert (flow.cpu() - ref.detach()).abs().max().item() < 2e-2 * ref.abs().max().item()
+    (flow * R.to(dev)).sum().backward()
+    errs = []
+    for k, p in m.named_parameters():
+        r = sd[k].grad
+        assert p.grad is not None and r is not None, k
+        sc = r.abs().max().item()
+        errs.append(((p.grad.float().cpu() - r).abs().max().item() / sc, k, sc))
+    errs.sort(reverse=True)
+    print('FlowNet largest relative gradient errors:', [(round(e, 3), k, round(sc, 4)) for e, k, sc in errs[:6]])
+    assert len(errs) == 33
+    for e, k, sc in errs:
+        assert e < 1.5e-1, (k, e, sc)
+    assert sum(1 for e, _, _ in errs if e < 6e-2) >= 24, errs[:10]
+    # (the deep levels are 1 x 2 .. 4 x 8 pixels: a LeakyReLU input with the other sign than the oracle's changes a whole column of a
+    # weight gradient.) Independent check on the device alone: directional derivatives along sign(grad) by central differences
+    params = dict(m.named_parameters())
+    Rd = R.to(dev)
+
+    def value():
+        with torch.no_grad():
+            return float((flownet_train_forward(m, pairs.to(dev), [meta]) * Rd).sum())
+    for k in ('deconv4.conv.weight', 'conv3.0.conv.weight', 'upsample_flow3.conv.weight', 'predict_flow4.conv.weight'):
+        p_, g_ = params[k], params[k].grad.float()
+        u = torch.sign(g_)
+        # (the packed weights are fp16: a step below their spacing is lost in the rounding unless many weights average it out)
+        eps = (1e-3 if p_.numel() > 100000 else (1e-2 if p_.numel() > 1000 else 4e-2)) * p_.detach().abs().mean().item()
+        with torch.no_grad():
+            p_.add_(eps * u)
+        vp = value()
+        with torch.no_grad():
+            p_.sub_(2 * eps * u)
+        vm = value()
+        with torch.no_grad():
+            p_.add_(eps * u)
+        fd, an = (vp - vm) / (2 * eps), float((g_ * u).sum())
+        print(k, 'finite difference', fd, 'analytic', an)
+        assert abs(fd - an) <= 0.06 * abs(an), (k, fd, an)
+
+
+def test_dff_trains_the_flow_network_too(dev):
+    """DFF.forward_train with `motion` NOT frozen (the reference's configs): the loss gradient reaches FlowNetSimple through
+    d(loss)/d(flow) of the feature warp. Loss and the gradients of detector AND flow network against autograd over the oracle."""
+    import lowlightenvironmentvideoobjectdetection_amd.models as M
+    from oracle import detector as OD
+    from oracle.anchors import AnchorGenerator
+    from oracle.flownet import flownet_forward
+    from oracle.temporal import flow_warp_feats
+    from oracle.training import retina_loss
+    Hh, Ww = 128, 256
+    model = randomize(M.build_model(dict(type='DFF', detector=_cfg_det(), motion=dict(type='FlowNetSimple', img_scale_factor=0.5))), seed=41, cls_bias=-2.0)
+    mref = _flownet(7)
+    model.motion.load_state_dict(mref.state_dict())
+    model.invalidate_plans()
+    base = smooth_image(1, Hh, Ww, seed=43)
+    g = torch.Generator().manual_seed(44)
+    img = base + 0.05 * torch.randn(1, 3, Hh, Ww, generator=g)
+    ref_img = torch.roll(base, shifts=(2, -3), dims=(2, 3)) + 0.05 * torch.randn(1, 3, Hh, Ww, generator=g)
+    meta = dict(img_shape=(Hh, Ww, 3), pad_shape=(Hh, Ww, 3), scale_factor=1.0, is_video_data=True, frame_id=3,
+                img_norm_cfg=dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True))
+    gtb, gtl = [torch.tensor([[10., 12., 90., 100.], [60., 30., 200., 120.]])], [torch.tensor([1, 3])]
+    sd = {k: v.detach().clone().float() for k, v in model.state_dict().items()}
+    names = [n for n, p in model.named_parameters() if p.requires_grad]
+    for n in names:
+        sd[n].requires_grad_(True)
+    dsd = {k[len('detector.'):]: v for k, v in sd.items() if k.startswith('detector.')}
+    msd = {k[len('motion.'):]: v for k, v in sd.items() if k.startswith('motion.')}
+    flow = flownet_forward(msd, torch.cat((img, ref_img), 1), meta, 0.5, 5.0)
+    x = [flow_warp_feats(f, flow) for f in OD.fpn_forward(dsd, OD.resnet_forward(dsd, ref_img, depth=50))]
+    cls, reg = OD.retina_head_forward(dsd, x, stacked_convs=2)
+    ag = AnchorGenerator(octave_base_scale=4, scales_per_octave=3, ratios=[0.5, 1.0, 2.0], strides=[8, 16, 32, 64, 128])
+    lo = retina_loss(cls, reg, gtb, gtl, [meta], ag, NCLS)
+    ref_total = sum(lo['loss_cls']) + sum(lo['loss_bbox'])
+    ref_total.backward()
+    model = model.to(dev).train()
+    losses = model(img=img.to(dev), img_metas=[meta], gt_bboxes=[b.to(dev) for b in gtb], gt_labels=[l.to(dev) for l in gtl],
+                   ref_img=ref_img.unsqueeze(0).to(dev), ref_img_metas=[[meta]], ref_gt_bboxes=None, ref_gt_labels=None, return_loss=True)
+    total = sum(losses['loss_cls']) + sum(losses['loss_bbox'])
+    assert abs(total.item() - ref_total.item()) < 2e-2 * abs(ref_total.item()), (total.item(), ref_total.item())
+    total.backward()
+    params = dict(model.named_parameters())
+    errs_m, errs_d = [], []
+    for k in names:
+        r = sd[k].grad
+        frozen = k.startswith(('detector.backbone.conv1', 'detector.backbone.bn1', 'detector.backbone.layer1.'))
+        if frozen or r is None:
+            continue
+        gq = params[k].grad
+        assert gq is not None, k
+        sc = r.abs().max().item()
+        if sc < 1e-10:
+            continue
+        (errs_m if k.startswith('motion.') else errs_d).append(((gq.float().cpu() - r).abs().max().item() / sc, k, sc))
+    errs_m.sort(reverse=True); errs_d.sort(reverse=True)
+    print('motion:', [(round(e, 3), k, round(sc, 6)) for e, k, sc in errs_m[:5]], 'detector:', [(round(e, 3), k) for e, k, _ in errs_d[:3]])
+    assert len(errs_m) == 33 and len(errs_d) > 100
+    assert all(e < 1e-1 for e, _, _ in errs_d)
+    # the flow gradient is a sum over every warped pixel of products of feature differences: looser than the conv-only paths
+    assert sum(1 for e, _, _ in errs_m if e < 1.5e-1) >= 28 and all(e < 3e-1 for e, _, _ in errs_m), errs_m[:6]
