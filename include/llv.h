@@ -230,6 +230,8 @@ int llv_convpair_extents(const llv_inputcv_desc* desc, int output_block, llv_ext
 
 /* 3x3 stride-2 pad-1 max pooling, NHWC fp16, c multiple of 8. */
 int llv_maxpool3x3s2_nhwc(const void* x, void* y, int batch, int h, int w, int c, void* stream);
+/* y (n, ceil(h/2), ceil(w/2), y_ld) = the even pixels of x (n, h, w, x_ld): what a 1x1 / stride-2 convolution reads, as a dense map. */
+int llv_subsample2_nhwc(const void* x, void* y, int n, int h, int w, int c, int x_ld, int y_ld, void* stream);
 /* Its backward pass (training with an unfrozen stem, frozen_stages = -1 as in the authors' configs): dx += dy routed to each window's
  * first maximum in scan order (ATen's tie rule); x = the pooling input, *_ld = channels per pixel of each buffer. Gather form, no atomics. */
 int llv_maxpool3x3s2_nhwc_bwd(const void* x, const void* dy, void* dx, int batch, int h, int w, int c, int x_ld, int dy_ld, int dx_ld, void* stream);

@@ -167,6 +167,7 @@ SIGNATURES = {
     'llv_inputcvblock_fwd': (_I, [C.POINTER(InputCvDesc), _P]),
     'llv_outputcvblock_fwd': (_I, [C.POINTER(InputCvDesc), _P]),
     'llv_maxpool3x3s2_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _P]),
+    'llv_subsample2_nhwc': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'llv_maxpool3x3s2_nhwc_bwd': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _P]),
     'llv_pack_nchw_f32_to_nhwc_f16': (_I, [_P, _P, _I, _I, _I, _I, _I, _P, _P, _P]),
     'llv_unpack_nhwc_f16_to_nchw_f32': (_I, [_P, _P, _I, _I, _I, _I, _I, _P]),

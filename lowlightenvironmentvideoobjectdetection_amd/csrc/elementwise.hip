@@ -764,6 +764,32 @@ extern "C" int llv_convlstm_gate(const void* gates, float* c, const float* scale
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
+// y[n][oy][ox][:] = x[n][2 oy][2 ox][:]: the pixels a 1x1 / stride-2 convolution reads, as a dense map (the downsample conv of a ResNet
+// stage's first block then shares its launch with conv3: engine.build_resnet). 16 bytes per lane.
+__global__ void subsample2_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y, int n, int h, int w, int c8, int ho, int wo, int x_ld,
+                                  int y_ld) {
+    const long total = (long)n * ho * wo * c8;
+    for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < (unsigned)total; i += gridDim.x * blockDim.x) {
+        const int cv = (int)(i % c8);
+        unsigned p = i / c8;
+        const int ox = (int)(p % wo); p /= wo;
+        const int oy = (int)(p % ho);
+        const int b = (int)(p / ho);
+        *reinterpret_cast<f16x8*>(y + (((long)b * ho + oy) * wo + ox) * y_ld + cv * 8) =
+            *reinterpret_cast<const f16x8*>(x + (((long)b * h + 2 * oy) * w + 2 * ox) * x_ld + cv * 8);
+    }
+}
+
+extern "C" int llv_subsample2_nhwc(const void* x, void* y, int n, int h, int w, int c, int x_ld, int y_ld, void* stream) {
+    if (!x || !y || n < 1 || h < 1 || w < 1 || c < 8 || (c & 7) || x_ld < c || y_ld < c || ((x_ld | y_ld) & 7)) return LLV_E_BADARG;
+    const int ho = (h - 1) / 2 + 1, wo = (w - 1) / 2 + 1;
+    const long total = (long)n * ho * wo * (c / 8);
+    if (total >= (1L << 31)) return LLV_E_UNSUPPORTED;
+    hipLaunchKernelGGL(subsample2_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, (const _Float16*)x, (_Float16*)y, n, h, w, c / 8,
+                       ho, wo, x_ld, y_ld);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
 extern "C" int llv_pack_nchw_f32_to_nhwc_f16(const float* x, void* y, int batch, int c, int h, int w, int c_pad,
                                              const float* scale, const float* shift, void* stream) {
     if (!x || !y || batch < 1 || c < 1 || h < 1 || w < 1 || c_pad < c || (c_pad & 7)) return LLV_E_BADARG;

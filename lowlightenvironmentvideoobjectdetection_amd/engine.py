@@ -279,7 +279,15 @@ def build_resnet(b: Builder, sd, x, depth=50, strides=(1, 2, 2, 2), style='pytor
             kcat = (kind == 'bottleneck' and fuse_blocks and i not in dark_stages and (q + 'downsample.0.weight') in sd and stride == 1 and
                     sd[q + 'downsample.0.weight'].shape[1] == sd[q + 'conv3.weight'].shape[1] and x.shape[-1] == sd[q + 'conv3.weight'].shape[1]
                     and sd[q + 'conv3.weight'].shape[1] % 32 == 0 and _os.environ.get('LLV_KCAT', '1') != '0')
-            if (q + 'downsample.0.weight') in sd and not kcat:          # res_layer.py:36-58: conv1x1(stride) + BN
+            # the strided first blocks (pytorch style: stride on conv2) do the same over THREE sources of MID channels each: conv2 writes
+            # its MID channels into rows of 2 MID, the block input's even pixels (what the stride-2 downsample conv reads) are gathered
+            # into a dense 2 MID-channel map by llv_subsample2_nhwc and enter as two halves (equal widths and pitches are what the
+            # multi-source launch wants). R-50 layer2.0 / 3.0 / 4.0 at 16 frames: 287 / 200 / 168 us -> ~150 / 110 / 95.
+            mid = sd[q + 'conv3.weight'].shape[1] if kind == 'bottleneck' else 0
+            kcat3 = (kind == 'bottleneck' and fuse_blocks and i not in dark_stages and (q + 'downsample.0.weight') in sd and stride == 2 and
+                     style == 'pytorch' and dil == 1 and x.shape[-1] == 2 * mid and sd[q + 'downsample.0.weight'].shape[1] == 2 * mid and
+                     mid % 32 == 0 and _os.environ.get('LLV_KCAT', '1') != '0')
+            if (q + 'downsample.0.weight') in sd and not kcat and not kcat3:          # res_layer.py:36-58: conv1x1(stride) + BN
                 identity = b.conv(q + 'downsample', x, ops.pack_conv(sd[q + 'downsample.0.weight'], None, stride, 0,
                                                                      bn=_bn(sd, q + 'downsample.1'), eps=BN_EPS))
             if kind == 'bottleneck' and fuse_blocks and i not in dark_stages and identity is x and stride == 1 and dil == 1 and \
@@ -294,9 +302,19 @@ def build_resnet(b: Builder, sd, x, depth=50, strides=(1, 2, 2, 2), style='pytor
                 s1, s2 = (1, stride) if style == 'pytorch' else (stride, 1)          # resnet.py:151-156
                 o = b.conv(q + 'conv1', x, ops.pack_conv(sd[q + 'conv1.weight'], None, s1, 0, bn=_bn(sd, q + 'bn1'),
                                                          eps=BN_EPS), CONV_RELU)
-                o = b.conv(q + 'conv2', o, ops.pack_conv(sd[q + 'conv2.weight'], None, s2, dil, bn=_bn(sd, q + 'bn2'),
-                                                         eps=BN_EPS, dilation=dil), CONV_RELU)
-                if kcat:
+                pc2 = ops.pack_conv(sd[q + 'conv2.weight'], None, s2, dil, bn=_bn(sd, q + 'bn2'), eps=BN_EPS, dilation=dil)
+                if kcat3:
+                    n_, h_, w_, c_ = o.shape
+                    ho_, wo_ = ops.conv_out_size(h_, w_, pc2)
+                    t2 = b.buf(n_, ho_, wo_, 2 * mid)                # conv2's MID channels in rows of 2 MID
+                    b.conv_desc(q + 'conv2', pc2, [o], t2, n_, [(h_, w_, ho_, wo_, 0, 0)], c_, 2 * mid, flags=CONV_RELU)
+                    xs_ = b.buf(n_, ho_, wo_, 2 * mid)               # the block input at the pixels the stride-2 downsample conv reads
+                    b.plan.add(q + 'subsample', lib().llv_subsample2_nhwc, (C.c_void_p(x.data_ptr()), C.c_void_p(xs_.data_ptr()), n_, x.shape[1],
+                                                                           x.shape[2], 2 * mid, x.shape[-1], 2 * mid), 0.0, 2.0 * 2 * xs_.numel())
+                    o = t2
+                else:
+                    o = b.conv(q + 'conv2', o, pc2, CONV_RELU)
+                if kcat or kcat3:
                     def fold(wk, bnk):
                         w = sd[wk].detach().double().cpu()
                         gamma, beta, mean, var = [t.detach().double().cpu() for t in _bn(sd, bnk)]
@@ -304,9 +322,10 @@ def build_resnet(b: Builder, sd, x, depth=50, strides=(1, 2, 2, 2), style='pytor
                         return w * sc.view(-1, 1, 1, 1), beta - mean * sc
                     w3, b3 = fold(q + 'conv3.weight', q + 'bn3')
                     wd, bd = fold(q + 'downsample.0.weight', q + 'downsample.1')
-                    pcc = ops.pack_conv(torch.cat([w3, wd], 1).float(), (b3 + bd).float(), 1, 0, n_src=2)
+                    pcc = ops.pack_conv(torch.cat([w3, wd], 1).float(), (b3 + bd).float(), 1, 0, n_src=3 if kcat3 else 2)
                     pcc.true_macs_per_pixel = w3.shape[0] * (w3.shape[1] + wd.shape[1])
-                    x = b.conv(q + 'conv3+downsample', [o, x], pcc, CONV_RELU)
+                    srcs = [o, xs_, xs_[..., mid:]] if kcat3 else [o, x]
+                    x = b.conv(q + 'conv3+downsample', srcs, pcc, CONV_RELU)
                 else:
                     x = b.conv(q + 'conv3', o, ops.pack_conv(sd[q + 'conv3.weight'], None, 1, 0, bn=_bn(sd, q + 'bn3'),
                                                              eps=BN_EPS), CONV_RELU | CONV_RES_ADD, res=identity)
