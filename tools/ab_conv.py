@@ -13,6 +13,8 @@ shapes = [  # name, n, cin, cout, h, w, k, stride
     ('fdvd64 3x3 368x640 b6', 6, 64, 64, 368, 640, 3, 1),
     ('fdvd up1.2 64->128 3x3 368x640 b6', 6, 64, 128, 368, 640, 3, 1),
     ('fdvd inc1 96->32 3x3 736x1280 b2', 2, 96, 32, 736, 1280, 3, 1),
+    ('retina_reg 256->36 3x3 92x160 b1', 1, 256, 36, 92, 160, 3, 1),
+    ('fpn out 256->256 3x3 23x40 b1', 1, 256, 256, 23, 40, 3, 1),
 ]
 tiles = [int(t) for t in (sys.argv[1].split(',') if len(sys.argv) > 1 else '1,6'.split(','))]
 if len(sys.argv) > 2:                                     # optional: indices of the shapes to run
