@@ -67,11 +67,26 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const float* __restrict__
     }
     unsigned m = 0;
     const unsigned utotal = (unsigned)total, uC = (unsigned)C;        // n * C < 2^31 (checked by the caller)
-    for (unsigned e = blockIdx.x * blockDim.x + threadIdx.x; e < utotal; e += gridDim.x * blockDim.x) {
+    const int lane = threadIdx.x & 63;
+    for (unsigned base = blockIdx.x * blockDim.x; base < utotal; base += gridDim.x * blockDim.x) {      // block-uniform trip count
+        const unsigned e = base + threadIdx.x;
         const unsigned i = e / uC, c = e - i * uC;
-        const float s = scores[(long)i * c_ld + c];
-        if (s > thr) {
-            const int slot = atomicAdd(&cnt_in[c], 1);
+        const float s = e < utotal ? scores[(long)i * c_ld + c] : 0.f;
+        const bool hit = e < utotal && s > thr;
+        int slot = 0;
+        if (C == 1) {
+            // one list: a wavefront takes its slots with ONE atomic (6000 lanes on one word serialise in L2: 71 us of the RPN's step)
+            const unsigned long long m64 = __ballot(hit);
+            if (m64) {
+                const int leader = __ffsll((long long)m64) - 1;
+                int b0 = 0;
+                if (lane == leader) b0 = atomicAdd(&cnt_in[0], __popcll(m64));
+                slot = __shfl(b0, leader) + __popcll(m64 & ((1ull << lane) - 1ull));
+            }
+        } else if (hit) {
+            slot = atomicAdd(&cnt_in[c], 1);
+        }
+        if (hit) {
             if ((unsigned)slot >= (unsigned)n) { LLV_GUARD_TRIP(); continue; }   // a class list holds at most n keys (counter not zeroed?)
             // score_factors multiply AFTER the threshold test (bbox_nms.py:52-62)
             cand[(long)c * n + slot] = llv::make_key(factors ? s * factors[i] : s, e);
@@ -225,7 +240,7 @@ __global__ __launch_bounds__(1024) void nms_class_kernel(const float* __restrict
     const uint64_t* src = cand + (long)c * n;
     for (int i = threadIdx.x; i < np2; i += blockDim.x) keys[i] = i < cnt ? src[i] : 0ull;
     __syncthreads();
-    llv::bitonic_sort_desc(keys, np2);
+    llv::block_sort_desc(keys, np2);
     {
         // boxes_for_nms = boxes + idxs.to(boxes) * (max_coordinate + 1)   (mmcv batched_nms)
         __shared__ int s_nkept[2];
@@ -240,6 +255,184 @@ __global__ __launch_bounds__(1024) void nms_class_kernel(const float* __restrict
         const int nk = greedy_scan_block(keys, cnt, iou_thr, max_num, kept, cls_keys + (long)c * max_num, box_of, s_nkept);
         if (threadIdx.x == 0) cls_cnt[c] = nk;
     }
+}
+
+// ---- one long list (num_classes == 1, n >= kMaskMinN: the RPN's 6000 proposals of a single-level neck) ---------------------------------
+// nms_class_kernel tests every candidate against every box kept so far on ONE compute unit: cnt * kept IoUs (1.8 M for 6000 x 300), 190 us.
+// Here the IoUs go to the whole chip and the serial part only combines bits:
+//   nms_sort_kernel    the class kernel's load + sort; sorted keys and their boxes go to the workspace
+//   nms_mask_kernel    mask[i][q] = bits j of { 64 q + j > i and IoU(box i, box 64 q + j) > thr }, a 64 x 64 tile per wavefront, upper triangle
+//   nms_reduce_kernel  one workgroup of 4 waves walks the list 256 boxes at a time: wave w resolves its 64 boxes against the removed word
+//                      of its chunk (a scalar loop over the alive bits, the tile's diagonal word by readlane), ORs the kept rows' words for
+//                      the rest of the 256 into the removed words, and after the four waves all threads OR the kept rows' remaining words
+//                      (one coalesced pass, LDS atomics). A box is removed by exactly the kept boxes before it: the class kernel's result.
+constexpr int kMaskMinN = 2048;
+
+__host__ __device__ inline int mask_row_words(int n) { return (((n + 63) >> 6) + 3) & ~3; }     // 32-byte multiples: a thread reads 4 words
+
+__global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict__ boxes, int n, const unsigned* maxc_u, const int* cnt_in,
+                                                       const uint64_t* cand, uint64_t* skeys, float4* sbox, long ws_stride) {
+    {
+        const int img = blockIdx.y;
+        boxes += (long)img * n * 4;
+        cnt_in = reinterpret_cast<const int*>(reinterpret_cast<const char*>(cnt_in) + img * ws_stride);
+        cand = reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(cand) + img * ws_stride);
+        skeys = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(skeys) + img * ws_stride);
+        sbox = reinterpret_cast<float4*>(reinterpret_cast<char*>(sbox) + img * ws_stride);
+    }
+    (void)maxc_u;                                            // class 0: the offset c * (max_coordinate + 1) is 0
+    int cnt = cnt_in[0];
+    if (cnt < 0 || cnt > n) { if (threadIdx.x == 0) LLV_GUARD_TRIP(); cnt = cnt < 0 ? 0 : n; }
+    if (cnt == 0) return;
+    extern __shared__ __attribute__((aligned(16))) unsigned char sm[];
+    uint64_t* keys = reinterpret_cast<uint64_t*>(sm);
+    const int np2 = llv::next_pow2(cnt);
+    for (int i = threadIdx.x; i < np2; i += blockDim.x) keys[i] = i < cnt ? cand[i] : 0ull;
+    __syncthreads();
+    llv::block_sort_desc(keys, np2);
+    for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
+        const uint64_t key = keys[i];
+        unsigned flat = llv::key_index(key);
+        if (flat >= (unsigned)n) { LLV_GUARD_TRIP(); flat = 0; }
+        skeys[i] = key;
+        sbox[i] = reinterpret_cast<const float4*>(boxes)[flat];
+    }
+}
+
+__global__ __launch_bounds__(64) void nms_mask_kernel(const float4* __restrict__ sbox, const int* cnt_in, uint64_t* mask, int n, int nw,
+                                                     float thr, long ws_stride) {
+    const int q = blockIdx.x, r = blockIdx.y, lane = threadIdx.x;
+    if (q < r) return;
+    {
+        const int img = blockIdx.z;
+        cnt_in = reinterpret_cast<const int*>(reinterpret_cast<const char*>(cnt_in) + img * ws_stride);
+        sbox = reinterpret_cast<const float4*>(reinterpret_cast<const char*>(sbox) + img * ws_stride);
+        mask = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(mask) + img * ws_stride);
+    }
+    int cnt = cnt_in[0];
+    cnt = cnt < 0 ? 0 : (cnt > n ? n : cnt);
+    if (64 * q >= cnt) return;                               // r <= q: the row chunk holds candidates too
+    __shared__ float4 cb[64];
+    const int j0 = 64 * q;
+    cb[lane] = j0 + lane < cnt ? sbox[j0 + lane] : make_float4(0.f, 0.f, 0.f, 0.f);
+    __syncthreads();
+    const int i = 64 * r + lane;
+    if (i >= cnt) return;
+    const float4 bi = sbox[i];
+    const int jn = cnt - j0 < 64 ? cnt - j0 : 64;
+    unsigned long long bits = 0ull;
+    for (int jj = 0; jj < jn; ++jj)
+        if (j0 + jj > i && iou_gt(bi, cb[jj], thr)) bits |= 1ull << jj;
+    mask[(long)i * nw + q] = bits;
+}
+
+__device__ __forceinline__ unsigned long long uniform64(unsigned long long v) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)v), hi = (unsigned)__builtin_amdgcn_readfirstlane((int)(unsigned)(v >> 32));
+    return ((unsigned long long)hi << 32) | lo;
+}
+__device__ __forceinline__ unsigned long long readlane64(unsigned long long v, int t) {
+    const unsigned lo = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)v, t), hi = (unsigned)__builtin_amdgcn_readlane((int)(unsigned)(v >> 32), t);
+    return ((unsigned long long)hi << 32) | lo;
+}
+
+__global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restrict__ skeys, const int* cnt_in, const uint64_t* __restrict__ mask,
+                                                        int n, int nw, int max_num, int* cls_cnt, uint64_t* cls_keys, long ws_stride) {
+    {
+        const int img = blockIdx.y;
+        cnt_in = reinterpret_cast<const int*>(reinterpret_cast<const char*>(cnt_in) + img * ws_stride);
+        skeys = reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(skeys) + img * ws_stride);
+        mask = reinterpret_cast<const uint64_t*>(reinterpret_cast<const char*>(mask) + img * ws_stride);
+        cls_cnt = reinterpret_cast<int*>(reinterpret_cast<char*>(cls_cnt) + img * ws_stride);
+        cls_keys = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(cls_keys) + img * ws_stride);
+    }
+    int cnt = cnt_in[0];
+    cnt = cnt < 0 ? 0 : (cnt > n ? n : cnt);
+    const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    __shared__ unsigned long long rem[kMaxN / 64 + 4];       // removed bits, one word per chunk of 64
+    __shared__ int s_list[256];                              // rows kept in the current 256
+    __shared__ int s_nk, s_k;
+    for (int i = tid; i < kMaxN / 64 + 4; i += 256) rem[i] = 0ull;
+    if (tid == 0) { s_nk = 0; s_k = 0; }
+    __syncthreads();
+    const int nchunk = (cnt + 63) >> 6;
+    // row i = 64 * (c0 + wave) + lane: its words c0 + w2 >= its own chunk (chunks past the list were never written) and its key
+    auto load_row = [&](int c0, unsigned long long (&dw)[4], uint64_t& key) {
+        const int i = 64 * (c0 + wave) + lane;
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2)
+            dw[w2] = (i < cnt && w2 >= wave && c0 + w2 < nchunk) ? mask[(long)i * nw + c0 + w2] : 0ull;
+        key = i < cnt ? skeys[i] : 0ull;
+    };
+    unsigned long long dw[4], dwn[4] = {0ull, 0ull, 0ull, 0ull};
+    uint64_t key, keyn = 0ull;
+    load_row(0, dw, key);
+    for (int c0 = 0; c0 < nchunk; c0 += 4) {
+        const int q = c0 + wave, i = 64 * q + lane;
+        const bool valid = i < cnt;
+#pragma unroll
+        for (int w = 0; w < 4; ++w) {
+            if (wave == w) {
+                int nk = s_nk;
+                const int k0 = s_k;
+                unsigned long long a = uniform64(~rem[q] & __ballot(valid));
+                unsigned long long kept = 0ull;
+                const int nk0 = nk;
+                while (a && nk < max_num) {
+                    const int t = __ffsll((long long)a) - 1;
+                    kept |= 1ull << t;
+                    ++nk;
+                    a &= ~readlane64(dw[w], t);
+                    a &= ~(1ull << t);
+                }
+                const bool mine = (kept >> lane) & 1ull;
+#pragma unroll
+                for (int w2 = w + 1; w2 < 4; ++w2) {         // the kept rows' words for the later chunks of this 256
+                    unsigned long long v = mine ? dw[w2] : 0ull;
+#pragma unroll
+                    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
+                    if (lane == 0 && v) rem[c0 + w2] |= v;
+                }
+                if (mine) {
+                    const int rank = __popcll(kept & ((1ull << lane) - 1ull));
+                    cls_keys[nk0 + rank] = key;
+                    s_list[k0 + rank] = i;
+                }
+                if (lane == 0) { s_nk = nk; s_k = k0 + __popcll(kept); }
+            }
+            __syncthreads();
+        }
+        const int k = s_k, nk_all = s_nk;
+        const int wlo = c0 + 4, wf = nchunk - wlo;
+        if (wf > 0) load_row(wlo, dwn, keyn);                // in flight together with the far words below: one wait for both
+        if (wf > 0 && k > 0 && nk_all < max_num) {
+            const int tot = k * wf;
+            for (int e0 = tid; e0 < tot; e0 += 1024) {          // 4 independent loads in flight per thread, then the ORs
+                unsigned long long v[4];
+                int wd[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int e = e0 + 256 * u;
+                    const int r = e < tot ? e / wf : 0;
+                    wd[u] = wlo + (e < tot ? e - r * wf : 0);
+                    v[u] = e < tot ? mask[(long)s_list[r] * nw + wd[u]] : 0ull;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u)
+                    if (v[u]) atomicOr(&rem[wd[u]], v[u]);
+            }
+        }
+        __syncthreads();
+        if (tid == 0) s_k = 0;
+        if (nk_all >= max_num) break;                        // uniform
+        __syncthreads();
+#pragma unroll
+        for (int w2 = 0; w2 < 4; ++w2) {
+            asm volatile("" : "+v"(dwn[w2]));                // keeps the wait for the prefetched row behind the far words' loads
+            dw[w2] = dwn[w2];
+        }
+        key = keyn;
+    }
+    if (tid == 0) cls_cnt[0] = s_nk;
 }
 
 // one workgroup: merge the per-class kept lists, global (score desc, flat asc) order, top max_num
@@ -289,13 +482,13 @@ __global__ __launch_bounds__(1024) void nms_merge_kernel(const float* __restrict
         llv::block_select_top(keys, total, k, top, s_hist, s_sel);
         for (int i = k + threadIdx.x; i < kp2; i += blockDim.x) top[i] = 0;
         __syncthreads();
-        llv::bitonic_sort_desc(top, kp2);
+        llv::block_sort_desc(top, kp2);
         keys = top;
     } else {
         const int np2 = llv::next_pow2(total > 1 ? total : 1);
         for (int i = total + threadIdx.x; i < np2; i += blockDim.x) keys[i] = 0;
         __syncthreads();
-        llv::bitonic_sort_desc(keys, np2);
+        llv::block_sort_desc(keys, np2);
     }
     for (int i = threadIdx.x; i < k; i += blockDim.x) {
         const uint64_t key = keys[i];
@@ -322,7 +515,7 @@ __global__ __launch_bounds__(256) void nms_plain_kernel(const float* __restrict_
     for (int i = threadIdx.x; i < np2; i += blockDim.x)
         keys[i] = i < n ? llv::make_key(scores[i], (unsigned)i) : 0ull;
     __syncthreads();
-    llv::bitonic_sort_desc(keys, np2);
+    llv::block_sort_desc(keys, np2);
     __shared__ int s_nk;
     if (threadIdx.x < 64) {
         auto box_of = [&](unsigned idx) { return reinterpret_cast<const float4*>(boxes)[idx]; };
@@ -346,6 +539,7 @@ inline void nms_init_once() {
     static bool done = false;
     if (done) return;
     allow_big_lds(nms_class_kernel);
+    allow_big_lds(nms_sort_kernel);
     allow_big_lds(nms_merge_kernel);
     allow_big_lds(nms_plain_kernel);
     done = true;
@@ -361,10 +555,15 @@ extern "C" size_t llv_multiclass_nms_lds_bytes(int n, int max_num) {
 }
 extern "C" size_t llv_multiclass_nms_lds_limit(void) { return kLdsLimit; }
 
+static bool mask_path(int n, int num_classes) { return num_classes == 1 && n >= kMaskMinN; }
+
 static size_t mnms_ws_one(int n, int num_classes, int max_num) {
     // [maxc | cnt_in[C]] | cls_cnt[C] (memset together) | cls_keys[C][max_num] | cand[C][n]
-    return al(16 + (size_t)num_classes * 4) + al((size_t)num_classes * 4) + al((size_t)num_classes * max_num * 8) +
-           al((size_t)num_classes * (size_t)(n > 0 ? n : 1) * 8);
+    size_t b = al(16 + (size_t)num_classes * 4) + al((size_t)num_classes * 4) + al((size_t)num_classes * max_num * 8) +
+               al((size_t)num_classes * (size_t)(n > 0 ? n : 1) * 8);
+    if (mask_path(n, num_classes))                           // | sorted keys[n] | sorted boxes[n] | mask[n][row words]
+        b += al((size_t)n * 8) + al((size_t)n * 16) + al((size_t)n * mask_row_words(n) * 8);
+    return b;
 }
 
 extern "C" size_t llv_multiclass_nms_batched_workspace_bytes(int batch, int n, int num_classes, int max_num) {
@@ -420,8 +619,19 @@ extern "C" int llv_multiclass_nms_batched_ex(const float* boxes, const float* sc
         const size_t lds = (size_t)np2 * 8 + (size_t)max_num * 16;
         // a class list of a few hundred candidates (the 80-class heads) gains nothing from 16 waves; the RPN's single 6000-box list does
         const int cls_threads = n >= 2048 && num_classes <= 8 ? 1024 : 256;
-        hipLaunchKernelGGL(nms_class_kernel, dim3(num_classes, batch), dim3(cls_threads), lds, st, boxes, n, num_classes, iou_thr, max_num,
-                           maxc_u, cnt_in, cand, cls_cnt, cls_keys, stride, cs);
+        if (mask_path(n, num_classes)) {
+            const size_t o_sk = o_cand + al((size_t)n * 8), o_sb = o_sk + al((size_t)n * 8), o_mask = o_sb + al((size_t)n * 16);
+            uint64_t* skeys = (uint64_t*)(ws + o_sk);
+            float4* sbox = (float4*)(ws + o_sb);
+            uint64_t* mask = (uint64_t*)(ws + o_mask);
+            const int nw = mask_row_words(n), nch = (n + 63) / 64;
+            hipLaunchKernelGGL(nms_sort_kernel, dim3(1, batch), dim3(1024), (size_t)np2 * 8, st, boxes, n, maxc_u, cnt_in, cand, skeys, sbox, stride);
+            hipLaunchKernelGGL(nms_mask_kernel, dim3(nch, nch, batch), dim3(64), 0, st, sbox, cnt_in, mask, n, nw, iou_thr, stride);
+            hipLaunchKernelGGL(nms_reduce_kernel, dim3(1, batch), dim3(256), 0, st, skeys, cnt_in, mask, n, nw, max_num, cls_cnt, cls_keys, stride);
+        } else {
+            hipLaunchKernelGGL(nms_class_kernel, dim3(num_classes, batch), dim3(cls_threads), lds, st, boxes, n, num_classes, iou_thr, max_num,
+                               maxc_u, cnt_in, cand, cls_cnt, cls_keys, stride, cs);
+        }
     }
     int mp2 = 1;
     while (mp2 < num_classes * max_num) mp2 <<= 1;
@@ -519,7 +729,7 @@ __global__ __launch_bounds__(1024) void yolo_select_kernel(const YoloSelArgs a) 
         llv::block_select_top(keys, a.n, a.m, sel, hist, sh);
         for (int i = a.m + tid; i < mp; i += blockDim.x) sel[i] = 0;
         __syncthreads();
-        llv::bitonic_sort_desc(sel, mp);
+        llv::block_sort_desc(sel, mp);
     }
     const float* boxes = a.boxes + (long)img * a.n * 4;
     const float* pred = a.pred + (long)img * (a.n / a.A) * a.ld;

@@ -61,6 +61,65 @@ __device__ inline void bitonic_sort_desc(uint64_t* keys, int n) {
     }
 }
 
+// The same contract as bitonic_sort_desc for lists of IPT = n / blockDim.x >= 2 keys per thread: a merge sort. Every thread sorts its
+// IPT consecutive keys in registers, then log2(n / IPT) rounds merge neighbouring runs: thread t owns outputs [IPT * t, IPT * t + IPT) of
+// its pair of runs, finds where they start in the two runs by a binary search along the merge path's diagonal and merges IPT keys
+// serially out of LDS. O(n log n) key moves and 2 barriers per round -- 8192 keys: 10 rounds, where the bitonic network above runs 91
+// compare-exchange passes over all of them (the RPN's 6000-candidate lists are sorted twice per frame, one workgroup each time).
+template <int IPT>
+__device__ inline void merge_sort_desc_t(uint64_t* keys, int n) {
+    const int o = IPT * (int)threadIdx.x;
+    uint64_t v[IPT];
+#pragma unroll
+    for (int s = 0; s < IPT; ++s) v[s] = keys[o + s];
+#pragma unroll
+    for (int r = 0; r < IPT; ++r) {
+#pragma unroll
+        for (int s = r & 1; s + 1 < IPT; s += 2) {
+            const uint64_t a = v[s], b = v[s + 1];
+            v[s] = a > b ? a : b;
+            v[s + 1] = a > b ? b : a;
+        }
+    }
+#pragma unroll
+    for (int s = 0; s < IPT; ++s) keys[o + s] = v[s];
+    __syncthreads();
+    for (int L = IPT; L < n; L <<= 1) {
+        const int P = o & ~(2 * L - 1);
+        const uint64_t* A = keys + P;
+        const uint64_t* B = A + L;
+        const int d = o - P;                                 // this thread's outputs start d keys into the merged pair
+        int lo = d > L ? d - L : 0, hi = d < L ? d : L;      // how many of those d come from A
+        while (lo < hi) {
+            const int mid = (lo + hi) >> 1;
+            if (A[mid] >= B[d - 1 - mid]) lo = mid + 1; else hi = mid;
+        }
+        int ia = lo, ib = d - lo;
+        uint64_t ka = ia < L ? A[ia] : 0ull, kb = ib < L ? B[ib] : 0ull;
+#pragma unroll
+        for (int s = 0; s < IPT; ++s) {
+            const bool ta = ib >= L || (ia < L && ka >= kb);
+            v[s] = ta ? ka : kb;
+            if (ta) { ++ia; ka = ia < L ? A[ia] : 0ull; }
+            else { ++ib; kb = ib < L ? B[ib] : 0ull; }
+        }
+        __syncthreads();
+#pragma unroll
+        for (int s = 0; s < IPT; ++s) keys[o + s] = v[s];
+        __syncthreads();
+    }
+}
+
+// keys[0..n) descending, n a power of two, all threads of the block call: the merge sort for 2..16 keys per thread, else the network
+__device__ inline void block_sort_desc(uint64_t* keys, int n) {
+    const int bd = (int)blockDim.x;
+    if (n == 2 * bd) merge_sort_desc_t<2>(keys, n);
+    else if (n == 4 * bd) merge_sort_desc_t<4>(keys, n);
+    else if (n == 8 * bd) merge_sort_desc_t<8>(keys, n);
+    else if (n == 16 * bd) merge_sort_desc_t<16>(keys, n);
+    else bitonic_sort_desc(keys, n);
+}
+
 __device__ __forceinline__ int next_pow2(int v) {
     int p = 1;
     while (p < v) p <<= 1;

@@ -39,6 +39,41 @@ def test_multiclass_nms_index_exact(dev, n, C, dens):
     assert torch.equal(d.cpu(), d_ref)      # boxes and scores are copied, not recomputed: bit-exact
 
 
+@pytest.mark.parametrize('n,iou,max_num,dup', [(2048, 0.7, 300, False), (2113, 0.5, 100, False), (6000, 0.7, 300, False), (6000, 0.7, 300, True),
+                                               (6000, 0.3, 2000, False), (12276, 0.7, 1000, False), (16384, 0.7, 300, False)])
+def test_single_list_nms_index_exact(dev, n, iou, max_num, dup):
+    """One class and >= 2048 boxes (the RPN's nms_pre = 6000 list of the SELSA configs, mmtracking/configs/_base_/models/
+    faster_rcnn_r50_dc5.py:44-50): the sort -> IoU bit mask -> bit reduction kernels of nms.hip instead of the one-workgroup class
+    kernel; index-exact against the oracle, also with duplicated boxes and tied scores, lists that end before max_num is reached, the
+    12,276-anchor list of the reference's get_bboxes fixture and the 16,384-box limit; and as a batch of two different images."""
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    from oracle.nms import multiclass_nms as oracle_mnms
+    g = torch.Generator().manual_seed(n * 7 + max_num)
+    def make(seed_off):
+        gg = torch.Generator().manual_seed(n * 7 + max_num + seed_off)
+        boxes = _clustered_boxes(n, gg)
+        scores = torch.rand(n, 1, generator=gg)
+        if dup:
+            boxes[n // 2:] = boxes[:n - n // 2]
+            scores = (torch.randint(1, 40, (n, 1), generator=gg).float() / 40.0)
+        return boxes, torch.cat([scores, torch.zeros(n, 1)], 1)
+    cfg = dict(type='nms', iou_threshold=iou)
+    imgs = [make(0), make(1)]
+    refs = [oracle_mnms(b, s, 0.05, cfg, max_num, return_inds=True) for b, s in imgs]
+    for (b, s), (d_ref, l_ref, k_ref) in zip(imgs, refs):
+        d, l, k = ops.multiclass_nms(b.to(dev), s.to(dev), 0.05, cfg, max_num, return_inds=True)
+        assert torch.equal(k.cpu(), k_ref), 'kept indices differ'
+        assert torch.equal(l.cpu(), l_ref) and torch.equal(d.cpu(), d_ref)
+    bufs = ops.NmsBuffers(n, 1, max_num, dev, batch=2)
+    ops.multiclass_nms_into(torch.stack([b for b, _ in imgs]).to(dev), torch.stack([s for _, s in imgs]).to(dev).contiguous(), 0.05, iou, bufs,
+                            num_classes=1)
+    cnt = bufs.count.cpu()
+    for i, (d_ref, l_ref, k_ref) in enumerate(refs):
+        assert int(cnt[i]) == len(k_ref)
+        assert torch.equal(bufs.dets[i, :len(k_ref)].cpu(), d_ref)
+    assert ops.guard_trips() == 0
+
+
 def test_multiclass_nms_ties_and_duplicates(dev):
     from lowlightenvironmentvideoobjectdetection_amd import ops
     from oracle.nms import multiclass_nms as oracle_mnms
