@@ -274,7 +274,7 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const DecK k) {
         const int np2t = llv::next_pow2(nT > 1 ? nT : 1);
         for (int i = tid; i < np2t; i += blockDim.x) tbuf[i] = i < nT ? Tl[i] : 0ull;
         __syncthreads();
-        llv::block_sort_desc(tbuf, np2t);
+        llv::block_sort_desc(tbuf, np2t, nT);
         for (int i = tid; i < m; i += blockDim.x) fin[nA + i] = tbuf[i];
         __syncthreads();
     } else {
@@ -282,7 +282,7 @@ __global__ __launch_bounds__(1024) void topk_final_kernel(const DecK k) {
         // of the distinct 64-bit keys straight from the global list, no sort of T at all
         if (m > 0) llv::block_select_top(Tl, nT, m, fin + nA, hist, sh_sel);
     }
-    llv::block_sort_desc(fin, np2k);
+    llv::block_sort_desc(fin, np2k, kk);
     for (int i = tid; i < kk; i += blockDim.x) {
         unsigned idx = llv::key_index(fin[i]);
         if (idx >= (unsigned)n) { LLV_GUARD_TRIP(); idx = 0; }     // a padding key (0) or a corrupt one

@@ -76,7 +76,7 @@ __global__ __launch_bounds__(64) void eval_tpfp_kernel(const float* __restrict__
     const int P = llv::next_pow2(m);
     for (int i = lane; i < P; i += 64) keys[i] = i < m ? llv::make_key(dets[(long)(d0 + i) * 5 + 4], (uint32_t)i) : 0ull;
     __syncthreads();
-    llv::block_sort_desc(keys, P);
+    llv::block_sort_desc(keys, P, m);
     if (MODE == 0) {
         // the detection's best gt does not depend on the matching state: ious.max(axis=1) / argmax (first maximum)
         for (int i = lane; i < m; i += 64) {

@@ -54,7 +54,7 @@ __device__ __forceinline__ bool iou_gt(const float4 a, const float4 b, float thr
 __global__ __launch_bounds__(256) void nms_scan_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
                                                       const float* __restrict__ factors,
                                                       int n, int C, int c_ld, float thr, unsigned* maxc_u,
-                                                      int* cnt_in, uint64_t* cand, long ws_stride, int cs) {
+                                                      int* cnt_in, uint64_t* cand, long ws_stride, int cs, int single_list) {
     const long total = (long)n * C;
     {   // image = blockIdx.y: inputs are [batch][n][...], the workspace repeats every ws_stride bytes
         const int img = blockIdx.y;
@@ -65,6 +65,7 @@ __global__ __launch_bounds__(256) void nms_scan_kernel(const float* __restrict__
         cnt_in = reinterpret_cast<int*>(reinterpret_cast<char*>(cnt_in) + img * ws_stride);
         cand = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(cand) + img * ws_stride);
     }
+    if (single_list && reinterpret_cast<const int*>(maxc_u)[1] == 0) return;     // nms_presorted_kernel found the list in order: nothing to collect
     unsigned m = 0;
     const unsigned utotal = (unsigned)total, uC = (unsigned)C;        // n * C < 2^31 (checked by the caller)
     const int lane = threadIdx.x & 63;
@@ -240,7 +241,7 @@ __global__ __launch_bounds__(1024) void nms_class_kernel(const float* __restrict
     const uint64_t* src = cand + (long)c * n;
     for (int i = threadIdx.x; i < np2; i += blockDim.x) keys[i] = i < cnt ? src[i] : 0ull;
     __syncthreads();
-    llv::block_sort_desc(keys, np2);
+    llv::block_sort_desc(keys, np2, cnt);
     {
         // boxes_for_nms = boxes + idxs.to(boxes) * (max_coordinate + 1)   (mmcv batched_nms)
         __shared__ int s_nkept[2];
@@ -270,6 +271,41 @@ constexpr int kMaskMinN = 2048;
 
 __host__ __device__ inline int mask_row_words(int n) { return (((n + 63) >> 6) + 3) & ~3; }     // 32-byte multiples: a thread reads 4 words
 
+// The RPN hands its proposals over in top-k order (score descending, ties by anchor: decode.hip), which is the order the sort would
+// produce: this pass writes the keys and boxes in place as the sorted list, counts them, and raises header word 1 ("unsorted") when it
+// sees a key smaller than its successor. Only then do nms_scan_kernel / nms_sort_kernel do their work (they run either way: the launch
+// list of a captured step is fixed).
+__global__ __launch_bounds__(256) void nms_presorted_kernel(const float* __restrict__ boxes, const float* __restrict__ scores,
+                                                           const float* __restrict__ factors, int n, int c_ld, float thr, int* hdr,
+                                                           uint64_t* skeys, float4* sbox, long ws_stride) {
+    {
+        const int img = blockIdx.y;
+        boxes += (long)img * n * 4;
+        scores += (long)img * n * c_ld;
+        if (factors) factors += (long)img * n;
+        hdr = reinterpret_cast<int*>(reinterpret_cast<char*>(hdr) + img * ws_stride);
+        skeys = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(skeys) + img * ws_stride);
+        sbox = reinterpret_cast<float4*>(reinterpret_cast<char*>(sbox) + img * ws_stride);
+    }
+    const int i = blockIdx.x * 256 + threadIdx.x;
+    auto key_of = [&](int j) -> uint64_t {
+        if (j >= n) return 0ull;
+        const float s = scores[(long)j * c_ld];
+        return s > thr ? llv::make_key(factors ? s * factors[j] : s, (unsigned)j) : 0ull;
+    };
+    const uint64_t key = key_of(i);
+    const bool bad = i < n && key < key_of(i + 1);
+    if (i < n) {
+        skeys[i] = key;
+        sbox[i] = reinterpret_cast<const float4*>(boxes)[i];
+    }
+    const unsigned long long hits = __ballot(key != 0ull), bads = __ballot(bad);
+    if ((threadIdx.x & 63) == 0) {
+        if (hits) atomicAdd(&hdr[2], __popcll(hits));
+        if (bads) atomicOr(&hdr[1], 1);
+    }
+}
+
 __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict__ boxes, int n, const unsigned* maxc_u, const int* cnt_in,
                                                        const uint64_t* cand, uint64_t* skeys, float4* sbox, long ws_stride) {
     {
@@ -280,7 +316,12 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict_
         skeys = reinterpret_cast<uint64_t*>(reinterpret_cast<char*>(skeys) + img * ws_stride);
         sbox = reinterpret_cast<float4*>(reinterpret_cast<char*>(sbox) + img * ws_stride);
     }
-    (void)maxc_u;                                            // class 0: the offset c * (max_coordinate + 1) is 0
+    // class 0: the offset c * (max_coordinate + 1) is 0. Header: word 0 the max coordinate, 1 "unsorted", 2 the presorted pass's count
+    const int* hdr = reinterpret_cast<const int*>(reinterpret_cast<const char*>(maxc_u) + blockIdx.y * ws_stride);
+    if (hdr[1] == 0) {                                       // the list arrived sorted: skeys / sbox are in place
+        if (threadIdx.x == 0) const_cast<int*>(cnt_in)[0] = hdr[2];
+        return;
+    }
     int cnt = cnt_in[0];
     if (cnt < 0 || cnt > n) { if (threadIdx.x == 0) LLV_GUARD_TRIP(); cnt = cnt < 0 ? 0 : n; }
     if (cnt == 0) return;
@@ -289,7 +330,7 @@ __global__ __launch_bounds__(1024) void nms_sort_kernel(const float* __restrict_
     const int np2 = llv::next_pow2(cnt);
     for (int i = threadIdx.x; i < np2; i += blockDim.x) keys[i] = i < cnt ? cand[i] : 0ull;
     __syncthreads();
-    llv::block_sort_desc(keys, np2);
+    llv::block_sort_desc(keys, np2, cnt);
     for (int i = threadIdx.x; i < cnt; i += blockDim.x) {
         const uint64_t key = keys[i];
         unsigned flat = llv::key_index(key);
@@ -482,13 +523,13 @@ __global__ __launch_bounds__(1024) void nms_merge_kernel(const float* __restrict
         llv::block_select_top(keys, total, k, top, s_hist, s_sel);
         for (int i = k + threadIdx.x; i < kp2; i += blockDim.x) top[i] = 0;
         __syncthreads();
-        llv::block_sort_desc(top, kp2);
+        llv::block_sort_desc(top, kp2, k);
         keys = top;
     } else {
         const int np2 = llv::next_pow2(total > 1 ? total : 1);
         for (int i = total + threadIdx.x; i < np2; i += blockDim.x) keys[i] = 0;
         __syncthreads();
-        llv::block_sort_desc(keys, np2);
+        llv::block_sort_desc(keys, np2, total);
     }
     for (int i = threadIdx.x; i < k; i += blockDim.x) {
         const uint64_t key = keys[i];
@@ -515,7 +556,7 @@ __global__ __launch_bounds__(256) void nms_plain_kernel(const float* __restrict_
     for (int i = threadIdx.x; i < np2; i += blockDim.x)
         keys[i] = i < n ? llv::make_key(scores[i], (unsigned)i) : 0ull;
     __syncthreads();
-    llv::block_sort_desc(keys, np2);
+    llv::block_sort_desc(keys, np2, n);
     __shared__ int s_nk;
     if (threadIdx.x < 64) {
         auto box_of = [&](unsigned idx) { return reinterpret_cast<const float4*>(boxes)[idx]; };
@@ -612,15 +653,19 @@ extern "C" int llv_multiclass_nms_batched_ex(const float* boxes, const float* sc
     if (n > 0) {
         long g = ((long)n * num_classes + 255) / 256;
         g = g > 256 ? 256 : g;
+        const bool single = mask_path(n, num_classes);
+        const size_t o_sk = o_cand + al((size_t)n * 8), o_sb = o_sk + al((size_t)n * 8), o_mask = o_sb + al((size_t)n * 16);
+        if (single)
+            hipLaunchKernelGGL(nms_presorted_kernel, dim3((n + 255) / 256, batch), dim3(256), 0, st, boxes, scores, score_factors, n, c_ld,
+                               score_thr, (int*)ws, (uint64_t*)(ws + o_sk), (float4*)(ws + o_sb), stride);
         hipLaunchKernelGGL(nms_scan_kernel, dim3((int)g, batch), dim3(256), 0, st, boxes, scores, score_factors, n, num_classes, c_ld, score_thr,
-                           maxc_u, cnt_in, cand, stride, cs);
+                           maxc_u, cnt_in, cand, stride, cs, single ? 1 : 0);
         int np2 = 1;
         while (np2 < n) np2 <<= 1;
         const size_t lds = (size_t)np2 * 8 + (size_t)max_num * 16;
         // a class list of a few hundred candidates (the 80-class heads) gains nothing from 16 waves; the RPN's single 6000-box list does
         const int cls_threads = n >= 2048 && num_classes <= 8 ? 1024 : 256;
-        if (mask_path(n, num_classes)) {
-            const size_t o_sk = o_cand + al((size_t)n * 8), o_sb = o_sk + al((size_t)n * 8), o_mask = o_sb + al((size_t)n * 16);
+        if (single) {
             uint64_t* skeys = (uint64_t*)(ws + o_sk);
             float4* sbox = (float4*)(ws + o_sb);
             uint64_t* mask = (uint64_t*)(ws + o_mask);
@@ -729,7 +774,7 @@ __global__ __launch_bounds__(1024) void yolo_select_kernel(const YoloSelArgs a) 
         llv::block_select_top(keys, a.n, a.m, sel, hist, sh);
         for (int i = a.m + tid; i < mp; i += blockDim.x) sel[i] = 0;
         __syncthreads();
-        llv::block_sort_desc(sel, mp);
+        llv::block_sort_desc(sel, mp, a.m);
     }
     const float* boxes = a.boxes + (long)img * a.n * 4;
     const float* pred = a.pred + (long)img * (a.n / a.A) * a.ld;

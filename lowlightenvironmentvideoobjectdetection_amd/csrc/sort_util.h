@@ -61,14 +61,16 @@ __device__ inline void bitonic_sort_desc(uint64_t* keys, int n) {
     }
 }
 
-// The same contract as bitonic_sort_desc for lists of IPT = n / blockDim.x >= 2 keys per thread: a merge sort. Every thread sorts its
-// IPT consecutive keys in registers, then log2(n / IPT) rounds merge neighbouring runs: thread t owns outputs [IPT * t, IPT * t + IPT) of
+// A merge sort for lists of 2..16 keys per thread, DESCENDING, in place in LDS: keys[0 .. IPT * blockDim.x). Every thread sorts its IPT
+// consecutive keys in registers, then log2(blockDim.x) rounds merge neighbouring runs: thread t owns outputs [IPT * t, IPT * t + IPT) of
 // its pair of runs, finds where they start in the two runs by a binary search along the merge path's diagonal and merges IPT keys
-// serially out of LDS. O(n log n) key moves and 2 barriers per round -- 8192 keys: 10 rounds, where the bitonic network above runs 91
-// compare-exchange passes over all of them (the RPN's 6000-candidate lists are sorted twice per frame, one workgroup each time).
+// serially out of LDS. O(n log n) key moves -- 8192 keys: 10 rounds, where the bitonic network above runs 91 compare-exchange passes
+// over all of them (the RPN's 6000-candidate lists are sorted per frame, one workgroup each time). The first six rounds stay inside a
+// wavefront's own 64 * IPT keys and need no workgroup barrier. IPT need not be a power of two: 6000 keys sort as 6 x 1024, not as 8192.
 template <int IPT>
-__device__ inline void merge_sort_desc_t(uint64_t* keys, int n) {
+__device__ inline void merge_sort_desc_t(uint64_t* keys) {
     const int o = IPT * (int)threadIdx.x;
+    const int n = IPT * (int)blockDim.x;
     uint64_t v[IPT];
 #pragma unroll
     for (int s = 0; s < IPT; ++s) v[s] = keys[o + s];
@@ -83,9 +85,11 @@ __device__ inline void merge_sort_desc_t(uint64_t* keys, int n) {
     }
 #pragma unroll
     for (int s = 0; s < IPT; ++s) keys[o + s] = v[s];
-    __syncthreads();
-    for (int L = IPT; L < n; L <<= 1) {
-        const int P = o & ~(2 * L - 1);
+    __builtin_amdgcn_wave_barrier();
+    int sh = 0;                                              // run length L = IPT << sh, threads per pair 2 << sh
+    for (int L = IPT; L < n; L <<= 1, ++sh) {
+        const bool in_wave = sh < 6;                         // the pair's 2 << sh threads sit in one wavefront
+        const int P = (int)(threadIdx.x >> (sh + 1)) * 2 * L;
         const uint64_t* A = keys + P;
         const uint64_t* B = A + L;
         const int d = o - P;                                 // this thread's outputs start d keys into the merged pair
@@ -103,22 +107,39 @@ __device__ inline void merge_sort_desc_t(uint64_t* keys, int n) {
             if (ta) { ++ia; ka = ia < L ? A[ia] : 0ull; }
             else { ++ib; kb = ib < L ? B[ib] : 0ull; }
         }
-        __syncthreads();
+        if (in_wave) __builtin_amdgcn_wave_barrier(); else __syncthreads();
 #pragma unroll
         for (int s = 0; s < IPT; ++s) keys[o + s] = v[s];
-        __syncthreads();
+        if (in_wave && sh < 5) __builtin_amdgcn_wave_barrier(); else __syncthreads();     // the next round reaches across wavefronts
     }
+    __syncthreads();
 }
 
-// keys[0..n) descending, n a power of two, all threads of the block call: the merge sort for 2..16 keys per thread, else the network
-__device__ inline void block_sort_desc(uint64_t* keys, int n) {
+// keys[0..n) descending; n a power of two with padding keys 0 behind the cnt <= n real ones; all threads of the block call.
+// 2..16 keys per thread: the merge sort over the first ceil(cnt / blockDim) * blockDim keys (the rest is padding, already in place).
+__device__ inline void block_sort_desc(uint64_t* keys, int n, int cnt) {
     const int bd = (int)blockDim.x;
-    if (n == 2 * bd) merge_sort_desc_t<2>(keys, n);
-    else if (n == 4 * bd) merge_sort_desc_t<4>(keys, n);
-    else if (n == 8 * bd) merge_sort_desc_t<8>(keys, n);
-    else if (n == 16 * bd) merge_sort_desc_t<16>(keys, n);
-    else bitonic_sort_desc(keys, n);
+    const int ipt = (cnt + bd - 1) / bd;
+    if (n < 2 * bd || ipt > 16 || (bd & (bd - 1))) { bitonic_sort_desc(keys, n); return; }
+    switch (ipt < 2 ? 2 : ipt) {
+        case 2: merge_sort_desc_t<2>(keys); break;
+        case 3: merge_sort_desc_t<3>(keys); break;
+        case 4: merge_sort_desc_t<4>(keys); break;
+        case 5: merge_sort_desc_t<5>(keys); break;
+        case 6: merge_sort_desc_t<6>(keys); break;
+        case 7: merge_sort_desc_t<7>(keys); break;
+        case 8: merge_sort_desc_t<8>(keys); break;
+        case 9: merge_sort_desc_t<9>(keys); break;
+        case 10: merge_sort_desc_t<10>(keys); break;
+        case 11: merge_sort_desc_t<11>(keys); break;
+        case 12: merge_sort_desc_t<12>(keys); break;
+        case 13: merge_sort_desc_t<13>(keys); break;
+        case 14: merge_sort_desc_t<14>(keys); break;
+        case 15: merge_sort_desc_t<15>(keys); break;
+        default: merge_sort_desc_t<16>(keys); break;
+    }
 }
+__device__ inline void block_sort_desc(uint64_t* keys, int n) { block_sort_desc(keys, n, n); }
 
 __device__ __forceinline__ int next_pow2(int v) {
     int p = 1;

@@ -39,13 +39,16 @@ def test_multiclass_nms_index_exact(dev, n, C, dens):
     assert torch.equal(d.cpu(), d_ref)      # boxes and scores are copied, not recomputed: bit-exact
 
 
+@pytest.mark.parametrize('presorted', [False, True])
 @pytest.mark.parametrize('n,iou,max_num,dup', [(2048, 0.7, 300, False), (2113, 0.5, 100, False), (6000, 0.7, 300, False), (6000, 0.7, 300, True),
                                                (6000, 0.3, 2000, False), (12276, 0.7, 1000, False), (16384, 0.7, 300, False)])
-def test_single_list_nms_index_exact(dev, n, iou, max_num, dup):
+def test_single_list_nms_index_exact(dev, n, iou, max_num, dup, presorted):
     """One class and >= 2048 boxes (the RPN's nms_pre = 6000 list of the SELSA configs, mmtracking/configs/_base_/models/
     faster_rcnn_r50_dc5.py:44-50): the sort -> IoU bit mask -> bit reduction kernels of nms.hip instead of the one-workgroup class
     kernel; index-exact against the oracle, also with duplicated boxes and tied scores, lists that end before max_num is reached, the
-    12,276-anchor list of the reference's get_bboxes fixture and the 16,384-box limit; and as a batch of two different images."""
+    12,276-anchor list of the reference's get_bboxes fixture and the 16,384-box limit; and as a batch of two different images.
+    presorted: the rows arrive in score order (as the RPN's top-k hands them over), where the device skips its sort; in the batch only the
+    first image does, so both branches run inside one launch."""
     from lowlightenvironmentvideoobjectdetection_amd import ops
     from oracle.nms import multiclass_nms as oracle_mnms
     g = torch.Generator().manual_seed(n * 7 + max_num)
@@ -56,6 +59,10 @@ def test_single_list_nms_index_exact(dev, n, iou, max_num, dup):
         if dup:
             boxes[n // 2:] = boxes[:n - n // 2]
             scores = (torch.randint(1, 40, (n, 1), generator=gg).float() / 40.0)
+        if presorted and seed_off == 0:
+            order = torch.sort(scores[:, 0], descending=True, stable=True)[1]
+            boxes, scores = boxes[order].contiguous(), scores[order].contiguous()
+            scores[-5:] = 0.01                                 # a tail below score_thr, still in order
         return boxes, torch.cat([scores, torch.zeros(n, 1)], 1)
     cfg = dict(type='nms', iou_threshold=iou)
     imgs = [make(0), make(1)]
