@@ -263,13 +263,13 @@ __global__ __launch_bounds__(1024) void nms_class_kernel(const float* __restrict
 // Here the IoUs go to the whole chip and the serial part only combines bits:
 //   nms_sort_kernel    the class kernel's load + sort; sorted keys and their boxes go to the workspace
 //   nms_mask_kernel    mask[i][q] = bits j of { 64 q + j > i and IoU(box i, box 64 q + j) > thr }, a 64 x 64 tile per wavefront, upper triangle
-//   nms_reduce_kernel  one workgroup of 4 waves walks the list 256 boxes at a time: wave w resolves its 64 boxes against the removed word
+//   nms_reduce_kernel  one workgroup of 8 waves walks the list 512 boxes at a time: wave w resolves its 64 boxes against the removed word
 //                      of its chunk (a scalar loop over the alive bits, the tile's diagonal word by readlane), ORs the kept rows' words for
-//                      the rest of the 256 into the removed words, and after the four waves all threads OR the kept rows' remaining words
+//                      the rest of the 512 into the removed words, and after the eight waves all threads OR the kept rows' remaining words
 //                      (one coalesced pass, LDS atomics). A box is removed by exactly the kept boxes before it: the class kernel's result.
 constexpr int kMaskMinN = 2048;
 
-__host__ __device__ inline int mask_row_words(int n) { return (((n + 63) >> 6) + 3) & ~3; }     // 32-byte multiples: a thread reads 4 words
+__host__ __device__ inline int mask_row_words(int n) { return (((n + 63) >> 6) + 7) & ~7; }     // 64-byte multiples: a thread reads 8 words in a row
 
 // The RPN hands its proposals over in top-k order (score descending, ties by anchor: decode.hip), which is the order the sort would
 // produce: this pass writes the keys and boxes in place as the sorted list, counts them, and raises header word 1 ("unsorted") when it
@@ -376,8 +376,12 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
     return ((unsigned long long)hi << 32) | lo;
 }
 
-__global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restrict__ skeys, const int* cnt_in, const uint64_t* __restrict__ mask,
-                                                        int n, int nw, int max_num, int* cls_cnt, uint64_t* cls_keys, long ws_stride) {
+constexpr int kRedWaves = 8;                                 // boxes per step of the reduction = 64 * kRedWaves
+
+__global__ __launch_bounds__(64 * kRedWaves) void nms_reduce_kernel(const uint64_t* __restrict__ skeys, const int* cnt_in,
+                                                                   const uint64_t* __restrict__ mask, int n, int nw, int max_num,
+                                                                   int* cls_cnt, uint64_t* cls_keys, long ws_stride) {
+    constexpr int NW = kRedWaves, NT = 64 * NW;
     {
         const int img = blockIdx.y;
         cnt_in = reinterpret_cast<const int*>(reinterpret_cast<const char*>(cnt_in) + img * ws_stride);
@@ -389,29 +393,31 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restr
     int cnt = cnt_in[0];
     cnt = cnt < 0 ? 0 : (cnt > n ? n : cnt);
     const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-    __shared__ unsigned long long rem[kMaxN / 64 + 4];       // removed bits, one word per chunk of 64
-    __shared__ int s_list[256];                              // rows kept in the current 256
+    __shared__ unsigned long long rem[kMaxN / 64 + NW];      // removed bits, one word per chunk of 64
+    __shared__ int s_list[NT];                               // rows kept in the current step
     __shared__ int s_nk, s_k;
-    for (int i = tid; i < kMaxN / 64 + 4; i += 256) rem[i] = 0ull;
+    for (int i = tid; i < kMaxN / 64 + NW; i += NT) rem[i] = 0ull;
     if (tid == 0) { s_nk = 0; s_k = 0; }
     __syncthreads();
     const int nchunk = (cnt + 63) >> 6;
     // row i = 64 * (c0 + wave) + lane: its words c0 + w2 >= its own chunk (chunks past the list were never written) and its key
-    auto load_row = [&](int c0, unsigned long long (&dw)[4], uint64_t& key) {
+    auto load_row = [&](int c0, unsigned long long (&dw)[NW], uint64_t& key) {
         const int i = 64 * (c0 + wave) + lane;
 #pragma unroll
-        for (int w2 = 0; w2 < 4; ++w2)
+        for (int w2 = 0; w2 < NW; ++w2)
             dw[w2] = (i < cnt && w2 >= wave && c0 + w2 < nchunk) ? mask[(long)i * nw + c0 + w2] : 0ull;
         key = i < cnt ? skeys[i] : 0ull;
     };
-    unsigned long long dw[4], dwn[4] = {0ull, 0ull, 0ull, 0ull};
+    unsigned long long dw[NW], dwn[NW];
+#pragma unroll
+    for (int w2 = 0; w2 < NW; ++w2) dwn[w2] = 0ull;
     uint64_t key, keyn = 0ull;
     load_row(0, dw, key);
-    for (int c0 = 0; c0 < nchunk; c0 += 4) {
+    for (int c0 = 0; c0 < nchunk; c0 += NW) {
         const int q = c0 + wave, i = 64 * q + lane;
         const bool valid = i < cnt;
 #pragma unroll
-        for (int w = 0; w < 4; ++w) {
+        for (int w = 0; w < NW; ++w) {
             if (wave == w) {
                 int nk = s_nk;
                 const int k0 = s_k;
@@ -425,15 +431,10 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restr
                     a &= ~readlane64(dw[w], t);
                     a &= ~(1ull << t);
                 }
-                const bool mine = (kept >> lane) & 1ull;
+                if ((kept >> lane) & 1ull) {
 #pragma unroll
-                for (int w2 = w + 1; w2 < 4; ++w2) {         // the kept rows' words for the later chunks of this 256
-                    unsigned long long v = mine ? dw[w2] : 0ull;
-#pragma unroll
-                    for (int o = 32; o > 0; o >>= 1) v |= __shfl_xor(v, o);
-                    if (lane == 0 && v) rem[c0 + w2] |= v;
-                }
-                if (mine) {
+                    for (int w2 = w + 1; w2 < NW; ++w2)      // the kept rows' words for the later chunks of this step
+                        if (dw[w2]) atomicOr(&rem[c0 + w2], dw[w2]);
                     const int rank = __popcll(kept & ((1ull << lane) - 1ull));
                     cls_keys[nk0 + rank] = key;
                     s_list[k0 + rank] = i;
@@ -443,16 +444,16 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restr
             __syncthreads();
         }
         const int k = s_k, nk_all = s_nk;
-        const int wlo = c0 + 4, wf = nchunk - wlo;
+        const int wlo = c0 + NW, wf = nchunk - wlo;
         if (wf > 0) load_row(wlo, dwn, keyn);                // in flight together with the far words below: one wait for both
         if (wf > 0 && k > 0 && nk_all < max_num) {
             const int tot = k * wf;
-            for (int e0 = tid; e0 < tot; e0 += 1024) {          // 4 independent loads in flight per thread, then the ORs
+            for (int e0 = tid; e0 < tot; e0 += 4 * NT) {     // 4 independent loads in flight per thread, then the ORs
                 unsigned long long v[4];
                 int wd[4];
 #pragma unroll
                 for (int u = 0; u < 4; ++u) {
-                    const int e = e0 + 256 * u;
+                    const int e = e0 + NT * u;
                     const int r = e < tot ? e / wf : 0;
                     wd[u] = wlo + (e < tot ? e - r * wf : 0);
                     v[u] = e < tot ? mask[(long)s_list[r] * nw + wd[u]] : 0ull;
@@ -467,7 +468,7 @@ __global__ __launch_bounds__(256) void nms_reduce_kernel(const uint64_t* __restr
         if (nk_all >= max_num) break;                        // uniform
         __syncthreads();
 #pragma unroll
-        for (int w2 = 0; w2 < 4; ++w2) {
+        for (int w2 = 0; w2 < NW; ++w2) {
             asm volatile("" : "+v"(dwn[w2]));                // keeps the wait for the prefetched row behind the far words' loads
             dw[w2] = dwn[w2];
         }
@@ -672,7 +673,7 @@ extern "C" int llv_multiclass_nms_batched_ex(const float* boxes, const float* sc
             const int nw = mask_row_words(n), nch = (n + 63) / 64;
             hipLaunchKernelGGL(nms_sort_kernel, dim3(1, batch), dim3(1024), (size_t)np2 * 8, st, boxes, n, maxc_u, cnt_in, cand, skeys, sbox, stride);
             hipLaunchKernelGGL(nms_mask_kernel, dim3(nch, nch, batch), dim3(64), 0, st, sbox, cnt_in, mask, n, nw, iou_thr, stride);
-            hipLaunchKernelGGL(nms_reduce_kernel, dim3(1, batch), dim3(256), 0, st, skeys, cnt_in, mask, n, nw, max_num, cls_cnt, cls_keys, stride);
+            hipLaunchKernelGGL(nms_reduce_kernel, dim3(1, batch), dim3(64 * kRedWaves), 0, st, skeys, cnt_in, mask, n, nw, max_num, cls_cnt, cls_keys, stride);
         } else {
             hipLaunchKernelGGL(nms_class_kernel, dim3(num_classes, batch), dim3(cls_threads), lds, st, boxes, n, num_classes, iou_thr, max_num,
                                maxc_u, cnt_in, cand, cls_cnt, cls_keys, stride, cs);

@@ -82,11 +82,30 @@ class SelsaKeyPlan:
         from .selsa import linear_pc
         nf = head.num_shared_fcs
         self._kv = []
+        def merged_pc(*fcs):
+            """several fully connected layers over the same rows as ONE 1x1 convolution: output channels side by side (the K sum of
+            every output is the layer's own: only the launch count changes -- each of these small-M products is launch-bound)"""
+            wt = torch.cat([m.weight.detach().float().cpu() for m in fcs], 0)
+            bs = torch.cat([m.bias.detach().float().cpu() for m in fcs], 0)
+            return ops.pack_conv(wt.view(wt.shape[0], wt.shape[1], 1, 1), bs, 1, 0)
+
+        def conv_view(name, xv, x_ld, pc, flags=0):
+            """b.conv on a channel slice of a wider buffer (row stride x_ld)"""
+            n_, h_, w_, _ = xv.shape
+            out = b.buf(n_, h_, w_, pc.groups * pc.cout, dtype=torch.float32 if flags & CONV_OUT_F32 else torch.float16)
+            b.conv_desc(name, pc, [xv], out, n_, [(h_, w_, h_, w_, 0, 0)], x_ld, out.shape[-1], None, 0, flags)
+            return out
+
         x, r = roi, roi
+        xr = None                              # rows [0, P): the key chain's input to the next fc, rows [P, 2P): the reference chain's
         for i, fc in enumerate(head.shared_fcs):
             pc = linear_pc(fc, roi_hw=(ph, pw) if i == 0 else None)
-            x_pre = b.conv(f'head.fc{i}', x, pc)                               # (P, 1, 1, F) fp16, no activation: it is also the residual
-            r_pre = x_pre if (i == 0) else b.conv(f'head.fc{i}.ref', r, pc)    # the reference chain's pre-activation
+            if i == 0:
+                x_pre = b.conv(f'head.fc{i}', x, pc)                           # (P, 1, 1, F) fp16, no activation: it is also the residual
+                r_pre = x_pre                                                  # the reference chain's pre-activation
+            else:                                                              # both chains through the same weights: one launch over 2P rows
+                xr_pre = b.conv(f'head.fc{i}', xr, pc)
+                x_pre, r_pre = xr_pre[:P], xr_pre[P:]
             ag = head.aggregator[i]
             nbk, Fc = ag.num_attention_blocks, x_pre.shape[-1]
             d = Fc // nbk
@@ -96,26 +115,38 @@ class SelsaKeyPlan:
             kw = b.buf(nbk, m_pad, kp)
             vw = b.buf(nbk, ops.round_up(d, 16), m_pad)
             self._kv.append((kw, vw, ms, nbk, d, Fc, m_pad, kp))             # the static rows are packed by set_static
-            xe = b.conv(f'head.agg{i}.fc_embed', x_pre, linear_pc(ag.fc_embed))
-            re_l = b.conv(f'head.agg{i}.ref_fc_embed', r_pre, linear_pc(ag.ref_fc_embed))
-            rn_l = b.conv(f'head.agg{i}.ref_fc', r_pre, linear_pc(ag.ref_fc))
-            b.plan.add(f'head.agg{i}.pack_k', L.llv_selsa_pack_kv, (ops._ptr(re_l), ops._ptr(kw), P, ms, nbk, d, Fc, m_pad, kp, 0))
-            b.plan.add(f'head.agg{i}.pack_v', L.llv_selsa_pack_kv, (ops._ptr(rn_l), ops._ptr(vw), P, ms, nbk, d, Fc, vw.shape[1], m_pad, 1))
+            if i == 0:                         # fc_embed, ref_fc_embed and ref_fc all read x_pre
+                e3 = b.conv(f'head.agg{i}.embed3', x_pre, merged_pc(ag.fc_embed, ag.ref_fc_embed, ag.ref_fc))
+                ld = e3.shape[-1]
+                xe, xe_ld = e3[..., :Fc], ld
+                re_l, rn_l, r_ld = e3[..., Fc:2 * Fc], e3[..., 2 * Fc:3 * Fc], ld
+            else:
+                xe, xe_ld = b.conv(f'head.agg{i}.fc_embed', x_pre, linear_pc(ag.fc_embed)), Fc
+                e2 = b.conv(f'head.agg{i}.ref_embed2', r_pre, merged_pc(ag.ref_fc_embed, ag.ref_fc))
+                re_l, rn_l, r_ld = e2[..., :Fc], e2[..., Fc:2 * Fc], e2.shape[-1]
+            b.plan.add(f'head.agg{i}.pack_k', L.llv_selsa_pack_kv, (ops._ptr(re_l), ops._ptr(kw), P, ms, nbk, d, r_ld, m_pad, kp, 0))
+            b.plan.add(f'head.agg{i}.pack_v', L.llv_selsa_pack_kv, (ops._ptr(rn_l), ops._ptr(vw), P, ms, nbk, d, r_ld, vw.shape[1], m_pad, 1))
             pck = ops.PackedConv(w=kw, bias=torch.zeros(nbk * m_pad, device=device), cin=d, cout=m_pad, w_rows=m_pad, k_pad=kp, kh=1, kw=1,
                                  stride=1, pad=0, groups=nbk, true_macs_per_pixel=(ms + P) * Fc)
             pcv = ops.PackedConv(w=vw, bias=torch.zeros(nbk * d, device=device), cin=m_pad, cout=d, w_rows=vw.shape[1], k_pad=m_pad, kh=1, kw=1,
                                  stride=1, pad=0, groups=nbk, true_macs_per_pixel=(ms + P) * Fc)
-            s = b.conv(f'head.agg{i}.scores', xe.view(1, P, 1, Fc), pck, CONV_OUT_F32)
+            s = conv_view(f'head.agg{i}.scores', xe.as_strided((1, P, 1, Fc), (P * xe_ld, xe_ld, xe_ld, 1)), xe_ld, pck, CONV_OUT_F32)
             pwt = b.buf(1, P, 1, nbk * m_pad)
             b.plan.add(f'head.agg{i}.softmax', L.llv_selsa_softmax, (ops._ptr(s), ops._ptr(pwt), P, nbk, m_pad, ms, P, ops._ptr(self.count),
                                                                     C.c_float(1.0 / d ** 0.5)))
             x_new = b.conv(f'head.agg{i}.values', pwt, pcv)                    # (1, P, 1, F)
             # relu(x_pre + fc(x_new)) = the residual + ReLU epilogue of the aggregator's last fc (selsa_bbox_head.py:78-80)
-            x = b.conv(f'head.agg{i}.fc', x_new.view(P, 1, 1, Fc), linear_pc(ag.fc), CONV_RELU | CONV_RES_ADD, res=x_pre.view(P, 1, 1, Fc))
-            if i + 1 < nf:                     # the reference chain's input to the next fc: relu(r_pre), element-wise on the rows already there
-                r = b.buf(*r_pre.shape)        # (y * (y > 0) = llv_relu_bwd with dy = y; bit-identical to the fc's ReLU epilogue, whose
-                b.plan.add(f'head.fc{i}.ref_relu', L.llv_relu_bwd,          # re-run of the 12544-wide first fc cost 73 us per frame)
-                           (ops._ptr(r_pre), None, ops._ptr(r_pre), ops._ptr(r), C.c_int64(r_pre.numel())), 0.0, 4.0 * r_pre.numel())
+            if i + 1 < nf:
+                xr = b.buf(2 * P, 1, 1, Fc)
+                x = b.conv(f'head.agg{i}.fc', x_new.view(P, 1, 1, Fc), linear_pc(ag.fc), CONV_RELU | CONV_RES_ADD, res=x_pre.view(P, 1, 1, Fc),
+                           out=xr[:P])
+                # the reference chain's input to the next fc: relu(r_pre), element-wise on the rows already there (y * (y > 0) =
+                # llv_relu_bwd with dy = y; bit-identical to the fc's ReLU epilogue, whose re-run of the 12544-wide first fc cost
+                # 73 us per frame)
+                b.plan.add(f'head.fc{i}.ref_relu', L.llv_relu_bwd,
+                           (ops._ptr(r_pre), None, ops._ptr(r_pre), ops._ptr(xr[P:]), C.c_int64(r_pre.numel())), 0.0, 4.0 * r_pre.numel())
+            else:
+                x = b.conv(f'head.agg{i}.fc', x_new.view(P, 1, 1, Fc), linear_pc(ag.fc), CONV_RELU | CONV_RES_ADD, res=x_pre.view(P, 1, 1, Fc))
         ncl = head.num_classes
         cls_l = b.conv('head.fc_cls', x, linear_pc(head.fc_cls), CONV_OUT_F32)                  # (P, 1, 1, >= ncl + 1) fp32
         reg_l = b.conv('head.fc_reg', x, linear_pc(head.fc_reg), CONV_OUT_F32)                  # (P, 1, 1, 4 * ncl)
