@@ -556,6 +556,10 @@ int llv_pack_results(const float* dets, const int64_t* labels, const int32_t* co
  * the last reset (0 with consistent inputs; > 0 means launches of a step ran on counters that were not zeroed or on lists that
  * changed between passes, which without the guards is an out-of-bounds store). Synchronises the device; never call while capturing. */
 int llv_guard_trips(uint64_t* count_host, int reset);
+/* The same count written by one kernel at this point of the stream: *dst (device-visible: device memory or device-mapped pinned host
+ * memory) = guards fired since the last reset. For the end of a captured step, next to llv_pack_results; the first call must be
+ * made outside a stream capture (it looks the counters' addresses up). */
+int llv_guard_trips_to(uint32_t* dst, void* stream);
 
 /* Test-time image pipeline of the reference in one pass:
  * SeqBrighten (mmtracking/mmtrack/datasets/pipelines/transforms.py:376-432: one gain amp = m*h*w*3 / sum(frame0/255) for the

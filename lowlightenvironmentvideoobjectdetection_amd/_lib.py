@@ -211,6 +211,7 @@ SIGNATURES = {
     'llv_copy_d2d': (_I, [_P, _P, _Z, _P]),
     'llv_pack_results': (_I, [_P, _P, _P, _I, _I, _P, _P, _P]),
     'llv_guard_trips': (_I, [C.POINTER(C.c_uint64), _I]),
+    'llv_guard_trips_to': (_I, [_P, _P]),
     'llv_roi_align': (_I, [_P, _P, _P] + [_I] * 8 + [_F, _I, _I, _I, _P]),
     'llv_selsa_pack_kv': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _I, _I, _P]),
     'llv_selsa_softmax': (_I, [_P, _P, _L, _I, _I, _I, _I, _P, _F, _P]),

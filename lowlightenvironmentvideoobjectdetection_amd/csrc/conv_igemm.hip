@@ -2388,6 +2388,11 @@ unsigned int llv_conv_guard_trips_(int reset) {
     return v;
 }
 
+unsigned int* llv_conv_guard_addr_() {
+    void* p = nullptr;
+    return hipGetSymbolAddress(&p, HIP_SYMBOL(g_conv_guard_trips)) == hipSuccess ? (unsigned int*)p : nullptr;
+}
+
 #include "conv_tap512.inc"
 
 struct LaunchPlan { int tile, splits, nk_per; long m; };

@@ -171,26 +171,25 @@ __global__ __launch_bounds__(256) void topk_threshold_kernel(const DecK k) {
         if (threadIdx.x == 0) { meta[0] = -1; meta[1] = 0; }
         return;
     }
-    __shared__ unsigned part[256];
     const unsigned* h = hist_i + l * kBins;
     constexpr int PER = kBins / 256;
     const int top = kBins - 1 - threadIdx.x * PER;   // this thread owns bins top, top-1, ..., top-PER+1
+    unsigned hv[PER];
     unsigned s = 0;
-    for (int i = 0; i < PER; ++i) s += h[top - i];
-    part[threadIdx.x] = s;
-    __syncthreads();
-    if (threadIdx.x == 0) {
-        unsigned cum = 0;
-        int t = 0;
-        for (; t < 255; ++t) {
-            if (cum + part[t] >= (unsigned)kk) break;
-            cum += part[t];
-        }
-        int b = kBins - 1 - t * PER;
-        const int lo = b - PER + 1;
-        for (; b > lo; --b) {
-            if (cum + h[b] >= (unsigned)kk) break;
-            cum += h[b];
+#pragma unroll
+    for (int i = 0; i < PER; ++i) { hv[i] = h[top - i]; s += hv[i]; }
+    // scores in the bins above this thread's: a block scan instead of one thread walking the 256 partial sums (15 us per frame)
+    __shared__ int scr[17];
+    int total = 0;
+    unsigned cum = (unsigned)llv::block_exclusive_scan((int)s, scr, &total);
+    const bool owner = threadIdx.x == 255 ? cum < (unsigned)kk : (cum < (unsigned)kk && cum + s >= (unsigned)kk);
+    if (owner) {                                     // exactly one thread (the last one also when fewer than kk scores exist at all)
+        int b = top;
+        const int lo = top - PER + 1;
+#pragma unroll
+        for (int i = 0; i < PER; ++i) {
+            if (b > lo && cum + hv[i] < (unsigned)kk) { cum += hv[i]; --b; }
+            else break;
         }
         meta[0] = b;           // b*
         meta[1] = (int)cum;    // scores in bins above b*  (< kk)
@@ -475,6 +474,29 @@ extern "C" int llv_guard_trips(uint64_t* count_host, int reset) {
     }
     *count_host = (uint64_t)v + (uint64_t)llv_nms_guard_trips_(reset) + (uint64_t)llv_conv_guard_trips_(reset);
     return LLV_OK;
+}
+
+// The same sum as ONE kernel node at the end of a step: *dst (device-visible, e.g. pinned host memory next to the packed results) =
+// guards fired since the last reset. The host reads it after the synchronisation it does anyway, instead of three synchronous symbol
+// reads per hand-over (60-80 us of a 2 ms single-frame step).
+unsigned int* llv_nms_guard_addr_();
+unsigned int* llv_conv_guard_addr_();
+namespace {
+__global__ void guard_sum_kernel(const unsigned* a, const unsigned* b, const unsigned* c, unsigned* dst) { *dst = *a + *b + *c; }
+}
+extern "C" int llv_guard_trips_to(uint32_t* dst, void* stream) {
+    if (!dst) return LLV_E_BADARG;
+    static unsigned* addr[3] = {nullptr, nullptr, nullptr};
+    if (!addr[0]) {                                          // first call outside any capture (the plans' warm-up run)
+        void* p = nullptr;
+        if (hipGetSymbolAddress(&p, HIP_SYMBOL(g_guard_trips)) != hipSuccess) return LLV_E_LAUNCH;
+        unsigned* n_ = llv_nms_guard_addr_();
+        unsigned* c_ = llv_conv_guard_addr_();
+        if (!p || !n_ || !c_) return LLV_E_LAUNCH;
+        addr[1] = n_; addr[2] = c_; addr[0] = (unsigned*)p;
+    }
+    hipLaunchKernelGGL(guard_sum_kernel, dim3(1), dim3(1), 0, (hipStream_t)stream, addr[0], addr[1], addr[2], dst);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
 // delta2bbox for (n, 4) boxes and (n, 4k) deltas: the bbox heads' class-specific decode (delta_xywh_bbox_coder.py:134-237), the same

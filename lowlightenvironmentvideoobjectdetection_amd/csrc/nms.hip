@@ -726,6 +726,11 @@ extern "C" int llv_nms(const float* boxes, const float* scores, int n, float iou
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
+unsigned int* llv_nms_guard_addr_() {
+    void* p = nullptr;
+    return hipGetSymbolAddress(&p, HIP_SYMBOL(g_guard_trips)) == hipSuccess ? (unsigned int*)p : nullptr;
+}
+
 unsigned int llv_nms_guard_trips_(int reset) {
     unsigned int v = 0;
     (void)hipMemcpyFromSymbol(&v, HIP_SYMBOL(g_guard_trips), sizeof(v));

@@ -823,6 +823,7 @@ class EnhanceDetectPlan:
         self.cnt_dev = torch.zeros((batch,), device=device, dtype=torch.int32)
         self.res_host = torch.zeros((batch, k, 6), dtype=torch.float32).pin_memory()
         self.cnt_host = torch.zeros((batch,), dtype=torch.int32).pin_memory()
+        self.guard_host = torch.zeros((1,), dtype=torch.int32).pin_memory()     # llv_guard_trips_to: the step's last kernel node
         self._graph = None
         self._zero_copy = False
 
@@ -852,6 +853,8 @@ class EnhanceDetectPlan:
                                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
             raise LlvError(f'llv_pack_results: {lib().llv_strerror(rc).decode()} ({rc})')
+        check(lib().llv_guard_trips_to(C.c_void_p(self.guard_host.data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+              'llv_guard_trips_to')
 
     def _body(self, window, carry=False):
         self._enhance(window, carry)
@@ -911,7 +914,8 @@ class EnhanceDetectPlan:
 
     def results(self):
         torch.cuda.current_stream().synchronize()
-        ops.raise_on_guard_trips('EnhanceDetectPlan.results')
+        if int(self.guard_host[0]):              # written by the step's last kernel (no extra device round trip per hand-over)
+            ops.raise_on_guard_trips('EnhanceDetectPlan.results')
         out = []
         for n in range(self.batch):
             k = int(self.cnt_host[n])
@@ -1018,6 +1022,7 @@ class PipelinedStreamingPlan:
         k = self.det.post.nb.max_num
         self.res_host = [torch.zeros((batch, k, 6), dtype=torch.float32).pin_memory() for _ in range(2)]
         self.cnt_host = [torch.zeros((batch,), dtype=torch.int32).pin_memory() for _ in range(2)]
+        self.guard_host = [torch.zeros((1,), dtype=torch.int32).pin_memory() for _ in range(2)]
         self.side = torch.cuda.Stream(device)
         self.side2 = torch.cuda.Stream(device) if stages == 3 else None
         self._graphs = [None, None]
@@ -1047,6 +1052,8 @@ class PipelinedStreamingPlan:
                                     C.c_void_p(torch.cuda.current_stream().cuda_stream))
         if rc != 0:
             raise LlvError(f'llv_pack_results: {lib().llv_strerror(rc).decode()} ({rc})')
+        check(lib().llv_guard_trips_to(C.c_void_p(self.guard_host[k].data_ptr()), C.c_void_p(torch.cuda.current_stream().cuda_stream)),
+              'llv_guard_trips_to')
 
     def _detect(self, k):
         self._run_range(k, 0, len(self.dets[k].plan.steps))
@@ -1124,8 +1131,9 @@ class PipelinedStreamingPlan:
     def results(self):
         """Detections of the window most recently detected: [(dets (k, 5), labels (k,))] per image."""
         torch.cuda.synchronize()
-        ops.raise_on_guard_trips('PipelinedStreamingPlan.results')
         k = self._last
+        if int(self.guard_host[k][0]):
+            ops.raise_on_guard_trips('PipelinedStreamingPlan.results')
         out = []
         for n in range(self.batch):
             c = int(self.cnt_host[k][n])

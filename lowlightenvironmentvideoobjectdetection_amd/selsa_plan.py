@@ -180,6 +180,9 @@ class SelsaKeyPlan:
         b.plan.keep += [self.res_host, self.cnt_host]
         b.plan.add('results', L.llv_pack_results, (ops._ptr(self.out.dets), ops._ptr(self.out.labels), ops._ptr(self.out.count), 1, k,
                                                    C.c_void_p(self.res_host.data_ptr()), C.c_void_p(self.cnt_host.data_ptr())))
+        self.guard_host = torch.zeros((1,), dtype=torch.int32).pin_memory()
+        b.plan.keep.append(self.guard_host)
+        b.plan.add('guards', L.llv_guard_trips_to, (C.c_void_p(self.guard_host.data_ptr()),))
         self.num_classes = ncl
         self._graph = None
         self.use_graph = use_graph
@@ -214,7 +217,8 @@ class SelsaKeyPlan:
         else:
             self.plan.run()
         torch.cuda.current_stream().synchronize()
-        ops.raise_on_guard_trips('SelsaKeyPlan.run')
+        if int(self.guard_host[0]):              # the step's last kernel wrote the capacity-guard count next to the results
+            ops.raise_on_guard_trips('SelsaKeyPlan.run')
         k = int(self.cnt_host[0])
         r = self.res_host[0, :k]
         return r[:, :5].clone(), r[:, 5].long()
