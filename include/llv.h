@@ -672,6 +672,8 @@ int llv_conv2d_nhwc_dgrad(const llv_conv_desc* fwd, const void* w_dgrad, const f
 /* dx = (dy [+ dy2]) * (y > 0); dy2 and y may be NULL (then: plain sum / plain copy). n fp16 elements, multiple of 8.
  * torch autograd of F.relu(x [+ identity]) (resnet.py:292-296). */
 int llv_relu_bwd(const void* dy, const void* dy2, const void* y, void* dx, int64_t n, void* stream);
+/* The same for the block output y = relu(v + identity) in one pass: dy *= (y > 0) in place, then gres += dy (the identity's gradient). */
+int llv_relu_res_bwd(void* dy, const void* y, void* gres, int64_t n, void* stream);
 /* Backward of a LeakyReLU epilogue (Darknet / YOLOV3Neck ConvModules), with the residual of a ResBlock (y = res + act(v), darknet.py:50-57)
  * when res != NULL: gres += dy (when gres != NULL), then dy *= (y - res > 0 ? 1 : slope) in place. `rows` rows of c halfs, own pitches. */
 int llv_act_bwd(void* dy, const void* y, const void* res, void* gres, int64_t rows, int c, int dy_ld, int y_ld, int res_ld, int gres_ld,

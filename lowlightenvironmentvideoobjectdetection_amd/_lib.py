@@ -230,6 +230,7 @@ SIGNATURES = {
     'llv_fold_bias': (_I, [_P, _P, _P, _P, _P, _F, _P, _I, _P]),
     'llv_unpack_wgrad': (_I, [_P, _P, _P, _P, _P, _P, _F, _P, _P, _P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'llv_relu_bwd': (_I, [_P, _P, _P, _P, _L, _P]),
+    'llv_relu_res_bwd': (_I, [_P, _P, _P, _L, _P]),
     'llv_act_bwd': (_I, [_P, _P, _P, _P, _L, _I, _I, _I, _I, _I, _F, _P]),
     'llv_upsample2x_nhwc_bwd': (_I, [_P, _P, _I, _I, _I, _I, _I, _I, _P]),
     'llv_bias_grad': (_I, [_P, _L, _I, _I, _P, _P]),

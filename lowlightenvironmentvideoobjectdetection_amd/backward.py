@@ -109,6 +109,11 @@ def relu_bwd(dy: torch.Tensor, y: Optional[torch.Tensor], dx: torch.Tensor, dy2:
                              dx.data_ptr(), n, _stream()), 'llv_relu_bwd')
 
 
+def relu_res_bwd(dy: torch.Tensor, y: torch.Tensor, gres: torch.Tensor):
+    """dy *= (y > 0) in place, then gres += dy: the block output relu(v + identity) in one pass (contiguous fp16 buffers)."""
+    check(lib().llv_relu_res_bwd(dy.data_ptr(), y.data_ptr(), gres.data_ptr(), dy.numel(), _stream()), 'llv_relu_res_bwd')
+
+
 def act_bwd(dy: torch.Tensor, y: torch.Tensor, res: Optional[torch.Tensor], gres: Optional[torch.Tensor], slope: float):
     """llv_act_bwd over (..., C) fp16 tensors whose last-but-one stride is their row pitch: gres += dy; dy *= (y - res > 0 ? 1 : slope)."""
     c = y.shape[-1]

@@ -268,6 +268,22 @@ __global__ void relu_bwd_kernel(const _Float16* dy, const _Float16* dy2, const _
     }
 }
 
+// the block output of a Bottleneck, y = relu(v + identity): dy *= (y > 0) in place and gres += dy, one pass instead of two
+__global__ void relu_res_bwd_kernel(_Float16* dy, const _Float16* y, _Float16* gres, long nvec) {
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < nvec; i += (long)gridDim.x * blockDim.x) {
+        f16x8 g = reinterpret_cast<const f16x8*>(dy)[i];
+        const f16x8 o = reinterpret_cast<const f16x8*>(y)[i];
+        f16x8 r = reinterpret_cast<const f16x8*>(gres)[i];
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            g[e] = (float)o[e] > 0.f ? g[e] : (_Float16)0.f;
+            r[e] = (_Float16)((float)r[e] + (float)g[e]);
+        }
+        reinterpret_cast<f16x8*>(dy)[i] = g;
+        reinterpret_cast<f16x8*>(gres)[i] = r;
+    }
+}
+
 // column sums of a [m][c] fp16 matrix (row stride ld) into fp32: one block = 64 rows x 256 channels-of-8... simple form:
 // blockIdx.x = channel group of 64, blockIdx.y = row split; lanes = channels, rows strided; fp32 atomics at the end.
 __global__ __launch_bounds__(256) void bias_grad_kernel(const _Float16* dy, long m, int c, int ld, float* out, long rows_per) {
@@ -619,6 +635,16 @@ extern "C" int llv_relu_bwd(const void* dy, const void* dy2, const void* y, void
     grid = grid > 4096 ? 4096 : grid;
     hipLaunchKernelGGL(relu_bwd_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (const _Float16*)dy, (const _Float16*)dy2,
                        (const _Float16*)y, (_Float16*)dx, nvec);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_relu_res_bwd(void* dy, const void* y, void* gres, int64_t n, void* stream) {
+    if (!dy || !y || !gres || n < 0 || (n & 7)) return LLV_E_BADARG;
+    if (n == 0) return LLV_OK;
+    const long nvec = n >> 3;
+    long grid = (nvec + 255) / 256;
+    grid = grid > 4096 ? 4096 : grid;
+    hipLaunchKernelGGL(relu_res_bwd_kernel, dim3((int)grid), dim3(256), 0, (hipStream_t)stream, (_Float16*)dy, (const _Float16*)y, (_Float16*)gres, nvec);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 

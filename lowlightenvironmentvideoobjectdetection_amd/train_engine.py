@@ -273,11 +273,27 @@ class TrainGraph:
             if phase == 'weight':
                 flags = 0                                        # masks and routing belong to the data phase
             # rows of y this launch wrote: per segment (batch*ho*wo rows at y offset)
+            fused_res = False
             if flags & CONV_RELU:
-                for (h, w, ho, wo, xo, yo) in op['segs']:
-                    n = op['batch'] * ho * wo
-                    yv, gv = self._rows(op['y'], yo, n), self._rows(gy, yo, n)
-                    B.relu_bwd(gv, yv, gv)
+                gres = None
+                if (flags & CONV_RES_ADD) and not (flags & (CONV_RES_UPS | CONV_LEAKY)) and op['res'] is not None and _sptr(op['res']) in self.req:
+                    gres = self.gview(op['res'])
+                if gres is not None and len(op['segs']) == 1 and op['segs'][0][5] == 0 and gy.is_contiguous() and gres.is_contiguous() \
+                        and op['y'].is_contiguous() and gy.numel() == gres.numel() == op['y'].numel():
+                    B.relu_res_bwd(gy, op['y'], gres)            # mask + the identity's gradient in one pass (a Bottleneck's output)
+                    fused_res = True
+                else:
+                    # rows this launch wrote, neighbouring levels of a pyramid buffer as one range (the head towers: 1 launch, not 5)
+                    spans = []
+                    for (h, w, ho, wo, xo, yo) in sorted(op['segs'], key=lambda s_: s_[5]):
+                        n = op['batch'] * ho * wo
+                        if spans and spans[-1][0] + spans[-1][1] == yo:
+                            spans[-1][1] += n
+                        else:
+                            spans.append([yo, n])
+                    for yo, n in spans:
+                        yv, gv = self._rows(op['y'], yo, n), self._rows(gy, yo, n)
+                        B.relu_bwd(gv, yv, gv)
             if flags & CONV_LEAKY:
                 # LeakyReLU epilogue (Darknet / YOLOV3Neck ConvModules); with LLV_CONV_ACT_FIRST the residual joins AFTER the activation
                 # (ResBlock: y = res + act(v)): the residual takes dY as it is, the conv's own dY gets the activation's slope
@@ -286,7 +302,7 @@ class TrainGraph:
                     raise LlvError(f"{op['name']}: backward of LeakyReLU(v + res) is not built (ResBlocks add after the activation)")
                 gres = self.gview(res) if res is not None and _sptr(res) in self.req else None
                 B.act_bwd(gy, op['y'], res, gres, op.get('act_slope', 0.0))
-            elif (flags & CONV_RES_ADD) and op['res'] is not None and _sptr(op['res']) in self.req:
+            elif (flags & CONV_RES_ADD) and not fused_res and op['res'] is not None and _sptr(op['res']) in self.req:
                 gres = self.gview(op['res'])
                 if flags & CONV_RES_UPS:
                     B.upsample_add_bwd(gy, gres, accumulate=True)

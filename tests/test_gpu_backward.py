@@ -187,3 +187,23 @@ def test_maxpool_bwd_matches_autograd(dev, n, h, w, c):
     assert ((got != 0) == (xr.grad.half() != 0)).all()
     check(lib().llv_maxpool3x3s2_nhwc_bwd(ops._ptr(xd), ops._ptr(dyd), ops._ptr(dx), n, h, w, c, c, c, c, st), 'llv_maxpool3x3s2_nhwc_bwd')
     assert (dx.float().permute(0, 3, 1, 2).cpu() - 2 * xr.grad).abs().max().item() < 8e-3
+
+
+def test_relu_res_bwd_equals_the_two_passes(dev):
+    """llv_relu_res_bwd (the block output relu(v + identity): mask and the identity's gradient in one pass) == llv_relu_bwd twice, bit for bit,
+    and == autograd of relu(v + r) in fp32 up to the fp16 rounding of the stored sum."""
+    from lowlightenvironmentvideoobjectdetection_amd import backward as B
+    g = torch.Generator().manual_seed(5)
+    n = 2 * 23 * 40 * 64
+    y = torch.relu(torch.randn(n, generator=g)).half().to(dev)
+    dy = torch.randn(n, generator=g).half().to(dev)
+    gres0 = torch.randn(n, generator=g).half().to(dev)
+    dy_a, gres_a = dy.clone(), gres0.clone()
+    B.relu_bwd(dy_a, y, dy_a)
+    B.relu_bwd(gres_a, None, gres_a, dy2=dy_a)
+    dy_b, gres_b = dy.clone(), gres0.clone()
+    B.relu_res_bwd(dy_b, y, gres_b)
+    assert torch.equal(dy_a, dy_b) and torch.equal(gres_a, gres_b)
+    want = dy.float() * (y.float() > 0)
+    assert torch.equal(dy_b.float(), want)
+    assert (gres_b.float() - (gres0.float() + want)).abs().max().item() < 4e-3
