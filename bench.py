@@ -147,6 +147,7 @@ def train_bench(args, world, rank, dev):
     t0 = time.perf_counter()
     for _ in range(args.steps):
         out = ts.step_fused(img, metas, gtb, gtl)
+    t_enq = time.perf_counter() - t0             # host time to enqueue the steps (no synchronisation inside a step)
     torch.cuda.synchronize()
     if world > 1:
         dist.barrier()
@@ -173,7 +174,8 @@ def train_bench(args, world, rank, dev):
                        'parallelism': f'data parallel x{world}: bucketed all-reduce of {ts.flat_g.numel() * 4 / 1e6:.0f} MB fp32 gradients '
                                       f'in {len(ts.buckets)} buckets, overlapped with backward',
                        'algorithmic_gflop_per_image': round(flops / nb / 1e9, 1), 'last_loss': out['log_vars']['loss']},
-            'achieved_tflops': round(flops * args.steps / dt / 1e12, 2)}), flush=True)
+            'achieved_tflops': round(flops * args.steps / dt / 1e12, 2),
+            'host_enqueue_ms_per_step': round(t_enq / args.steps * 1e3, 4)}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -232,12 +232,20 @@ class JobTables:
     def valid(self):
         return self.sig == self.rec.signature()
 
-    def launch(self):
+    def launch(self, dgrad_stream=None):
+        """dgrad_stream: the data-gradient filters are not read before the backward pass -- their table may run on this stream beside
+        whatever follows on the current one (forked here; the caller joins it before the first data-gradient launch)."""
         L, st = lib(), _stream()
         if self.t_pack is not None:
             check(L.llv_pack_conv_weights_batched(self.t_pack.data_ptr(), self.n[0], self.b_pack, st), 'llv_pack_conv_weights_batched')
         if self.t_dgrad is not None:
-            check(L.llv_pack_dgrad_weights_batched(self.t_dgrad.data_ptr(), self.n[3], self.b_dgrad, st), 'llv_pack_dgrad_weights_batched')
+            if dgrad_stream is not None:
+                dgrad_stream.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(dgrad_stream):
+                    check(L.llv_pack_dgrad_weights_batched(self.t_dgrad.data_ptr(), self.n[3], self.b_dgrad, _stream()),
+                          'llv_pack_dgrad_weights_batched')
+            else:
+                check(L.llv_pack_dgrad_weights_batched(self.t_dgrad.data_ptr(), self.n[3], self.b_dgrad, st), 'llv_pack_dgrad_weights_batched')
         if self.t_fold is not None:
             check(L.llv_fold_bias_batched(self.t_fold.data_ptr(), self.n[1], self.b_fold, st), 'llv_fold_bias_batched')
         if self.t_unpack is not None:

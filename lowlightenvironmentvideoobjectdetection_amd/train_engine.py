@@ -190,6 +190,8 @@ class TrainGraph:
     def _sig(self):
         return tuple(t.data_ptr() for t in self.params.values()) + tuple(t.data_ptr() for t in self.buffers.values())
 
+    dgrad_stream = None      # TrainStep: the side stream the data-gradient filters are re-packed on (beside the forward pass)
+
     def _batched(self, key, record, extra_sig=()):
         """Run `record()` (a sequence of B.pack_weights / fold_bias / unpack_wgrad_device calls) as job tables: recorded once, then one
         launch per table for as long as no parameter, buffer or destination tensor has moved."""
@@ -200,7 +202,7 @@ class TrainGraph:
                 record()
             tab = self._tables[key] = B.JobTables(rec, self.device)
             tab.sig = sig
-        tab.launch()
+        tab.launch(self.dgrad_stream)
 
     def repack(self):
         """Write the current parameter values into every trainable launch's packed weights (+ its dgrad filter):
@@ -541,9 +543,18 @@ class TrainStep:
         self._segs = segs
 
         def fwd():
-            g.repack()
+            # the data-gradient filters (a transposing re-pack of all trainable weights, 150 us) are first read by the backward pass:
+            # forked onto the side stream here, joined at the end of the forward graph
+            cur = torch.cuda.current_stream()
+            g.dgrad_stream = self._wstream
+            try:
+                g.repack()
+            finally:
+                g.dgrad_stream = None
             ops.pack_input(self.img_static, 8, out=g.x_in)
             g.plan.run()
+            if self._wstream is not None:
+                cur.wait_stream(self._wstream)
 
         def seg_data(k):
             g.backward_ops(self._segs[k][0], None, phase='data')
