@@ -138,7 +138,7 @@ def train_bench(args, world, rank, dev):
         gtl.append(torch.from_numpy(rs.randint(0, NUM_CLASSES, 10)).long().to(dev))
     metas = [dict(img_shape=img_shape, pad_shape=pad_shape, scale_factor=1.0)] * nb
     ts = train_engine.TrainStep(det, nb, hp, wp, dev, lr=0.01 / 16 * nb * world,      # linear scaling from 16 images at lr 0.01
-                                bucket_mb=float(os.environ.get('LLV_BUCKET_MB', '25')))
+                                bucket_mb=float(os.environ.get('LLV_BUCKET_MB', '18')))
     for _ in range(args.warmup):
         out = ts.step_fused(img, metas, gtb, gtl)
     if world > 1:

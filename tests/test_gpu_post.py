@@ -273,3 +273,29 @@ def test_delta2bbox_kernel_vs_oracle(dev):
         assert got.shape == ref.shape
         assert (got - ref).abs().max().item() <= 1e-5 * ref.abs().max().item()
     assert ops.delta2bbox(r[:0].to(dev), d[:0].to(dev)).shape == (0, 4 * k)
+
+
+def test_guard_count_written_by_a_kernel(dev):
+    """llv_guard_trips_to (the count a captured step hands over next to its results) == llv_guard_trips, into device memory and into
+    device-mapped pinned host memory, before and after a post-processing launch on the same stream."""
+    import ctypes as C
+    from lowlightenvironmentvideoobjectdetection_amd import ops
+    from lowlightenvironmentvideoobjectdetection_amd._lib import check, lib
+    ops.guard_trips(reset=True)
+    st = C.c_void_p(torch.cuda.current_stream().cuda_stream)
+    word = torch.full((1,), 77, dtype=torch.int32, device=dev)
+    host = torch.full((1,), 77, dtype=torch.int32).pin_memory()
+    check(lib().llv_guard_trips_to(C.c_void_p(word.data_ptr()), st), 'llv_guard_trips_to')
+    check(lib().llv_guard_trips_to(C.c_void_p(host.data_ptr()), st), 'llv_guard_trips_to')
+    torch.cuda.synchronize()
+    assert int(word[0]) == 0 and int(host[0]) == 0 and ops.guard_trips() == 0
+    n, ncls = 64, 1
+    g = torch.Generator().manual_seed(0)
+    boxes = _clustered_boxes(n, g).to(dev)
+    scores = torch.rand(n, 1, generator=g).to(dev).contiguous()
+    bufs = ops.NmsBuffers(n, ncls, 10, dev)
+    L = lib()
+    ops.multiclass_nms_into(boxes, scores, 0.05, 0.5, bufs, num_classes=1)
+    check(L.llv_guard_trips_to(C.c_void_p(host.data_ptr()), st), 'llv_guard_trips_to')
+    torch.cuda.synchronize()
+    assert int(host[0]) == ops.guard_trips()
