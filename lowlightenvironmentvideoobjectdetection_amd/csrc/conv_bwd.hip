@@ -630,8 +630,8 @@ extern "C" int llv_conv2d_nhwc_wgrad(const llv_conv_desc* d, const void* dy, int
     const int bco = big ? 128 : 64, bci = big ? 128 : 64;
     const long tiles = (long)((d->cout + bco - 1) / bco) * ((d->cin + bci - 1) / bci) * d->kh * d->kw * d->groups;
     // Every pixel split adds a whole dW tile of fp32 atomics (64 KiB per 128 x 128 tile): with 1024 workgroups of >= 256 pixels each a
-    // 256 -> 256 3x3 layer sent 64 MB of atomics at a 2.4 MB gradient and the launches were bound by them. Two workgroups per CU of
-    // >= 512 pixels: 165.6 -> 171.3 images/s on the training step (LLV_WGRAD_WGS / LLV_WGRAD_MINPX: the sweep's knobs; 768 pixels and
+    // 256 -> 256 3x3 layer sent 64 MB of atomics at a 2.4 MB gradient and the launches were bound by them. 1.5 workgroups per CU of
+    // >= 512 pixels: 165.6 -> 172-177 images/s on the training step (LLV_WGRAD_WGS / LLV_WGRAD_MINPX: the sweep's knobs; 768 pixels and
     // more lose again, the chip runs empty on the small maps).
     static const long target_wgs = getenv("LLV_WGRAD_WGS") && atol(getenv("LLV_WGRAD_WGS")) > 0 ? atol(getenv("LLV_WGRAD_WGS")) : 384;
     static const long min_px = getenv("LLV_WGRAD_MINPX") && atol(getenv("LLV_WGRAD_MINPX")) > 0 ? atol(getenv("LLV_WGRAD_MINPX")) : 512;
