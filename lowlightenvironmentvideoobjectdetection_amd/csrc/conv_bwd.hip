@@ -626,14 +626,18 @@ extern "C" int llv_conv2d_nhwc_wgrad(const llv_conv_desc* d, const void* dy, int
     a.H = d->seg_h[0]; a.W = d->seg_w[0]; a.Ho = d->seg_ho[0]; a.Wo = d->seg_wo[0];
     a.xoff = (int)d->seg_xoff[0]; a.yoff = (int)d->seg_yoff[0];
     a.m_total = (int)m; a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
-    const bool big = d->cout > 64 && d->cin > 64;
+    // 64 x 64 tiles unless both channel counts exceed 512: a workgroup's pixel split ends in fp32 atomics over its whole dW tile, 16 KiB
+    // for a 64 x 64 tile against 64 KiB for 128 x 128, and on single-image maps the launches are bound by those atomics, not by the MFMA
+    // operand traffic the larger tile saves (same-box sweep on the training step: 128 x 128 tiles 177, 64 x 64 tiles 182 images/s)
+    static const long small_max = getenv("LLV_WGRAD_SMALLMAX") ? atol(getenv("LLV_WGRAD_SMALLMAX")) : 512;
+    const bool big = d->cout > small_max && d->cin > small_max;
     const int bco = big ? 128 : 64, bci = big ? 128 : 64;
     const long tiles = (long)((d->cout + bco - 1) / bco) * ((d->cin + bci - 1) / bci) * d->kh * d->kw * d->groups;
     // Every pixel split adds a whole dW tile of fp32 atomics (64 KiB per 128 x 128 tile): with 1024 workgroups of >= 256 pixels each a
-    // 256 -> 256 3x3 layer sent 64 MB of atomics at a 2.4 MB gradient and the launches were bound by them. 1.5 workgroups per CU of
-    // >= 512 pixels: 165.6 -> 172-177 images/s on the training step (LLV_WGRAD_WGS / LLV_WGRAD_MINPX: the sweep's knobs; 768 pixels and
-    // more lose again, the chip runs empty on the small maps).
-    static const long target_wgs = getenv("LLV_WGRAD_WGS") && atol(getenv("LLV_WGRAD_WGS")) > 0 ? atol(getenv("LLV_WGRAD_WGS")) : 384;
+    // 256 -> 256 3x3 layer sent 64 MB of atomics at a 2.4 MB gradient and the launches were bound by them. Pixel splits of
+    // >= 512 pixels: 165.6 -> 171 images/s on the training step (LLV_WGRAD_WGS / LLV_WGRAD_MINPX: the sweep's knobs; 768 pixels and
+    // more lose again, the chip runs empty on the small maps); with the 64 x 64 tiles above, four workgroups per CU again.
+    static const long target_wgs = getenv("LLV_WGRAD_WGS") && atol(getenv("LLV_WGRAD_WGS")) > 0 ? atol(getenv("LLV_WGRAD_WGS")) : 1024;
     static const long min_px = getenv("LLV_WGRAD_MINPX") && atol(getenv("LLV_WGRAD_MINPX")) > 0 ? atol(getenv("LLV_WGRAD_MINPX")) : 512;
     long splits = (target_wgs + tiles - 1) / tiles;
     const long max_splits = (m + min_px - 1) / min_px;
