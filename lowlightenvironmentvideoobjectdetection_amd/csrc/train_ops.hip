@@ -282,30 +282,44 @@ __global__ __launch_bounds__(256) void retina_loss_kernel(const llv_retina_loss_
         int pp = 0, ch = threadIdx.x;
         while (ch >= AC) { ch -= AC; ++pp; }
         while (pp < np) {
-            const long row = d.level_off[l] + pn0 + pp;          // row of the pixel-major buffers
-            const int a = s_anchor[ch];
-            const bool pos = s_label[pp * kRlMaxA + a] == (int)s_cls[ch];
-            const float w = s_w[pp * kRlMaxA + a];
-            const float xi = d.cls[row * d.cls_ld + ch];
-            const float e = expf(-fabsf(xi));
-            const float r = 1.f / (1.f + e);
-            const float p = xi >= 0.f ? r : e * r;               // sigmoid(x)
-            const float sp = log1pf(e);
-            const float log_p = -(fmaxf(-xi, 0.f) + sp), log_1mp = -(fmaxf(xi, 0.f) + sp);
-            float loss, grad;
-            if (pos) {
-                const float m = g2 ? (1.f - p) * (1.f - p) : powf(1.f - p, d.gamma);
-                loss = -d.alpha * (m * log_p);
-                grad = -d.alpha * (m * (1.f - p - d.gamma * p * log_p));
-            } else {
-                const float m = g2 ? p * p : powf(p, d.gamma);
-                loss = -(1.f - d.alpha) * (m * log_1mp);
-                grad = -(1.f - d.alpha) * (m * (d.gamma * (1.f - p) * log_1mp - p));
+            // four logits of this thread in flight (one was a chain of exposed load latencies: 45 per thread on the finest level)
+            constexpr int U = 4;
+            int pps[U], chs[U];
+            float xs[U];
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                pps[u] = pp; chs[u] = ch;
+                xs[u] = pp < np ? d.cls[(d.level_off[l] + pn0 + pp) * (long)d.cls_ld + ch] : 0.f;
+                ch += blockDim.x;
+                while (ch >= AC) { ch -= AC; ++pp; }
             }
-            lc += loss * w;
-            dcls[row * d.dcls_ld + ch] = (_Float16)(grad * w * gs_cls);
-            ch += blockDim.x;
-            while (ch >= AC) { ch -= AC; ++pp; }
+#pragma unroll
+            for (int u = 0; u < U; ++u) {
+                if (pps[u] >= np) break;
+                const int pq = pps[u], cq = chs[u];
+                const long row = d.level_off[l] + pn0 + pq;      // row of the pixel-major buffers
+                const int a = s_anchor[cq];
+                const bool pos = s_label[pq * kRlMaxA + a] == (int)s_cls[cq];
+                const float w = s_w[pq * kRlMaxA + a];
+                const float xi = xs[u];
+                const float e = expf(-fabsf(xi));
+                const float r = 1.f / (1.f + e);
+                const float p = xi >= 0.f ? r : e * r;           // sigmoid(x)
+                const float sp = log1pf(e);
+                const float log_p = -(fmaxf(-xi, 0.f) + sp), log_1mp = -(fmaxf(xi, 0.f) + sp);
+                float loss, grad;
+                if (pos) {
+                    const float m = g2 ? (1.f - p) * (1.f - p) : powf(1.f - p, d.gamma);
+                    loss = -d.alpha * (m * log_p);
+                    grad = -d.alpha * (m * (1.f - p - d.gamma * p * log_p));
+                } else {
+                    const float m = g2 ? p * p : powf(p, d.gamma);
+                    loss = -(1.f - d.alpha) * (m * log_1mp);
+                    grad = -(1.f - d.alpha) * (m * (d.gamma * (1.f - p) * log_1mp - p));
+                }
+                lc += loss * w;
+                dcls[row * d.dcls_ld + cq] = (_Float16)(grad * w * gs_cls);
+            }
         }
         for (int t = threadIdx.x; t < np * A * 4; t += blockDim.x) {      // the group's box terms: t = (pixel, anchor, coordinate)
             const int e = t & 3, pa = t >> 2;
