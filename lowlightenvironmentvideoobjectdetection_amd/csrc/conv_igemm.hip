@@ -2347,8 +2347,10 @@ int pick_splits(int tile, int cout, long m, int groups, int nk, int flags) {
     // at 160-255 workgroups a short reduction (< 48 k-steps) is not worth the extra epilogue launch (single-image layer3 conv1, 232
     // workgroups, K = 1024: 14.7 us unsplit against 24.9 us split in three, in isolation); a long one is (layer3 conv2, K = 2304)
     if (blocks >= 256 || nk < 16 || (blocks >= 160 && nk < 48)) return 1;
-    long s = (512 + blocks - 1) / blocks;
-    if (s > nk / 8) s = nk / 8;
+    static const long split_target = getenv("LLV_SPLIT_TARGET") && atol(getenv("LLV_SPLIT_TARGET")) > 0 ? atol(getenv("LLV_SPLIT_TARGET")) : 512;
+    static const long split_min_nk = getenv("LLV_SPLIT_MIN_NK") && atol(getenv("LLV_SPLIT_MIN_NK")) > 0 ? atol(getenv("LLV_SPLIT_MIN_NK")) : 8;
+    long s = (split_target + blocks - 1) / blocks;
+    if (s > nk / split_min_nk) s = nk / split_min_nk;
     if (s > 32) s = 32;
     return s < 2 ? 1 : (int)s;
 }
