@@ -14,8 +14,10 @@ whose weight tensor IS the ConvTranspose weight (cin, cout, 4, 4) read as (Cout_
   weight grad.   dW = wgrad_V(input = dy, output gradient = x)   llv_conv2d_nhwc_wgrad; unpacked as V's (Cout_V, Cin_V, 4, 4) = the
                  ConvTranspose2d parameter's own layout
 
-so no host-side re-packing happens between optimizer steps. crop_like (:16-20) must be a no-op: the scaled image size has to be a
-multiple of 64 (otherwise a level's transposed conv is one pixel larger than its skip tensor; the training graph refuses)."""
+so no host-side re-packing happens between optimizer steps. crop_like (:16-20: the transposed conv's output cut to its skip tensor's
+size from the top-left corner, e.g. 24 -> 23 rows at the reference's 360 x 640 scaled frames) is a tape entry of its own: the transposed
+conv writes its full 2h x 2w map, the crop copies the kept window, and its backward adds the window's gradient into the full map's
+(the cut rows / columns keep the zeros zero_act_grads left)."""
 import ctypes as C
 import math
 
@@ -47,8 +49,7 @@ class _Deconv:
         n, h, wd, x_ld = x.shape
         _, h2, w2, y_ld = y.shape
         if (h2, w2) != (2 * h, 2 * wd):
-            raise LlvError(f'{wkey}: transposed conv {h}x{wd} -> {2 * h}x{2 * wd} against a {h2}x{w2} skip tensor: crop_like is not a no-op '
-                           '(training FlowNetSimple wants an image whose scaled size is a multiple of 64)')
+            raise LlvError(f'{wkey}: transposed conv {h}x{wd} -> {2 * h}x{2 * wd} written into a {h2}x{w2} buffer (crop_like is a tape entry of its own)')
         self.n, self.h, self.w, self.x_ld, self.y_ld = n, h, wd, x_ld, y_ld
         self.seg = (h2, w2, h, wd, 0, 0)                         # V's forward geometry: (2h, 2w) -> (h, w)
         # V^T (the layer's forward): window of the stride-1 conv over x that emits the four output phases
@@ -104,6 +105,18 @@ def _deconv_bwd(g, op):
     op['deconv'].backward(g)
 
 
+def _crop_fwd(full, out, stream=None):
+    """crop_like (flownet_simple.py:16-20): out = full[:, :h, :w]"""
+    out.copy_(full[:, :out.shape[1], :out.shape[2], :])
+    return 0
+
+
+def _crop_bwd(g, op):
+    full, out = op['xs'][0], op['y']
+    if _sptr(full) in g.req:
+        g.gview(full)[:, :out.shape[1], :out.shape[2], :].add_(g.gview(out))
+
+
 def _concat_bwd(g, op):
     gcat = g.gview(op['y'])
     o = 0
@@ -125,8 +138,6 @@ class FlowNetTrainGraph(train_engine.TrainGraph):
         self._init_common(motion, dict(motion.named_parameters()), dict(motion.named_buffers()), device, batch, loss_scale)
         s = float(motion.img_scale_factor)
         ho, wo = int(math.floor(height * s)), int(math.floor(width * s))
-        if ho % 64 or wo % 64:
-            raise LlvError(f'FlowNetSimple training: the scaled image ({ho} x {wo}) must be a multiple of 64 (crop_like must be a no-op)')
         b = engine.Builder(device)
         self.builder = b
         sd = engine._cpu_sd(motion.state_dict())
@@ -166,12 +177,19 @@ class FlowNetTrainGraph(train_engine.TrainGraph):
             up = b.buf(batch, th, tw, 8)
             dpl = int(self.params[f'deconv{lvl}.conv.weight'].shape[1])
             dec = b.buf(batch, th, tw, dpl)
+            if th > 2 * ch or tw > 2 * cw:
+                raise LlvError(f'FlowNetSimple level {lvl}: skip tensor {th}x{tw} larger than the transposed conv\'s {2 * ch}x{2 * cw}')
             for nm, xin, yout, act in ((f'upsample_flow{lvl}', fl, up, False), (f'deconv{lvl}', cat, dec, True)):
-                dc = _Deconv(self, nm + '.conv.weight', xin, yout, act)
+                crop = (th, tw) != (2 * ch, 2 * cw)
+                yfull = b.buf(batch, 2 * ch, 2 * cw, yout.shape[-1]) if crop else yout
+                dc = _Deconv(self, nm + '.conv.weight', xin, yfull, act)
                 self.deconvs.append(dc)
                 b.plan.add('flow.' + nm, dc.forward, (), 0.0, 0.0)
                 b.plan.keep += [dc.pcd.w, dc.pcd.bias, dc.pcv.w, dc.pcv.bias]
-                b.tape.append(dict(name='flow.' + nm, custom=True, xs=[xin], y=yout, bwd=_deconv_bwd, deconv=dc))
+                b.tape.append(dict(name='flow.' + nm, custom=True, xs=[xin], y=yfull, bwd=_deconv_bwd, deconv=dc))
+                if crop:
+                    b.plan.add('flow.' + nm + '.crop_like', _crop_fwd, (yfull, yout), 0.0, 4.0 * yout.numel())
+                    b.tape.append(dict(name='flow.' + nm + '.crop_like', custom=True, xs=[yfull], y=yout, bwd=_crop_bwd))
             ncat = b.buf(batch, th, tw, tc + dpl + 8)
             o = 0
             for src in (tgt, dec, up):

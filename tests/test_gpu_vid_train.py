@@ -266,14 +266,16 @@ def _flownet(seed):
     return m
 
 
-def test_flownet_training_graph_vs_oracle(dev):
+@pytest.mark.parametrize('Hh,Ww', [(128, 256), (184, 320)])
+def test_flownet_training_graph_vs_oracle(dev, Hh, Ww):
     """flow_train.FlowNetTrainGraph: FlowNetSimple's flow and d(<flow, R>)/d(parameter) of all 33 tensors (9 convs with LeakyReLU, 5
     predict_flow convs, 4 + 4 transposed convs run as data gradients of 4x4 / stride-2 convs, the three-way concatenations, the final
-    bilinear x8) against autograd over oracle/flownet.py."""
+    bilinear x8) against autograd over oracle/flownet.py. 184 x 320: the scaled 92 x 160 frame is not a multiple of 64, so crop_like
+    (flownet_simple.py:16-20) cuts level 5's transposed convs 4 x 6 -> 3 x 5 and level 2's 24 x 40 -> 23 x 40 (as the reference's own
+    360 x 640 scaled frames do at levels 4 and 3)."""
     from lowlightenvironmentvideoobjectdetection_amd.flow_train import flownet_train_forward
     from oracle.flownet import flownet_forward
     m = _flownet(3)
-    Hh, Ww = 128, 256
     base = smooth_image(2, Hh, Ww, seed=5)
     pairs = torch.cat([base, torch.roll(base, shifts=(2, -3), dims=(2, 3))], 1)
     meta = dict(img_shape=(Hh, Ww, 3), pad_shape=(Hh, Ww, 3), img_norm_cfg=dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True))
@@ -297,7 +299,7 @@ def test_flownet_training_graph_vs_oracle(dev):
     assert len(errs) == 33
     for e, k, sc in errs:
         assert e < 1.5e-1, (k, e, sc)
-    assert sum(1 for e, _, _ in errs if e < 6e-2) >= 24, errs[:10]
+    assert sum(1 for e, _, _ in errs if e < 6e-2) >= (24 if (Hh, Ww) == (128, 256) else 18), errs[:10]      # (deepest maps 2 x 3 at 184 x 320)
     # (the deep levels are 1 x 2 .. 4 x 8 pixels: a LeakyReLU input with the other sign than the oracle's changes a whole column of a
     # weight gradient.) Independent check on the device alone: directional derivatives along sign(grad) by central differences
     params = dict(m.named_parameters())
@@ -306,7 +308,12 @@ def test_flownet_training_graph_vs_oracle(dev):
     def value():
         with torch.no_grad():
             return float((flownet_train_forward(m, pairs.to(dev), [meta]) * Rd).sum())
-    for k in ('deconv4.conv.weight', 'conv3.0.conv.weight', 'upsample_flow3.conv.weight', 'predict_flow4.conv.weight'):
+    keys = ('deconv4.conv.weight', 'conv3.0.conv.weight', 'upsample_flow3.conv.weight', 'predict_flow4.conv.weight')
+    if (Hh, Ww) != (128, 256):        # the layers whose outputs crop_like cuts (levels 5 and 2), and one below them
+        # (upsample_flow5 / 2 are cut too, but their directional derivative is 1e-6 of these: below the fp16 noise of the value; the
+        # comparison with the oracle's gradient above covers them)
+        keys = ('deconv5.conv.weight', 'deconv2.conv.weight', 'conv3.0.conv.weight')
+    for k in keys:
         p_, g_ = params[k], params[k].grad.float()
         u = torch.sign(g_)
         # (the packed weights are fp16: a step below their spacing is lost in the rounding unless many weights average it out)
@@ -321,7 +328,8 @@ def test_flownet_training_graph_vs_oracle(dev):
             p_.add_(eps * u)
         fd, an = (vp - vm) / (2 * eps), float((g_ * u).sum())
         print(k, 'finite difference', fd, 'analytic', an)
-        assert abs(fd - an) <= 0.06 * abs(an), (k, fd, an)
+        # (64-element tensors take the coarse step above: second-order terms and LeakyReLU kinks of the 2 x 3 .. 6 x 10 maps show)
+        assert abs(fd - an) <= (0.06 if p_.numel() > 1000 else 0.10) * abs(an), (k, fd, an)
 
 
 def test_dff_trains_the_flow_network_too(dev):
