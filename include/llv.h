@@ -306,8 +306,11 @@ int llv_multiclass_nms(const float* boxes, const float* scores, int n, int num_c
 size_t llv_multiclass_nms_batched_workspace_bytes(int batch, int n, int num_classes, int max_num);
 /* LDS one class list needs (candidate keys padded to a power of two + max_num kept boxes) and the limit a launch may use:
  * a geometry above the limit is refused with LLV_E_UNSUPPORTED before anything is launched (a failed launch would poison a
- * stream capture). n <= 8192 always fits; 8192 < n <= 16384 fits for max_num <= 1536. */
+ * stream capture). n <= 8192 always fits; 8192 < n <= 16384 fits for max_num <= 1536.
+ * _ex also takes num_classes: a single-class list of >= 2048 boxes (an RPN level: mmdetection/mmdet/models/dense_heads/rpn_head.py:88-234
+ * with nms_pre = 12000, max_per_img = 2000) runs on the sort + bit-mask kernels, which hold only the keys in LDS, whatever max_num. */
 size_t llv_multiclass_nms_lds_bytes(int n, int max_num);
+size_t llv_multiclass_nms_lds_bytes_ex(int n, int max_num, int num_classes);
 size_t llv_multiclass_nms_lds_limit(void);
 int llv_multiclass_nms_batched(const float* boxes, const float* scores, int batch, int n, int num_classes, int c_ld,
                                float score_thr, float iou_thr, int max_num, float* dets, int64_t* labels,

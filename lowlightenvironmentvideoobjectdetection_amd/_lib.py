@@ -179,6 +179,7 @@ SIGNATURES = {
     'llv_multiclass_nms': (_I, [_P, _P, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
     'llv_multiclass_nms_batched_workspace_bytes': (_Z, [_I, _I, _I, _I]),
     'llv_multiclass_nms_lds_bytes': (_Z, [_I, _I]),
+    'llv_multiclass_nms_lds_bytes_ex': (_Z, [_I, _I, _I]),
     'llv_multiclass_nms_lds_limit': (_Z, []),
     'llv_multiclass_nms_batched': (_I, [_P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),
     'llv_multiclass_nms_batched_sf': (_I, [_P, _P, _P, _I, _I, _I, _I, _F, _F, _I, _P, _P, _P, _P, _P, _Z, _P]),

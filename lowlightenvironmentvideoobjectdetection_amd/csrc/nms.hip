@@ -599,6 +599,16 @@ extern "C" size_t llv_multiclass_nms_lds_limit(void) { return kLdsLimit; }
 
 static bool mask_path(int n, int num_classes) { return num_classes == 1 && n >= kMaskMinN; }
 
+extern "C" size_t llv_multiclass_nms_lds_bytes_ex(int n, int max_num, int num_classes) {
+    // one class and a long list: nms_sort_kernel (keys only) + the bit-mask kernels, which keep nothing of size max_num in LDS
+    if (mask_path(n, num_classes)) {
+        int np2 = 1;
+        while (np2 < n) np2 <<= 1;
+        return (size_t)np2 * 8;
+    }
+    return llv_multiclass_nms_lds_bytes(n, max_num);
+}
+
 static size_t mnms_ws_one(int n, int num_classes, int max_num) {
     // [maxc | cnt_in[C]] | cls_cnt[C] (memset together) | cls_keys[C][max_num] | cand[C][n]
     size_t b = al(16 + (size_t)num_classes * 4) + al((size_t)num_classes * 4) + al((size_t)num_classes * max_num * 8) +
@@ -636,7 +646,7 @@ extern "C" int llv_multiclass_nms_batched_ex(const float* boxes, const float* sc
     if (n > 0 && (!boxes || !scores)) return LLV_E_BADARG;
     if (workspace_bytes < llv_multiclass_nms_batched_workspace_bytes(batch, n, num_classes, max_num)) return LLV_E_WORKSPACE;
     if (n > kMaxN || (long)num_classes * max_num > kMaxMerge || (long)n * num_classes > 0x7fffffffL || batch > 65535) return LLV_E_UNSUPPORTED;
-    if (llv_multiclass_nms_lds_bytes(n, max_num) > kLdsLimit) return LLV_E_UNSUPPORTED;   // refused here, not as a failed launch
+    if (llv_multiclass_nms_lds_bytes_ex(n, max_num, num_classes) > kLdsLimit) return LLV_E_UNSUPPORTED;   // refused here, not as a failed launch
     hipStream_t st = (hipStream_t)stream;
     nms_init_once();
     char* ws = (char*)workspace;

@@ -454,6 +454,13 @@ extern "C" int llv_iou_assign(const float* gt, int k, const float* anchors, cons
     int* gt_argmax = (int*)(ws + al((size_t)k * 4));
     int* argmax = (int*)(ws + 2 * al((size_t)k * 4));
     hipLaunchKernelGGL(init_gt_ws, dim3(1), dim3(256), 0, st, gt_max_u, gt_argmax, k);
+    // pass A keeps the gt boxes and a [4 waves][k] table of running maxima in dynamic LDS: k * 32 bytes, 128 KiB at the documented
+    // limit k = 4096 -- above HIP's 64 KiB default, inside gfx950's 160 KiB once the kernel has opted in (once per process)
+    static bool big_lds = false;
+    if (!big_lds) {
+        (void)hipFuncSetAttribute(reinterpret_cast<const void*>(assign_pass_a), hipFuncAttributeMaxDynamicSharedMemorySize, 4096 * 32);
+        big_lds = true;
+    }
     const int g = grid1d(n, 256);
     hipLaunchKernelGGL(assign_pass_a, dim3(g > 256 ? 256 : g), dim3(256), (size_t)k * 32, st, (const float4*)gt, k,
                        (const float4*)anchors, valid, (long)n, max_overlaps, argmax, gt_max_u);

@@ -1,7 +1,10 @@
 """Multi-GPU plumbing: one process per GPU, RCCL through torch.distributed ('nccl' backend name on ROCm).
 
-Inference shards by whole video (per-video state lives on one device), with no data-path collective; the only
-exchange is the final gather of results to rank 0 (reference: pickle files + barrier, mmtracking/mmtrack/apis/test.py:125-173).
+Inference shards with no data-path collective, two ways: a dataset of several videos by WHOLE video (shard_videos: per-video state
+lives on one device, as the reference's DistributedVideoSampler does), and a single long clip BY FRAME into contiguous segments with
+a halo that rebuilds the state of the one-rank run at each boundary (shard_clip: FastDVDnet 2 + 2 frames, DFF restart on a key frame,
+FGFA / LLVOD window warm-up). The only exchange is the final gather of results to rank 0 (reference: pickle files + barrier,
+mmtracking/mmtrack/apis/test.py:125-173).
 Training averages gradients (mmdetection/mmdet/core/utils/dist_utils.py:10-51)."""
 from collections import OrderedDict
 

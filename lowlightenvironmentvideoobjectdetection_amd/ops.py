@@ -601,8 +601,8 @@ def multiclass_nms(multi_bboxes, multi_scores, score_thr, nms_cfg, max_num=-1, r
                            f'(num_classes * max_num <= 8192); pass max_num <= {8192 // max(num_classes, 1)}')
     if num_classes * cap > 8192:
         raise LlvError(f'multiclass_nms: num_classes * max_num = {num_classes * cap} > 8192 (merge limit of the device NMS)')
-    if lib().llv_multiclass_nms_lds_bytes(n, cap) > lib().llv_multiclass_nms_lds_limit():
-        raise LlvError(f'multiclass_nms: {n} boxes with max_num={cap} need {lib().llv_multiclass_nms_lds_bytes(n, cap)} bytes of LDS per class '
+    if lib().llv_multiclass_nms_lds_bytes_ex(n, cap, num_classes) > lib().llv_multiclass_nms_lds_limit():
+        raise LlvError(f'multiclass_nms: {n} boxes with max_num={cap} need {lib().llv_multiclass_nms_lds_bytes_ex(n, cap, num_classes)} bytes of LDS per class '
                        f'list (limit {lib().llv_multiclass_nms_lds_limit()}); lists above 8192 boxes take max_num <= 1536')
     # the buffers of a (n, classes, cap) geometry are kept between calls, per device and per stream (reuse is stream-ordered; the
     # results are cloned out below, so a caller on another stream never sees a buffer this one is still writing)

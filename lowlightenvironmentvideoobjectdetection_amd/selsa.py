@@ -22,36 +22,7 @@ from . import ops
 from ._lib import CONV_OUT_F32, LlvError, check, lib
 from .core.bbox import bbox2result
 from .registry import AGGREGATORS, HEADS, ROI_EXTRACTORS, build, build_aggregator
-
-
-def linear_pc(fc, roi_hw=None):
-    """The packed weights of a fully connected layer as the convolution engine reads them: a 1x1 convolution over rows, or -- for the
-    first shared fc, whose input is the flattened (C, ph, pw) RoI map -- a ph x pw "valid" convolution over the NHWC RoI features
-    (the K index c*ph*pw + y*pw + x of the Linear weight is exactly conv weight [out][c][y][x]). Kept on the layer until weight or
-    bias change."""
-    w = fc.weight
-    key = (w.data_ptr(), w._version, str(w.device), None if fc.bias is None else (fc.bias.data_ptr(), fc.bias._version), roi_hw)
-    if getattr(fc, '_llv_pc_key', None) != key:
-        wt = w.detach().float().cpu()
-        if roi_hw is None:
-            wt = wt.view(wt.shape[0], wt.shape[1], 1, 1)
-        else:
-            wt = wt.view(wt.shape[0], wt.shape[1] // (roi_hw[0] * roi_hw[1]), roi_hw[0], roi_hw[1])
-        fc._llv_pc = ops.pack_conv(wt, None if fc.bias is None else fc.bias.detach().float().cpu(), 1, 0).to(w.device)
-        fc._llv_pc_key = key
-    return fc._llv_pc
-
-
-def _lin(fc, x):
-    """fc(x) on the in-tree implicit-GEMM kernel (fp16 operands, fp32 accumulation, fp32 out: the arithmetic type of the rest of the
-    path): x (rows, K) -> (rows, out) fp32."""
-    pc = linear_pc(fc)
-    n, k = x.shape
-    x16 = x.to(torch.float16).contiguous().view(1, n, 1, k)
-    if k % 8:
-        raise LlvError('fully connected layer: the input width must be a multiple of 8')
-    y = ops.conv2d(x16, pc, flags=CONV_OUT_F32)
-    return y.view(n, -1)[:, :fc.out_features]
+from .roi_heads import BBoxHeadMixin, _gpu, _lin, bbox2roi, linear_pc  # noqa: F401  (re-exported: selsa_plan, tests)
 
 
 def selsa_attention(x_embed, ref_embed, ref_new, num_blocks):
@@ -82,12 +53,6 @@ def selsa_attention(x_embed, ref_embed, ref_new, num_blocks):
     p = torch.empty((1, n, 1, nb * m_pad), device=dev, dtype=torch.float16)
     check(L.llv_selsa_softmax(s.data_ptr(), p.data_ptr(), n, nb, m_pad, m, 0, None, 1.0 / d ** 0.5, st), 'llv_selsa_softmax')
     return ops.conv2d(p, pcv).view(n, c)
-
-
-def _gpu(*ts):
-    for t in ts:
-        if t is not None and not t.is_cuda:
-            raise LlvError('the SELSA RoI head runs on an MI355X only (RoIAlign / NMS kernels, device GEMMs); no CPU path')
 
 
 @AGGREGATORS.register_module()
@@ -128,7 +93,7 @@ class SelsaAggregator(nn.Module):
 
 
 @HEADS.register_module()
-class SelsaBBoxHead(nn.Module):
+class SelsaBBoxHead(BBoxHeadMixin, nn.Module):
     """ConvFCBBoxHead restricted to what the SELSA configs use: `num_shared_fcs` fully connected layers (no convs), one
     SelsaAggregator after each, fc_cls (num_classes + 1) and fc_reg (4 or 4 * num_classes)."""
 
@@ -140,11 +105,10 @@ class SelsaBBoxHead(nn.Module):
         super().__init__()
         if num_shared_convs or num_cls_convs or num_cls_fcs or num_reg_convs or num_reg_fcs or with_avg_pool or not (with_cls and with_reg):
             raise NotImplementedError('SelsaBBoxHead: only the shared-fc form of the SELSA configs is built')
-        from .registry import build_bbox_coder
         self.num_shared_fcs, self.num_classes, self.reg_class_agnostic = num_shared_fcs, num_classes, reg_class_agnostic
         self.in_channels, self.fc_out_channels = in_channels, fc_out_channels
         self.roi_feat_size = (roi_feat_size, roi_feat_size) if isinstance(roi_feat_size, int) else tuple(roi_feat_size)
-        self.bbox_coder = build_bbox_coder(bbox_coder)
+        self._build_losses(bbox_coder, loss_cls, loss_bbox, reg_decoded_bbox)
         last = in_channels * self.roi_feat_size[0] * self.roi_feat_size[1]
         self.shared_fcs = nn.ModuleList()
         for i in range(num_shared_fcs):
@@ -152,13 +116,6 @@ class SelsaBBoxHead(nn.Module):
         self.fc_cls = nn.Linear(fc_out_channels, num_classes + 1)
         self.fc_reg = nn.Linear(fc_out_channels, 4 if reg_class_agnostic else 4 * num_classes)
         self.aggregator = nn.ModuleList([build_aggregator(aggregator) for _ in range(num_shared_fcs)])
-        from .registry import LOSSES
-        self.reg_decoded_bbox = reg_decoded_bbox
-        if reg_decoded_bbox:
-            raise NotImplementedError('SelsaBBoxHead: reg_decoded_bbox (IoU losses on decoded boxes) is not on this path')
-        # bbox_head.py:28-36 defaults
-        self.loss_cls = build(dict(loss_cls or dict(type='CrossEntropyLoss', use_sigmoid=False, loss_weight=1.0)), LOSSES)
-        self.loss_bbox = build(dict(loss_bbox or dict(type='SmoothL1Loss', beta=1.0, loss_weight=1.0)), LOSSES)
 
     def init_weights(self):                      # bbox_head.py:93-101, convfc_bbox_head.py:119-127
         nn.init.normal_(self.fc_cls.weight, 0, 0.01); nn.init.constant_(self.fc_cls.bias, 0)
@@ -195,55 +152,6 @@ class SelsaBBoxHead(nn.Module):
             x = F.relu(x)
         return self.fc_cls(x), self.fc_reg(x)
 
-    def _get_target_single(self, pos_bboxes, neg_bboxes, pos_gt_bboxes, pos_gt_labels, cfg):
-        """bbox_head.py:103-150"""
-        from .training import _bbox2delta
-        num_pos, num_neg = pos_bboxes.size(0), neg_bboxes.size(0)
-        num_samples = num_pos + num_neg
-        labels = pos_bboxes.new_full((num_samples,), self.num_classes, dtype=torch.long)
-        label_weights = pos_bboxes.new_zeros(num_samples)
-        bbox_targets = pos_bboxes.new_zeros(num_samples, 4)
-        bbox_weights = pos_bboxes.new_zeros(num_samples, 4)
-        if num_pos > 0:
-            labels[:num_pos] = pos_gt_labels
-            pw = cfg['pos_weight'] if isinstance(cfg, dict) else cfg.pos_weight
-            label_weights[:num_pos] = 1.0 if pw <= 0 else pw
-            bbox_targets[:num_pos, :] = _bbox2delta(pos_bboxes, pos_gt_bboxes, self.bbox_coder.means, self.bbox_coder.stds)
-            bbox_weights[:num_pos, :] = 1
-        if num_neg > 0:
-            label_weights[-num_neg:] = 1.0
-        return labels, label_weights, bbox_targets, bbox_weights
-
-    def get_targets(self, sampling_results, gt_bboxes, gt_labels, rcnn_train_cfg, concat=True):
-        """bbox_head.py:152-207"""
-        outs = [self._get_target_single(r.pos_bboxes, r.neg_bboxes, r.pos_gt_bboxes, r.pos_gt_labels, rcnn_train_cfg) for r in sampling_results]
-        cols = list(zip(*outs))
-        if concat:
-            return tuple(torch.cat(c, 0) for c in cols)
-        return tuple(list(c) for c in cols)
-
-    def loss(self, cls_score, bbox_pred, rois, labels, label_weights, bbox_targets, bbox_weights, reduction_override=None):
-        """bbox_head.py:209-268: softmax cross entropy over all sampled RoIs (llv_softmax_ce), box loss over the positives' own class."""
-        from .losses import accuracy
-        losses = dict()
-        if cls_score is not None:
-            avg_factor = max(torch.sum(label_weights > 0).float().item(), 1.)
-            if cls_score.numel() > 0:
-                losses['loss_cls'] = self.loss_cls(cls_score, labels, label_weights, avg_factor=avg_factor, reduction_override=reduction_override)
-                losses['acc'] = accuracy(cls_score, labels)
-        if bbox_pred is not None:
-            pos_inds = (labels >= 0) & (labels < self.num_classes)
-            if pos_inds.any():
-                if self.reg_class_agnostic:
-                    pos_bbox_pred = bbox_pred.view(bbox_pred.size(0), 4)[pos_inds]
-                else:
-                    pos_bbox_pred = bbox_pred.view(bbox_pred.size(0), -1, 4)[pos_inds, labels[pos_inds]]
-                losses['loss_bbox'] = self.loss_bbox(pos_bbox_pred, bbox_targets[pos_inds], bbox_weights[pos_inds], avg_factor=bbox_targets.size(0),
-                                                     reduction_override=reduction_override)
-            else:
-                losses['loss_bbox'] = bbox_pred[pos_inds].sum()
-        return losses
-
     def forward(self, x, ref_x, ref_branch=None):
         """x [N, C, H, W] key-frame RoI features, ref_x [M, C, H, W] (or None with a precomputed `ref_branch` over the same M rows)
         -> (cls_score [N, classes+1], bbox_pred [N, 4*classes])."""
@@ -258,34 +166,6 @@ class SelsaBBoxHead(nn.Module):
             x = _lin(fc, x)
             x = F.relu(x + self.aggregator[i](x, ref_pre, ref_side=(r_embed, r_new)))
         return _lin(self.fc_cls, x), _lin(self.fc_reg, x)
-
-    def _decode(self, rois, deltas, max_shape, scale_factor=None):
-        """delta_xywh_bbox_coder.py:134-237 for (n, 4) rois and (n, 4k) deltas: one llv_delta2bbox launch (clip to max_shape, optional
-        division by the scale factor)."""
-        return ops.delta2bbox(rois, deltas, self.bbox_coder.means, self.bbox_coder.stds,
-                              max_shape if self.bbox_coder.clip_border else None, 16 / 1000, self.bbox_coder.clip_border, scale_factor)
-
-    def get_bboxes(self, rois, cls_score, bbox_pred, img_shape, scale_factor, rescale=False, cfg=None):
-        """bbox_head.py:270-371 (one image): softmax, per-class delta2bbox clipped to the image, optional rescale, multiclass NMS."""
-        _gpu(rois, cls_score, bbox_pred)
-        scores = F.softmax(cls_score.float(), dim=-1)
-        bboxes = self._decode(rois[:, 1:].float(), bbox_pred.float(), img_shape, scale_factor if rescale else None)
-        if cfg is None:
-            return bboxes, scores
-        if bboxes.size(0) == 0:
-            return bboxes.new_zeros((0, 5)), bboxes.new_zeros((0,), dtype=torch.long)
-        return ops.multiclass_nms(bboxes.contiguous(), scores.contiguous(), cfg['score_thr'], cfg['nms'], cfg['max_per_img'])
-
-
-def bbox2roi(bbox_list):
-    """mmdetection/mmdet/core/bbox/transforms.py:72-96."""
-    rois_list = []
-    for img_id, bboxes in enumerate(bbox_list):
-        if bboxes.size(0) > 0:
-            rois_list.append(torch.cat([bboxes.new_full((bboxes.size(0), 1), img_id), bboxes[:, :4]], dim=-1))
-        else:
-            rois_list.append(bboxes.new_zeros((0, 5)))
-    return torch.cat(rois_list, 0)
 
 
 @HEADS.register_module()
@@ -443,7 +323,15 @@ class TwoStageDetector(BaseDetector):
                        'key + reference frames); a single-image Faster R-CNN step is outside SURVEY section 8')
 
     def simple_test(self, img, img_metas, proposals=None, rescale=False):
-        raise LlvError('the two-stage detector is driven by the SELSA video detector here (key + reference frames)')
+        """two_stage.py:178-190: backbone + neck, RPN proposals, roi_head.simple_test -- for a StandardRoIHead. (SelsaRoIHead pools from
+        reference frames as well and is driven by the SELSA video detectors.)"""
+        from .roi_heads import StandardRoIHead
+        if not isinstance(self.roi_head, StandardRoIHead):
+            raise LlvError('the two-stage detector with a SELSA RoI head is driven by the SELSA video detector (key + reference frames)')
+        self._check_input(img)
+        x = self.extract_feat(img.float())
+        proposal_list = self.rpn_head.simple_test_rpn(x, img_metas) if proposals is None else proposals
+        return self.roi_head.simple_test(x, proposal_list, img_metas, rescale=rescale)
 
 
 @DETECTORS.register_module()

@@ -150,6 +150,11 @@ def selsa_fastdvd_forward_train(model, img, img_metas, gt_bboxes, gt_labels, ref
     assert ref_img.shape[1] == 4, 'FastDVDnet support frames is 4.'
     if img.shape[1] % 4 == 0:
         raise LlvError('SelsaFastDVDnetDetect.forward_train: RAW (4-channel) input is not on this path (FastDVDnet plan takes RGB frames)')
+    if model.with_cleaner and any(p.requires_grad for p in model.cleaner.parameters()):
+        # the reference trains an unfrozen cleaner through the detection losses and the denoising loss (:171-200); its backward pass is
+        # not built here, and a loss_denoising term without a gradient behind it would look live in the logs
+        raise LlvError("SelsaFastDVDnetDetect.forward_train: freeze the cleaner (frozen_modules='cleaner', as the authors' config does); "
+                       "training it is not built")
     noise_img, clean_img = img[:, :3], img[:, 3:]
     noise_ref, clean_ref = ref_img[:, :, :3], ref_img[:, :, 3:]
     clean_imgs = torch.cat([clean_ref[0][:2], clean_img, clean_ref[0][2:]], dim=0).float()

@@ -1,6 +1,10 @@
 """Video detectors with the reference's interface (mmtracking/mmtrack/models/vid/base.py:15-326) and the
-enhance -> detect wiring of mmtracking/mmtrack/models/vid/selsa_fastdvd_darkfarm.py:151-184,294-319, for a
-single-stage (dense head) detector.
+enhance -> detect wiring of mmtracking/mmtrack/models/vid/selsa_fastdvd_darkfarm.py:151-184,294-319.
+
+DFF / FGFA / LLVOD take either kind of detector, as the reference's do (`hasattr(self.detector, 'roi_head')`, dff.py:153,245,
+fgfa.py:165,344, llvod.py:124,225): a dense-head one (RetinaNet; everything after the frame features is one launch plan) or a
+two-stage one (the reference's own `configs/vid/dff`, `configs/vid/fgfa` on faster_rcnn_r50_dc5: feature maps at module level, then
+`rpn_head.simple_test_rpn` and `roi_head.simple_test`, `TwoStageVideoMixin` below; training in vid_two_stage_train.py).
 
 The reference's SelsaFastDVDnetDetect asserts a two-stage detector (`roi_head`, :37-38) and its single-stage test
 branches are broken, so the dense-head variant is registered here as `FastDVDnetDetect` with the
@@ -111,6 +115,42 @@ class BaseVideoDetector(PlannedModule):
         state. apis.single_gpu_test calls it before a clip segment, whose first frame need not be frame 0."""
         self.memo = None
         self._stream_state = None
+
+
+def _add_noise(train_cfg):
+    """The authors' forward_train of LLVOD / FGFA passes EVERY training batch through general_clean_noise_pairs (llvod.py:91,
+    fgfa.py:141-147); no reference config carries a switch, so the default is on. train_cfg['add_noise'] = False turns it off."""
+    return bool((train_cfg or {}).get('add_noise', True))
+
+
+def flow_warp_feats(x, flow):
+    """mmtracking/mmtrack/core/motion/flow.py:4-41 at module level: x (N, C, h, w) fp32 on the GPU, flow (N, 2, Hf, Wf) -> warped
+    (N, C, h, w) fp32 (llv_flow_warp on the NHWC fp16 form of the map)."""
+    c = x.shape[1]
+    cp = ops.round_up(c, 8)
+    y = ops.flow_warp(ops.pack_input(x.float().contiguous(), cp), flow.float().contiguous())
+    return ops.unpack_output(y, c)
+
+
+class TwoStageVideoMixin:
+    """The `hasattr(self.detector, 'roi_head')` branches of the reference's flow / aggregation video detectors."""
+
+    @property
+    def two_stage(self):
+        return hasattr(self.detector, 'roi_head')
+
+    def _detect_two_stage(self, x, img_metas, proposals, rescale):
+        """dff.py:245-253 = fgfa.py:344-352 = llvod.py:225-233."""
+        det = self.detector
+        proposal_list = det.rpn_head.simple_test_rpn(x, img_metas) if proposals is None else proposals
+        outs = det.roi_head.simple_test(x, proposal_list, img_metas, rescale=rescale)
+        return dict(bbox_results=outs[0])
+
+    def _check_two_stage(self):
+        from .roi_heads import StandardRoIHead
+        if self.two_stage and not isinstance(self.detector.roi_head, StandardRoIHead):
+            raise LlvError(f'{type(self).__name__}: a two-stage detector needs a StandardRoIHead here (roi_head.simple_test(x, proposals, '
+                           f'img_metas)); {type(self.detector.roi_head).__name__} takes reference features and belongs to SELSA')
 
 
 @MODELS.register_module()
@@ -240,9 +280,9 @@ class FastDVDnetDetect(BaseVideoDetector):
 
 
 @MODELS.register_module()
-class LLVOD(BaseVideoDetector):
-    """Temporal feature aggregation without optical flow (mmtracking/mmtrack/models/vid/llvod.py:17-254), for a
-    dense-head detector: the pyramid features of the last `memo_len` frames (reference: 32, llvod.py:163) live in a
+class LLVOD(TwoStageVideoMixin, BaseVideoDetector):
+    """Temporal feature aggregation without optical flow (mmtracking/mmtrack/models/vid/llvod.py:17-254). Dense-head
+    detector: the pyramid features of the last `memo_len` frames (reference: 32, llvod.py:163) live in a
     device ring buffer together with their embeddings; each new frame costs one backbone+FPN pass and one embedding
     conv, then per level `EmbedAggregator(x_key, refs)` (key excluded from the references, llvod.py:201-206), the
     RetinaHead on the aggregated pyramid, decode and NMS.
@@ -251,6 +291,8 @@ class LLVOD(BaseVideoDetector):
     `ref_img` frames are pushed into the ring before `img`; frame_id == 0 resets it. The reference's own control
     flow for this class cannot run (assert frame_id == 1 next to `if frame_id == 0`, NameError on
     general_clean_noise_pairs), so the window bookkeeping here is the plain sliding one.
+    Two-stage detector (llvod.py:124-145,225-233): the same sliding window over module-level feature maps
+    (`_simple_test_two_stage`), `aggregator(x_key, refs)` per level, then RPN + StandardRoIHead.
     """
 
     def __init__(self, detector, aggregator, pretrains=None, frozen_modules=None, train_cfg=None, test_cfg=None,
@@ -259,8 +301,7 @@ class LLVOD(BaseVideoDetector):
         from .registry import build_aggregator
         self.detector = build_detector(detector)
         self.aggregator = build_aggregator(aggregator)
-        if hasattr(self.detector, 'roi_head'):
-            raise LlvError('LLVOD here drives a dense-head (single-stage) detector; two-stage is out of scope')
+        self._check_two_stage()
         self.train_cfg, self.test_cfg, self.memo_len = train_cfg, test_cfg, memo_len
         self.memo = None
         self.init_weights(pretrains)
@@ -284,21 +325,27 @@ class LLVOD(BaseVideoDetector):
                 m.invalidate_plans()
 
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, ref_img, ref_img_metas=None, ref_gt_bboxes=None, ref_gt_labels=None,
-                      gt_bboxes_ignore=None, **kwargs):
-        """llvod.py:45-154 for a dense-head detector: the key frame is put in the middle of its references (:87-88), every frame goes
+                      gt_bboxes_ignore=None, gt_masks=None, proposals=None, **kwargs):
+        """llvod.py:45-154: the key frame is put in the middle of its references (:87-88), every frame goes
         through backbone + FPN, per level `aggregator(feat[key], feat[others])` (:107-112), then bbox_head.forward_train (:148-150).
         The reference's body also (a) adds synthetic noise (general_clean_noise_pairs, :91: applied here when train_cfg['add_noise']
         is true, on un-normalised frames as the reference's data pipeline delivers them) and (b) regresses the noisy frames' features
         onto a `cleaner`'s (:93-94,114-118), which needs a backbone returning two feature sets and exists only with the authors'
-        DarkResNet: without a cleaner (`with_cleaner` false) that term is absent there too."""
+        DarkResNet: without a cleaner (`with_cleaner` false) that term is absent there too.
+        Input contract of the noise step: un-normalised 0..255 frames (BGR as the loader delivers them); `train_cfg=dict(add_noise=False)`
+        switches it off (the parity tests do: random draws cannot be shared with the CPU oracle)."""
         from . import vid_train
         self._check_input(img)
         assert len(img) == 1, 'video detector only support 1 batch size per gpu for now.'
         index = ref_img.shape[1] // 2
         all_imgs = torch.cat((ref_img[0][:index], img, ref_img[0][index:]), dim=0)
-        if (self.train_cfg or {}).get('add_noise', False):
+        if _add_noise(self.train_cfg):
             from .core.add_noise import general_clean_noise_pairs
             all_imgs, _ = general_clean_noise_pairs(all_imgs, constant=[0.5, 0.5])
+        if self.two_stage:
+            from .vid_two_stage_train import video_two_stage_forward_train
+            return video_two_stage_forward_train(self, 'llvod', all_imgs.float().contiguous(), None, index, img_metas, gt_bboxes, gt_labels,
+                                                 gt_bboxes_ignore, proposals, gt_masks=gt_masks)
         return vid_train.video_forward_train(self, 'llvod', all_imgs.float().contiguous(), None, index, img_metas, gt_bboxes, gt_labels,
                                              gt_bboxes_ignore)
 
@@ -344,9 +391,34 @@ class LLVOD(BaseVideoDetector):
         m['valid'] = min(m['valid'] + 1, self.memo_len)
         return slot
 
-    def simple_test(self, img, img_metas, ref_img=None, ref_img_metas=None, rescale=False, **kwargs):
+    def _simple_test_two_stage(self, img, img_metas, ref_img, proposals, rescale):
+        """The sliding window of `simple_test` below over module-level feature maps: every frame (references first, then the key frame)
+        goes through `detector.extract_feat` once and joins the last `memo_len` frames' maps; per level aggregator(x_key, the others)."""
+        frame_id = img_metas[0].get('frame_id', -1)
+        if self.memo is None or frame_id == 0:
+            self.memo = dict(feats=None)
+        new = []
+        if ref_img is not None:
+            refs = ref_img[0] if isinstance(ref_img, (list, tuple)) else ref_img
+            refs = refs[0] if refs.dim() == 5 else refs
+            new += [refs[i:i + 1] for i in range(refs.shape[0])]
+        new.append(img)
+        for f in new:
+            x = self.detector.extract_feat(f.float())
+            m = self.memo['feats']
+            self.memo['feats'] = [t.clone() for t in x] if m is None else [torch.cat((a, t), 0)[-self.memo_len:] for a, t in zip(m, x)]
+        feats = self.memo['feats']
+        if feats[0].shape[0] < 2:
+            agg = tuple(f[-1:] for f in feats)                          # no references yet: the frame's own features
+        else:
+            agg = tuple(self.aggregator(f[-1:], f[:-1].contiguous()) for f in feats)
+        return self._detect_two_stage(agg, img_metas, proposals, rescale)
+
+    def simple_test(self, img, img_metas, ref_img=None, ref_img_metas=None, proposals=None, rescale=False, **kwargs):
         self._check_input(img)
         assert len(img) == 1, 'video detectors take 1 image per GPU (llvod.py:65)'
+        if self.two_stage:
+            return self._simple_test_two_stage(img, img_metas, ref_img, proposals, rescale)
         n, c, h, w = img.shape
         plan = self._plan((h, w, str(img.device)), lambda: self._make_plan(h, w, img.device))
         frame_id = img_metas[0].get('frame_id', -1)
@@ -424,8 +496,8 @@ def _warp_pyramid(src_levels, flow, dst_levels):
 
 
 @MODELS.register_module()
-class DFF(BaseVideoDetector):
-    """Deep Feature Flow (mmtracking/mmtrack/models/vid/dff.py:11-282) for a dense-head detector: every
+class DFF(TwoStageVideoMixin, BaseVideoDetector):
+    """Deep Feature Flow (mmtracking/mmtrack/models/vid/dff.py:11-282), dense-head or two-stage detector: every
     `test_cfg.key_frame_interval`-th frame runs backbone + FPN and caches image and pyramid; the frames in between
     run FlowNetSimple on (frame, key frame) and warp the cached pyramid (dff.py:205-216), then the head."""
 
@@ -434,8 +506,7 @@ class DFF(BaseVideoDetector):
         from .registry import build_motion
         self.detector = build_detector(detector)
         self.motion = build_motion(motion)
-        if hasattr(self.detector, 'roi_head'):
-            raise LlvError('DFF here drives a dense-head (single-stage) detector; two-stage is out of scope')
+        self._check_two_stage()
         self.train_cfg, self.test_cfg = train_cfg, test_cfg or dict()
         self.memo = None
         self.init_weights(pretrains)
@@ -459,9 +530,10 @@ class DFF(BaseVideoDetector):
                 m.invalidate_plans()
 
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, ref_img, ref_img_metas=None, ref_gt_bboxes=None, ref_gt_labels=None,
-                      gt_bboxes_ignore=None, **kwargs):
-        """dff.py:49-182, single-stage branch: flow = motion(cat(img, ref)); the REFERENCE frame's pyramid is warped to the key frame
-        (or used as it is for still-image data, :143-144) and fed to bbox_head.forward_train with the key frame's ground truth.
+                      gt_bboxes_ignore=None, gt_masks=None, proposals=None, **kwargs):
+        """dff.py:49-182: flow = motion(cat(img, ref)); the REFERENCE frame's features are warped to the key frame (or used as they are
+        for still-image data, :143-144) and fed, with the key frame's ground truth, to bbox_head.forward_train (dense head, :174-177) or
+        to rpn_head.forward_train + roi_head.forward_train (two-stage, :153-173: vid_two_stage_train.py).
         The flow network trains with the detector unless it is frozen (vid_train.motion_flow)."""
         from . import vid_train
         self._check_input(img)
@@ -471,11 +543,29 @@ class DFF(BaseVideoDetector):
         flow = None
         if is_video_data:
             flow = vid_train.motion_flow(self, torch.cat((img.float(), ref), dim=1), img_metas)
+        if self.two_stage:
+            from .vid_two_stage_train import video_two_stage_forward_train
+            return video_two_stage_forward_train(self, 'dff', ref, flow, 0, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, proposals,
+                                                 warp=is_video_data, gt_masks=gt_masks)
         return vid_train.video_forward_train(self, 'dff', ref, flow, 0, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, warp=is_video_data)
 
-    def simple_test(self, img, img_metas, ref_img=None, ref_img_metas=None, rescale=False, **kwargs):
+    def extract_feats(self, img, img_metas):
+        """dff.py:184-217 at module level (the two-stage branch): tuple of NCHW fp32 maps."""
+        key_frame_interval = self.test_cfg.get('key_frame_interval', 10)
+        frame_id = img_metas[0].get('frame_id', -1)
+        assert frame_id >= 0
+        if frame_id % key_frame_interval == 0 or self.memo is None:
+            x = self.detector.extract_feat(img.float())
+            self.memo = dict(img=img.float().clone(), feats=[t.clone() for t in x])
+            return tuple(x)
+        flow = self.motion(torch.cat((img.float(), self.memo['img']), dim=1), img_metas)
+        return tuple(flow_warp_feats(f, flow) for f in self.memo['feats'])
+
+    def simple_test(self, img, img_metas, ref_img=None, ref_img_metas=None, proposals=None, rescale=False, **kwargs):
         self._check_input(img)
         assert len(img) == 1, 'Dff video detectors only support 1 batch size per gpu for now.'
+        if self.two_stage:
+            return self._detect_two_stage(self.extract_feats(img, img_metas), img_metas, proposals, rescale)
         n, c, h, w = img.shape
         st = self._plan(('stages', h, w, str(img.device)), lambda: _StagePlans(self.detector, h, w, img.device, [1]))
         key_frame_interval = self.test_cfg.get('key_frame_interval', 10)
@@ -494,8 +584,8 @@ class DFF(BaseVideoDetector):
 
 
 @MODELS.register_module()
-class FGFA(BaseVideoDetector):
-    """Flow-Guided Feature Aggregation (mmtracking/mmtrack/models/vid/fgfa.py:12-384) for a dense-head detector,
+class FGFA(TwoStageVideoMixin, BaseVideoDetector):
+    """Flow-Guided Feature Aggregation (mmtracking/mmtrack/models/vid/fgfa.py:12-384), dense-head or two-stage detector,
     both test-time branches of extract_feats (fgfa.py:196-284). Adaptive stride (`frame_stride < 1`): the reference
     frames given with frame 0 stay in the memo; every frame: backbone + FPN, FlowNetSimple on (frame, each memo frame),
     warp the memo pyramids, EmbedAggregator(x, cat(x, warped)) per level, head. Fixed stride: the memo is a sliding
@@ -508,8 +598,7 @@ class FGFA(BaseVideoDetector):
         self.detector = build_detector(detector)
         self.motion = build_motion(motion)
         self.aggregator = build_aggregator(aggregator)
-        if hasattr(self.detector, 'roi_head'):
-            raise LlvError('FGFA here drives a dense-head (single-stage) detector; two-stage is out of scope')
+        self._check_two_stage()
         self.train_cfg, self.test_cfg = train_cfg, test_cfg
         self.memo = None
         self.init_weights(pretrains)
@@ -535,22 +624,28 @@ class FGFA(BaseVideoDetector):
                 m.invalidate_plans()
 
     def forward_train(self, img, img_metas, gt_bboxes, gt_labels, ref_img, ref_img_metas=None, ref_gt_bboxes=None, ref_gt_labels=None,
-                      gt_bboxes_ignore=None, **kwargs):
-        """fgfa.py:52-194, single-stage branch: flows = motion(cat(img, ref_i)) for every reference, all frames through backbone + FPN,
-        per level `aggregator(feat[img], flow_warp_feats(feat[refs], flows))` (:155-160), bbox_head.forward_train. The authors' noise
-        injection (:141-147) is applied when train_cfg['add_noise'] is true. The flow network trains too unless it is frozen."""
+                      gt_bboxes_ignore=None, gt_masks=None, proposals=None, **kwargs):
+        """fgfa.py:52-194: flows = motion(cat(img, ref_i)) for every reference, all frames through backbone + neck, per level
+        `aggregator(feat[img], flow_warp_feats(feat[refs], flows))` (:155-160), then bbox_head.forward_train (dense head, :186-189) or
+        rpn_head.forward_train + roi_head.forward_train (two-stage, :165-185: vid_two_stage_train.py). The authors' noise injection
+        (:141-147, every training batch) runs unless train_cfg['add_noise'] is false (input contract: un-normalised 0..255 frames).
+        The flow network trains too unless it is frozen."""
         from . import vid_train
         self._check_input(img)
         assert len(img) == 1, 'fgfa video detectors only support 1 batch size per gpu for now.'
         refs = ref_img[0].float()
         img = img.float()
-        if (self.train_cfg or {}).get('add_noise', False):
+        if _add_noise(self.train_cfg):
             from .core.add_noise import general_clean_noise_pairs
             noise, _ = general_clean_noise_pairs(torch.cat([img, refs], dim=0), constant=[0.5, 0.5])
             img, refs = noise[[0]], noise[1:]
         nr = refs.shape[0]
         flows = vid_train.motion_flow(self, torch.cat((img.repeat(nr, 1, 1, 1), refs), dim=1), img_metas)
         all_imgs = torch.cat((img, refs), dim=0).contiguous()
+        if self.two_stage:
+            from .vid_two_stage_train import video_two_stage_forward_train
+            return video_two_stage_forward_train(self, 'fgfa', all_imgs, flows, 0, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, proposals,
+                                                 gt_masks=gt_masks)
         return vid_train.video_forward_train(self, 'fgfa', all_imgs, flows, 0, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore)
 
     def _agg_plan(self, st, n_slots, key_slot, device):
@@ -581,9 +676,62 @@ class FGFA(BaseVideoDetector):
         b.plan.keep += [emb]
         return b.plan, stack
 
-    def simple_test(self, img, img_metas, ref_img=None, ref_img_metas=None, rescale=False, **kwargs):
+    def extract_feats(self, img, img_metas, ref_img, ref_img_metas=None):
+        """fgfa.py:196-284 at module level (the two-stage branch): tuple of aggregated NCHW fp32 maps. ref_img (N, C, H, W) or None."""
+        frame_id = img_metas[0].get('frame_id', -1)
+        assert frame_id >= 0
+        num_left = img_metas[0].get('num_left_ref_imgs', -1)
+        frame_stride = img_metas[0].get('frame_stride', -1)
+        ext = lambda t: self.detector.extract_feat(t.float())
+        if frame_stride < 1:                                            # adaptive stride
+            if frame_id == 0 or self.memo is None:
+                if ref_img is None:
+                    raise LlvError('frame 0 of a video needs ref_img (fgfa.py:224-230,234-246)')
+                self.memo = dict(img=ref_img.float(), feats=[t.clone() for t in ext(ref_img)])
+            x = ext(img)
+        else:                                                           # fixed stride
+            if frame_id == 0 or self.memo is None:
+                if ref_img is None:
+                    raise LlvError('frame 0 of a video needs ref_img (fgfa.py:224-230,234-246)')
+                self.memo = dict(img=ref_img.float(), feats=[t.clone() for t in ext(ref_img)])
+                x = [f[[num_left]] for f in self.memo['feats']]
+            elif frame_id % frame_stride == 0:
+                assert ref_img is not None
+                ref_x = ext(ref_img)
+                k = ref_img.shape[0]
+                self.memo['feats'] = [torch.cat((m, r), dim=0)[k:] for m, r in zip(self.memo['feats'], ref_x)]
+                x = [f[[num_left]] for f in self.memo['feats']]
+                self.memo['img'] = torch.cat((self.memo['img'], ref_img.float()), dim=0)[k:]
+            else:
+                assert ref_img is None
+                x = ext(img)
+        nr = self.memo['img'].shape[0]
+        flows = self.motion(torch.cat((img.float().repeat(nr, 1, 1, 1), self.memo['img']), dim=1), img_metas)
+        agg_x = []
+        for i in range(len(x)):
+            stack = flow_warp_feats(self.memo['feats'][i], flows)
+            if frame_stride < 1:
+                stack = torch.cat((x[i], stack), dim=0)
+            else:
+                stack[num_left] = x[i][0]
+            agg_x.append(self.aggregator(x[i], stack.contiguous()))
+        return tuple(agg_x)
+
+    def simple_test(self, img, img_metas, ref_img=None, ref_img_metas=None, proposals=None, rescale=False, **kwargs):
         self._check_input(img)
         assert len(img) == 1, 'fgfa video detectors only support 1 batch size per gpu for now.'
+        if self.two_stage:
+            refs = None
+            if ref_img is not None:
+                refs = ref_img[0] if isinstance(ref_img, (list, tuple)) else ref_img
+                refs = refs[0] if refs.dim() == 5 else refs
+            if (self.test_cfg or {}).get('add_noise', False):
+                # the authors' evaluation hack (fgfa.py:330-335: clean test frames darkened / noised on the fly). Unconditional there --
+                # and with `ref_img.size(0)` on a frame without references it raises -- so it is opt-in here (test_cfg['add_noise'])
+                from .core.add_noise import general_clean_noise_pairs
+                noise, _ = general_clean_noise_pairs(img if refs is None else torch.cat([img, refs], dim=0), constant=[0.5, 0.5])
+                img, refs = noise[[0]], (None if refs is None else noise[1:])
+            return self._detect_two_stage(self.extract_feats(img, img_metas, refs), img_metas, proposals, rescale)
         n, c, h, w = img.shape
         frame_id = img_metas[0].get('frame_id', -1)
         assert frame_id >= 0

@@ -17,8 +17,9 @@ bilinear resize), which flow_train.FlowNetTrainGraph carries through FlowNetSimp
 
 The authors' forward_train of FGFA / LLVOD first passes the frames through general_clean_noise_pairs (random Poisson / Gaussian /
 row noise; core/utils/add_noise.py:13-52 -- the import is commented out in fgfa.py:8 / llvod.py:6, so the reference raises
-NameError there as it stands). It is restated as `add_noise.general_clean_noise_pairs` on the device and applied when
-train_cfg['add_noise'] is true; parity tests run without it (random draws cannot be shared with the CPU oracle)."""
+NameError there as it stands). It is restated as `add_noise.general_clean_noise_pairs` on the device and applied to every training
+batch, as the reference's body does, unless train_cfg['add_noise'] is false; parity tests switch it off (random draws cannot be
+shared with the CPU oracle)."""
 import ctypes as C
 
 import torch
@@ -37,7 +38,7 @@ class VideoTrainGraph(train_engine.TrainGraph):
 
     def __init__(self, model, mode, n_frames, height, width, device, key_slot=0, warp=True, loss_scale=512.0):
         det = model.detector
-        head, neck, bb = det.bbox_head, det.neck, det.backbone
+        bb = det.backbone
         self._init_common(det, dict(model.named_parameters()), dict(model.named_buffers()), device, 1, loss_scale)
         self.mode, self.n_frames, self.key_slot, self.warp = mode, n_frames, key_slot, bool(warp)
         b = engine.Builder(device)
@@ -45,9 +46,8 @@ class VideoTrainGraph(train_engine.TrainGraph):
         sd = engine._cpu_sd(model.state_dict())
         nf = n_frames
         self.x_in = b.buf(nf, height, width, 8)
-        feats = engine.build_resnet(b, sd, self.x_in, bb.depth, bb.strides, bb.style, bb.out_indices, p='detector.backbone.')
-        pyr = engine.build_fpn(b, sd, feats, neck.start_level, -1, neck.num_outs, neck.add_extra_convs, neck.relu_before_extra_convs,
-                               p='detector.neck.')
+        feats = engine.build_resnet(b, sd, self.x_in, p='detector.backbone.', **bb.plan_kwargs())
+        pyr = self._build_neck(b, sd, det, feats)
         self.frame_pyramid = pyr
         c = pyr.buf.shape[-1]
         hw = pyr.level_hw
@@ -97,13 +97,22 @@ class VideoTrainGraph(train_engine.TrainGraph):
         else:
             head_in = stack                                # dff: the warped pyramid of the one reference frame
         self.pyramid = head_in                             # what TrainGraph.forward / set_logit_grads index the logits with
-        self.cls_buf, self.reg_buf = engine.build_retina_head(b, sd, head_in, head.stacked_convs, True, p='detector.bbox_head.',
-                                                              pingpong=False)
+        self._build_head(b, sd, det, head_in)
         fs = getattr(bb, 'frozen_stages', -1)
         frozen = (['stem.'] if fs >= 0 else []) + [f'detector.backbone.layer{i}.' for i in range(1, fs + 1)]
         self._finish(b, frozen)
         self._dx32 = {}
         self.want_dflow, self.dflow = False, None
+
+    # ---- what sits on either side of the temporal part: FPN + RetinaHead here, ChannelMapper + RPN convs in TwoStageVideoGraph
+    def _build_neck(self, b, sd, det, feats):
+        neck = det.neck
+        return engine.build_fpn(b, sd, feats, neck.start_level, -1, neck.num_outs, neck.add_extra_convs, neck.relu_before_extra_convs,
+                                p='detector.neck.')
+
+    def _build_head(self, b, sd, det, head_in):
+        self.cls_buf, self.reg_buf = engine.build_retina_head(b, sd, head_in, det.bbox_head.stacked_convs, True, p='detector.bbox_head.',
+                                                              pingpong=False)
 
     # ---- the flow field (an input of every step, not a parameter)
     def set_flow(self, flow):

@@ -10,6 +10,9 @@ fp32 on the CPU under autograd. Only tests/ may import this file.
   SelsaRoIHead.forward_train        mmtracking/mmtrack/models/roi_heads/selsa_roi_head.py:10-111
   BBoxHead.get_targets / loss       mmdetection/mmdet/models/roi_heads/bbox_heads/bbox_head.py:103-268
   binary_cross_entropy              mmdetection/mmdet/models/losses/cross_entropy_loss.py:43-96
+  ConvFCBBoxHead.forward            mmdetection/mmdet/models/roi_heads/bbox_heads/convfc_bbox_head.py:129-160 (shared-fc form: Shared2FCBBoxHead)
+  StandardRoIHead.simple_test / forward_train   mmdetection/mmdet/models/roi_heads/standard_roi_head.py:70-139,238-268, test_mixins.py:50-170
+  DFF / FGFA / LLVOD two-stage branches         mmtracking/mmtrack/models/vid/dff.py:139-173,245-253, fgfa.py:149-185,344-352, llvod.py:124-145
 
 Parity unpinned for the sampler (the reference holds no vector for it): RandomSampler draws with torch.randperm when it has more
 candidates than it wants, which no two implementations reproduce; the tests size `num` so that every candidate is taken (the
@@ -174,5 +177,50 @@ def selsa_roi_head_forward_train(sd, p_head, x, ref_x, proposals, ref_proposals,
     ref_feats = roi_align(ref_x, ref_rois, 7, 1.0 / featmap_stride, 2, True)
     cls_score, bbox_pred = selsa_bbox_head_forward(sd, p_head, feats, ref_feats, num_shared_fcs, num_attention_blocks)
     targets = bbox_head_targets([(pos_b, neg_b, pos_gt, pos_lab)], gt_bboxes, num_classes, pos_weight)
+    losses = bbox_head_loss(cls_score, bbox_pred, *targets, num_classes, box_loss)
+    return losses, dict(rois=rois, cls_score=cls_score, bbox_pred=bbox_pred, targets=targets)
+
+
+# ------------------------------------------------------------------------------------------------
+# the plain two-stage head of the reference's DFF / FGFA configs (faster_rcnn_r50_dc5.py:38-62)
+# ------------------------------------------------------------------------------------------------
+def shared_fc_bbox_head_forward(sd, p, x, num_shared_fcs=2):
+    """ConvFCBBoxHead.forward with shared fcs only: flatten -> (fc, ReLU) x n -> fc_cls, fc_reg."""
+    x = x.flatten(1)
+    for i in range(num_shared_fcs):
+        x = F.relu(F.linear(x, sd[f'{p}shared_fcs.{i}.weight'], sd[f'{p}shared_fcs.{i}.bias']))
+    return F.linear(x, sd[p + 'fc_cls.weight'], sd[p + 'fc_cls.bias']), F.linear(x, sd[p + 'fc_reg.weight'], sd[p + 'fc_reg.bias'])
+
+
+def standard_roi_head_simple_test(sd, p, x, proposals, img_shape, scale_factor, test_cfg, featmap_stride=16, num_shared_fcs=2,
+                                  means=(0., 0., 0., 0.), stds=(0.2, 0.2, 0.2, 0.2), rescale=False):
+    """One image: x (1, C, h, w), proposals (k, 5) -> (dets (m, 5), labels (m,), cls_score, bbox_pred). BBoxHead.get_bboxes
+    (bbox_head.py:270-371): softmax, class-specific delta2bbox clipped to img_shape, optional rescale, multiclass NMS."""
+    from .bbox import delta2bbox
+    from .nms import multiclass_nms
+    rois = bbox2roi([proposals])
+    feats = roi_align(x, rois, 7, 1.0 / featmap_stride, 2, True)
+    cls_score, bbox_pred = shared_fc_bbox_head_forward(sd, p, feats, num_shared_fcs)
+    scores = F.softmax(cls_score, dim=-1)
+    bboxes = delta2bbox(rois[:, 1:], bbox_pred, means, stds, max_shape=img_shape)
+    if rescale:
+        bboxes = bboxes / bboxes.new_tensor(scale_factor).repeat(bboxes.size(-1) // 4)
+    dets, labels = multiclass_nms(bboxes, scores, test_cfg['score_thr'], test_cfg['nms'], test_cfg['max_per_img'])
+    return dets, labels, cls_score, bbox_pred
+
+
+def standard_roi_head_forward_train(sd, p_head, x, proposals, gt_bboxes, gt_labels, assigner, sampler, num_classes, featmap_stride=16,
+                                    num_shared_fcs=2, box_loss='smooth_l1', pos_weight=-1, stds=(0.2, 0.2, 0.2, 0.2)):
+    """standard_roi_head.py:70-139 for one image; x (1, C, h, w) carries the graph, the proposals do not."""
+    props = proposals.detach()
+    ar = assigner.assign(props[:, :4], gt_bboxes, None, gt_labels)
+    pos, neg, boxes, gt_inds, _ = sampler.sample(ar.gt_inds, ar.labels, props, gt_bboxes, gt_labels)
+    pos_b, neg_b = boxes[pos], boxes[neg]
+    pos_gt = gt_bboxes[gt_inds[pos] - 1]
+    pos_lab = gt_labels[gt_inds[pos] - 1]
+    rois = bbox2roi([torch.cat([pos_b, neg_b])])
+    feats = roi_align(x, rois, 7, 1.0 / featmap_stride, 2, True)
+    cls_score, bbox_pred = shared_fc_bbox_head_forward(sd, p_head, feats, num_shared_fcs)
+    targets = bbox_head_targets([(pos_b, neg_b, pos_gt, pos_lab)], gt_bboxes, num_classes, pos_weight, stds=stds)
     losses = bbox_head_loss(cls_score, bbox_pred, *targets, num_classes, box_loss)
     return losses, dict(rois=rois, cls_score=cls_score, bbox_pred=bbox_pred, targets=targets)

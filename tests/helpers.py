@@ -171,3 +171,14 @@ def detection_parity_report(res, ref, iou_thr=0.9, score_tol=0.03):
                corner_px=dict(max=float(c.max()), mean=float(c.mean()), p95=float(np.percentile(c, 95))),
                score=dict(max=float(d.max()), mean=float(d.mean()), p95=float(np.percentile(d, 95))))
     return out
+
+
+def grad_metrics(g, r):
+    """A device gradient `g` against the oracle's `r` for one parameter tensor -> (max-abs error / max-abs of r, cosine, relative L2 error,
+    max-abs of r). The max-abs bound alone cannot tell fp16 rounding (cosine ~ 1, error spread evenly) from a mis-routed gradient of a
+    small tensor (cosine far from 1); the training-parity tests assert all three."""
+    g, r = g.detach().double().cpu().flatten(), r.detach().double().cpu().flatten()
+    scale = r.abs().max().item()
+    nr = r.norm().item()
+    cos = float(torch.dot(g, r) / (g.norm() * r.norm()).clamp(min=1e-300))
+    return (g - r).abs().max().item() / max(scale, 1e-300), cos, (g - r).norm().item() / max(nr, 1e-300), scale

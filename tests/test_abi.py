@@ -29,6 +29,21 @@ def test_header_symbols_are_exported_and_bound():
     assert _lib.lib().llv_strerror(-1) == b'bad argument'
 
 
+def test_clean_build(tmp_path):
+    """The whole library compiles from its sources alone (no prebuilt object is picked up): a from-scratch `make` into a scratch
+    directory, the same recipe `__graft_entry__.build(clean=True)` runs in-tree, exports exactly the header's symbols."""
+    import subprocess
+    out = tmp_path / 'libllv.so'
+    subprocess.run(['make', '-C', os.path.join(ROOT, 'lowlightenvironmentvideoobjectdetection_amd', 'csrc'), '-j8', f'BUILD={tmp_path}/build',
+                    f'OUT={out}'], check=True, stdout=subprocess.DEVNULL, stderr=subprocess.DEVNULL)
+    assert len(list((tmp_path / 'build').glob('*.o'))) == 11
+    h = ctypes.CDLL(str(out))
+    for n in _declared():
+        assert hasattr(h, n), n
+    h.llv_abi_version.restype = ctypes.c_int
+    assert h.llv_abi_version() == 2
+
+
 def test_no_kernel_needs_scratch_memory_or_spills():
     """Every kernel of libllv.so runs out of registers and LDS alone: private segment (scratch) 0 bytes, no VGPR spills. Round 1's
     implicit-GEMM kernels indexed a table of their three source pointers per lane, which the compiler put in scratch memory

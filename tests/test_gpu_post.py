@@ -41,7 +41,8 @@ def test_multiclass_nms_index_exact(dev, n, C, dens):
 
 @pytest.mark.parametrize('presorted', [False, True])
 @pytest.mark.parametrize('n,iou,max_num,dup', [(2048, 0.7, 300, False), (2113, 0.5, 100, False), (6000, 0.7, 300, False), (6000, 0.7, 300, True),
-                                               (6000, 0.3, 2000, False), (12276, 0.7, 1000, False), (16384, 0.7, 300, False)])
+                                               (6000, 0.3, 2000, False), (12276, 0.7, 1000, False), (16384, 0.7, 300, False),
+                                               (12000, 0.7, 2000, False)])      # rpn nms_pre = 12000, max_per_img = 2000 (the mask path holds nothing of size max_num in LDS)
 def test_single_list_nms_index_exact(dev, n, iou, max_num, dup, presorted):
     """One class and >= 2048 boxes (the RPN's nms_pre = 6000 list of the SELSA configs, mmtracking/configs/_base_/models/
     faster_rcnn_r50_dc5.py:44-50): the sort -> IoU bit mask -> bit reduction kernels of nms.hip instead of the one-workgroup class

@@ -16,7 +16,8 @@ def _boxes(n, g, size=256.):
     return torch.cat([xy, (xy + wh).clamp(max=size)], 1)
 
 
-@pytest.mark.parametrize('k,n,assign_all', [(7, 5000, True), (3, 777, False), (1, 64, True), (40, 20000, True)])
+@pytest.mark.parametrize('k,n,assign_all', [(7, 5000, True), (3, 777, False), (1, 64, True), (40, 20000, True),
+                                            (2049, 3000, True), (4096, 2500, False)])      # k * 32 bytes of LDS in pass A: above 64 KiB
 def test_iou_assign_matches_oracle(dev, k, n, assign_all):
     from lowlightenvironmentvideoobjectdetection_amd import ops
     from oracle.training import MaxIoUAssigner

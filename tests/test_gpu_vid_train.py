@@ -84,8 +84,8 @@ def _build(kind, seed):
     flow = dict(type='FlowNetSimple', img_scale_factor=0.5)
     agg = dict(type='EmbedAggregator', num_convs=1, channels=64, kernel_size=3)
     cfg = dict(dff=dict(type='DFF', detector=_cfg_det(), motion=flow, frozen_modules=['motion']),
-               fgfa=dict(type='FGFA', detector=_cfg_det(), motion=flow, aggregator=agg, frozen_modules=['motion']),
-               llvod=dict(type='LLVOD', detector=_cfg_det(), aggregator=agg))[kind]
+               fgfa=dict(type='FGFA', detector=_cfg_det(), motion=flow, aggregator=agg, frozen_modules=['motion'], train_cfg=dict(add_noise=False)),
+               llvod=dict(type='LLVOD', detector=_cfg_det(), aggregator=agg, train_cfg=dict(add_noise=False)))[kind]
     model = randomize(M.build_model(cfg), seed=seed, cls_bias=-2.0)
     if hasattr(model, 'motion'):
         with torch.no_grad():
@@ -404,7 +404,8 @@ def test_fgfa_trains_the_flow_network_too(dev):
     from oracle.training import retina_loss
     Hh, Ww, nr = 128, 256, 2
     agg = dict(type='EmbedAggregator', num_convs=1, channels=64, kernel_size=3)
-    model = randomize(M.build_model(dict(type='FGFA', detector=_cfg_det(), motion=dict(type='FlowNetSimple', img_scale_factor=0.5), aggregator=agg)),
+    model = randomize(M.build_model(dict(type='FGFA', detector=_cfg_det(), motion=dict(type='FlowNetSimple', img_scale_factor=0.5), aggregator=agg,
+                                         train_cfg=dict(add_noise=False))),
                       seed=51, cls_bias=-2.0)
     model.motion.load_state_dict(_flownet(8).state_dict())
     model.invalidate_plans()
