@@ -427,6 +427,13 @@ int llv_retina_loss(const llv_retina_loss_desc* desc, void* stream);
 int llv_modulated_deform_im2col(const void* x, const float* om, void* col, int n, int h, int w, int c, int x_ld, int om_ld,
                                 int col_ld, int kh, int kw, int stride, int pad, int dilation, int deform_groups, int ho,
                                 int wo, void* stream);
+/* Its backward (mmcv modulated_deformable_col2im + col2im_coord, the gradient path of ModulatedDCNPack in training): from the column
+ * gradient dcol (n,ho,wo,col_ld) fp16, ACCUMULATE into dx (n,h,w,c) fp32 the input gradient and into dom (n,ho,wo,om_ld) fp32 the
+ * gradient of the raw conv_offset output: offsets (dy, dx of every tap) and mask LOGITS (the sigmoid's derivative included). Same
+ * geometry arguments and border rule as the forward; both outputs must be zeroed (or hold what to add to) by the caller. */
+int llv_modulated_deform_col2im(const void* dcol, const void* x, const float* om, float* dx, float* dom, int n, int h, int w, int c,
+                                int x_ld, int om_ld, int col_ld, int kh, int kw, int stride, int pad, int dilation, int deform_groups,
+                                int ho, int wo, void* stream);
 
 /* Element-wise steps of TemporalAttentionFusion.forward (denoising_aggregator.py:135-152) on contiguous NHWC fp16 tensors with
  * m channels (m % 8 == 0). The reference's loop over the reference frame i is batched: pair (i, j) = image i*n + j.
@@ -546,6 +553,13 @@ int llv_copy_d2d(void* dst, const void* src, size_t bytes, void* stream);
  * input; act (rows, act_ld) fp16 = relu(h * scale + shift) is the block's norm2 + ReLU (eval-mode BatchNorm as a per-channel affine). */
 int llv_convlstm_gate(const void* gates, float* c, const float* scale, const float* shift, void* h, void* act, int64_t rows, int p,
                       int gates_ld, int h_ld, int act_ld, void* stream);
+/* Its backward for one frame: gates as above, c_prev (rows, p) fp32 the cell state BEFORE the frame; dh (rows, h_ld) fp16 the gradient
+ * the recurrent consumer (the next frame's conv2) sent to h, or null; dact (rows, act_ld) fp16 the gradient of act; dc_in (rows, p) fp32
+ * the gradient the next frame sent to this frame's new cell state, or null -> dgates (rows, gates_ld) fp16, dc_prev (rows, p) fp32 (may
+ * alias dc_in), and -- unless null -- ADDS into dscale / dshift [p] fp32 the gradients of the affine (norm2's gamma / sqrt(var + eps), beta). */
+int llv_convlstm_gate_bwd(const void* gates, const float* c_prev, const float* scale, const float* shift, const void* dh, const void* dact,
+                          const float* dc_in, void* dgates, float* dc_prev, float* dscale, float* dshift, int64_t rows, int p,
+                          int gates_ld, int h_ld, int act_ld, void* stream);
 
 /* bbox2result's device-to-host step (mmdetection/mmdet/core/bbox/transforms.py:99-116) as one kernel: the NMS outputs of `batch`
  * images (dets [batch][max_num][5] fp32, labels [batch][max_num] int64, count [batch] int32) -> rows [batch][max_num][6] fp32

@@ -204,6 +204,7 @@ SIGNATURES = {
     'llv_iou_assign_workspace_bytes': (_Z, [_I, _L]),
     'llv_iou_assign': (_I, [_P, _I, _P, _P, _L, _F, _F, _F, _I, _I, _P, _P, _P, _Z, _P]),
     'llv_modulated_deform_im2col': (_I, [_P, _P, _P] + [_I] * 15 + [_P]),
+    'llv_modulated_deform_col2im': (_I, [_P, _P, _P, _P, _P] + [_I] * 15 + [_P]),
     'llv_taf_pair_concat': (_I, [_P, _P, _I, _I, _I, _I, _P]),
     'llv_taf_mul_ref': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
     'llv_taf_softmax_fuse': (_I, [_P, _P, _P, _I, _I, _I, _I, _P]),
@@ -243,6 +244,7 @@ SIGNATURES = {
     'llv_yolo_select_workspace_bytes': (_Z, [_I, _I]),
     'llv_yolo_select': (_I, [_P, _P, _P, _I, _I, _I, _I, _I, _I, _I, _F, _P, _L, _L, _P, _P, _P, _P, _Z, _P]),
     'llv_convlstm_gate': (_I, [_P, _P, _P, _P, _P, _P, _L, _I, _I, _I, _I, _P]),
+    'llv_convlstm_gate_bwd': (_I, [_P] * 11 + [_L, _I, _I, _I, _I, _P]),
     'llv_pack_conv_weights_batched': (_I, [_P, _I, _I, _P]),
     'llv_fold_bias_batched': (_I, [_P, _I, _I, _P]),
     'llv_pack_dgrad_weights_batched': (_I, [_P, _I, _I, _P]),

@@ -165,8 +165,18 @@ class DenoisingAggregator(PlannedModule):
         out = engine.build_denoising_aggregator(b, engine._cpu_sd(self.state_dict()), x_in, n, **self.plan_kwargs())
         return b.plan, x_in, out
 
+    def forward_train(self, x):
+        """The same block under autograd (dev_autograd.py: every convolution and the deformable convolution a differentiable device
+        op -- forward, data and weight gradients on libllv.so; mmcv modulated_deform_conv2d's gradients w.r.t. input, offsets and
+        mask = llv_modulated_deform_col2im): x (N, C, H, W) fp32 -> (N, C, H, W) fp32 carrying the graph to x and to every parameter."""
+        from . import dev_autograd as D
+        assert x.shape[1] == self.in_channels
+        return D.from_dev(D.denoising_aggregator_forward(self, D.to_dev(x)), self.in_channels)
+
     def forward(self, x):
         self._check_input(x)
+        if torch.is_grad_enabled() and x.requires_grad:
+            return self.forward_train(x)
         n, c, h, w = x.shape
         assert c == self.in_channels
         plan, x_in, out = self._plan((n, h, w, str(x.device)), lambda: self.make_plan(n, h, w, x.device))
@@ -218,9 +228,19 @@ class Denoising2Aggergator(PlannedModule):
                                                          self.with_taf)
         return b.plan, xs, last, outs, total
 
+    def forward_train(self, x_noise, all_x):
+        """forward under autograd (dev_autograd.py), same arguments and return value: gradients reach every x_noise[i], all_x[-1] and
+        every parameter."""
+        from . import dev_autograd as D
+        outs, total = D.denoising2_aggregator_forward(self, [D.to_dev(t) for t in x_noise], D.to_dev(all_x[-1]))
+        s = D.from_dev(total, all_x[-1].shape[1])
+        return tuple(D.from_dev(o, t.shape[1]) for o, t in zip(outs, x_noise)), tuple(s for _ in all_x)
+
     def forward(self, x_noise, all_x):
         for t in tuple(x_noise) + (all_x[-1],):
             self._check_input(t)
+        if torch.is_grad_enabled() and any(t.requires_grad for t in tuple(x_noise) + (all_x[-1],)):
+            return self.forward_train(x_noise, all_x)
         n = x_noise[0].shape[0]
         shapes = tuple(tuple(t.shape[1:]) for t in x_noise)
         last_shape = tuple(all_x[-1].shape[1:])

@@ -206,6 +206,14 @@ class ResNet(PlannedModule):
 
     dark_stages = ()
 
+    def forward_train(self, x):
+        """The stages under autograd (dev_autograd.resnet_forward: every convolution a differentiable device op; the denoising plugins of
+        InsertResNet and the ConvLSTM blocks of DarkResNet included): (N, 3, H, W) fp32 -> tuple of NCHW fp32 stage outputs carrying the
+        graph to every trainable parameter. The dense detectors do not come through here (their whole step is one launch tape,
+        train_engine.py); this is the training path of the backbones whose blocks fuse the frames of the batch."""
+        from . import dev_autograd as D
+        return D.resnet_forward(self, x)
+
     def plan_kwargs(self):
         kw = dict(depth=self.depth, strides=self.strides, style=self.style, out_indices=self.out_indices,
                   num_stages=self.num_stages, dilations=tuple(self.dilations))

@@ -97,6 +97,74 @@ __global__ __launch_bounds__(256) void mdcn_im2col_kernel(const _Float16* __rest
 }
 
 
+// ---- backward of the column step (mmcv modulated_deformable_col2im_gpu_kernel + modulated_deformable_col2im_coord_gpu_kernel in ONE
+// pass): one thread = the forward's item (pixel, tap k, 8 channels). Reads the column gradient g[8], re-derives the sample position and
+// the four corners, then
+//   dx[corner][c]          += g[c] * m * w_corner                                   (32 fp32 atomics at most)
+//   d(dy), d(dx) of the tap += sum_c g[c] * m * d(bilinear)/d(py, px)                (dmcn_get_coordinate_weight: -hx v00 - lx v01 + hx v10 + lx v11,
+//                                                                                     -hy v00 + hy v01 - ly v10 + ly v11; a corner outside the image is 0)
+//   d(mask logit)           += sum_c g[c] * bilinear(x)[c] * m (1 - m)               (mmcv returns d/d(mask); the sigmoid is the caller's in the reference
+//                                                                                     and is folded in here, as the forward folds it)
+// A sample outside (-1, h) x (-1, w) contributes nothing, as in the forward. dx fp32 (n, h, w, c), dom fp32 (n, ho, wo, om_ld): both accumulated.
+__global__ __launch_bounds__(256) void mdcn_col2im_kernel(const _Float16* __restrict__ dcol, const _Float16* __restrict__ x,
+                                                         const float* __restrict__ om, float* __restrict__ dx, float* __restrict__ dom, int h, int w,
+                                                         int c8, int x_ld, int om_ld, int col_ld, int kh, int kw, int stride, int pad, int dilation,
+                                                         int dg, int cg8, int ho, int wo) {
+    const unsigned K = kh * kw;
+    const unsigned total = (unsigned)wo * K * c8;
+    const unsigned row = blockIdx.y;
+    const int c = c8 * 8;
+    for (unsigned t = blockIdx.x * blockDim.x + threadIdx.x; t < total; t += gridDim.x * blockDim.x) {
+        const unsigned cv = t % (unsigned)c8;
+        const unsigned p = t / (unsigned)c8;
+        const unsigned ox = p / K, k = p - ox * K;
+        const unsigned img = row / (unsigned)ho, oy = row - img * ho;
+        const unsigned g = cv / (unsigned)cg8;
+        const long pix = (long)row * wo + ox;
+        const float* o = om + pix * om_ld;
+        const float2 d = *reinterpret_cast<const float2*>(o + (g * K + k) * 2);
+        const float ml = o[2 * dg * K + g * K + k];
+        const unsigned ki = k / (unsigned)kw, kj = k - ki * kw;
+        const float m = 1.f / (1.f + __expf(-ml));
+        const float py = (float)((int)oy * stride - pad + (int)ki * dilation) + d.x;
+        const float px = (float)((int)ox * stride - pad + (int)kj * dilation) + d.y;
+        if (!(py > -1.f && px > -1.f && py < (float)h && px < (float)w)) continue;
+        const f16x8 gv = *reinterpret_cast<const f16x8*>(dcol + pix * col_ld + (k * c8 + cv) * 8);
+        const int y0 = (int)floorf(py), x0 = (int)floorf(px);
+        const int y1 = y0 + 1, x1 = x0 + 1;
+        const float ly = py - (float)y0, lx = px - (float)x0, hy = 1.f - ly, hx = 1.f - lx;
+        const bool v00 = y0 >= 0 && x0 >= 0, v01 = y0 >= 0 && x1 <= w - 1, v10 = y1 <= h - 1 && x0 >= 0, v11 = y1 <= h - 1 && x1 <= w - 1;
+        const _Float16* xb = x + (long)img * h * w * x_ld + cv * 8;
+        const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        const f16x8 c00 = v00 ? *reinterpret_cast<const f16x8*>(xb + ((long)y0 * w + x0) * x_ld) : zero;
+        const f16x8 c01 = v01 ? *reinterpret_cast<const f16x8*>(xb + ((long)y0 * w + x1) * x_ld) : zero;
+        const f16x8 c10 = v10 ? *reinterpret_cast<const f16x8*>(xb + ((long)y1 * w + x0) * x_ld) : zero;
+        const f16x8 c11 = v11 ? *reinterpret_cast<const f16x8*>(xb + ((long)y1 * w + x1) * x_ld) : zero;
+        float* db = dx + (long)img * h * w * c + cv * 8;
+        float gy = 0.f, gx = 0.f, gm = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float ge = (float)gv[e];
+            const float a = (float)c00[e], b = (float)c01[e], cc = (float)c10[e], dd = (float)c11[e];
+            gy += ge * (-hx * a - lx * b + hx * cc + lx * dd);
+            gx += ge * (-hy * a + hy * b - ly * cc + ly * dd);
+            gm += ge * (hy * hx * a + hy * lx * b + ly * hx * cc + ly * lx * dd);
+            const float gmv = ge * m;
+            if (gmv != 0.f) {
+                if (v00) atomicAdd(db + ((long)y0 * w + x0) * c + e, gmv * hy * hx);
+                if (v01) atomicAdd(db + ((long)y0 * w + x1) * c + e, gmv * hy * lx);
+                if (v10) atomicAdd(db + ((long)y1 * w + x0) * c + e, gmv * ly * hx);
+                if (v11) atomicAdd(db + ((long)y1 * w + x1) * c + e, gmv * ly * lx);
+            }
+        }
+        float* go = dom + pix * om_ld;
+        atomicAdd(go + (g * K + k) * 2, gy * m);
+        atomicAdd(go + (g * K + k) * 2 + 1, gx * m);
+        atomicAdd(go + 2 * dg * K + g * K + k, gm * m * (1.f - m));
+    }
+}
+
+
 // ---- element-wise steps of TemporalAttentionFusion.forward (denoising_aggregator.py:135-152), NHWC fp16, 8 channels per lane.
 // The reference loops over the reference frame i and works on the n frames j at once; here the n*n (i, j) pairs are one
 // batch, pair (i, j) at image index i*n + j.
@@ -205,6 +273,27 @@ extern "C" int llv_modulated_deform_im2col(const void* x, const float* om, void*
     if ((long)n * ho > 65535) return LLV_E_UNSUPPORTED;
     hipLaunchKernelGGL(mdcn_im2col_kernel, dim3((unsigned)bx, (unsigned)(n * ho)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)x, om,
                        (_Float16*)col, h, w, c / 8, x_ld, om_ld, col_ld, kh, kw, stride, pad, dilation, deform_groups,
+                       c / deform_groups / 8, ho, wo);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
+extern "C" int llv_modulated_deform_col2im(const void* dcol, const void* x, const float* om, float* dx, float* dom, int n, int h, int w, int c,
+                                           int x_ld, int om_ld, int col_ld, int kh, int kw, int stride, int pad, int dilation, int deform_groups,
+                                           int ho, int wo, void* stream) {
+    if (!dcol || !x || !om || !dx || !dom || n <= 0 || h <= 0 || w <= 0 || c <= 0 || kh <= 0 || kw <= 0 || stride <= 0 || dilation <= 0 ||
+        deform_groups <= 0 || ho <= 0 || wo <= 0)
+        return LLV_E_BADARG;
+    if ((c & 7) || (x_ld & 7) || (col_ld & 7) || x_ld < c || col_ld < kh * kw * c || om_ld < 3 * deform_groups * kh * kw || (om_ld & 1))
+        return LLV_E_BADARG;
+    if (c % deform_groups || ((c / deform_groups) & 7)) return LLV_E_UNSUPPORTED;
+    if (ho != (h + 2 * pad - (dilation * (kh - 1) + 1)) / stride + 1 || wo != (w + 2 * pad - (dilation * (kw - 1) + 1)) / stride + 1)
+        return LLV_E_BADARG;
+    if ((long)wo * kh * kw * (c / 8) >= (1L << 30) || (long)n * ho > 65535) return LLV_E_UNSUPPORTED;
+    const long row_items = (long)wo * kh * kw * (c / 8);
+    long bx = (row_items + 255) / 256;
+    bx = bx < 1 ? 1 : bx;
+    hipLaunchKernelGGL(mdcn_col2im_kernel, dim3((unsigned)bx, (unsigned)(n * ho)), dim3(256), 0, (hipStream_t)stream, (const _Float16*)dcol,
+                       (const _Float16*)x, om, dx, dom, h, w, c / 8, x_ld, om_ld, col_ld, kh, kw, stride, pad, dilation, deform_groups,
                        c / deform_groups / 8, ho, wo);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }

@@ -764,6 +764,69 @@ extern "C" int llv_convlstm_gate(const void* gates, float* c, const float* scale
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
+// Backward of convlstm_gate_kernel. Per element, with the forward's si, sf, so, sg (sigmoid of the four gate blocks -- the reference puts
+// the sigmoid on g as well), c_prev, cn = sf c_prev + si sg, hv = so tanh(cn), a = hv scale + shift:
+//   d(hv) = dh (the recurrent consumer's gradient, the next frame's conv2) + (a > 0 ? dact * scale : 0)
+//   d(cn) = dc (from the next frame: sf_next * its d(cn)) + d(hv) * so * (1 - tanh(cn)^2)
+//   dgates = (d(cn) sg si(1-si), d(cn) c_prev sf(1-sf), d(hv) tanh(cn) so(1-so), d(cn) si sg(1-sg)); dc_prev = d(cn) * sf
+//   dscale[ch] += (a > 0) dact hv, dshift[ch] += (a > 0) dact (the affine of norm2: d(gamma) = dscale / sqrt(var + eps), d(beta) = dshift)
+// dh / dc_in may be null (the last frame). dc_prev may alias dc_in. dgates fp16 (the conv's gradient operand), the state gradients fp32.
+__global__ void convlstm_gate_bwd_kernel(const _Float16* __restrict__ gates, const float* __restrict__ c_prev, const float* __restrict__ scale,
+                                         const float* __restrict__ shift, const _Float16* __restrict__ dh, const _Float16* __restrict__ dact,
+                                         const float* dc_in, _Float16* __restrict__ dgates, float* dc_prev, float* __restrict__ dscale,
+                                         float* __restrict__ dshift, long rows, int p8, int gates_ld, int h_ld, int act_ld) {
+    const long total = rows * p8;
+    const int P = p8 * 8;
+    for (long i = blockIdx.x * (long)blockDim.x + threadIdx.x; i < total; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / p8;
+        const int cv = (int)(i - r * p8) * 8;
+        const _Float16* gr = gates + r * gates_ld + cv;
+        const f16x8 gi = *reinterpret_cast<const f16x8*>(gr), gf = *reinterpret_cast<const f16x8*>(gr + P);
+        const f16x8 go = *reinterpret_cast<const f16x8*>(gr + 2 * P), gg = *reinterpret_cast<const f16x8*>(gr + 3 * P);
+        const f16x8 zero = {0, 0, 0, 0, 0, 0, 0, 0};
+        const f16x8 dhv = dh ? *reinterpret_cast<const f16x8*>(dh + r * h_ld + cv) : zero;
+        const f16x8 dav = *reinterpret_cast<const f16x8*>(dact + r * act_ld + cv);
+        f16x8 di, df, dO, dG;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+            const float si = 1.f / (1.f + expf(-(float)gi[e])), sf = 1.f / (1.f + expf(-(float)gf[e]));
+            const float so = 1.f / (1.f + expf(-(float)go[e])), sg = 1.f / (1.f + expf(-(float)gg[e]));
+            const float cp = c_prev[r * P + cv + e];
+            const float cn = sf * cp + si * sg;
+            const float th = tanhf(cn);
+            const float hv = so * th;
+            const float a = hv * scale[cv + e] + shift[cv + e];
+            const float da = a > 0.f ? (float)dav[e] : 0.f;
+            if (dscale && da != 0.f) { atomicAdd(dscale + cv + e, da * hv); atomicAdd(dshift + cv + e, da); }
+            const float dhv_ = (float)dhv[e] + da * scale[cv + e];
+            const float dcn = (dc_in ? dc_in[r * P + cv + e] : 0.f) + dhv_ * so * (1.f - th * th);
+            di[e] = (_Float16)(dcn * sg * si * (1.f - si));
+            df[e] = (_Float16)(dcn * cp * sf * (1.f - sf));
+            dO[e] = (_Float16)(dhv_ * th * so * (1.f - so));
+            dG[e] = (_Float16)(dcn * si * sg * (1.f - sg));
+            dc_prev[r * P + cv + e] = dcn * sf;
+        }
+        _Float16* dr = dgates + r * gates_ld + cv;
+        *reinterpret_cast<f16x8*>(dr) = di;
+        *reinterpret_cast<f16x8*>(dr + P) = df;
+        *reinterpret_cast<f16x8*>(dr + 2 * P) = dO;
+        *reinterpret_cast<f16x8*>(dr + 3 * P) = dG;
+    }
+}
+
+extern "C" int llv_convlstm_gate_bwd(const void* gates, const float* c_prev, const float* scale, const float* shift, const void* dh, const void* dact,
+                                     const float* dc_in, void* dgates, float* dc_prev, float* dscale, float* dshift, int64_t rows, int p,
+                                     int gates_ld, int h_ld, int act_ld, void* stream) {
+    if (!gates || !c_prev || !scale || !shift || !dact || !dgates || !dc_prev || rows < 1 || p < 8 || (p & 7) || gates_ld < 4 * p || h_ld < p ||
+        act_ld < p || ((gates_ld | h_ld | act_ld) & 7) || ((dscale == nullptr) != (dshift == nullptr)))
+        return LLV_E_BADARG;
+    const long total = rows * (p / 8);
+    hipLaunchKernelGGL(convlstm_gate_bwd_kernel, dim3(grid_for(total)), dim3(kBlock), 0, (hipStream_t)stream, (const _Float16*)gates, c_prev, scale,
+                       shift, (const _Float16*)dh, (const _Float16*)dact, dc_in, (_Float16*)dgates, dc_prev, dscale, dshift, (long)rows, p / 8,
+                       gates_ld, h_ld, act_ld);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+}
+
 // y[n][oy][ox][:] = x[n][2 oy][2 ox][:]: the pixels a 1x1 / stride-2 convolution reads, as a dense map (the downsample conv of a ResNet
 // stage's first block then shares its launch with conv3: engine.build_resnet). 16 bytes per lane.
 __global__ void subsample2_kernel(const _Float16* __restrict__ x, _Float16* __restrict__ y, int n, int h, int w, int c8, int ho, int wo, int x_ld,

@@ -63,6 +63,14 @@ def _gpu(*ts):
             raise LlvError('the RoI heads run on an MI355X only (RoIAlign / NMS kernels, device GEMMs); no CPU path')
 
 
+def _wants_autograd(head, *xs):
+    """Training call of a box head: gradients are being recorded and either an input carries one (the RoI features of a training graph)
+    or the head itself is in train() mode with trainable layers. Everything else -- eval() mode, torch.no_grad() -- is the test-time
+    path on the in-tree kernels."""
+    return torch.is_grad_enabled() and (any(x is not None and x.requires_grad for x in xs) or
+                                        (head.training and any(p.requires_grad for p in head.parameters())))
+
+
 def bbox2roi(bbox_list):
     """mmdetection/mmdet/core/bbox/transforms.py:72-96."""
     rois_list = []
@@ -192,7 +200,7 @@ class BBoxHead(BBoxHeadMixin, nn.Module):
     def forward(self, x):
         _gpu(x)
         x = x.flatten(1)
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if _wants_autograd(self, x):
             return self.fc_cls(x), self.fc_reg(x)
         return _lin(self.fc_cls, x.float()), _lin(self.fc_reg, x.float())
 
@@ -294,7 +302,7 @@ class ConvFCBBoxHead(BBoxHeadMixin, nn.Module):
     def forward(self, x):
         """x (k, C, ph, pw) RoI features on the GPU -> (cls_score (k, classes + 1), bbox_pred (k, 4 or 4 * classes)) fp32."""
         _gpu(x)
-        if torch.is_grad_enabled() and (x.requires_grad or any(p.requires_grad for p in self.parameters())):
+        if _wants_autograd(self, x):
             return self.forward_autograd(x)
         return self._branches(x.float(), _roi_conv, _lin)
 

@@ -22,7 +22,7 @@ from . import ops
 from ._lib import CONV_OUT_F32, LlvError, check, lib
 from .core.bbox import bbox2result
 from .registry import AGGREGATORS, HEADS, ROI_EXTRACTORS, build, build_aggregator
-from .roi_heads import BBoxHeadMixin, _gpu, _lin, bbox2roi, linear_pc  # noqa: F401  (re-exported: selsa_plan, tests)
+from .roi_heads import BBoxHeadMixin, _gpu, _lin, _wants_autograd, bbox2roi, linear_pc  # noqa: F401  (re-exported: selsa_plan, tests)
 
 
 def selsa_attention(x_embed, ref_embed, ref_new, num_blocks):
@@ -156,7 +156,7 @@ class SelsaBBoxHead(BBoxHeadMixin, nn.Module):
         """x [N, C, H, W] key-frame RoI features, ref_x [M, C, H, W] (or None with a precomputed `ref_branch` over the same M rows)
         -> (cls_score [N, classes+1], bbox_pred [N, 4*classes])."""
         _gpu(x, ref_x)
-        if torch.is_grad_enabled() and ref_branch is None and ref_x is not None and (x.requires_grad or ref_x.requires_grad):
+        if ref_branch is None and ref_x is not None and _wants_autograd(self, x, ref_x):
             return self.forward_autograd(x, ref_x)
         if ref_branch is None:
             ref_branch = self.ref_branch(ref_x)

@@ -81,6 +81,7 @@ def _build(kind, seed, train=False, freeze_motion=True):
         for n, p in det.roi_head.named_parameters():
             p.copy_(torch.randn(p.shape, generator=g) * ((1.5 / p.shape[1]) ** 0.5 if p.dim() == 2 else 0.1))
         det.roi_head.bbox_head.fc_reg.weight.mul_(0.3)
+        det.roi_head.bbox_head.fc_cls.weight.mul_(3.0)      # peaked softmax, as a trained head's: flat scores make the top-100 cut a coin toss
         if hasattr(model, 'motion'):
             randomize(model.motion, seed=seed + 5)
             for name, p in model.motion.named_parameters():
@@ -107,14 +108,14 @@ def _feats(sd, img, p='detector.'):
     return channel_mapper_forward(sd, resnet_forward(sd, img, prefix=p + 'backbone.', **DEPTH_KW)[-1:], p + 'neck.')[0]
 
 
-def _props(sd, f, p='detector.'):
+def _props(sd, f, p='detector.', hw=(H, W)):
     from oracle.anchors import AnchorGenerator
     from oracle.bbox import DeltaXYWHBBoxCoder
     from oracle.rpn import rpn_get_bboxes, rpn_head_forward
     ag = AnchorGenerator(strides=[16], ratios=[0.5, 1.0, 2.0], scales=[4, 8, 16, 32])
     with torch.no_grad():
         cls, reg = rpn_head_forward(sd, [f.detach()], p + 'rpn_head.')
-        return rpn_get_bboxes(cls, reg, ag, DeltaXYWHBBoxCoder(), (H, W, 3), RPN_CFG)
+        return rpn_get_bboxes(cls, reg, ag, DeltaXYWHBBoxCoder(), (hw[0], hw[1], 3), RPN_CFG)
 
 
 def _sub(sd, p):
@@ -134,17 +135,37 @@ def _hook_head(roi_head):
 
 
 def _check_frame(model, dev, sd, x_ref, out, cap, props, tag, p='detector.'):
-    """Device run (oracle proposals on both sides) against the oracle RoI head on the oracle's feature map x_ref."""
+    """Device run (oracle proposals on both sides) against the oracle RoI head on the oracle's feature map x_ref, stage by stage:
+    logits / deltas of every RoI, decoded class-specific boxes and softmax scores before NMS (tight), the device's detections ==
+    the ORACLE's multiclass NMS applied to the device's own pre-NMS tensors (exact: the NMS kernel is index-exact), and the fraction of
+    the oracle's final detections reproduced end to end (reported; greedy NMS at IoU 0.5 over 60 heavily overlapping random-weight
+    proposals x 6 classes flips on last-bit score differences and every flip changes which boxes survive)."""
+    from oracle.bbox import delta2bbox
+    from oracle.nms import multiclass_nms as oracle_mnms
     from oracle.two_stage import standard_roi_head_simple_test
+    det = model.detector if hasattr(model, 'detector') else model
     with torch.no_grad():
         d_ref, l_ref, cls_ref, reg_ref = standard_roi_head_simple_test(sd, p + 'roi_head.bbox_head.', x_ref, props, (H, W, 3), [1, 1, 1, 1], TEST_RCNN)
     e_cls = (cap['cls_score'].cpu() - cls_ref).abs().max().item() / cls_ref.abs().max().item()
     e_reg = (cap['bbox_pred'].cpu() - reg_ref).abs().max().item() / reg_ref.abs().max().item()
+    assert e_cls < 5e-3 and e_reg < 5e-3, (tag, e_cls, e_reg)
+    bh = det.roi_head.bbox_head
+    with torch.no_grad():
+        b_dev, s_dev = bh.get_bboxes(cap['rois'], cap['cls_score'], cap['bbox_pred'], (H, W, 3), [1, 1, 1, 1], cfg=None)
+    rois_ref = torch.cat([props.new_zeros(len(props), 1), props[:, :4]], 1)
+    b_ref = delta2bbox(rois_ref[:, 1:], reg_ref, (0., 0., 0., 0.), (0.2, 0.2, 0.2, 0.2), max_shape=(H, W, 3))
+    e_box = (b_dev.cpu() - b_ref).abs().max().item()
+    e_sc = (s_dev.cpu() - torch.softmax(cls_ref, -1)).abs().max().item()
+    assert e_box < 0.5 and e_sc < 5e-3, (tag, e_box, e_sc)
+    d2, l2 = oracle_mnms(b_dev.cpu(), s_dev.cpu(), TEST_RCNN['score_thr'], TEST_RCNN['nms'], TEST_RCNN['max_per_img'])
+    want = [d2[l2 == c].numpy() for c in range(NCLS)]
+    for c in range(NCLS):
+        assert out[c].shape == want[c].shape and np.array_equal(out[c], want[c]), (tag, c)
     ref = [d_ref[l_ref == c].numpy() for c in range(NCLS)]
     frac, n = match_detections(out, ref, iou_thr=0.9, score_tol=0.05)
-    print(f'{tag}: logits {e_cls:.2e}, deltas {e_reg:.2e} of their scale; {frac:.2f} of {n} oracle detections reproduced')
-    assert e_cls < 2e-2 and e_reg < 2e-2, (tag, e_cls, e_reg)
-    assert n >= 30 and frac >= 0.7 and abs(sum(len(o) for o in out) - len(d_ref)) <= 3, (tag, frac, n)
+    print(f'{tag}: logits {e_cls:.2e}, deltas {e_reg:.2e} of their scale; boxes {e_box:.3f} px, scores {e_sc:.1e}; NMS on the device tensors '
+          f'exact; {frac:.2f} of {n} oracle detections reproduced end to end')
+    assert n >= 30 and abs(sum(len(o) for o in out) - len(d_ref)) <= 3, (tag, frac, n)
     return n
 
 
@@ -225,9 +246,10 @@ def test_faster_rcnn_simple_test_vs_oracle(dev):
     cap = _hook_head(model.roi_head)
     with torch.no_grad():
         out = model(return_loss=False, img=[img.to(dev)], img_metas=[[img_meta(H, W)]], proposals=[[p.to(dev)]])
-        own = model(return_loss=False, img=[img.to(dev)], img_metas=[[img_meta(H, W)]])
     assert len(out) == 1 and len(out[0]) == NCLS
     _check_frame(model, dev, sd, f, out[0], cap, p, 'faster r-cnn', p='')
+    with torch.no_grad():
+        own = model(return_loss=False, img=[img.to(dev)], img_metas=[[img_meta(H, W)]])
     assert len(own[0]) == NCLS and sum(len(r) for r in own[0]) >= 30
     # rescale=True divides the boxes by the scale factor (bbox_head.py:340-347)
     meta2 = img_meta(H, W, scale=2.0)
@@ -347,7 +369,7 @@ def test_llvod_two_stage_sliding_window_vs_oracle(dev):
 
 
 # ------------------------------------------------------------------------------------------------ training
-def _oracle_train(kind, model, img, refs, meta, flow_grad=False):
+def _oracle_train(kind, model, img, refs, meta, flow_grad=False, hw=(H, W)):
     from oracle.anchors import AnchorGenerator
     from oracle.flownet import flownet_forward
     from oracle.rpn import rpn_head_forward
@@ -376,7 +398,7 @@ def _oracle_train(kind, model, img, refs, meta, flow_grad=False):
     cls, reg = rpn_head_forward(sd, [x], 'detector.rpn_head.')
     losses = rpn_loss(cls, reg, GTB, [meta], ag, MaxIoUAssigner(0.7, 0.3, 0.3, ignore_iof_thr=-1), RandomSampler(4096, 0.5, -1, False), allowed_border=0)
     losses = dict(loss_rpn_cls=sum(losses['loss_rpn_cls']), loss_rpn_bbox=sum(losses['loss_rpn_bbox']))
-    p_key = _props(sd, x)
+    p_key = _props(sd, x, hw=hw)
     roi_losses, _ = standard_roi_head_forward_train(sd, 'detector.roi_head.bbox_head.', x, p_key, GTB[0], GTL[0],
                                                     MaxIoUAssigner(0.5, 0.5, 0.5, ignore_iof_thr=-1), RandomSampler(512, 0.25, -1, True), NCLS)
     losses.update(roi_losses)
@@ -427,9 +449,9 @@ def test_video_two_stage_forward_train_matches_oracle(dev, kind, nr):
     print(kind, 'lowest cosines:', [(k, round(c, 5)) for k, e, c, l2, s in sorted(rows, key=lambda t: t[2])[:4]])
     for k, e, c, l2, s in rows:
         big = s > 1e-4 * top
-        assert e < (8e-2 if big else 1.6e-1), (k, e, s)
-        assert c > (0.995 if big else 0.98), (k, c, s)
-        assert l2 < (6e-2 if big else 1.5e-1), (k, l2, s)
+        assert e < (8e-2 if big else 1.6e-1), (k, e, s)          # first run: <= 4.6 %
+        assert c > (0.999 if big else 0.99), (k, c, s)             # first run: >= 0.9996
+        assert l2 < (4e-2 if big else 1e-1), (k, l2, s)            # first run: <= 2.2 %
     assert len(rows) > 40, len(rows)
     for k in ('detector.roi_head.bbox_head.shared_fcs.0.weight', 'detector.rpn_head.rpn_cls.weight', 'detector.neck.convs.0.conv.weight',
               'detector.backbone.layer4.1.conv2.weight', 'detector.backbone.layer2.0.conv1.weight'):
@@ -446,19 +468,21 @@ def test_dff_two_stage_trains_the_flow_network_too(dev):
     model = _build('dff', 361, train=True, freeze_motion=False)
     model.motion.load_state_dict(_flownet(7).state_dict())
     model.invalidate_plans()
-    base = smooth_image(1, H, W, seed=362)
+    Ww = 256
+    base = smooth_image(1, H, Ww, seed=362)
     g = torch.Generator().manual_seed(363)
-    img = base + 0.05 * torch.randn(1, 3, H, W, generator=g)
-    refs = torch.roll(base, shifts=(2, -3), dims=(2, 3)) + 0.05 * torch.randn(1, 3, H, W, generator=g)
-    meta = dict(img_meta(H, W), is_video_data=True, frame_id=3)
-    ref_losses, p_key, ref_grads = _oracle_train('dff', model, img, refs, meta, flow_grad=True)
+    img = base + 0.05 * torch.randn(1, 3, H, Ww, generator=g)
+    refs = torch.roll(base, shifts=(2, -3), dims=(2, 3)) + 0.05 * torch.randn(1, 3, H, Ww, generator=g)
+    meta = dict(img_meta(H, Ww), is_video_data=True, frame_id=3)
+    ref_losses, p_key, ref_grads = _oracle_train('dff', model, img, refs, meta, flow_grad=True, hw=(H, Ww))
     model = model.to(dev).train()
     model.detector.rpn_head.get_bboxes = lambda *a, **k: [p_key.to(dev)]
     losses = model(img=img.to(dev), img_metas=[meta], gt_bboxes=[b.to(dev) for b in GTB], gt_labels=[l.to(dev) for l in GTL],
                    ref_img=refs.unsqueeze(0).to(dev), ref_img_metas=[[meta]], ref_gt_bboxes=None, ref_gt_labels=None, return_loss=True)
+    tot = lambda v: sum(v) if isinstance(v, (list, tuple)) else v
     for k, v in ref_losses.items():
-        assert abs(float(losses[k]) - float(v)) <= 2e-2 * max(abs(float(v)), 1e-2), (k, float(losses[k]), float(v))
-    sum(v for k, v in losses.items() if 'loss' in k).backward()
+        assert abs(float(tot(losses[k])) - float(v)) <= 2e-2 * max(abs(float(v)), 1e-2), (k, float(tot(losses[k])), float(v))
+    sum(tot(v) for k, v in losses.items() if 'loss' in k).backward()
     params = dict(model.named_parameters())
     rows = []
     for k, r in ref_grads.items():
@@ -467,7 +491,7 @@ def test_dff_two_stage_trains_the_flow_network_too(dev):
         assert params[k].grad is not None, k
         rows.append((k,) + grad_metrics(params[k].grad, r))
     rows.sort(key=lambda t: -t[1])
-    print('motion:', [(k, round(e, 3), round(c, 4)) for k, e, c, l2, s in rows[:6]])
+    print('motion:', [(k, round(e, 3), round(c, 4), round(l2, 3)) for k, e, c, l2, s in rows[:8]])
     assert len(rows) == 33
     assert sum(1 for r in rows if r[1] < 1.5e-1) >= 28 and all(r[1] < 3e-1 for r in rows), rows[:6]
     assert sum(1 for r in rows if r[2] > 0.99) >= 28 and all(r[2] > 0.95 for r in rows), sorted(rows, key=lambda t: t[2])[:6]
