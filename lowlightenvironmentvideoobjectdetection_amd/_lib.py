@@ -23,6 +23,7 @@ CONV_OUT_F32 = 32
 CONV_LEAKY = 64
 CONV_ACT_FIRST = 128
 CONV_PS_EMAJOR = 256
+CONV_CLSMAX = 512
 
 TILE_AUTO, TILE_128x128, TILE_64x256, TILE_32x256, TILE_16x256, TILE_64x64 = 0, 1, 2, 3, 4, 5
 TILE_128x128_REGSTAGE = 6
@@ -121,6 +122,7 @@ class ConvDesc(C.Structure):
         ('dilation', C.c_int32),
         ('extents', C.POINTER(Extents)),
         ('offset_dev', C.c_void_p), ('offset_x', C.c_int32), ('offset_res', C.c_int32), ('offset_max', C.c_int64),
+        ('clsmax', C.c_void_p), ('seg_written', C.c_void_p), ('cls_c', C.c_int32), ('store_thr', C.c_float),
     ]
 
 
@@ -149,6 +151,7 @@ class DecodeDesc(C.Structure):
         ('batch', C.c_int32),
         ('img_h_b', C.c_float * LLV_MAX_BATCH), ('img_w_b', C.c_float * LLV_MAX_BATCH),
         ('scale_factor_b', (C.c_float * 4) * LLV_MAX_BATCH),
+        ('clsmax', C.c_void_p), ('seg_written', C.c_void_p), ('seg_tiles', C.c_int32),
     ]
 
 

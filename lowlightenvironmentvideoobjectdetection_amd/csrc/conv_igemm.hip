@@ -59,7 +59,17 @@ struct ConvKArgs {
     const long* off_dev;         // convpair2 only: *off_dev (fp16 elements) is added to x0..x2 (off_x) / res (off_res) at kernel start
     int off_x, off_res;
     long off_max;                // the largest offset the caller declared (llv_conv_desc.offset_max): the word is clamped to [0, off_max]
+    unsigned* clsmax;            // LLV_CONV_CLSMAX: [rows][cout / cls_c] running maximum logit per anchor (ordered-uint encoding)
+    unsigned char* segw;         //                  [rows][tiles_n] segment-stored flags
+    int cls_c;
+    float store_thr;
 };
+
+// order-preserving map float -> unsigned (a < b  <=>  enc(a) < enc(b)); 0 is below every float
+__device__ __forceinline__ unsigned f32_ordered(float f) {
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
 
 // source tensor s (0..2) of a multi-source launch, without a pointer table (see conv_igemm_glds_kernel)
 __device__ __forceinline__ const _Float16* src_sel(const ConvKArgs& a, int s) {
@@ -1549,6 +1559,57 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
         staged_store_shuffled<BN, 256>(a, tile, g, tile_n, loc);
         return;
     }
+    if (a.flags & LLV_CONV_CLSMAX) {
+        // class convolution of a dense head (host: OUT_F32, one group, no staging, cout % 16 == 0, cls_c % 16 == 0): a lane holds, per
+        // pixel row j, TN blocks of 4 channels; the four lanes fch = 0..3 of a pixel hold one 16-channel block together, and a block lies
+        // inside one anchor. Per anchor touched by this tile (at most three): maximum over the lane's blocks, over the four lanes (two
+        // lane swaps), one atomicMax per pixel. The pixel's 128-channel segment is stored only when it has a logit above store_thr.
+        const int A = a.cout / a.cls_c;
+        // (the bias is re-read here, as epi_compute does: keeping the pre-loop copy alive across the main loop would cost 32 registers)
+#pragma unroll
+        for (int j = 0; j < TM; ++j) {
+            const int prow = (2 * wave + (j >> 1)) * 32 + (j & 1) * 16 + frow;
+            EpiCtx ec;
+            const bool ok = loc(prow, ec);
+            int hot = 0;
+            float run = -INFINITY;
+#pragma unroll
+            for (int i = 0; i < TN; ++i) {
+                const int co0 = tile_n * BN + i * 16;
+                const bool live = co0 < a.cout;
+                if (live) {
+                    const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co0 + fch * 4);
+                    acc[i][j][0] += b4.x; acc[i][j][1] += b4.y; acc[i][j][2] += b4.z; acc[i][j][3] += b4.w;
+                    const float m4 = fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3]));
+                    run = fmaxf(run, m4);
+                    hot |= m4 > a.store_thr ? 1 : 0;
+                }
+                const int an = co0 / a.cls_c;
+                const bool last = i == TN - 1 || (co0 + 16) / a.cls_c != an || !(co0 + 16 < a.cout);
+                if (live && last) {                           // uniform over the wave: depends on i and the tile only
+                    float r = fmaxf(run, __shfl_xor(run, 16));
+                    r = fmaxf(r, __shfl_xor(r, 32));
+                    if (ok && fch == 0) atomicMax(a.clsmax + (long)ec.opix * A + an, f32_ordered(r));
+                    run = -INFINITY;
+                }
+            }
+            hot |= __shfl_xor(hot, 16);
+            hot |= __shfl_xor(hot, 32);
+            if (ok) {
+                if (fch == 0) a.segw[(long)ec.opix * a.tiles_n + tile_n] = (unsigned char)hot;
+                if (hot) {
+#pragma unroll
+                    for (int i = 0; i < TN; ++i) {
+                        const int co = tile_n * BN + i * 16 + fch * 4;
+                        if (co < a.cout)
+                            *reinterpret_cast<float4*>(reinterpret_cast<float*>(a.y) + (long)ec.opix * a.y_ld + co) =
+                                make_float4(acc[i][j][0], acc[i][j][1], acc[i][j][2], acc[i][j][3]);
+                    }
+                }
+            }
+        }
+        return;
+    }
 #pragma unroll
     for (int j = 0; j < TM; ++j) {
         const int prow = (2 * wave + (j >> 1)) * 32 + (j & 1) * 16 + frow;
@@ -2464,6 +2525,7 @@ extern "C" int llv_conv2d_plan(const llv_conv_desc* d, int* tile, int* k_splits)
     LaunchPlan lp;
     if (d->w_halo && !d->tile) { lp.tile = -1; lp.splits = 1; }        // conv3x3_halo_kernel
     else if (plan_launch(d, lp) != LLV_OK) return LLV_E_BADARG;
+    if ((d->flags & LLV_CONV_CLSMAX) && !(d->w_halo && !d->tile)) { lp.tile = LLV_TILE_TAP128; lp.splits = 1; }   // as conv_prepare forces it
     if (tile) *tile = lp.tile;
     if (k_splits) *k_splits = lp.splits;
     return LLV_OK;
@@ -2603,6 +2665,15 @@ static int conv_prepare(const llv_conv_desc* d, ConvPrepared& P) {
         }
     }
     plan_launch(d, lp);
+    k.clsmax = nullptr; k.segw = nullptr; k.cls_c = 0; k.store_thr = 0.f;
+    if (f & LLV_CONV_CLSMAX) {
+        if (!(f & LLV_CONV_OUT_F32) || (f & ~(LLV_CONV_OUT_F32 | LLV_CONV_CLSMAX)) || !d->clsmax || !d->seg_written || d->cls_c < 16 ||
+            (d->cls_c & 15) || d->cout % d->cls_c || d->groups != 1 || d->n_src != 1 || d->y_group_stride || d->k_splits > 1)
+            return LLV_E_BADARG;
+        if (!tap_eligible(d) || (d->tile && d->tile != LLV_TILE_TAP128)) return LLV_E_UNSUPPORTED;
+        lp.tile = LLV_TILE_TAP128; lp.splits = 1;          // the segment flags are per 128-channel tile
+        k.clsmax = d->clsmax; k.segw = d->seg_written; k.cls_c = d->cls_c; k.store_thr = d->store_thr;
+    }
     k.k_splits = lp.splits;
     k.nk_per = lp.nk_per;
     k.ws = (float*)d->workspace;

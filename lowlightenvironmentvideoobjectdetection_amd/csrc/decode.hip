@@ -46,6 +46,9 @@ struct DecK {
     int blk0[LLV_MAX_SEG + 1];  // first class_max block of each level
     int batch;                  // images (blockIdx.y); level l of image n starts n*h*w pixels after cls_off[l]
     float img_h_b[LLV_MAX_BATCH], img_w_b[LLV_MAX_BATCH], sf_b[LLV_MAX_BATCH][4];
+    unsigned* clsmax;           // logits from a LLV_CONV_CLSMAX launch: [rows][A] per-anchor maximum logit (ordered-uint), reset here
+    const unsigned char* segw;  //                                       [rows][seg_tiles] which 128-channel segments were stored
+    int seg_tiles;
 };
 
 // per-image views of the workspace / outputs (image = blockIdx.y)
@@ -151,6 +154,42 @@ __global__ __launch_bounds__(256) void class_max_kernel(const DecK k) {
             ms_i[k.a0[l] + loc] = m;
             atomicAdd(&lh[score_bin(m)], 1u);
         }
+    }
+    __syncthreads();
+    unsigned* gh = hist_i + l * kBins;
+    for (int i = threadIdx.x; i < kBins; i += 256) {
+        const unsigned v = lh[i];
+        if (v) atomicAdd(&gh[i], v);
+    }
+}
+
+// K1 for logits that come from a LLV_CONV_CLSMAX launch: the convolution's epilogue has already reduced every anchor's classes to
+// their maximum LOGIT (clsmax, order-preserving uint encoding); sigmoid is monotone, so sigmoid(max logit) is the max_c sigmoid(logit_c)
+// class_max_kernel computes -- from 4 bytes per anchor instead of 4 C. The entry is reset for the next step.
+__device__ __forceinline__ float f32_from_ordered(unsigned key) {
+    return __uint_as_float((key & 0x80000000u) ? (key & 0x7fffffffu) : ~key);
+}
+__global__ __launch_bounds__(256) void class_max_from_conv_kernel(const DecK k) {
+    __shared__ unsigned lh[kBins];
+    int l = 0;
+#pragma unroll
+    for (int s = 1; s < LLV_MAX_SEG; ++s)
+        if (s < k.n_levels && (int)blockIdx.x >= k.blk0[s]) l = s;
+    IMG_SETUP(k)
+    for (int i = threadIdx.x; i < kBins; i += 256) lh[i] = 0;
+    __syncthreads();
+    const int n = k.a0[l + 1] - k.a0[l];
+    const long cls_l = k.cls_off[l] + (long)img * k.h[l] * k.w[l];
+    const int first = (blockIdx.x - k.blk0[l]) * kAnchorsPerBlock;
+    const int nb = n - first < kAnchorsPerBlock ? n - first : kAnchorsPerBlock;
+    for (int a = threadIdx.x; a < nb; a += 256) {
+        const int loc = first + a;                       // consecutive lanes read consecutive words: (cell, anchor) order is the array's
+        unsigned* p = k.clsmax + cls_l * (long)k.A + loc;
+        const unsigned key = *p;
+        *p = 0u;
+        const float m = key ? sigmoidf_(f32_from_ordered(key)) : 0.f;
+        ms_i[k.a0[l] + loc] = m;
+        atomicAdd(&lh[score_bin(m)], 1u);
     }
     __syncthreads();
     unsigned* gh = hist_i + l * kBins;
@@ -304,7 +343,15 @@ __global__ void gather_decode_kernel(const DecK k) {
     const long ipix = (long)img * k.h[l] * k.w[l];
     const long oslot = (long)img * N_cand + slot;
     const T* pc = reinterpret_cast<const T*>(k.cls) + (k.cls_off[l] + ipix + cell) * (long)k.cls_ld + (long)an * k.C;
-    for (int c = threadIdx.x; c < k.C; c += blockDim.x) k.scores[oslot * k.C + c] = sigmoidf_((float)pc[c]);
+    if (k.segw) {
+        // a class whose 128-channel segment the convolution did not store had every logit <= its store threshold (below score_thr):
+        // score 0, which the NMS drops exactly as it would the true value
+        const unsigned char* fl = k.segw + (k.cls_off[l] + ipix + cell) * (long)k.seg_tiles;
+        for (int c = threadIdx.x; c < k.C; c += blockDim.x)
+            k.scores[oslot * k.C + c] = fl[(an * k.C + c) >> 7] ? sigmoidf_((float)pc[c]) : 0.f;
+    } else {
+        for (int c = threadIdx.x; c < k.C; c += blockDim.x) k.scores[oslot * k.C + c] = sigmoidf_((float)pc[c]);
+    }
     if (threadIdx.x == 0) {
         k.cand_anchor[oslot] = g;
         const int cy = cell / k.w[l], cx = cell - cy * k.w[l];
@@ -422,6 +469,9 @@ extern "C" int llv_retina_decode_topk(const llv_decode_desc* d, void* stream) {
     k.ms = (float*)(ws + w.ms); k.sel = (int*)(ws + w.sel);
     k.listA = (uint64_t*)(ws + w.listA); k.listT = (uint64_t*)(ws + w.listT);
     k.capA = d->nms_pre > 0 ? d->nms_pre : 1;
+    k.clsmax = d->clsmax; k.segw = d->seg_written; k.seg_tiles = d->seg_tiles;
+    if ((d->clsmax == nullptr) != (d->seg_written == nullptr)) return LLV_E_BADARG;
+    if (d->clsmax && (!d->logits_f32 || d->seg_tiles != (k.A * k.C + 127) / 128 || d->cls_ld < k.A * k.C)) return LLV_E_BADARG;
     hipStream_t st = (hipStream_t)stream;
     static bool attr_done = false;
     if (!attr_done) {
@@ -438,7 +488,9 @@ extern "C" int llv_retina_decode_topk(const llv_decode_desc* d, void* stream) {
         k.blk0[l] = nb;
         if (l < d->n_levels) nb += (k.a0[l + 1] - k.a0[l] + kAnchorsPerBlock - 1) / kAnchorsPerBlock;
     }
-    {
+    if (k.clsmax) {
+        hipLaunchKernelGGL(class_max_from_conv_kernel, dim3(nb, batch), dim3(256), 0, st, k);
+    } else {
         // 16-byte vector path: rows, anchors and the base pointer must be 16-byte multiples
         const int vec = k.f32 ? 4 : 8, esz = k.f32 ? 4 : 2;
         bool ok = (k.C % vec) == 0 && (k.cls_ld % vec) == 0 && k.C / vec <= kMaxVecPerAnchor && ((uintptr_t)k.cls & 15) == 0;

@@ -18,7 +18,8 @@ import numpy as np
 import torch
 
 from . import ops
-from ._lib import (CONV_ACT_FIRST, CONV_LEAKY, CONV_OUT_F32, CONV_PIXSHUF, CONV_RELU, CONV_RES_ADD, CONV_RES_RSUB, CONV_RES_UPS, LlvError, check, lib)
+from ._lib import (CONV_ACT_FIRST, CONV_CLSMAX, CONV_LEAKY, CONV_OUT_F32, CONV_PIXSHUF, CONV_RELU, CONV_RES_ADD, CONV_RES_RSUB, CONV_RES_UPS, LlvError, check,
+                   lib)
 
 BN_EPS = 1e-5
 # direct (halo-in-LDS) 3x3 kernel for the FastDVDnet layers: on by default; LLV_HALO=0 falls back to implicit GEMM
@@ -153,10 +154,12 @@ class Builder:
         return t
 
     def conv_desc(self, name, pc: ops.PackedConv, xs, y, batch, segs, x_ld, y_ld, res=None, res_ld=0, flags=0,
-                  res_hw=(0, 0), tile=0, y_group_stride=0, act_slope=0.0, ps_out=(0, 0)):
+                  res_hw=(0, 0), tile=0, y_group_stride=0, act_slope=0.0, ps_out=(0, 0), clsmax=None):
         pc.to(self.dev)
         d = ops.make_conv_desc(pc, xs, y, batch, segs, x_ld, y_ld, res, res_ld, flags, res_hw, tile, 0, y_group_stride,
-                               act_slope, ps_out)
+                               act_slope, ps_out, clsmax)
+        if clsmax is not None:
+            self.plan.keep += [clsmax[0], clsmax[1]]
         if self.select_batch is not None and self.select_batch != batch and tile == 0:
             d.batch = self.select_batch
             t_, k_ = C.c_int(0), C.c_int(0)
@@ -456,9 +459,20 @@ def build_fpn(b: Builder, sd, feats, start_level=0, end_level=-1, num_outs=None,
     return Pyramid(pyr, level_hw, lvl_off, batch)
 
 
-def build_retina_head(b: Builder, sd, pyr: Pyramid, stacked_convs=4, logits_f32=True, p='', pingpong=True):
+def fused_cls_eligible(sd, p, num_classes):
+    """The class convolution can carry the first step of get_bboxes in its epilogue (LLV_CONV_CLSMAX, include/llv.h): 3x3 conv with
+    whole 16-channel blocks per anchor."""
+    w = sd[p + 'retina_cls.weight']
+    return (_os.environ.get('LLV_FUSED_CLS', '1') != '0' and w.shape[-1] == 3 and w.shape[1] % 32 == 0 and num_classes % 16 == 0
+            and w.shape[0] % num_classes == 0)
+
+
+def build_retina_head(b: Builder, sd, pyr: Pyramid, stacked_convs=4, logits_f32=True, p='', pingpong=True, fused_cls=None):
     """retina_head.py:93-114. The levels share weights -> one multi-segment launch per layer; the cls and
-    reg towers run side by side (layer 0 as one 2x-wide conv on the shared input, layers 1.. as groups=2)."""
+    reg towers run side by side (layer 0 as one 2x-wide conv on the shared input, layers 1.. as groups=2).
+    fused_cls = dict(num_classes=C, score_thr=t) (inference plans whose logits go straight to PostProcess): the class convolution keeps
+    every anchor's maximum logit and stores only the 128-channel segments that hold a logit above logit(t) - margin; returns
+    (cls_buf, reg_buf, (clsmax, seg_written)) then."""
     batch, segs, tot = pyr.batch, pyr.segs(), pyr.total
     c_f = pyr.buf.shape[-1]
     pccls = ops.pack_conv(sd[p + 'retina_cls.weight'], sd[p + 'retina_cls.bias'], 1, 1)
@@ -467,6 +481,18 @@ def build_retina_head(b: Builder, sd, pyr: Pyramid, stacked_convs=4, logits_f32=
     of = CONV_OUT_F32 if logits_f32 else 0
     cls_buf = b.buf(tot, pccls.cout, dtype=odt)
     reg_buf = b.buf(tot, pcreg.cout, dtype=odt)
+    cm, cflag = None, 0
+    if fused_cls is not None:
+        if not logits_f32:
+            raise LlvError('build_retina_head: the fused class maximum works on fp32 logits')
+        ncls = int(fused_cls['num_classes'])
+        thr = float(fused_cls.get('score_thr', 0.0))
+        # a segment whose logits are all <= store_thr is never read as a score above score_thr: logit(score_thr) minus a margin that covers
+        # the difference between this comparison on the logit and the NMS's on sigmoid(logit)
+        import math
+        store_thr = (math.log(thr / (1.0 - thr)) - 1e-2) if 0.0 < thr < 1.0 else -3.0e38
+        cm = (b.buf(tot, pccls.cout // ncls, dtype=torch.int32), b.buf(tot, (pccls.cout + 127) // 128, dtype=torch.uint8), ncls, store_thr)
+        cflag = CONV_CLSMAX
     if stacked_convs > 0:
         feat_ch = sd[p + 'cls_convs.0.conv.weight'].shape[0]
         ta = b.buf(tot, 2 * feat_ch)
@@ -484,11 +510,13 @@ def build_retina_head(b: Builder, sd, pyr: Pyramid, stacked_convs=4, logits_f32=
                 b.conv_desc(f'head.tower{i}', ops.stack_groups([pcc, pcr]), [cur], nxt, batch, segs, 2 * feat_ch,
                             2 * feat_ch, flags=CONV_RELU)
                 cur, nxt = nxt, cur
-        b.conv_desc('head.retina_cls', pccls, [cur[:, :feat_ch]], cls_buf, batch, segs, 2 * feat_ch, pccls.cout, flags=of)
+        b.conv_desc('head.retina_cls', pccls, [cur[:, :feat_ch]], cls_buf, batch, segs, 2 * feat_ch, pccls.cout, flags=of | cflag, clsmax=cm)
         b.conv_desc('head.retina_reg', pcreg, [cur[:, feat_ch:]], reg_buf, batch, segs, 2 * feat_ch, pcreg.cout, flags=of)
     else:
-        b.conv_desc('head.retina_cls', pccls, [pyr.buf], cls_buf, batch, segs, c_f, pccls.cout, flags=of)
+        b.conv_desc('head.retina_cls', pccls, [pyr.buf], cls_buf, batch, segs, c_f, pccls.cout, flags=of | cflag, clsmax=cm)
         b.conv_desc('head.retina_reg', pcreg, [pyr.buf], reg_buf, batch, segs, c_f, pcreg.cout, flags=of)
+    if fused_cls is not None:
+        return cls_buf, reg_buf, (cm[0], cm[1])
     return cls_buf, reg_buf
 
 
@@ -497,7 +525,7 @@ class PostProcess:
 
     def __init__(self, b: Builder, cls_buf, reg_buf, pyr: Pyramid, num_classes, anchor_generator, test_cfg,
                  target_means=(0., 0., 0., 0.), target_stds=(1., 1., 1., 1.), img_shapes=None, scale_factors=None,
-                 rescale=False, clip_border=True):
+                 rescale=False, clip_border=True, clsmax=None):
         tc = dict(test_cfg)
         nms_cfg = tc['nms']
         if nms_cfg.get('type', 'nms') != 'nms':
@@ -512,7 +540,8 @@ class PostProcess:
         # ONE batched decode and ONE batched NMS for all images of the step (image = blockIdx.y)
         self.dp = ops.make_decode_plan(cls_buf, reg_buf, pyr.level_hw, anchor_generator.strides, pyr.level_off, pyr.level_off,
                                        cls_buf.shape[-1], reg_buf.shape[-1], num_classes, A, anchor_generator.base_anchors,
-                                       tc.get('nms_pre', -1), target_means, target_stds, 16 / 1000, shapes, sfs, rescale, batch=nb_)
+                                       tc.get('nms_pre', -1), target_means, target_stds, 16 / 1000, shapes, sfs, rescale, batch=nb_,
+                                       clsmax=clsmax)
         self.nb = ops.NmsBuffers(self.dp.n_cand, num_classes, tc['max_per_img'], b.dev, batch=nb_)
         b.plan.keep += [self.dp, self.nb]
         b.plan.add('decode', lib().llv_retina_decode_topk, (C.byref(self.dp.desc),), 0.0,
@@ -562,7 +591,15 @@ class RetinaNetPlan:
                                            fuse_blocks=_os.environ.get("LLV_FUSED_BOTTLENECK", "1") != '0')
         self.pyramid = build_fpn(b, sd, self.backbone_feats, start_level, -1, num_outs, add_extra_convs,
                                  relu_before_extra_convs, p=prefix + 'neck.')
-        self.cls_buf, self.reg_buf = build_retina_head(b, sd, self.pyramid, stacked_convs, logits_f32, p=prefix + 'bbox_head.')
+        tcfg = dict(test_cfg or DEFAULT_TEST_CFG)
+        # the class convolution's epilogue does the first step of get_bboxes (per-anchor class maximum) and stores only the logit segments
+        # that can pass score_thr: the dense fp32 logits (941 MB per 16-frame step) are neither written nor read back by the decode
+        self.clsmax = None
+        if logits_f32 and fused_cls_eligible(sd, prefix + 'bbox_head.', num_classes):
+            self.cls_buf, self.reg_buf, self.clsmax = build_retina_head(b, sd, self.pyramid, stacked_convs, logits_f32, p=prefix + 'bbox_head.',
+                                                                        fused_cls=dict(num_classes=num_classes, score_thr=tcfg.get('score_thr', 0.0)))
+        else:
+            self.cls_buf, self.reg_buf = build_retina_head(b, sd, self.pyramid, stacked_convs, logits_f32, p=prefix + 'bbox_head.')
         if isinstance(anchor_generator, AnchorGenerator):
             ag = anchor_generator
         else:
@@ -573,8 +610,8 @@ class RetinaNetPlan:
         self.anchor_generator = ag
         if img_shapes is None:
             img_shapes = [(height, width, 3)] * batch
-        self.post = PostProcess(b, self.cls_buf, self.reg_buf, self.pyramid, num_classes, ag, test_cfg or DEFAULT_TEST_CFG,
-                                target_means, target_stds, img_shapes, scale_factors, rescale)
+        self.post = PostProcess(b, self.cls_buf, self.reg_buf, self.pyramid, num_classes, ag, tcfg,
+                                target_means, target_stds, img_shapes, scale_factors, rescale, clsmax=self.clsmax)
 
     def results(self):
         return self.post.results()

@@ -225,8 +225,9 @@ def conv_out_size(h, w, pc: PackedConv):
 def make_conv_desc(pc: PackedConv, xs: Sequence[torch.Tensor], y: torch.Tensor, batch: int,
                    segs: Sequence[tuple], x_ld: int, y_ld: int, res: Optional[torch.Tensor] = None,
                    res_ld: int = 0, flags: int = 0, res_hw=(0, 0), tile: int = 0, k_splits: int = 0,
-                   y_group_stride: int = 0, act_slope: float = 0.0, ps_out=(0, 0)) -> ConvDesc:
-    """segs: [(h, w, ho, wo, x_pixel_off, y_pixel_off), ...]"""
+                   y_group_stride: int = 0, act_slope: float = 0.0, ps_out=(0, 0), clsmax=None) -> ConvDesc:
+    """segs: [(h, w, ho, wo, x_pixel_off, y_pixel_off), ...]. clsmax = (clsmax uint32 [rows][A], seg_written uint8 [rows][tiles], cls_c,
+    store_thr) with the LLV_CONV_CLSMAX flag (include/llv.h)."""
     d = ConvDesc()
     for i in range(_lib.LLV_MAX_SRC):
         d.x[i] = xs[i].data_ptr() if i < len(xs) else 0
@@ -252,6 +253,8 @@ def make_conv_desc(pc: PackedConv, xs: Sequence[torch.Tensor], y: torch.Tensor, 
     d.act_slope = act_slope
     d.ps_out_h, d.ps_out_w = ps_out
     d.dilation = max(int(getattr(pc, 'dilation', 1)), 1)
+    if clsmax is not None:
+        d.clsmax, d.seg_written, d.cls_c, d.store_thr = clsmax[0].data_ptr(), clsmax[1].data_ptr(), int(clsmax[2]), float(clsmax[3])
     if pc.w_halo is not None and d.dilation == 1 and len(segs) == 1 and tile == 0 and segs[0][0] == segs[0][2] and segs[0][1] == segs[0][3]:
         d.w_halo, d.halo_bn = pc.w_halo.data_ptr(), pc.halo_bn
     else:
@@ -488,9 +491,9 @@ def set_decode_image_params(d: DecodeDesc, img_shapes, scale_factors, rescale, c
 
 def make_decode_plan(cls: torch.Tensor, reg: torch.Tensor, level_hw, strides, cls_off, reg_off, cls_ld, reg_ld,
                      num_classes, num_anchors, base_anchors, nms_pre, means, stds, wh_ratio_clip, img_shape,
-                     scale_factor, rescale, batch: int = 1) -> DecodePlan:
+                     scale_factor, rescale, batch: int = 1, clsmax=None) -> DecodePlan:
     """batch > 1: img_shape / scale_factor are per-image lists; level l of image n starts n*h*w pixels after cls_off[l];
-    outputs are (batch, n_cand, ...)."""
+    outputs are (batch, n_cand, ...). clsmax = (clsmax, seg_written) tensors of the LLV_CONV_CLSMAX launch that wrote `cls`."""
     _need_gpu(cls, reg)
     if batch > _lib.LLV_MAX_BATCH:
         raise LlvError(f'{batch} images per step: the post-processing descriptors take at most LLV_MAX_BATCH = {_lib.LLV_MAX_BATCH} '
@@ -531,9 +534,14 @@ def make_decode_plan(cls: torch.Tensor, reg: torch.Tensor, level_hw, strides, cl
     ws = torch.empty((max(wsb, 256),), device=dev, dtype=torch.uint8)
     d.boxes, d.scores, d.cand_anchor = boxes.data_ptr(), scores.data_ptr(), cand.data_ptr()
     d.workspace, d.workspace_bytes = ws.data_ptr(), wsb
+    keep = [cls, reg]
+    if clsmax is not None:
+        d.clsmax, d.seg_written = clsmax[0].data_ptr(), clsmax[1].data_ptr()
+        d.seg_tiles = (num_anchors * num_classes + 127) // 128
+        keep += list(clsmax)
     if batch == 1:
         boxes, scores, cand = boxes[0], scores[0], cand[0]
-    return DecodePlan(d, boxes, scores, cand, ws, ba, n_cand, keep=[cls, reg])
+    return DecodePlan(d, boxes, scores, cand, ws, ba, n_cand, keep=keep)
 
 
 def retina_decode_topk(plan: DecodePlan):

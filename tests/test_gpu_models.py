@@ -452,3 +452,46 @@ def test_dark_resnet_convlstm_stage_vs_oracle(dev):
     with pytest.raises(LlvError, match='Sizes of tensors must match'):
         m(smooth_image(2, H, W, seed=1).to(dev))
     assert m(smooth_image(1, H, W, seed=1).to(dev))[0].shape == (1, 512, H // 8, W // 8)
+
+
+@pytest.mark.parametrize('h,w,ncls,batch', [(192, 256, 80, 2), (128, 160, 16, 1)])
+def test_fused_class_maximum_epilogue_equals_the_dense_path(dev, monkeypatch, h, w, ncls, batch):
+    """LLV_CONV_CLSMAX: the class convolution keeps every anchor's maximum logit in its epilogue and stores only the
+    128-channel logit segments that can pass score_thr; the decode reads those instead of the dense fp32 logits. Against the SAME plan
+    built with LLV_FUSED_CLS=0 (dense fp32 logits + class_max_kernel): candidate anchors, boxes and order identical; candidate scores
+    identical wherever they exceed score_thr (0 otherwise); detections and labels bit for bit; most segments are not stored."""
+    from lowlightenvironmentvideoobjectdetection_amd import engine, ops
+    reg = _registry()
+    det = randomize(reg.build_detector(retinanet_cfg(num_classes=ncls)), seed=17, cls_bias=-1.5)
+    img = smooth_image(batch, h, w, seed=18)
+    calibrate_cls(det, img[:1], target_mean=-5.0)
+    sd = det.state_dict()
+    tcfg = dict(det.bbox_head.test_cfg)
+
+    def run(fused):
+        monkeypatch.setenv('LLV_FUSED_CLS', '1' if fused else '0')
+        p = engine.RetinaNetPlan(sd, ncls, batch, h, w, dev, test_cfg=tcfg)
+        assert (p.clsmax is not None) == fused
+        kernels = [p.plan.kernel_of.get(s[0]) for s in p.plan.steps if s[0] == 'head.retina_cls']
+        assert kernels == ['conv3x3_tap_kernel<128>'], kernels
+        ops.pack_input(img.to(dev), 8, out=p.x_in)
+        for _ in range(2):                       # twice: the running maxima are reset by the decode for the next step
+            p.plan.run()
+        torch.cuda.synchronize()
+        dp = p.post.dp
+        return p, dp.cand_anchor.clone().cpu(), dp.boxes.clone().cpu(), dp.scores.clone().cpu(), p.results()
+    pf, ca_f, bx_f, sc_f, res_f = run(True)
+    pd, ca_d, bx_d, sc_d, res_d = run(False)
+    assert torch.equal(ca_f, ca_d) and torch.equal(bx_f, bx_d)
+    thr = tcfg['score_thr']
+    above = sc_d > thr
+    assert above.sum().item() > 50
+    assert torch.equal(sc_f[above], sc_d[above])
+    assert bool(((sc_f == sc_d) | (sc_f == 0)).all()) and bool((sc_f[~above] <= thr).all())
+    for (df, lf), (dd, ld_) in zip(res_f, res_d):
+        assert torch.equal(df, dd) and torch.equal(lf, ld_) and len(df) > 5
+    segw = pf.clsmax[1]
+    frac = float(segw.float().mean())
+    print(f'{ncls} classes, batch {batch}: {frac * 100:.1f} % of the 128-channel logit segments stored; {int(above.sum())} candidate scores above score_thr')
+    assert frac < 0.5
+    assert int(pf.clsmax[0].abs().max()) == 0          # left zeroed for the next step
