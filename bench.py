@@ -391,8 +391,9 @@ def selsa_bench(args, world, rank, dev):
             'unit': 'frames/s', 'n_gpus': world, 'steps': args.steps, 'warmup': args.warmup, 'ms_per_step': round(dt / args.steps * 1e3, 4),
             'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None, 'dtype': 'f16', 'data': 'synthetic',
             'config': {'workload': f'SURVEY 8f.4: SELSA (FasterRCNN R-50 DC5 + ChannelMapper + RPN 300 proposals + SelsaRoIHead, {NC} classes), '
-                                   f'{args.width}x{args.height} frames, 2 reference frames in the memo, module-level eager calls',
-                       'frames_per_step': 1, 'hip_graph': False, 'detections_last_step': int(sum(len(r) for r in res))}}), flush=True)
+                                   f'{args.width}x{args.height} frames, 2 reference frames in the memo; frame 0 of the video through the module-level path, every key frame '
+                                   f'after it = one captured launch list (selsa_plan.SelsaKeyPlan)',
+                       'frames_per_step': 1, 'hip_graph': bool(model.use_key_plan), 'detections_last_step': int(sum(len(r) for r in res))}}), flush=True)
     if world > 1:
         dist.destroy_process_group()
 

@@ -102,9 +102,10 @@ typedef struct llv_extents {
                                 * get_bboxes (anchor_head.py:636-711: sigmoid, per-anchor class maximum) in its epilogue: with OUT_F32 on the
                                 * 3x3/s1/p1 tap kernel (128-channel tile), channels a*cls_c + c. The launch atomically maximises
                                 * clsmax[row*A + a] (A = cout / cls_c) with the order-preserving uint encoding of every logit of anchor a, and
-                                * stores a pixel's 128-channel segment of y only if one of its logits exceeds store_thr, recording that in
-                                * seg_written[row*ceil(cout/128) + tile]. llv_retina_decode_topk reads both (llv_decode_desc.clsmax /
-                                * seg_written): the dense fp32 logits are neither written in full nor read back. cls_c % 16 == 0. */
+                                * stores a pixel's 16-channel block of y only if one of its logits exceeds store_thr, recording that as bit
+                                * (block % 8) of seg_written[row*ceil(cout/128) + block/8]. llv_retina_decode_topk reads both
+                                * (llv_decode_desc.clsmax / seg_written): the dense fp32 logits are neither written in full nor read back.
+                                * cls_c % 16 == 0. */
 
 /*
  * One convolution launch, implicit GEMM on MFMA (fp16 in, fp32 accumulate).
@@ -176,7 +177,7 @@ typedef struct llv_conv_desc {
     int64_t offset_max;
     /* LLV_CONV_CLSMAX (see the flag): */
     uint32_t* clsmax;        /* [rows of y][cout / cls_c], zero before the launch (llv_retina_decode_topk leaves it zeroed again) */
-    uint8_t* seg_written;    /* [rows of y][ceil(cout / 128)], every entry of a computed pixel written (0 / 1) */
+    uint8_t* seg_written;    /* [rows of y][ceil(cout / 128)]: one bit per 16-channel block; every entry of a computed pixel is written */
     int32_t cls_c;           /* classes per anchor */
     float store_thr;         /* a segment is stored when one of its logits is > store_thr: pass logit(score_thr) minus a margin */
 } llv_conv_desc;
@@ -296,9 +297,9 @@ typedef struct llv_decode_desc {
     float img_h_b[LLV_MAX_BATCH], img_w_b[LLV_MAX_BATCH];
     float scale_factor_b[LLV_MAX_BATCH][4];
     /* cls written by a LLV_CONV_CLSMAX launch (both NULL otherwise): clsmax [rows][A] holds every anchor's maximum logit (read instead of
-     * the logits for the per-anchor score, and reset to zero here); seg_written [rows][seg_tiles] says which 128-channel segments of a
-     * pixel's logits were stored -- a candidate's classes in a segment that was not read as score 0 (all of them were <= store_thr, i.e.
-     * below score_thr: the NMS that follows drops them either way). logits_f32 must be 1. */
+     * the logits for the per-anchor score, and reset to zero here); seg_written [rows][seg_tiles] says, one bit per 16-channel block,
+     * which parts of a pixel's logits were stored -- a candidate's classes in a block that was not are read as score 0 (all of them were
+     * <= store_thr, i.e. below score_thr: the NMS that follows drops them either way). logits_f32 must be 1. */
     uint32_t* clsmax;
     const uint8_t* seg_written;
     int32_t seg_tiles;

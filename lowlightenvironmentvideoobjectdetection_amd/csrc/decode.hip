@@ -344,11 +344,13 @@ __global__ void gather_decode_kernel(const DecK k) {
     const long oslot = (long)img * N_cand + slot;
     const T* pc = reinterpret_cast<const T*>(k.cls) + (k.cls_off[l] + ipix + cell) * (long)k.cls_ld + (long)an * k.C;
     if (k.segw) {
-        // a class whose 128-channel segment the convolution did not store had every logit <= its store threshold (below score_thr):
-        // score 0, which the NMS drops exactly as it would the true value
+        // a class whose 16-channel block the convolution did not store had every logit of the block <= its store threshold (below
+        // score_thr): score 0, which the NMS drops exactly as it would the true value. One byte per 128 channels, bit = block.
         const unsigned char* fl = k.segw + (k.cls_off[l] + ipix + cell) * (long)k.seg_tiles;
-        for (int c = threadIdx.x; c < k.C; c += blockDim.x)
-            k.scores[oslot * k.C + c] = fl[(an * k.C + c) >> 7] ? sigmoidf_((float)pc[c]) : 0.f;
+        for (int c = threadIdx.x; c < k.C; c += blockDim.x) {
+            const int ch = an * k.C + c;
+            k.scores[oslot * k.C + c] = ((fl[ch >> 7] >> ((ch >> 4) & 7)) & 1) ? sigmoidf_((float)pc[c]) : 0.f;
+        }
     } else {
         for (int c = threadIdx.x; c < k.C; c += blockDim.x) k.scores[oslot * k.C + c] = sigmoidf_((float)pc[c]);
     }

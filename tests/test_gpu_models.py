@@ -473,7 +473,7 @@ def test_fused_class_maximum_epilogue_equals_the_dense_path(dev, monkeypatch, h,
         p = engine.RetinaNetPlan(sd, ncls, batch, h, w, dev, test_cfg=tcfg)
         assert (p.clsmax is not None) == fused
         kernels = [p.plan.kernel_of.get(s[0]) for s in p.plan.steps if s[0] == 'head.retina_cls']
-        assert kernels == ['conv3x3_tap_kernel<128>'], kernels
+        assert len(kernels) == 1 and (not fused or kernels == ['conv3x3_tap_kernel<128>']), kernels      # the segment flags are per 128-channel tile
         ops.pack_input(img.to(dev), 8, out=p.x_in)
         for _ in range(2):                       # twice: the running maxima are reset by the decode for the next step
             p.plan.run()
@@ -482,16 +482,29 @@ def test_fused_class_maximum_epilogue_equals_the_dense_path(dev, monkeypatch, h,
         return p, dp.cand_anchor.clone().cpu(), dp.boxes.clone().cpu(), dp.scores.clone().cpu(), p.results()
     pf, ca_f, bx_f, sc_f, res_f = run(True)
     pd, ca_d, bx_d, sc_d, res_d = run(False)
-    assert torch.equal(ca_f, ca_d) and torch.equal(bx_f, bx_d)
     thr = tcfg['score_thr']
     above = sc_d > thr
     assert above.sum().item() > 50
-    assert torch.equal(sc_f[above], sc_d[above])
-    assert bool(((sc_f == sc_d) | (sc_f == 0)).all()) and bool((sc_f[~above] <= thr).all())
-    for (df, lf), (dd, ld_) in zip(res_f, res_d):
-        assert torch.equal(df, dd) and torch.equal(lf, ld_) and len(df) > 5
+    dense_kernel = [pd.plan.kernel_of.get(s[0]) for s in pd.plan.steps if s[0] == 'head.retina_cls'][0]
+    if dense_kernel.startswith('conv3x3_tap_kernel'):
+        # the dense plan's class convolution is a tap kernel too (64- or 128-channel tile: the same accumulation order): bit for bit
+        assert torch.equal(ca_f, ca_d) and torch.equal(bx_f, bx_d)
+        assert torch.equal(sc_f[above], sc_d[above])
+        assert bool(((sc_f == sc_d) | (sc_f == 0)).all()) and bool((sc_f[~above] <= thr).all())
+        for (df, lf), (dd, ld_) in zip(res_f, res_d):
+            assert torch.equal(df, dd) and torch.equal(lf, ld_) and len(df) > 5
+    else:
+        # a small launch: the dense plan's planner took the split-K implicit-GEMM kernel, whose sums are accumulated in another order
+        # (last-bit differences in the logits); the fused epilogue always runs on the tap kernel
+        same = ca_f == ca_d
+        assert same.float().mean().item() > 0.99
+        assert torch.allclose(sc_f[same][above[same]], sc_d[same][above[same]], atol=2e-5)
+        assert bool((sc_f[~above & same] <= thr + 1e-5).all())
+        for (df, lf), (dd, ld_) in zip(res_f, res_d):
+            assert len(df) == len(dd) and len(df) > 5 and (lf == ld_).float().mean().item() > 0.95
     segw = pf.clsmax[1]
-    frac = float(segw.float().mean())
-    print(f'{ncls} classes, batch {batch}: {frac * 100:.1f} % of the 128-channel logit segments stored; {int(above.sum())} candidate scores above score_thr')
-    assert frac < 0.5
+    stored = sum(int(((segw >> b) & 1).sum()) for b in range(8))
+    frac = stored / (segw.shape[0] * (9 * ncls // 16))
+    print(f'{ncls} classes, batch {batch}: {frac * 100:.1f} % of the 16-channel logit blocks stored; {int(above.sum())} candidate scores above score_thr')
+    assert 0 < frac < 0.5
     assert int(pf.clsmax[0].abs().max()) == 0          # left zeroed for the next step
