@@ -318,9 +318,11 @@ class TwoStageDetector(BaseDetector):
             return tuple(x[:ref_len]), self.neck(tuple(x[ref_len:]))
         return self.neck(x)
 
-    def forward_train(self, *a, **k):
-        raise LlvError('the two-stage detector is trained through the SELSA video detectors here (SELSA / SelsaFastDVDnetDetect.forward_train: '
-                       'key + reference frames); a single-image Faster R-CNN step is outside SURVEY section 8')
+    def forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None, proposals=None, **kwargs):
+        """two_stage.py:115-176 for a StandardRoIHead (two_stage_train.faster_rcnn_forward_train). With a SELSA RoI head the detector is
+        trained through the SELSA video detectors (SELSA / SelsaFastDVDnetDetect.forward_train: key + reference frames)."""
+        from .two_stage_train import faster_rcnn_forward_train
+        return faster_rcnn_forward_train(self, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_masks, proposals, **kwargs)
 
     def simple_test(self, img, img_metas, proposals=None, rescale=False):
         """two_stage.py:178-190: backbone + neck, RPN proposals, roi_head.simple_test -- for a StandardRoIHead. (SelsaRoIHead pools from

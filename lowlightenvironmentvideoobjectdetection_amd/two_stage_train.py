@@ -32,7 +32,7 @@ class TwoStageBody(train_engine.TrainGraph):
         if neck is None or len(neck.convs) != 1 or len(bb.out_indices) < 1 or len(rpn.anchor_generator.strides) != 1:
             raise LlvError('two-stage training graph: a one-conv ChannelMapper on the last backbone output and a single RPN level '
                            '(the geometry of the SELSA configs)')
-        self.key = int(key)
+        self.key = None if key is None else int(key)       # None: the RPN runs on every frame (a plain Faster R-CNN batch)
         self._init_common(det, dict(model.named_parameters()), dict(model.named_buffers()), device, 1, loss_scale)
         self.n_frames = n_frames
         b = engine.Builder(device)
@@ -45,7 +45,7 @@ class TwoStageBody(train_engine.TrainGraph):
                                                                    1, (nconv.kernel_size[0] - 1) // 2), CONV_RELU if neck.act else 0)
         self.f, self.f_channels = f, nconv.out_channels
         pk = lambda name, pad: ops.pack_conv(sd[f'detector.rpn_head.{name}.weight'], sd[f'detector.rpn_head.{name}.bias'], 1, pad)
-        t = b.conv('detector.rpn_head.rpn_conv', f[self.key:self.key + 1], pk('rpn_conv', 1), CONV_RELU)
+        t = b.conv('detector.rpn_head.rpn_conv', f if self.key is None else f[self.key:self.key + 1], pk('rpn_conv', 1), CONV_RELU)
         self.rpn_cls = b.conv('detector.rpn_head.rpn_cls', t, pk('rpn_cls', 0), CONV_OUT_F32)
         self.rpn_reg = b.conv('detector.rpn_head.rpn_reg', t, pk('rpn_reg', 0), CONV_OUT_F32)
         self.n_cls, self.n_reg = rpn.num_anchors * rpn.cls_out_channels, rpn.num_anchors * 4
@@ -169,4 +169,47 @@ def selsa_fastdvd_forward_train(model, img, img_metas, gt_bboxes, gt_labels, ref
         losses[f'loss_denoising_{model.loss_type}'] = fn(denoised, clean_imgs)
     losses.update(_two_stage_losses(model, denoised.contiguous(), 2, img_metas, gt_bboxes, gt_labels, ref_img_metas, gt_bboxes_ignore,
                                     proposals, ref_proposals))
+    return losses
+
+
+class _AsVideoModel(torch.nn.Module):
+    """A detector under the name the training graph's parameter keys use (`detector.*`)."""
+
+    def __init__(self, det):
+        super().__init__()
+        self.detector = det
+
+
+def faster_rcnn_forward_train(det, img, img_metas, gt_bboxes, gt_labels, gt_bboxes_ignore=None, gt_masks=None, proposals=None, **kwargs):
+    """TwoStageDetector.forward_train (mmdetection/mmdet/models/detectors/two_stage.py:115-176) for a batch of still images with a
+    StandardRoIHead: backbone + neck + RPN convs of all images as one training graph (TwoStageBody with the RPN on every frame), RPN loss
+    and proposals per image, StandardRoIHead.forward_train on the graph's feature map."""
+    from .roi_heads import StandardRoIHead
+    if img.device.type != 'cuda':
+        raise LlvError('forward_train runs on the MI355X (conv forward/backward kernels); no CPU fallback')
+    if not isinstance(det.roi_head, StandardRoIHead):
+        raise LlvError('the two-stage detector with a SELSA RoI head is trained through the SELSA video detectors (key + reference frames)')
+    n, _, h, w = img.shape
+    dev = img.device
+    for m in (det, det.backbone, det.neck, det.rpn_head):               # inference plans hold packed copies of the parameters
+        if hasattr(m, '_plans'):
+            for k in [k for k in m._plans if not (isinstance(k, tuple) and k and k[0] == 'train2')]:
+                del m._plans[k]
+    wrap = det.__dict__.get('_llv_as_video')
+    if wrap is None:
+        wrap = det.__dict__['_llv_as_video'] = _AsVideoModel(det)
+    graph = det._plan(('train2', n, h, w, None, str(dev)), lambda: TwoStageBody(wrap, n, h, w, dev, key=None))
+    f, rpn_cls, rpn_reg = TwoStageFunction.apply(graph, img.float().contiguous(), *[graph.params[k] for k in graph.trainable])
+    x = (f,)
+    gt_bboxes = [b.to(dev) for b in gt_bboxes]
+    gt_labels = [l.to(dev) for l in gt_labels]
+    losses = dict()
+    if det.with_rpn:
+        tc, sc = det.train_cfg or {}, det.test_cfg or {}
+        rpn_losses, proposal_list = det.rpn_head.forward_train(x, img_metas, gt_bboxes, gt_labels=None, gt_bboxes_ignore=gt_bboxes_ignore,
+                                                               proposal_cfg=tc.get('rpn_proposal', sc.get('rpn')), outs=([rpn_cls], [rpn_reg]))
+        losses.update(rpn_losses)
+    else:
+        proposal_list = proposals
+    losses.update(det.roi_head.forward_train(x, img_metas, proposal_list, gt_bboxes, gt_labels, gt_bboxes_ignore, gt_masks, **kwargs))
     return losses

@@ -8,7 +8,7 @@ The samplers' `num` is sized so that every candidate is taken (RandomSampler dra
 import pytest
 import torch
 
-from helpers import img_meta, randomize, smooth_image
+from helpers import grad_metrics, img_meta, randomize, smooth_image
 
 pytestmark = pytest.mark.gpu
 
@@ -67,7 +67,7 @@ def _oracle_step(sd, frames, key, depth_kw, p_ext, num_fcs, ncls):
     return losses, p_key, p_ref, aux
 
 
-def _compare(model, dev, run, ref_losses, ref_grads, p_key, p_ref, frozen_prefixes, loss_tol, grad_tol):
+def _compare(model, dev, run, ref_losses, ref_grads, p_key, p_ref, frozen_prefixes, loss_tol, grad_tol, cos_tol=0.997):
     rpn = model.detector.rpn_head
     rpn.get_bboxes = lambda *a, **k: [p_key.to(dev)]
     rpn.simple_test_rpn = lambda *a, **k: [p.to(dev) for p in p_ref]
@@ -95,12 +95,17 @@ def _compare(model, dev, run, ref_losses, ref_grads, p_key, p_ref, frozen_prefix
         if scale < 1e-6 * top:                          # e.g. ref_fc_embed.bias: the softmax over the references cancels it exactly
             assert g.abs().max().item() < 1e-4 * top, k
             continue
-        errs.append(((g.float().cpu() - r).abs().max().item() / scale, k, scale))
+        e_, cos, l2, _ = grad_metrics(g, r)
+        errs.append((e_, k, scale, cos, l2))
         checked += 1
     errs.sort(reverse=True)
-    print('largest relative gradient errors:', [(round(e, 3), k, round(sc, 5)) for e, k, sc in errs[:8]])
-    for err, k, scale in errs:
-        assert err < (grad_tol if scale > 1e-4 * top else 2 * grad_tol), (k, err, scale)
+    print('largest relative gradient errors:', [(round(e, 3), k, round(sc, 5)) for e, k, sc, _, _ in errs[:8]])
+    print('lowest cosines:', [(k, round(c, 5), round(l2, 3)) for _, k, _, c, l2 in sorted(errs, key=lambda t: t[3])[:6]])
+    for err, k, scale, cos, l2 in errs:
+        big = scale > 1e-4 * top
+        assert err < (grad_tol if big else 2 * grad_tol), (k, err, scale)
+        # cosine / relative L2 beside the max-abs bound: a mis-routed gradient shows up as a cosine far from 1
+        assert cos > (cos_tol if big else 1 - 10 * (1 - cos_tol)) and l2 < (1.2 * grad_tol if big else 3 * grad_tol), (k, cos, l2, scale)
     return checked
 
 
@@ -179,7 +184,7 @@ def test_selsa_fastdvdnet_detect_forward_train_matches_oracle(dev):
     def run():
         return model(img=img.to(dev), img_metas=[meta], gt_bboxes=[b.to(dev) for b in GTB], gt_labels=[l.to(dev) for l in GTL],
                      ref_img=ref_img.to(dev), ref_img_metas=[[meta] * 4], ref_gt_bboxes=None, ref_gt_labels=None, return_loss=True)
-    checked = _compare(model, dev, run, ref_losses, ref_grads, p_key, p_ref, ('cleaner.',), 5e-2, 2e-1)
+    checked = _compare(model, dev, run, ref_losses, ref_grads, p_key, p_ref, ('cleaner.',), 5e-2, 2e-1, cos_tol=0.98)
     assert checked > 50, checked
     p = dict(model.named_parameters())
     assert p['detector.roi_head.bbox_roi_extractor.embed_network.conv.weight'].grad is not None

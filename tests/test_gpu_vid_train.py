@@ -7,7 +7,7 @@ import ctypes as C
 import pytest
 import torch
 
-from helpers import randomize, retinanet_cfg, smooth_image
+from helpers import grad_metrics, randomize, retinanet_cfg, smooth_image
 
 pytestmark = pytest.mark.gpu
 
@@ -178,14 +178,19 @@ def test_video_forward_train_matches_oracle(dev, kind, nr):
         scale = r.abs().max().item()
         if scale < 1e-10:
             continue
-        err = (g.float().cpu() - r).abs().max().item() / scale
+        err, cos, l2, _ = grad_metrics(g, r)
         worst = max(worst, err)
-        errs.append((err, k, scale))
+        errs.append((err, k, scale, cos, l2))
         checked += 1
     errs.sort(reverse=True)
-    print(kind, 'largest relative gradient errors:', [(round(e, 3), k, round(sc, 4)) for e, k, sc in errs[:6]])
-    for err, k, scale in errs:
-        assert err < (8e-2 if scale > 1e-4 * top else 1.5e-1), (k, err, scale)
+    print(kind, 'largest relative gradient errors:', [(round(e, 3), k, round(sc, 4)) for e, k, sc, _, _ in errs[:6]])
+    print(kind, 'lowest cosines:', [(k, round(c, 5), round(l2, 3)) for _, k, _, c, l2 in sorted(errs, key=lambda t: t[3])[:5]])
+    for err, k, scale, cos, l2 in errs:
+        big = scale > 1e-4 * top
+        assert err < (8e-2 if big else 1.5e-1), (k, err, scale)
+        # max-abs over max-abs cannot tell fp16 rounding from a mis-routed gradient; cosine and relative L2 can. The fp16
+        # storage floor itself is 3 % relative L2 through a handful of ReLU layers (tests/test_gpu_dcn_train.py measures it)
+        assert cos > (0.997 if big else 0.98) and l2 < (8e-2 if big else 2e-1), (k, cos, l2, scale)
     assert checked > 100, checked
     if kind != 'dff':
         assert params['aggregator.embed_convs.0.conv.weight'].grad is not None

@@ -495,3 +495,50 @@ def test_dff_two_stage_trains_the_flow_network_too(dev):
     assert len(rows) == 33
     assert sum(1 for r in rows if r[1] < 1.5e-1) >= 28 and all(r[1] < 3e-1 for r in rows), rows[:6]
     assert sum(1 for r in rows if r[2] > 0.99) >= 28 and all(r[2] > 0.95 for r in rows), sorted(rows, key=lambda t: t[2])[:6]
+
+
+def test_faster_rcnn_forward_train_matches_oracle(dev):
+    """TwoStageDetector.forward_train (two_stage.py:115-176) on one still image: the DC5 Faster R-CNN's four losses and every trainable
+    gradient against autograd over the oracle (the video detectors' shared tail, without the temporal part)."""
+    from oracle.anchors import AnchorGenerator
+    from oracle.rpn import rpn_head_forward
+    from oracle.training import MaxIoUAssigner
+    from oracle.two_stage import RandomSampler, rpn_loss, standard_roi_head_forward_train
+    model = _build('frcnn', 371, train=True)
+    img = smooth_image(1, H, W, seed=372)
+    meta = img_meta(H, W)
+    sd, names = _sd(model, grad=True)
+    x = _feats(sd, img, '')
+    cls, reg = rpn_head_forward(sd, [x], 'rpn_head.')
+    ag = AnchorGenerator(strides=[16], ratios=[0.5, 1.0, 2.0], scales=[4, 8, 16, 32])
+    ref = rpn_loss(cls, reg, GTB, [meta], ag, MaxIoUAssigner(0.7, 0.3, 0.3, ignore_iof_thr=-1), RandomSampler(4096, 0.5, -1, False), allowed_border=0)
+    ref = dict(loss_rpn_cls=sum(ref['loss_rpn_cls']), loss_rpn_bbox=sum(ref['loss_rpn_bbox']))
+    p_key = _props(sd, x, '')
+    roi_losses, _ = standard_roi_head_forward_train(sd, 'roi_head.bbox_head.', x, p_key, GTB[0], GTL[0], MaxIoUAssigner(0.5, 0.5, 0.5, ignore_iof_thr=-1),
+                                                    RandomSampler(512, 0.25, -1, True), NCLS)
+    ref.update(roi_losses)
+    sum(v for k, v in ref.items() if 'loss' in k).backward()
+    model = model.to(dev).train()
+    model.rpn_head.get_bboxes = lambda *a, **k: [p_key.to(dev)]
+    losses = model(img=img.to(dev), img_metas=[meta], gt_bboxes=[b.to(dev) for b in GTB], gt_labels=[l.to(dev) for l in GTL], return_loss=True)
+    tot = lambda v: sum(v) if isinstance(v, (list, tuple)) else v
+    for k, v in ref.items():
+        assert abs(float(tot(losses[k])) - float(v)) <= 2e-2 * max(abs(float(v)), 1e-2), (k, float(tot(losses[k])), float(v))
+    sum(tot(v) for k, v in losses.items() if 'loss' in k).backward()
+    params = dict(model.named_parameters())
+    top = max(sd[n].grad.abs().max().item() for n in names if sd[n].grad is not None)
+    rows = []
+    for k in names:
+        r = sd[k].grad
+        if k.startswith(('backbone.conv1', 'backbone.bn1', 'backbone.layer1.')) or r is None:
+            assert params[k].grad is None or params[k].grad.abs().max().item() == 0, k
+            continue
+        if r.abs().max().item() < 1e-6 * top:
+            continue
+        rows.append((k,) + grad_metrics(params[k].grad, r))
+    rows.sort(key=lambda t: -t[1])
+    print('faster r-cnn largest max-abs errors:', [(k, round(e, 3), round(c, 5), round(l2, 3)) for k, e, c, l2, s in rows[:5]])
+    for k, e, c, l2, s in rows:
+        big = s > 1e-4 * top
+        assert e < (8e-2 if big else 1.6e-1) and c > (0.999 if big else 0.99) and l2 < (4e-2 if big else 1e-1), (k, e, c, l2)
+    assert len(rows) > 40
