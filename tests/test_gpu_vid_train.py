@@ -190,7 +190,7 @@ def test_video_forward_train_matches_oracle(dev, kind, nr):
         assert err < (8e-2 if big else 1.5e-1), (k, err, scale)
         # max-abs over max-abs cannot tell fp16 rounding from a mis-routed gradient; cosine and relative L2 can. The fp16
         # storage floor itself is 3 % relative L2 through a handful of ReLU layers (tests/test_gpu_dcn_train.py measures it)
-        assert cos > (0.997 if big else 0.98) and l2 < (8e-2 if big else 2e-1), (k, cos, l2, scale)
+        assert cos > (0.999 if big else 0.98) and l2 < (5e-2 if big else 2e-1), (k, cos, l2, scale)      # first run: cosine >= 0.99957, L2 <= 3 %
     assert checked > 100, checked
     if kind != 'dff':
         assert params['aggregator.embed_convs.0.conv.weight'].grad is not None
