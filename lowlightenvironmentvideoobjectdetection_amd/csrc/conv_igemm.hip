@@ -1856,7 +1856,24 @@ __device__ __forceinline__ int patch_off32(int py, int px, int c8) {   // 64-B p
     return (py * PATCH_W + px) * 64 + ((c8 ^ (((px >> 2) & 1) << 1)) << 4);
 }
 
-template <int CK0, int BN2>
+// LDS layouts of convpair2_kernel<.., PL = true> (round 4; PL = false is the round-3 layout, kept for the same-box A/B LLV_CP2_PLANES=0):
+//  * the intermediate (the first conv's output on the halo tile, the second conv's pixel operand) is CHANNEL-CHUNK-MAJOR: four planes of
+//    340 x 16 B, plane c8 = channels 8 c8 .. 8 c8 + 7. The first conv's lanes hold 4 channels of 16 CONSECUTIVE halo pixels per fragment
+//    row: in the pixel-major image (64-B pixels) those 16 ds_write_b64 land on 4 bank positions (4-way conflict, 16 LDS-array cycles per
+//    wave-instruction instead of 4); in a plane they are 16 B apart (2-way). The second conv's ds_read_b128 stay conflict-free: the lane
+//    group {fch 0: pixels 0-3, 12-15; fch 1: pixels 4-11} reads two planes a multiple of 256 B apart at complementary pixel sets.
+//  * the InputCvBlock's 16-B-pixel patch has a row pitch of 50 pixels instead of 36: with a pitch = 2 (mod 16) the patch index of halo
+//    pixel hp under tap (tr, tq) is hp + 2 tr + tq (mod 16) -- consecutive across the wrap from one halo row to the next -- and the two
+//    taps a ds_read_b128 lane group mixes (t, t + 1) never put different pixels on one bank (the pair (0,2) | (1,0) did: 2-way).
+// PMC round 3: SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE = 29.5 % (OutputCvBlock) and 33.6 % (InputCvBlock) in the round-3 layout.
+constexpr int CP2_PLANE = 5632;                              // 340 pixels x 16 B rounded up to a multiple of 256 B; 4 planes = TAP_HBYTES
+static_assert(4 * CP2_PLANE <= TAP_HBYTES && CP2_PLANE >= HALO_PX * 16 && CP2_PLANE % 256 == 0, "halo planes");
+template <bool PL>
+__device__ __forceinline__ int cp2_halo_off(int hy, int hx, int c8) {
+    return PL ? c8 * CP2_PLANE + (hy * (HALO_TW + 2) + hx) * 16 : tap_halo_off(hy, hx, c8);
+}
+
+template <int CK0, int BN2, bool PL>
 __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a_in, const HaloArgs h, const PreArgs pre, const Pair2Args q) {
     // sliding window over a resident clip (llv_conv_desc.offset_dev): one scalar load, added to the source / residual bases
     ConvKArgs a = a_in;
@@ -1877,8 +1894,10 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a_in,
     constexpr int MTW = (NMT + 3) / 4;                       // per wave (<= 6)
     constexpr int NKS0 = (9 * CK0 + 31) / 32;                // k-steps of the first conv (3 or 9)
     constexpr int WROW0 = CK0 == 8 ? 104 : 296, WROW1 = 296;
-    constexpr int PATCH_B = PATCH_PX * CK0 * 2;              // 6912 / 27648
-    constexpr int PATCH_PIECES = (PATCH_B + 1023) / 1024;    // 7 / 27
+    constexpr int PW = (PL && CK0 == 8) ? 50 : PATCH_W;      // patch row pitch in pixels (see above)
+    constexpr int PPX = PW * PATCH_H;                        // patch pixels incl. the pitch padding
+    constexpr int PATCH_B = PPX * CK0 * 2;                   // 6912 (9600 with the 50-pixel pitch) / 27648
+    constexpr int PATCH_PIECES = (PATCH_B + 1023) / 1024;    // 7 (10) / 27
     constexpr int W0_B = 32 * WROW0 * 2, W1_B = BN2 * WROW1 * 2;               // bytes per group in global memory
     // LDS images of the weights: [k-step][row][32 halfs] with lds_off's swizzle (the padded global rows are gathered
     // into it by the DMA), so fragment reads are conflict-free under ds_read_b128's real lane grouping
@@ -1886,7 +1905,7 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a_in,
     constexpr int NPB = G > 1 ? 2 : 1;                       // patch / w0 buffers
     constexpr int O_PATCH = 0, O_W0 = O_PATCH + NPB * PATCH_PIECES * 1024, O_HALO = O_W0 + NPB * W0_PIECES * 1024;
     constexpr int O_W1 = O_HALO + TAP_HBYTES, SMEM = O_W1 + W1_PIECES * 1024;
-    constexpr int ROWB = (HALO_TW + 2) * 64, PROWB = PATCH_W * (CK0 * 2);
+    constexpr int ROWB = (HALO_TW + 2) * (PL ? 16 : 64), PROWB = PW * (CK0 * 2);
     constexpr int PPW = (PATCH_PIECES + 3) / 4, W0PW = (W0_PIECES + 3) / 4, W1PW = (W1_PIECES + 3) / 4;
     static_assert(2 * SMEM <= 160 * 1024, "two workgroups per CU");
     static_assert(256 * (BN2 + 8) * 2 <= TAP_HBYTES, "the epilogue tile reuses the halo buffer");
@@ -1927,10 +1946,10 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a_in,
         if (CK0 == 8) { pp = pc * 64 + lane; c8 = 0; }
         else { pp = pc * 16 + (lane >> 2); c8 = lane & 3; }
         ppy[i] = -1000000; ppx[i] = 0; pc8[i] = 0;
-        if (pp < PATCH_PX) {
-            const int py = pp / PATCH_W, px = pp - py * PATCH_W;
+        if (pp < PPX) {
+            const int py = pp / PW, px = pp - py * PW;
             if (CK0 == 32) c8 ^= ((px >> 2) & 1) << 1;
-            ppy[i] = py - 2; ppx[i] = px - 2; pc8[i] = c8 * 16;
+            if (px < PATCH_W) { ppy[i] = py - 2; ppx[i] = px - 2; pc8[i] = c8 * 16; }      // pitch padding: reads zero, like outside the image
         }
     }
     auto set_pvo = [&](const Tile& t) __attribute__((always_inline)) {
@@ -1993,13 +2012,13 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a_in,
                 int tap = ks * 4 + fch;                        // one 8-channel pixel per k chunk
                 tap = tap > 8 ? 8 : tap;                       // k >= 72: zero weights, any valid address
                 const int tr = tap / 3, tq = tap - 3 * tr;
-                pa[it][ks] = ((hy + tr) * PATCH_W + hx + tq) * 16;
+                pa[it][ks] = ((hy + tr) * PW + hx + tq) * 16;
             }
         } else {
 #pragma unroll
             for (int tq = 0; tq < 3; ++tq) pa[it][tq] = patch_off32(hy, hx + tq, fch);
         }
-        hw[it] = hp < HALO_PX ? tap_halo_off(hy, hx, fch >> 1) + (fch & 1) * 8 : -1;
+        hw[it] = hp < HALO_PX ? cp2_halo_off<PL>(hy, hx, fch >> 1) + (fch & 1) * 8 : -1;
         hyx[it] = hp < HALO_PX ? (hy << 8) | hx : -1;
     }
     auto inside_of = [&](const Tile& t) __attribute__((always_inline)) {
@@ -2016,7 +2035,7 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a_in,
 #pragma unroll
     for (int j = 0; j < TM; ++j)
 #pragma unroll
-        for (int tq = 0; tq < 3; ++tq) hb[j][tq] = tap_halo_off(2 * wave + (j >> 1), (j & 1) * 16 + frow + tq, fch);
+        for (int tq = 0; tq < 3; ++tq) hb[j][tq] = cp2_halo_off<PL>(2 * wave + (j >> 1), (j & 1) * 16 + frow + tq, fch);
 
     float4 bias4[TN2];
 #pragma unroll
@@ -2127,7 +2146,7 @@ __global__ __launch_bounds__(256, 2) void convpair2_kernel(const ConvKArgs a_in,
                     if (border && !((inside >> it) & 1u)) { o0 = z4; o1 = z4; }
                     if (hw[it] >= 0) {
                         *reinterpret_cast<f16x4*>(smem + O_HALO + hw[it]) = o0;          // channels 4*fch .. (16-B slot fch>>1)
-                        *reinterpret_cast<f16x4*>(smem + O_HALO + (hw[it] ^ 32)) = o1;   // channels 16 + 4*fch .. (slot 2 + (fch>>1))
+                        *reinterpret_cast<f16x4*>(smem + O_HALO + (PL ? hw[it] + 2 * CP2_PLANE : (hw[it] ^ 32))) = o1;   // channels 16 + 4*fch .. (chunk 2 + (fch>>1))
                     }
                     c0 = (f32x4){b0.x, b0.y, b0.z, b0.w};
                     c1 = (f32x4){b1.x, b1.y, b1.z, b1.w};
@@ -2762,6 +2781,9 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
 }
 
 
+// round-4 LDS layouts of the fused CvBlock kernels (halo planes, 50-pixel patch pitch); LLV_CP2_PLANES=0: the round-3 layouts (A/B)
+static bool cp2_planes() { const char* e = getenv("LLV_CP2_PLANES"); return !(e && e[0] == '0'); }
+
 struct PairPrepared {
     ConvKArgs k;
     HaloArgs h;
@@ -2849,8 +2871,14 @@ static int convpair_launch(const llv_inputcv_desc* p, void* stream, bool output_
     ConvKArgs& k = P.k;
     HaloArgs& h = P.h;
     if (P.v2) {
-        if (output_block) hipLaunchKernelGGL((convpair2_kernel<32, 16>), dim3(P.grid2), dim3(256), 0, (hipStream_t)stream, k, h, P.pre, P.q);
-        else hipLaunchKernelGGL((convpair2_kernel<8, 32>), dim3(P.grid2), dim3(256), 0, (hipStream_t)stream, k, h, P.pre, P.q);
+        static const bool planes = cp2_planes();
+        if (planes) {
+            if (output_block) hipLaunchKernelGGL((convpair2_kernel<32, 16, true>), dim3(P.grid2), dim3(256), 0, (hipStream_t)stream, k, h, P.pre, P.q);
+            else hipLaunchKernelGGL((convpair2_kernel<8, 32, true>), dim3(P.grid2), dim3(256), 0, (hipStream_t)stream, k, h, P.pre, P.q);
+        } else {
+            if (output_block) hipLaunchKernelGGL((convpair2_kernel<32, 16, false>), dim3(P.grid2), dim3(256), 0, (hipStream_t)stream, k, h, P.pre, P.q);
+            else hipLaunchKernelGGL((convpair2_kernel<8, 32, false>), dim3(P.grid2), dim3(256), 0, (hipStream_t)stream, k, h, P.pre, P.q);
+        }
         return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
     }
     if (output_block) hipLaunchKernelGGL((convpair_kernel<32, 16>), dim3(h.nblk), dim3(256), P.lds, (hipStream_t)stream, k, h, P.pre);
