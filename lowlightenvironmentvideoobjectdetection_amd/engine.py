@@ -169,8 +169,15 @@ class Builder:
                 d.tile, d.k_splits = t_.value, k_.value
         m = sum(batch * s[2] * s[3] for s in segs)
         flops = 2.0 * m * pc.true_macs_per_pixel
-        nbytes = 2.0 * (sum(batch * s[0] * s[1] for s in segs) * pc.cin * pc.groups + m * pc.cout * pc.groups) + \
-            pc.w.numel() * 2.0
+        # algorithmic bytes of the launch: input once, weights once, output once in its own type, the residual once where there is one
+        # (round 3 left the residual and the fp32 output's second half out: the identity read of a Bottleneck's conv3 made its counter
+        # bytes look like 1.9x "over-fetch", which it is not)
+        out_b = 4.0 if (flags & CONV_OUT_F32) else 2.0
+        nbytes = 2.0 * sum(batch * s[0] * s[1] for s in segs) * pc.cin * pc.groups + out_b * m * pc.cout * pc.groups + pc.w.numel() * 2.0
+        if res is not None:
+            nbytes += 2.0 * pc.cout * pc.groups * (batch * res_hw[0] * res_hw[1] if (flags & CONV_RES_UPS) else m)
+        if clsmax is not None:          # the mandatory part only: maxima + flags; the stored logit blocks depend on the data
+            nbytes += m * (4.0 * (pc.cout // clsmax[2]) + (pc.cout + 127) // 128) - out_b * m * pc.cout * pc.groups
         wsb = ops.conv_workspace_bytes(d)
         if wsb:
             if self._ws is None or self._ws.numel() < wsb:
