@@ -97,3 +97,18 @@ class FastDVDnet(PlannedModule):
             plan.plan.run()
             outs.append(ops.unpack_output(plan.out, 3))
         return torch.cat(outs, 0)
+
+
+from .backbones import ResNet  # noqa: E402
+
+
+@CLEANER.register_module()
+class ResCleaner(ResNet):
+    """mmtracking/mmtrack/models/cleaners/resclean.py:6-20: "ResNet cleaner for feature extracting to supervise noise feature" -- mmdet's
+    ResNet (depth 50 / 101) under the CLEANER registry, fed the clean frames; the authors' `llvod_l1234*` configs build it as
+    `cleaner=dict(type='ResCleaner', depth=50, ...)` and freeze it (`frozen_modules='cleaner'`). Forward = the ResNet launch plan."""
+
+    def __init__(self, depth=50, **kwargs):
+        if depth not in (50, 101):
+            raise KeyError(f'invalid depth {depth} for resnet')          # resclean.py:13-16: arch_settings holds 50 and 101 only
+        super().__init__(depth, **kwargs)

@@ -106,7 +106,7 @@ __device__ __forceinline__ void wave_hist_add(unsigned* base, unsigned key, bool
 // max goes to an LDS slot, and one lane per anchor folds that anchor's C/VEC slots. The order of the max does
 // not change its value, so the result is bit-identical to the one-lane-per-anchor loop (kept as VEC = 1 for
 // layouts whose rows are not 16-byte multiples).
-constexpr int kAnchorsPerBlock = 256;
+constexpr int kAnchorsPerBlock = 256;        // == the block size of the class-maximum kernels (class_max_from_conv_kernel: one anchor per lane)
 constexpr int kMaxVecPerAnchor = 32;
 template <typename T, int VEC>
 __global__ __launch_bounds__(256) void class_max_kernel(const DecK k) {
@@ -182,14 +182,21 @@ __global__ __launch_bounds__(256) void class_max_from_conv_kernel(const DecK k) 
     const long cls_l = k.cls_off[l] + (long)img * k.h[l] * k.w[l];
     const int first = (blockIdx.x - k.blk0[l]) * kAnchorsPerBlock;
     const int nb = n - first < kAnchorsPerBlock ? n - first : kAnchorsPerBlock;
-    for (int a = threadIdx.x; a < nb; a += 256) {
-        const int loc = first + a;                       // consecutive lanes read consecutive words: (cell, anchor) order is the array's
-        unsigned* p = k.clsmax + cls_l * (long)k.A + loc;
-        const unsigned key = *p;
-        *p = 0u;
-        const float m = key ? sigmoidf_(f32_from_ordered(key)) : 0.f;
-        ms_i[k.a0[l] + loc] = m;
-        atomicAdd(&lh[score_bin(m)], 1u);
+    {
+        // one anchor per lane (kAnchorsPerBlock == blockDim.x); most scores of a frame fall into a handful of low bins, so the
+        // histogram update is aggregated over the wave (one LDS atomic per distinct bin instead of 64 on the same word)
+        const int a = threadIdx.x;
+        const bool valid = a < nb;
+        float m = 0.f;
+        if (valid) {
+            const int loc = first + a;                   // consecutive lanes read consecutive words: (cell, anchor) order is the array's
+            unsigned* p = k.clsmax + cls_l * (long)k.A + loc;
+            const unsigned key = *p;
+            *p = 0u;
+            m = key ? sigmoidf_(f32_from_ordered(key)) : 0.f;
+            ms_i[k.a0[l] + loc] = m;
+        }
+        wave_hist_add(lh, (unsigned)score_bin(m), valid);
     }
     __syncthreads();
     unsigned* gh = hist_i + l * kBins;
