@@ -395,7 +395,7 @@ class LLVOD(TwoStageVideoMixin, BaseVideoDetector):
         """The sliding window of `simple_test` below over module-level feature maps: every frame (references first, then the key frame)
         goes through `detector.extract_feat` once and joins the last `memo_len` frames' maps; per level aggregator(x_key, the others)."""
         frame_id = img_metas[0].get('frame_id', -1)
-        if self.memo is None or frame_id == 0:
+        if self.memo is None or frame_id == 0 or 'feats' not in self.memo:     # (apis.prepare_segment leaves the ring form's counters)
             self.memo = dict(feats=None)
         new = []
         if ref_img is not None:
@@ -682,7 +682,10 @@ class FGFA(TwoStageVideoMixin, BaseVideoDetector):
         assert frame_id >= 0
         num_left = img_metas[0].get('num_left_ref_imgs', -1)
         frame_stride = img_metas[0].get('frame_stride', -1)
-        ext = lambda t: self.detector.extract_feat(t.float())
+        ext1 = lambda t: self.detector.extract_feat(t.float())
+        # references one frame per launch set, as every later reference enters the window (tile / split-K choices follow the launch
+        # size): a clip segment that starts mid-video then rebuilds bit for bit the window the one-rank run has slid to
+        ext = lambda t: ext1(t) if t.shape[0] == 1 else tuple(torch.cat(l, 0) for l in zip(*[ext1(t[i:i + 1]) for i in range(t.shape[0])]))
         if frame_stride < 1:                                            # adaptive stride
             if frame_id == 0 or self.memo is None:
                 if ref_img is None:
