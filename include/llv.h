@@ -647,7 +647,8 @@ int llv_multiclass_nms_batched_ex(const float* boxes, const float* scores, const
  * wgrad: dw[g][co][tap*cin + ci] += sum over output pixels of dy[p][g*cout + co] * x[p @ tap][g*cin + ci]
  *   d      geometry and the INPUT tensor of the forward conv (x[0], x_ld, cin (padded), cout, w_rows, k_pad, kh, kw,
  *          stride, pad, groups, batch, segment 0: seg_h/w/ho/wo, seg_xoff = pixel offset of x, seg_yoff = of dy);
- *          one segment and one source per call (a shared-weight conv over pyramid levels = one call per level)
+ *          one source; segments = the pyramid levels a shared filter ran on (3x3 / stride 1 / pad 1: one launch over the patches of
+ *          all levels; other filters: one launch per segment)
  *   dy     fp16 NHWC gradient of the conv output (before the activation), row stride dy_ld
  *   dw     fp32, the packed weight layout [groups][w_rows][k_pad]; ACCUMULATED into (fp32 atomics): zero it first
  *   db     optional fp32 [groups*cout]: db[g*cout + co] += sum_p dy[p][g*cout + co] (the bias / BN-shift gradient,
@@ -655,6 +656,26 @@ int llv_multiclass_nms_batched_ex(const float* boxes, const float* scores, const
  * dgrad (below) is llv_conv2d_nhwc_fwd on re-packed weights (flipped taps, in/out transposed; stride 2 as a small
  * stride-1 window + PixelShuffle). */
 int llv_conv2d_nhwc_wgrad(const llv_conv_desc* d, const void* dy, int dy_ld, float* dw, float* db, void* stream);
+
+/* The weight gradients of SEVERAL convolutions as one launch per kernel kind. A single-image training step has ~80 weight-gradient
+ * launches and most of them cover a fraction of the chip; side by side they share one launch ramp and need fewer pixel splits (each
+ * split ends in fp32 atomics over its dW tile).
+ *   llv_conv2d_nhwc_wgrad_plan   host only, no launch: the job(s) of one convolution (arguments as llv_conv2d_nhwc_wgrad) -- one job
+ *                                for a 3x3 / stride-1 / pad-1 filter over all its segments (kind 2: all nine taps in a workgroup), one
+ *                                per segment otherwise (kind 0 / 1: one tap per workgroup, 64 x 64 / 128 x 128 tiles). `share` in (0, 1]:
+ *                                the fraction of the launch's work this convolution is (sizes its pixel splits; 1 = a launch of its own).
+ *                                jobs: room for LLV_MAX_SEG entries; n_jobs: how many were written; n_wg of each is set, wg_begin is 0.
+ *   llv_conv2d_nhwc_wgrad_jobs   one launch over a DEVICE table of jobs of ONE kind. The caller lays the jobs' workgroups side by side:
+ *                                wg_begin (a multiple of 8: the kernels place splits on XCDs by workgroup index) and
+ *                                wg2job[w] = index of the job that owns workgroup w, for w < total_wgs. */
+#define LLV_WGRAD_JOB_ARGS 368
+typedef struct llv_wgrad_job {
+    int32_t kind, wg_begin, n_wg, reserved;
+    unsigned char args[LLV_WGRAD_JOB_ARGS]; /* opaque: the kernel's argument block */
+} llv_wgrad_job;
+int llv_conv2d_nhwc_wgrad_plan(const llv_conv_desc* d, const void* dy, int dy_ld, float* dw, float* db, float share, llv_wgrad_job* jobs,
+                               int* n_jobs);
+int llv_conv2d_nhwc_wgrad_jobs(const llv_wgrad_job* jobs, const uint16_t* wg2job, int kind, int total_wgs, void* stream);
 
 /* Once per optimizer step: module parameters (fp32, torch's (Cout, Cin, kh, kw)) -> the fp16 layouts the conv kernels read,
  * eval-mode BatchNorm folded in (s = gamma * rsqrt(var + eps); gamma = var = NULL: no BN). Replaces ops.pack_conv's host

@@ -70,6 +70,15 @@ class FoldJob(C.Structure):
                 ('out', C.c_void_p), ('n', C.c_int32)]
 
 
+LLV_WGRAD_JOB_ARGS = 368
+
+
+class WgradJob(C.Structure):
+    """llv_wgrad_job"""
+    _fields_ = [('kind', C.c_int32), ('wg_begin', C.c_int32), ('n_wg', C.c_int32), ('reserved', C.c_int32),
+                ('args', C.c_ubyte * LLV_WGRAD_JOB_ARGS)]
+
+
 class UnpackJob(C.Structure):
     """llv_unpack_job"""
     _fields_ = [('dw', C.c_void_p), ('db', C.c_void_p), ('w', C.c_void_p), ('gamma', C.c_void_p), ('mean', C.c_void_p), ('var', C.c_void_p),
@@ -230,6 +239,8 @@ SIGNATURES = {
     'llv_delta2bbox': (_I, [_P, _P, _P, _L, _I, _P, _P, _F, _F, _F, _I, _P, _P]),
     'llv_eval_tpfp': (_I, [_P, _P, _P, _P, _P, _I, _I, _I, _P, _I, _F, _I, _L, _P, _P, _P]),
     'llv_conv2d_nhwc_wgrad': (_I, [C.POINTER(ConvDesc), _P, _I, _P, _P, _P]),
+    'llv_conv2d_nhwc_wgrad_plan': (_I, [C.POINTER(ConvDesc), _P, _I, _P, _P, _F, C.POINTER(WgradJob), C.POINTER(C.c_int)]),
+    'llv_conv2d_nhwc_wgrad_jobs': (_I, [_P, _P, _I, _I, _P]),
     'llv_conv2d_nhwc_dgrad': (_I, [C.POINTER(ConvDesc), _P, _P, _I, _I, _I, _I, _I, _P, _I, _P, _I, _I, _P, _Z, _P]),
     'llv_pack_conv_weights': (_I, [_P, _P, _P, _F, _P] + [_I] * 13 + [_P]),
     'llv_fold_bias': (_I, [_P, _P, _P, _P, _P, _F, _P, _I, _P]),

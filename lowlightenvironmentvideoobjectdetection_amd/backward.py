@@ -86,20 +86,80 @@ def dgrad_weight(weight: torch.Tensor, stride: int, pad: int, cin_pad: int) -> T
 # launches
 # ----------------------------------------------------------------------------------------------
 def conv_wgrad(x: torch.Tensor, dy: torch.Tensor, dw: torch.Tensor, *, cin_pad: int, cout: int, w_rows: int, k_pad: int,
-               kh: int, kw: int, stride: int, pad: int, groups: int, batch: int, seg: tuple, x_ld: int, dy_ld: int,
-               db: Optional[torch.Tensor] = None, dilation: int = 1):
-    """Accumulate the weight gradient of one segment into dw (fp32 [groups][w_rows][k_pad]) and, if given, the bias
-    gradient into db (fp32 [groups*cout]). seg = (h, w, ho, wo, x_pixel_off, dy_pixel_off)."""
+               kh: int, kw: int, stride: int, pad: int, groups: int, batch: int, seg: Optional[tuple] = None, x_ld: int = 0, dy_ld: int = 0,
+               db: Optional[torch.Tensor] = None, dilation: int = 1, segs: Optional[list] = None):
+    """Accumulate the weight gradient into dw (fp32 [groups][w_rows][k_pad]) and, if given, the bias gradient into db (fp32
+    [groups*cout]). seg = (h, w, ho, wo, x_pixel_off, dy_pixel_off); `segs` = several of them (the pyramid levels a shared filter ran
+    on): one call, and for 3x3 / stride-1 filters one launch whose pixel splits run over the patches of all levels."""
+    segs = [seg] if segs is None else list(segs)
+    d = _wgrad_desc(x, cin_pad=cin_pad, cout=cout, w_rows=w_rows, k_pad=k_pad, kh=kh, kw=kw, stride=stride, pad=pad, groups=groups,
+                    batch=batch, segs=segs, x_ld=x_ld, dilation=dilation)
+    check(lib().llv_conv2d_nhwc_wgrad(C.byref(d), dy.data_ptr(), dy_ld, dw.data_ptr(), db.data_ptr() if db is not None else None,
+                                      _stream()), 'llv_conv2d_nhwc_wgrad')
+
+
+def _wgrad_desc(x, *, cin_pad, cout, w_rows, k_pad, kh, kw, stride, pad, groups, batch, segs, x_ld, dilation):
     d = ConvDesc()
     d.x[0] = x.data_ptr()
-    d.n_src, d.n_seg = 1, 1
+    d.n_src, d.n_seg = 1, len(segs)
     d.x_ld = x_ld
     d.cin, d.cout, d.w_rows, d.k_pad = cin_pad, cout, w_rows, k_pad
     d.kh, d.kw, d.stride, d.pad, d.groups, d.batch = kh, kw, stride, pad, groups, batch
     d.dilation = dilation
-    d.seg_h[0], d.seg_w[0], d.seg_ho[0], d.seg_wo[0], d.seg_xoff[0], d.seg_yoff[0] = seg
-    check(lib().llv_conv2d_nhwc_wgrad(C.byref(d), dy.data_ptr(), dy_ld, dw.data_ptr(), db.data_ptr() if db is not None else None,
-                                      _stream()), 'llv_conv2d_nhwc_wgrad')
+    for i, sg in enumerate(segs):
+        d.seg_h[i], d.seg_w[i], d.seg_ho[i], d.seg_wo[i], d.seg_xoff[i], d.seg_yoff[i] = sg
+    return d
+
+
+class WgradGroup:
+    """The weight gradients of several convolutions as one launch per kernel kind (llv_conv2d_nhwc_wgrad_plan / _jobs): `calls` are
+    the keyword sets of conv_wgrad (x, dy, dw first). Planned once -- every pointer is that of a static buffer of the training graph --
+    then `launch()` per step. A convolution's pixel splits are sized by its share of the group's multiply-adds."""
+
+    def __init__(self, calls, device):
+        import numpy as np
+        from ._lib import LLV_MAX_SEG, WgradJob
+        self.keep = []
+        work = []
+        for c in calls:
+            segs = c['segs']
+            work.append(float(sum(c['batch'] * sg[2] * sg[3] for sg in segs)) * c['cin_pad'] * c['cout'] * c['groups'] * c['kh'] * c['kw'])
+
+        def plan(c, share):
+            d = _wgrad_desc(c['x'], **{k: c[k] for k in ('cin_pad', 'cout', 'w_rows', 'k_pad', 'kh', 'kw', 'stride', 'pad', 'groups', 'batch',
+                                                          'segs', 'x_ld', 'dilation')})
+            jobs = (WgradJob * LLV_MAX_SEG)()
+            n = C.c_int(0)
+            check(lib().llv_conv2d_nhwc_wgrad_plan(C.byref(d), c['dy'].data_ptr(), c['dy_ld'], c['dw'].data_ptr(),
+                                                   c['db'].data_ptr() if c['db'] is not None else None, float(share), jobs, C.byref(n)),
+                  'llv_conv2d_nhwc_wgrad_plan')
+            return [jobs[i] for i in range(n.value)]
+        kinds = [plan(c, 1.0)[0].kind for c in calls]
+        tot = {k: sum(w for w, kk in zip(work, kinds) if kk == k) for k in set(kinds)}
+        by_kind = {}
+        for c, w, k in zip(calls, work, kinds):
+            self.keep += [c['x'], c['dy'], c['dw'], c['db']]
+            for j in plan(c, max(w / tot[k], 1e-3)):
+                by_kind.setdefault(j.kind, []).append(j)
+        self.tables = []
+        for kind, jobs in sorted(by_kind.items()):
+            assert len(jobs) < 65536
+            begin, w2j = 0, []
+            arr = (WgradJob * len(jobs))()
+            for i, j in enumerate(jobs):
+                C.memmove(C.byref(arr[i]), C.byref(j), C.sizeof(WgradJob))
+                arr[i].wg_begin = begin
+                n = (j.n_wg + 7) // 8 * 8
+                w2j += [i] * n
+                begin += n
+            t_jobs = torch.from_numpy(np.frombuffer(bytes(arr), dtype=np.uint8).copy()).to(device)
+            t_map = torch.from_numpy(np.asarray(w2j, dtype=np.uint16).view(np.int16).copy()).to(device)
+            self.tables.append((kind, t_jobs, t_map, begin))
+
+    def launch(self):
+        L, st = lib(), _stream()
+        for kind, t_jobs, t_map, total in self.tables:
+            check(L.llv_conv2d_nhwc_wgrad_jobs(t_jobs.data_ptr(), t_map.data_ptr(), kind, total, st), 'llv_conv2d_nhwc_wgrad_jobs')
 
 
 def relu_bwd(dy: torch.Tensor, y: Optional[torch.Tensor], dx: torch.Tensor, dy2: Optional[torch.Tensor] = None):

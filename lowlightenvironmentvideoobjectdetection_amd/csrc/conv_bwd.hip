@@ -15,6 +15,9 @@
 // weight decay 1e-4).
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
+#include <string.h>
+#include <type_traits>
 #include "llv.h"
 
 namespace {
@@ -29,6 +32,41 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 }
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned char* lds, int voff, int soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
+}
+
+// Transposing LDS read as inline assembly. Through the builtin the compiler cannot tell the read from the LDS destination of the
+// DMA loads and puts `s_waitcnt vmcnt(0)` in front of the first fragment read after every prefetch -- the stages requested for later
+// k-steps were waited for at once and a workgroup never had more than one stage in flight (found in round 4 in the ISA of both
+// weight-gradient kernels). The counter waits for these reads are therefore written by hand: lds_wait<N>() leaves at most N of the
+// wave's LDS reads outstanding and ties the registers it guards, so their first use cannot move in front of it.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(unsigned long)((__attribute__((address_space(3))) const unsigned char*)p);
+}
+__device__ __forceinline__ h4 tr_read_asm(unsigned addr) {
+    h4 v;
+    asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+struct Frag2 { h4 lo, hi; };
+__device__ __forceinline__ Frag2 frag_read(unsigned lo_addr, unsigned hi_addr) {
+    Frag2 f;
+    f.lo = tr_read_asm(lo_addr);
+    f.hi = tr_read_asm(hi_addr);
+    return f;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait(Frag2& f) {
+    asm volatile("s_waitcnt lgkmcnt(%2)" : "+v"(f.lo), "+v"(f.hi) : "n"(N));
+}
+template <int N>
+__device__ __forceinline__ void lds_wait4(Frag2& a, Frag2& b, Frag2& c, Frag2& d) {
+    asm volatile("s_waitcnt lgkmcnt(%8)" : "+v"(a.lo), "+v"(a.hi), "+v"(b.lo), "+v"(b.hi), "+v"(c.lo), "+v"(c.hi), "+v"(d.lo), "+v"(d.hi) : "n"(N));
+}
+__device__ __forceinline__ f16x8 frag_join(const Frag2& f) {
+    f16x8 r;
+    __builtin_memcpy(&r, &f.lo, 8);
+    __builtin_memcpy(reinterpret_cast<unsigned char*>(&r) + 8, &f.hi, 8);
+    return r;
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -53,7 +91,9 @@ struct WgArgs {
     int xoff, yoff;             // pixel offsets of image 0 in x / dy
     int m_total, m_per_split;
     unsigned x_bytes, dy_bytes;
-    int tiles_ci;
+    int tiles_ci, tiles_co, tiles, splits;      // tiles = tiles_co * tiles_ci * taps * groups
+    int xq, chunk;              // splits < 8: xq = XCDs per split, chunk = tiles per XCD; splits >= 8: xq = 0
+    int knock;                  // experiment knob (LLV_WGRAD_KNOCK): 1 = plain stores instead of atomics (wrong sums, timing only), 2 = no write
 };
 
 template <int BC>
@@ -63,7 +103,7 @@ __device__ __forceinline__ int wg_swz(int row) {
 }
 
 template <int BCO, int BCI>
-__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
+__device__ __forceinline__ void conv_wgrad_body(const WgArgs& a, const int bid) {
     constexpr int TMO = BCO / 32, TNI = BCI / 32;            // MFMA tiles per wave (2 x 2 waves)
     constexpr int RBA = BCO * 2, RBB = BCI * 2;              // LDS row bytes
     constexpr int STAGE = 32 * (RBA + RBB);
@@ -78,11 +118,21 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
 
     const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int wr = wave & 1, wc = wave >> 1;
-    const int tile_ci = blockIdx.x % a.tiles_ci, tile_co = blockIdx.x / a.tiles_ci;
+    // One-dimensional grid, XCD-aware (workgroups go round-robin over the 8 XCDs in dispatch order, each XCD has its own L2): every
+    // workgroup of a pixel split reads the same slab of dY and X, so a split's tiles stay on ONE XCD (splits >= 8: XCD x takes the
+    // splits x, x + 8, ..) or on 8 / splits of them (xq > 0). With the split as the slowest grid dimension every XCD pulled every
+    // slab through the fabric: 8x the compulsory traffic on launches that have nothing else to wait for.
+    const int xcd = bid & 7, idx = bid >> 3;
+    int split, tl;
+    if (a.xq == 0) { split = xcd + 8 * (idx / a.tiles); tl = idx % a.tiles; }
+    else { split = xcd / a.xq; tl = (xcd % a.xq) * a.chunk + idx; }
+    if (split >= a.splits || tl >= a.tiles) return;
+    const int tile_ci = tl % a.tiles_ci, t2 = tl / a.tiles_ci;
+    const int tile_co = t2 % a.tiles_co, ty = t2 / a.tiles_co;
     const int ntap = a.kh * a.kw;
-    const int tap = blockIdx.y % ntap, g = blockIdx.y / ntap;
+    const int tap = ty % ntap, g = ty / ntap;
     const int tr = tap / a.kw, tq = tap - tr * a.kw;
-    const int m0 = blockIdx.z * a.m_per_split;
+    const int m0 = split * a.m_per_split;
     const int m1 = m0 + a.m_per_split < a.m_total ? m0 + a.m_per_split : a.m_total;
     const int nrows = m1 - m0;
     if (nrows <= 0) return;
@@ -170,11 +220,6 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
     const _Float16 one = (_Float16)1.f;
     const f16x8 ones = {one, one, one, one, one, one, one, one};
 
-    auto tr_read = [&](const unsigned char* base, int off) __attribute__((always_inline)) {
-        const h4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4f16((__attribute__((address_space(3))) h4*)(base + off));
-        return lo;
-    };
-
     // every wave issues the same number of DMA instructions per step when PA and PB are multiples of 4 (both tile shapes: 8 + 8 or
     // 4 + 4 pieces), so "at most one step's worth outstanding" is a compile-time count
     constexpr int PER_STEP = PAW + PBW;
@@ -188,21 +233,18 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");      // ... for every wave, and everyone is done reading buffer (ks - 1) % 3
                                                              // (__syncthreads() would drain the DMA queue: it emits vmcnt(0))
         if (ks + 2 < nk) issue(ks + 2, cur >= 1 ? cur - 1 : NST - 1);      // (ks + 2) % 3 == (ks - 1) % 3
-        const unsigned char* sA = smem + cur * STAGE;
-        const unsigned char* sB = sA + 32 * RBA;
+        const unsigned sA = lds_addr(smem) + cur * STAGE;
+        const unsigned sB = sA + 32 * RBA;
+        Frag2 ra[TMO], rb[TNI];
+#pragma unroll
+        for (int i = 0; i < TMO; ++i) ra[i] = frag_read(sA + fa[i], sA + fa[i] + 4 * RBA);
+#pragma unroll
+        for (int j = 0; j < TNI; ++j) rb[j] = frag_read(sB + fb[j], sB + fb[j] + 4 * RBB);
         f16x8 af[TMO], bf[TNI];
 #pragma unroll
-        for (int i = 0; i < TMO; ++i) {
-            const h4 lo = tr_read(sA, fa[i]), hi = tr_read(sA, fa[i] + 4 * RBA);
-            __builtin_memcpy(&af[i], &lo, 8);
-            __builtin_memcpy(reinterpret_cast<unsigned char*>(&af[i]) + 8, &hi, 8);
-        }
+        for (int i = 0; i < TMO; ++i) { lds_wait<0>(ra[i]); af[i] = frag_join(ra[i]); }
 #pragma unroll
-        for (int j = 0; j < TNI; ++j) {
-            const h4 lo = tr_read(sB, fb[j]), hi = tr_read(sB, fb[j] + 4 * RBB);
-            __builtin_memcpy(&bf[j], &lo, 8);
-            __builtin_memcpy(reinterpret_cast<unsigned char*>(&bf[j]) + 8, &hi, 8);
-        }
+        for (int j = 0; j < TNI; ++j) { lds_wait<0>(rb[j]); bf[j] = frag_join(rb[j]); }
 #pragma unroll
         for (int i = 0; i < TMO; ++i)
 #pragma unroll
@@ -235,19 +277,308 @@ __global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) {
 #pragma unroll
             for (int e = 0; e < 4; ++e) {
                 const int co = co0 + wr * (BCO / 2) + i * 16 + 4 * (lane >> 4) + e;
-                if (co < a.cout) atomicAdd(dwg + (long)co * a.k_pad + tap * a.cin + ci, acc[i][j][e]);
+                if (co < a.cout) {
+                    if (a.knock == 0) atomicAdd(dwg + (long)co * a.k_pad + tap * a.cin + ci, acc[i][j][e]);
+                    else if (a.knock == 1) dwg[(long)co * a.k_pad + tap * a.cin + ci] = acc[i][j][e];
+                    else if (acc[i][j][e] == 123.456f) dwg[0] = 1.f;
+                }
             }
         }
     }
 }
 
+// Job tables: the weight gradients of several convolutions as ONE launch (llv_conv2d_nhwc_wgrad_jobs). A single-image training step
+// has ~80 of them and most cover a fraction of the chip for 15-30 us each, a third of which is launch ramp and the atomics of pixel
+// splits that only exist to fill the chip; side by side they need fewer splits and one ramp. wg2job[] names the job of every
+// workgroup; its arguments are read from the table and made wave-uniform (readfirstlane) before the body runs.
+template <class A>
+__device__ __forceinline__ A load_job_args(const llv_wgrad_job* __restrict__ job) {
+    static_assert(sizeof(A) % 4 == 0 && sizeof(A) <= sizeof(job->args), "job arguments fit the table entry");
+    A a;
+    const int* src = reinterpret_cast<const int*>(job->args);
+    int* dst = reinterpret_cast<int*>(&a);
+#pragma unroll
+    for (int i = 0; i < (int)(sizeof(A) / 4); ++i) dst[i] = __builtin_amdgcn_readfirstlane(src[i]);
+    return a;
+}
+
 template <int BCO, int BCI>
-int launch_wgrad(WgArgs& a, int splits, hipStream_t st) {
-    const int tiles_co = (a.cout + BCO - 1) / BCO;
-    a.tiles_ci = (a.cin + BCI - 1) / BCI;
-    dim3 grid(tiles_co * a.tiles_ci, a.kh * a.kw * a.groups, splits);
-    hipLaunchKernelGGL((conv_wgrad_kernel<BCO, BCI>), grid, dim3(256), 0, st, a);
-    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
+__global__ __launch_bounds__(256) void conv_wgrad_kernel(const WgArgs a) { conv_wgrad_body<BCO, BCI>(a, blockIdx.x); }
+
+template <int BCO, int BCI>
+__global__ __launch_bounds__(256) void conv_wgrad_jobs_kernel(const llv_wgrad_job* __restrict__ jobs, const unsigned short* __restrict__ wg2job) {
+    const llv_wgrad_job* job = jobs + __builtin_amdgcn_readfirstlane((int)wg2job[blockIdx.x]);
+    const int begin = __builtin_amdgcn_readfirstlane(job->wg_begin);
+    const WgArgs a = load_job_args<WgArgs>(job);
+    conv_wgrad_body<BCO, BCI>(a, (int)blockIdx.x - begin);
+}
+
+// tiles, splits -> the one-dimensional XCD-aware grid; returns its size
+template <class A>
+long set_grid(A& a, long splits) {
+    a.splits = (int)splits;
+    if (splits >= 8) { a.xq = 0; a.chunk = 0; return 8L * a.tiles * ((splits + 7) / 8); }
+    a.xq = 8 / (int)splits; a.chunk = (a.tiles + a.xq - 1) / a.xq;
+    return 8L * a.chunk;
+}
+
+// ------------------------------------------------------------------------------------------------
+// conv_wgrad3x3_kernel: the weight gradient of a 3x3 / stride 1 / pad 1 convolution with all NINE taps in one workgroup.
+// conv_wgrad_kernel above gives every tap its own workgroup: a 64 x 64 tile moves 8 KB from L2 to LDS for 16 MFMAs (32 FLOP/B) and
+// the launches sit at what the L2s deliver (1.08 GB in 88 us = 12 TB/s on the 92 x 160 head towers, 395 TFLOP/s). Here a workgroup
+// owns dW[64 co][9 taps][64 ci]; the pixel loop walks 8 x 8 patches of output pixels, per patch one dY tile (64 px x 64 co, 8 KB) and
+// one X tile with its one-pixel halo (10 x 10 px x 64 ci, 12.8 KB) serve 2 x 9 x 16 MFMAs: 72 B per MFMA instead of 512. Wave w holds
+// the 16 input channels 16w.. of all nine taps and all 64 output channels (9 x 4 accumulator tiles = 144 registers): the dY fragments
+// are read once per 32 pixels and reused by the nine taps, the X fragment of a tap is the same LDS tile at the tap's pixel shift
+// (the transposing read takes a row pointer per lane, so a shifted patch costs an instruction offset, not an address computation).
+// Both tiles keep memory's pixel-major rows (128 B per pixel); the 32-byte unit of a pixel is XOR-ed with (bit 1 of the column,
+// bit 0 of the row), which makes the 8 pixel rows x 32 B of a half-wave's transposing read cover all 64 banks once for every tap.
+// ------------------------------------------------------------------------------------------------
+struct Wg3Args {
+    const _Float16* x;
+    const _Float16* dy;
+    float* dw;
+    float* db;
+    int x_ld, dy_ld;
+    int cin, cout, k_pad, w_rows, groups, batch;
+    // segments (pyramid levels that share the filter): patches of all of them form one list that the pixel splits cut
+    int nseg;
+    int H[LLV_MAX_SEG], W[LLV_MAX_SEG];                 // = Ho, Wo
+    int xoff[LLV_MAX_SEG], yoff[LLV_MAX_SEG];           // pixel offset of image 0
+    int py_n[LLV_MAX_SEG], px_n[LLV_MAX_SEG];           // patches per image column / row
+    int pstart[LLV_MAX_SEG + 1];                        // first patch of the segment
+    int patches, per_split;
+    unsigned x_bytes, dy_bytes, dwg_bytes;              // dwg_bytes: cout rows of one group's dW (rows beyond are dropped by the buffer range)
+    int tiles_ci, tiles_co, tiles, splits, xq, chunk;   // as WgArgs
+    int knock;
+};
+
+__device__ __forceinline__ void conv_wgrad3x3_body(const Wg3Args& a, const int bid) {
+    constexpr int STAGE = 24 * 1024;          // 8 pieces of dY + 16 of X (13 used: 100 halo pixels), 1 KiB each: six per wave
+    constexpr int NST = 3;
+    constexpr int HW = 10;                    // halo tile width
+    __shared__ __attribute__((aligned(16))) unsigned char smem[NST * STAGE];
+
+    const int tid = threadIdx.x, lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int xcd = bid & 7, idx = bid >> 3;
+    int split, tl;
+    if (a.xq == 0) { split = xcd + 8 * (idx / a.tiles); tl = idx % a.tiles; }
+    else { split = xcd / a.xq; tl = (xcd % a.xq) * a.chunk + idx; }
+    if (split >= a.splits || tl >= a.tiles) return;
+    const int tile_ci = tl % a.tiles_ci, t2 = tl / a.tiles_ci;
+    const int tile_co = t2 % a.tiles_co, g = t2 / a.tiles_co;
+    const int co0 = tile_co * 64, ci0 = tile_ci * 64;
+    const int p0 = split * a.per_split;
+    const int p1 = p0 + a.per_split < a.patches ? p0 + a.per_split : a.patches;
+    const int np = p1 - p0;
+    if (np <= 0) return;
+
+    const __amdgpu_buffer_rsrc_t rY = make_rsrc(a.dy, a.dy_bytes);
+    const __amdgpu_buffer_rsrc_t rX = make_rsrc(a.x, a.x_bytes);
+
+    // ---- DMA slots of this wave: dY pieces wave, wave + 4 (patch rows), X pieces wave + 4 i (8 halo pixels each)
+    constexpr int NOCH = (int)0x80000000;
+    const int slot = lane >> 3, c16 = lane & 7;
+    int ych[2], ypy[2];                       // channel byte offset inside a pixel (NOCH: outside), patch row
+    const int ypx = slot;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+        const int py = wave + 4 * i;
+        const int f = ((ypx >> 1) & 1) | ((py & 1) << 1);
+        const int co = co0 + ((c16 ^ (f << 1)) << 3);
+        ypy[i] = py;
+        ych[i] = co < a.cout ? (g * a.cout + co) * 2 : NOCH;
+    }
+    int xch[4], xhy[4], xhx[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+        const int hp = (wave + 4 * i) * 8 + slot;
+        const int hy = hp / HW, hx = hp - hy * HW;
+        const int f = ((hx >> 1) & 1) | ((hy & 1) << 1);
+        const int ci = ci0 + ((c16 ^ (f << 1)) << 3);
+        xhy[i] = hy - 1; xhx[i] = hx - 1;
+        xch[i] = (hp < HW * HW && ci < a.cin) ? (g * a.cin + ci) * 2 : NOCH;
+    }
+    // ---- patch walk of the issue side: (segment, image, patch row, patch column); the segment's geometry in scalars
+    int iseg = 0, in_, ity, itx;
+    int sH, sW, sxo, syo, spy, spx;
+    // the segment table is read with a run-time index when the walk enters the next level: from LDS (indexing the argument block
+    // itself made the compiler spill it to scratch memory)
+    __shared__ int segtab[6][LLV_MAX_SEG + 3];
+    if (tid == 0) {
+#pragma unroll
+        for (int k = 0; k < LLV_MAX_SEG; ++k) {
+            segtab[0][k] = a.H[k]; segtab[1][k] = a.W[k]; segtab[2][k] = a.xoff[k];
+            segtab[3][k] = a.yoff[k]; segtab[4][k] = a.py_n[k]; segtab[5][k] = a.px_n[k];
+        }
+    }
+    __syncthreads();
+    auto load_seg = [&]() __attribute__((always_inline)) {
+        const int k = iseg < LLV_MAX_SEG ? iseg : LLV_MAX_SEG - 1;          // (one step past the last patch is never issued)
+        sH = __builtin_amdgcn_readfirstlane(segtab[0][k]); sW = __builtin_amdgcn_readfirstlane(segtab[1][k]);
+        sxo = __builtin_amdgcn_readfirstlane(segtab[2][k]); syo = __builtin_amdgcn_readfirstlane(segtab[3][k]);
+        spy = __builtin_amdgcn_readfirstlane(segtab[4][k]); spx = __builtin_amdgcn_readfirstlane(segtab[5][k]);
+    };
+    {
+        int pst = 0;
+#pragma unroll
+        for (int k = 1; k < LLV_MAX_SEG; ++k)
+            if (k < a.nseg && p0 >= a.pstart[k]) { iseg = k; pst = a.pstart[k]; }
+        load_seg();
+        const int per_img = spy * spx;
+        const int rel = p0 - pst;
+        in_ = rel / per_img;
+        const int r = rel - in_ * per_img;
+        ity = r / spx; itx = r - ity * spx;
+    }
+    auto issue = [&](int buf) __attribute__((always_inline)) {
+        unsigned char* sY = smem + buf * STAGE;
+        unsigned char* sX = sY + 8 * 1024;
+        const int y0 = ity * 8, x0 = itx * 8;
+        if (!(a.knock & 4)) {
+            const int pix0 = (in_ * sH + y0) * sW + x0;
+            const int by = (syo + pix0) * a.dy_ld * 2, bx = (sxo + pix0) * a.x_ld * 2;
+#pragma unroll
+            for (int i = 0; i < 2; ++i) {
+                const bool ok = ych[i] != NOCH && y0 + ypy[i] < sH && x0 + ypx < sW;
+                dma16(rY, sY + (wave + 4 * i) * 1024, ok ? by + (ypy[i] * sW + ypx) * a.dy_ld * 2 + ych[i] : (int)a.dy_bytes, 0);
+            }
+#pragma unroll
+            for (int i = 0; i < 4; ++i) {
+                const bool ok = xch[i] != NOCH && (unsigned)(y0 + xhy[i]) < (unsigned)sH && (unsigned)(x0 + xhx[i]) < (unsigned)sW;
+                dma16(rX, sX + (wave + 4 * i) * 1024, ok ? bx + (xhy[i] * sW + xhx[i]) * a.x_ld * 2 + xch[i] : (int)a.x_bytes, 0);
+            }
+        }
+        if (++itx == spx) {
+            itx = 0;
+            if (++ity == spy) {
+                ity = 0;
+                if (++in_ == a.batch) { in_ = 0; ++iseg; load_seg(); }
+            }
+        }
+    };
+
+    // ---- transposed fragment reads. k = 8 gq + (4 h + q): pixel (row gq, column 4 h + q) of a 4 x 8 half patch
+    const int gq = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
+    int fa[4][2], fb[3][2][2];
+#pragma unroll
+    for (int h = 0; h < 2; ++h) {
+        const int col = 4 * h + q;
+        const int f = ((col >> 1) & 1) | ((gq & 1) << 1);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) fa[i][h] = (gq * 8 + col) * 128 + ((i ^ f) << 5) + p * 8;
+    }
+#pragma unroll
+    for (int s3 = 0; s3 < 3; ++s3)
+#pragma unroll
+        for (int h = 0; h < 2; ++h) {
+            const int hx = 4 * h + q + s3;
+            const int fx = (hx >> 1) & 1;
+#pragma unroll
+            for (int rp = 0; rp < 2; ++rp) {
+                const int fy = (gq + rp) & 1;
+                fb[s3][h][rp] = 8 * 1024 + (gq * HW + hx) * 128 + ((wave ^ fx ^ (fy << 1)) << 5) + p * 8;
+            }
+        }
+
+    f32x4 acc[9][4];
+#pragma unroll
+    for (int t = 0; t < 9; ++t)
+#pragma unroll
+        for (int i = 0; i < 4; ++i) acc[t][i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const bool do_bias = a.db != nullptr && tile_ci == 0 && wave == 0;
+    f32x4 accb[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    const _Float16 one = (_Float16)1.f;
+    const f16x8 ones = {one, one, one, one, one, one, one, one};
+
+    constexpr int PER_STEP = 6;
+    issue(0);
+    if (np > 1) issue(1);
+    int cur = 0;
+    // two copies of the pixel loop (with / without the bias row sums) instead of a wave-uniform branch inside it: the branch cut the
+    // unrolled body into basic blocks the scheduler cannot move LDS reads across
+    auto pixel_loop = [&](auto with_bias) __attribute__((always_inline)) {
+    for (int ks = 0; ks < np; ++ks) {
+        if (ks + 1 < np) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(PER_STEP) : "memory");
+        else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (ks + 2 < np) issue(cur >= 1 ? cur - 1 : NST - 1);
+        const unsigned st = lds_addr(smem) + cur * STAGE;
+        if (a.knock & 8) { cur = cur + 1 == NST ? 0 : cur + 1; continue; }
+        // the X fragment of tap t + 1 is requested before the MFMAs of tap t are issued: lds_wait<2> = everything but those two reads
+        auto bfrag = [&](int t18) __attribute__((always_inline)) {
+            const int sub = t18 / 9, t = t18 - sub * 9, r = t / 3, s3 = t - r * 3;
+            const unsigned b = st + (4 * sub + r) * (HW * 128);
+            return frag_read(b + fb[s3][0][r & 1], b + fb[s3][1][r & 1]);
+        };
+        Frag2 rb = bfrag(0);
+#pragma unroll
+        for (int sub = 0; sub < 2; ++sub) {
+            Frag2 ra[4];
+#pragma unroll
+            for (int i = 0; i < 4; ++i) ra[i] = frag_read(st + sub * 4096 + fa[i][0], st + sub * 4096 + fa[i][1]);
+            f16x8 af[4];
+#pragma unroll
+            for (int t = 0; t < 9; ++t) {
+                Frag2 rn = rb;
+                const bool more = sub * 9 + t + 1 < 18;
+                if (more) rn = bfrag(sub * 9 + t + 1);
+                if (t == 0) {
+                    if (more) lds_wait4<2>(ra[0], ra[1], ra[2], ra[3]); else lds_wait4<0>(ra[0], ra[1], ra[2], ra[3]);
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) af[i] = frag_join(ra[i]);
+                    if constexpr (decltype(with_bias)::value) {
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) accb[i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], ones, accb[i], 0, 0, 0);
+                    }
+                }
+                if (more) lds_wait<2>(rb); else lds_wait<0>(rb);
+                const f16x8 bf = frag_join(rb);
+#pragma unroll
+                for (int i = 0; i < 4; ++i) acc[t][i] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[i], bf, acc[t][i], 0, 0, 0);
+                rb = rn;
+            }
+        }
+        cur = cur + 1 == NST ? 0 : cur + 1;
+    }
+    };
+    if (do_bias) pixel_loop(std::true_type{}); else pixel_loop(std::false_type{});
+    if (do_bias && (lane & 15) == 0) {
+#pragma unroll
+        for (int i = 0; i < 4; ++i)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+                const int co = co0 + i * 16 + 4 * (lane >> 4) + e;
+                if (co < a.cout) atomicAdd(a.db + g * a.cout + co, accb[i][e]);
+            }
+    }
+    // D[m = co][n = ci]: lane holds rows 4 * (lane >> 4) + e, column lane & 15. 576 values per lane: buffer atomics with one lane offset
+    // and a scalar offset per value; rows >= cout fall outside the buffer range and are dropped by the hardware (one compare-and-branch
+    // plus 64-bit address arithmetic per value made this epilogue 12 us of a 70 us launch)
+    if (a.knock & 3) return;
+    const __amdgpu_buffer_rsrc_t rW = make_rsrc(a.dw + (long)g * a.w_rows * a.k_pad, a.dwg_bytes);
+    const int ci = ci0 + wave * 16 + (lane & 15);
+    const int lane_off = ci < a.cin ? ((co0 + 4 * (lane >> 4)) * a.k_pad + ci) * 4 : 0x7ffffff0;
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            const int row_off = (i * 16 + e) * a.k_pad * 4;
+#pragma unroll
+            for (int t = 0; t < 9; ++t)
+                __builtin_amdgcn_raw_ptr_buffer_atomic_fadd_f32(acc[t][i][e], rW, lane_off, row_off + t * a.cin * 4, 0);
+        }
+}
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad3x3_kernel(const Wg3Args a) { conv_wgrad3x3_body(a, blockIdx.x); }
+
+__global__ __launch_bounds__(256, 2) void conv_wgrad3x3_jobs_kernel(const llv_wgrad_job* __restrict__ jobs, const unsigned short* __restrict__ wg2job) {
+    const llv_wgrad_job* job = jobs + __builtin_amdgcn_readfirstlane((int)wg2job[blockIdx.x]);
+    const int begin = __builtin_amdgcn_readfirstlane(job->wg_begin);
+    const Wg3Args a = load_job_args<Wg3Args>(job);
+    conv_wgrad3x3_body(a, (int)blockIdx.x - begin);
 }
 
 // ------------------------------------------------------------------------------------------------
@@ -607,48 +938,156 @@ __global__ __launch_bounds__(256) void unpack_wgrad_batched_kernel(const llv_unp
 
 }  // namespace
 
-extern "C" int llv_conv2d_nhwc_wgrad(const llv_conv_desc* d, const void* dy, int dy_ld, float* dw, float* db, void* stream) {
-    if (!d || !dy || !dw || !d->x[0] || d->n_seg != 1 || d->n_src != 1) return LLV_E_BADARG;
+static_assert(sizeof(WgArgs) <= LLV_WGRAD_JOB_ARGS && sizeof(Wg3Args) <= LLV_WGRAD_JOB_ARGS, "llv_wgrad_job holds either kernel's arguments");
+
+extern "C" int llv_conv2d_nhwc_wgrad_plan(const llv_conv_desc* d, const void* dy, int dy_ld, float* dw, float* db, float share,
+                                          llv_wgrad_job* jobs, int* n_jobs) {
+    if (!d || !dy || !dw || !jobs || !n_jobs || !d->x[0] || d->n_seg < 1 || d->n_seg > LLV_MAX_SEG || d->n_src != 1) return LLV_E_BADARG;
     if (d->cin <= 0 || (d->cin & 7) || d->cout <= 0 || d->groups < 1 || d->kh < 1 || d->kw < 1 || d->stride < 1 || d->pad < 0) return LLV_E_BADARG;
     if ((d->x_ld & 7) || (dy_ld & 7) || d->x_ld < d->groups * d->cin || dy_ld < d->groups * d->cout) return LLV_E_BADARG;
     if (d->k_pad < d->kh * d->kw * d->cin || d->w_rows < d->cout || d->batch < 1) return LLV_E_BADARG;
-    if (d->seg_h[0] < 1 || d->seg_w[0] < 1 || d->seg_ho[0] < 1 || d->seg_wo[0] < 1 || d->seg_xoff[0] < 0 || d->seg_yoff[0] < 0) return LLV_E_BADARG;
     if (((uintptr_t)d->x[0] | (uintptr_t)dy) & 15) return LLV_E_BADARG;
-    const long m = (long)d->batch * d->seg_ho[0] * d->seg_wo[0];
-    const size_t xb = ((size_t)d->seg_xoff[0] + (size_t)d->batch * d->seg_h[0] * d->seg_w[0]) * d->x_ld * 2;
-    const size_t yb = ((size_t)d->seg_yoff[0] + (size_t)m) * dy_ld * 2;
-    if (m > 0x7fffffffL || xb >= (1ull << 31) || yb >= (1ull << 31)) return LLV_E_UNSUPPORTED;
-    WgArgs a;
-    a.x = (const _Float16*)d->x[0]; a.dy = (const _Float16*)dy; a.dw = dw; a.db = db;
-    a.x_ld = d->x_ld; a.dy_ld = dy_ld; a.cin = d->cin; a.cout = d->cout; a.k_pad = d->k_pad; a.w_rows = d->w_rows;
-    a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.groups = d->groups;
-    a.dil = d->dilation > 1 ? d->dilation : 1;
-    a.H = d->seg_h[0]; a.W = d->seg_w[0]; a.Ho = d->seg_ho[0]; a.Wo = d->seg_wo[0];
-    a.xoff = (int)d->seg_xoff[0]; a.yoff = (int)d->seg_yoff[0];
-    a.m_total = (int)m; a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
-    // 64 x 64 tiles unless both channel counts exceed 512: a workgroup's pixel split ends in fp32 atomics over its whole dW tile, 16 KiB
-    // for a 64 x 64 tile against 64 KiB for 128 x 128, and on single-image maps the launches are bound by those atomics, not by the MFMA
-    // operand traffic the larger tile saves (same-box sweep on the training step: 128 x 128 tiles 177, 64 x 64 tiles 182 images/s)
-    static const long small_max = getenv("LLV_WGRAD_SMALLMAX") ? atol(getenv("LLV_WGRAD_SMALLMAX")) : 512;
-    const bool big = d->cout > small_max && d->cin > small_max;
-    const int bco = big ? 128 : 64, bci = big ? 128 : 64;
-    const long tiles = (long)((d->cout + bco - 1) / bco) * ((d->cin + bci - 1) / bci) * d->kh * d->kw * d->groups;
-    // Every pixel split adds a whole dW tile of fp32 atomics (64 KiB per 128 x 128 tile): with 1024 workgroups of >= 256 pixels each a
-    // 256 -> 256 3x3 layer sent 64 MB of atomics at a 2.4 MB gradient and the launches were bound by them. Pixel splits of
-    // >= 512 pixels: 165.6 -> 171 images/s on the training step (LLV_WGRAD_WGS / LLV_WGRAD_MINPX: the sweep's knobs; 768 pixels and
-    // more lose again, the chip runs empty on the small maps); with the 64 x 64 tiles above, four workgroups per CU again.
-    static const long target_wgs = getenv("LLV_WGRAD_WGS") && atol(getenv("LLV_WGRAD_WGS")) > 0 ? atol(getenv("LLV_WGRAD_WGS")) : 1024;
-    static const long min_px = getenv("LLV_WGRAD_MINPX") && atol(getenv("LLV_WGRAD_MINPX")) > 0 ? atol(getenv("LLV_WGRAD_MINPX")) : 512;
-    long splits = (target_wgs + tiles - 1) / tiles;
-    const long max_splits = (m + min_px - 1) / min_px;
-    if (splits > max_splits) splits = max_splits;
-    if (splits < 1) splits = 1;
-    long per = (m + splits - 1) / splits;
-    per = (per + 31) & ~31L;
-    splits = (m + per - 1) / per;
-    a.m_per_split = (int)per;
+    if (!(share > 0.f) || share > 1.f) share = 1.f;
+    size_t xb = 0, yb = 0;                 // bytes of x / dy the segments reach
+    for (int k = 0; k < d->n_seg; ++k) {
+        if (d->seg_h[k] < 1 || d->seg_w[k] < 1 || d->seg_ho[k] < 1 || d->seg_wo[k] < 1 || d->seg_xoff[k] < 0 || d->seg_yoff[k] < 0) return LLV_E_BADARG;
+        const size_t xk = ((size_t)d->seg_xoff[k] + (size_t)d->batch * d->seg_h[k] * d->seg_w[k]) * d->x_ld * 2;
+        const size_t yk = ((size_t)d->seg_yoff[k] + (size_t)d->batch * d->seg_ho[k] * d->seg_wo[k]) * dy_ld * 2;
+        xb = xk > xb ? xk : xb; yb = yk > yb ? yk : yb;
+    }
+    if (xb >= (1ull << 31) || yb >= (1ull << 31)) return LLV_E_UNSUPPORTED;
+    static const int knock = getenv("LLV_WGRAD_KNOCK") ? atoi(getenv("LLV_WGRAD_KNOCK")) : 0;
+    static const int use3 = getenv("LLV_WGRAD3") ? atoi(getenv("LLV_WGRAD3")) : 1;
+    bool all3 = use3 && d->kh == 3 && d->kw == 3 && d->stride == 1 && d->pad == 1 && d->dilation <= 1;
+    for (int k = 0; k < d->n_seg && all3; ++k) all3 = d->seg_ho[k] == d->seg_h[k] && d->seg_wo[k] == d->seg_w[k];
+    if (all3) {
+        Wg3Args b;
+        memset(&b, 0, sizeof(b));
+        b.x = (const _Float16*)d->x[0]; b.dy = (const _Float16*)dy; b.dw = dw; b.db = db;
+        b.x_ld = d->x_ld; b.dy_ld = dy_ld; b.cin = d->cin; b.cout = d->cout; b.k_pad = d->k_pad; b.w_rows = d->w_rows; b.groups = d->groups;
+        b.batch = d->batch; b.nseg = d->n_seg;
+        int np = 0;
+        for (int k = 0; k < LLV_MAX_SEG; ++k) {
+            const bool on = k < d->n_seg;
+            b.H[k] = on ? d->seg_h[k] : 1; b.W[k] = on ? d->seg_w[k] : 1;
+            b.xoff[k] = on ? (int)d->seg_xoff[k] : 0; b.yoff[k] = on ? (int)d->seg_yoff[k] : 0;
+            b.py_n[k] = (b.H[k] + 7) / 8; b.px_n[k] = (b.W[k] + 7) / 8;
+            b.pstart[k] = np;
+            if (on) np += d->batch * b.py_n[k] * b.px_n[k];
+        }
+        b.pstart[LLV_MAX_SEG] = np;
+        b.patches = np;
+        b.x_bytes = (unsigned)xb; b.dy_bytes = (unsigned)yb;
+        const size_t dwg = (size_t)d->cout * d->k_pad * 4;
+        if (dwg >= (1ull << 31)) return LLV_E_UNSUPPORTED;
+        b.dwg_bytes = (unsigned)dwg;
+        b.tiles_co = (d->cout + 63) / 64; b.tiles_ci = (d->cin + 63) / 64;
+        b.tiles = b.tiles_co * b.tiles_ci * d->groups;
+        // Pixel splits. A workgroup (one wave per SIMD) needs ~0.75 us per patch and ends in 9 x 64 x 64 fp32 atomics (147 KB; the
+        // atomics of a launch retire at ~1.5-2.7 TB/s), more than `share` x 256 workgroups share matrix cores with the rest of the
+        // launch: the split count with the lowest estimate among 1, 2, 4 and the multiples of 8 (whole XCDs per split).
+        // LLV_WGRAD3_SPLITS forces a count.
+        static const long forced = getenv("LLV_WGRAD3_SPLITS") ? atol(getenv("LLV_WGRAD3_SPLITS")) : 0;
+        const double dw_mb = (double)d->groups * dwg * 1e-6, room = 256.0 * share;
+        long sp = 1;
+        double best = 1e30;
+        static const long cand[] = {1, 2, 4, 8, 16, 24, 32, 48, 64};
+        for (long c : cand) {
+            if (c > np) break;
+            const double wg = (double)b.tiles * c;
+            const double per = (double)((np + c - 1) / c);
+            const double t = per * 0.75 * (wg > room ? wg / room : 1.0) + c * dw_mb / 2.0;
+            if (t < best) { best = t; sp = c; }
+        }
+        if (forced > 0) sp = forced < np ? forced : np;
+        b.per_split = (int)((np + sp - 1) / sp);
+        sp = (np + b.per_split - 1) / b.per_split;
+        b.knock = knock;
+        const long wgs = set_grid(b, sp);
+        jobs[0].kind = 2; jobs[0].wg_begin = 0; jobs[0].n_wg = (int)wgs; jobs[0].reserved = 0;
+        memcpy(jobs[0].args, &b, sizeof(b));
+        *n_jobs = 1;
+        return LLV_OK;
+    }
+    // every other geometry: one job per segment
+    for (int k = 0; k < d->n_seg; ++k) {
+        const long m = (long)d->batch * d->seg_ho[k] * d->seg_wo[k];
+        if (m > 0x7fffffffL) return LLV_E_UNSUPPORTED;
+        WgArgs a;
+        memset(&a, 0, sizeof(a));
+        a.x = (const _Float16*)d->x[0]; a.dy = (const _Float16*)dy; a.dw = dw; a.db = db;
+        a.x_ld = d->x_ld; a.dy_ld = dy_ld; a.cin = d->cin; a.cout = d->cout; a.k_pad = d->k_pad; a.w_rows = d->w_rows;
+        a.kh = d->kh; a.kw = d->kw; a.stride = d->stride; a.pad = d->pad; a.groups = d->groups;
+        a.dil = d->dilation > 1 ? d->dilation : 1;
+        a.H = d->seg_h[k]; a.W = d->seg_w[k]; a.Ho = d->seg_ho[k]; a.Wo = d->seg_wo[k];
+        a.xoff = (int)d->seg_xoff[k]; a.yoff = (int)d->seg_yoff[k];
+        a.m_total = (int)m; a.x_bytes = (unsigned)xb; a.dy_bytes = (unsigned)yb;
+        // 64 x 64 tiles unless both channel counts exceed 512: a workgroup's pixel split ends in fp32 atomics over its whole dW tile, 16 KiB
+        // for a 64 x 64 tile against 64 KiB for 128 x 128, and on single-image maps the launches are bound by those atomics, not by the MFMA
+        // operand traffic the larger tile saves (same-box sweep on the training step: 128 x 128 tiles 177, 64 x 64 tiles 182 images/s)
+        static const long small_max = getenv("LLV_WGRAD_SMALLMAX") ? atol(getenv("LLV_WGRAD_SMALLMAX")) : 512;
+        const bool big = d->cout > small_max && d->cin > small_max;
+        const int bco = big ? 128 : 64, bci = big ? 128 : 64;
+        a.tiles_co = (d->cout + bco - 1) / bco; a.tiles_ci = (d->cin + bci - 1) / bci;
+        a.tiles = a.tiles_co * a.tiles_ci * d->kh * d->kw * d->groups;
+        // Every pixel split adds a whole dW tile of fp32 atomics: as few as fill this job's share of the chip (1024 workgroups for a
+        // launch of its own; LLV_WGRAD_WGS), and at least LLV_WGRAD_MINPX pixels each (512: 768 and more lose again on the small maps)
+        static const long target_wgs = getenv("LLV_WGRAD_WGS") && atol(getenv("LLV_WGRAD_WGS")) > 0 ? atol(getenv("LLV_WGRAD_WGS")) : 1024;
+        static const long min_px = getenv("LLV_WGRAD_MINPX") && atol(getenv("LLV_WGRAD_MINPX")) > 0 ? atol(getenv("LLV_WGRAD_MINPX")) : 512;
+        long want = (long)(target_wgs * (double)share + 0.5);
+        if (want < 1) want = 1;
+        long splits = (want + a.tiles - 1) / a.tiles;
+        const long max_splits = (m + min_px - 1) / min_px;
+        if (splits > max_splits) splits = max_splits;
+        if (splits < 1) splits = 1;
+        // whole XCDs per split: 1, 2, 4 or a multiple of 8 splits (3 or 5..7 would leave XCDs without work)
+        if (splits >= 6) { splits = (splits + 7) / 8 * 8; if (splits > max_splits && splits > 8) splits -= 8; }
+        else if (splits == 3) splits = max_splits >= 4 ? 4 : 2;
+        else if (splits == 5) splits = 4;
+        long per = (m + splits - 1) / splits;
+        per = (per + 31) & ~31L;
+        splits = (m + per - 1) / per;
+        a.m_per_split = (int)per;
+        a.knock = knock;
+        const long wgs = set_grid(a, splits);
+        jobs[k].kind = big ? 1 : 0; jobs[k].wg_begin = 0; jobs[k].n_wg = (int)wgs; jobs[k].reserved = 0;
+        memcpy(jobs[k].args, &a, sizeof(a));
+    }
+    *n_jobs = d->n_seg;
+    return LLV_OK;
+}
+
+extern "C" int llv_conv2d_nhwc_wgrad(const llv_conv_desc* d, const void* dy, int dy_ld, float* dw, float* db, void* stream) {
+    llv_wgrad_job jobs[LLV_MAX_SEG];
+    int n = 0;
+    const int rc = llv_conv2d_nhwc_wgrad_plan(d, dy, dy_ld, dw, db, 1.f, jobs, &n);
+    if (rc != LLV_OK) return rc;
     hipStream_t st = (hipStream_t)stream;
-    return big ? launch_wgrad<128, 128>(a, (int)splits, st) : launch_wgrad<64, 64>(a, (int)splits, st);
+    for (int k = 0; k < n; ++k) {
+        const dim3 grid((unsigned)jobs[k].n_wg), block(256);
+        if (jobs[k].kind == 2) {
+            Wg3Args b;
+            memcpy(&b, jobs[k].args, sizeof(b));
+            hipLaunchKernelGGL(conv_wgrad3x3_kernel, grid, block, 0, st, b);
+        } else {
+            WgArgs a;
+            memcpy(&a, jobs[k].args, sizeof(a));
+            if (jobs[k].kind == 1) hipLaunchKernelGGL((conv_wgrad_kernel<128, 128>), grid, block, 0, st, a);
+            else hipLaunchKernelGGL((conv_wgrad_kernel<64, 64>), grid, block, 0, st, a);
+        }
+        if (hipGetLastError() != hipSuccess) return LLV_E_LAUNCH;
+    }
+    return LLV_OK;
+}
+
+extern "C" int llv_conv2d_nhwc_wgrad_jobs(const llv_wgrad_job* jobs, const uint16_t* wg2job, int kind, int total_wgs, void* stream) {
+    if (!jobs || !wg2job || kind < 0 || kind > 2 || total_wgs < 1) return LLV_E_BADARG;
+    hipStream_t st = (hipStream_t)stream;
+    const dim3 grid((unsigned)total_wgs), block(256);
+    if (kind == 2) hipLaunchKernelGGL(conv_wgrad3x3_jobs_kernel, grid, block, 0, st, jobs, (const unsigned short*)wg2job);
+    else if (kind == 1) hipLaunchKernelGGL((conv_wgrad_jobs_kernel<128, 128>), grid, block, 0, st, jobs, (const unsigned short*)wg2job);
+    else hipLaunchKernelGGL((conv_wgrad_jobs_kernel<64, 64>), grid, block, 0, st, jobs, (const unsigned short*)wg2job);
+    return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }
 
 extern "C" int llv_relu_bwd(const void* dy, const void* dy2, const void* y, void* dx, int64_t n, void* stream) {

@@ -260,6 +260,9 @@ class TrainGraph:
         weight gradients alone. A launch's dW depends only on its input activation and on dY as the data phase left it, nothing later
         in the pass writes that dY again, and dW is not read before the unpack -- so TrainStep replays the weight phase of one
         all-reduce bucket on a second stream beside the data phase of the next (single-image launches that each fill part of the chip)."""
+        if phase == 'weight' and self.group_wgrad:
+            self._wgrad_group(ops_rev).launch()
+            return
         for op in ops_rev:
             yp = _sptr(op['y'])
             if yp not in self.req:
@@ -311,10 +314,10 @@ class TrainGraph:
                 else:
                     B.relu_bwd(gres, None, gres, dy2=gy)
             if not op['frozen'] and phase != 'data':
-                for (h, w, ho, wo, xo, yo) in op['segs']:
-                    B.conv_wgrad(op['xs'][0], gy, op['dw'], cin_pad=pc.cin, cout=pc.cout,
-                                 w_rows=pc.w_rows, k_pad=pc.k_pad, kh=pc.kh, kw=pc.kw, stride=pc.stride, pad=pc.pad, groups=pc.groups,
-                                 batch=op['batch'], seg=(h, w, ho, wo, xo, yo), x_ld=op['x_ld'], dy_ld=dy_ld, db=op['db'], dilation=max(int(pc.dilation), 1))
+                B.conv_wgrad(op['xs'][0], gy, op['dw'], cin_pad=pc.cin, cout=pc.cout,
+                             w_rows=pc.w_rows, k_pad=pc.k_pad, kh=pc.kh, kw=pc.kw, stride=pc.stride, pad=pc.pad, groups=pc.groups,
+                             batch=op['batch'], segs=[tuple(sg) for sg in op['segs']], x_ld=op['x_ld'], dy_ld=dy_ld, db=op['db'],
+                             dilation=max(int(pc.dilation), 1))
             if phase == 'weight':
                 continue
             if op['need_dx']:
@@ -326,6 +329,26 @@ class TrainGraph:
                     B.conv_dgrad(gy, op['pcd'], gx, op['batch'], op['segs'], dy_ld, op['x_ld'], 0, accumulate=True)
             if on_op_done is not None and not op['frozen']:
                 on_op_done(op)
+
+    # the weight phase of a list of launches as one launch per kernel kind (B.WgradGroup); LLV_WGRAD_GROUP=0: one launch per conv
+    group_wgrad = os.environ.get('LLV_WGRAD_GROUP', '1') != '0'
+
+    def _wgrad_group(self, ops_list):
+        key = ('wgrad',) + tuple(id(op) for op in ops_list)
+        grp = self._tables.get(key)
+        if grp is None:
+            calls = []
+            for op in ops_list:
+                yp = _sptr(op['y'])
+                if yp not in self.req or op.get('custom') or op['frozen']:
+                    continue
+                pc = op['pc']
+                calls.append(dict(x=op['xs'][0], dy=self.gview(op['y']), dw=op['dw'], db=op['db'], cin_pad=pc.cin, cout=pc.cout, w_rows=pc.w_rows,
+                                  k_pad=pc.k_pad, kh=pc.kh, kw=pc.kw, stride=pc.stride, pad=pc.pad, groups=pc.groups, batch=op['batch'],
+                                  segs=[tuple(sg) for sg in op['segs']], x_ld=op['x_ld'], dy_ld=self.grads[yp].shape[-1],
+                                  dilation=max(int(pc.dilation), 1)))
+            grp = self._tables[key] = B.WgradGroup(calls, self.device)
+        return grp
 
     @staticmethod
     def _rows(t: torch.Tensor, off: int, n: int) -> torch.Tensor:

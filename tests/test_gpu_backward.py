@@ -54,6 +54,39 @@ def test_wgrad_matches_autograd(dev, cfg):
     assert _rel(B.unpack_wgrad(dw[0].cpu(), cout, cin, k, k, cin_pad), 2 * wt.grad) < 2e-3
 
 
+@pytest.mark.parametrize('k', [3, 1])
+def test_wgrad_over_pyramid_levels_in_one_call(dev, k):
+    """A filter shared by the pyramid levels (RetinaHead towers, retina_head.py:93-114): the levels as segments of ONE call -- for 3x3 /
+    stride 1 one launch whose pixel splits run over the 8 x 8 patches of all levels (ragged: 13 x 21, 7 x 11, 4 x 6 and 2 x 3 maps, two
+    images, 72 -> 40 channels), for other filters one launch per level -- equals autograd over the levels, bias gradient included."""
+    from lowlightenvironmentvideoobjectdetection_amd import backward as B
+    g = torch.Generator().manual_seed(5)
+    n, cin, cout = 2, 72, 40
+    sizes = [(13, 21), (7, 11), (4, 6), (2, 3)]
+    wt = (torch.randn(cout, cin, k, k, generator=g) / (cin * k * k) ** 0.5).requires_grad_()
+    bias = torch.zeros(cout, requires_grad=True)
+    xs = [torch.randn(n, cin, h, w, generator=g).half().float() for h, w in sizes]
+    dys = [torch.randn(n, cout, h, w, generator=g).half().float() for h, w in sizes]
+    for x, dy in zip(xs, dys):
+        F.conv2d(x, wt, bias, 1, k // 2).backward(dy)
+    tot = sum(n * h * w for h, w in sizes)
+    xbuf = torch.zeros(tot, cin, dtype=torch.float16)
+    dbuf = torch.zeros(tot, cout, dtype=torch.float16)
+    segs, o = [], 0
+    for (h, w), x, dy in zip(sizes, xs, dys):
+        xbuf[o:o + n * h * w] = _nhwc(x).reshape(-1, cin).half()
+        dbuf[o:o + n * h * w] = _nhwc(dy).reshape(-1, cout).half()
+        segs.append((h, w, h, w, o, o))
+        o += n * h * w
+    k_pad = k * k * cin
+    dw = torch.zeros(1, 48, k_pad, dtype=torch.float32, device=dev)
+    db = torch.zeros(cout, dtype=torch.float32, device=dev)
+    B.conv_wgrad(xbuf.to(dev), dbuf.to(dev), dw, cin_pad=cin, cout=cout, w_rows=48, k_pad=k_pad, kh=k, kw=k, stride=1, pad=k // 2, groups=1,
+                 batch=n, segs=segs, x_ld=cin, dy_ld=cout, db=db)
+    assert _rel(B.unpack_wgrad(dw[0].cpu(), cout, cin, k, k, cin), wt.grad) < 2e-3
+    assert _rel(db.cpu(), bias.grad) < 2e-3
+
+
 def test_wgrad_grouped_towers(dev):
     """groups=2 over a 2x64-channel tensor (the RetinaHead twin-tower layout)."""
     from lowlightenvironmentvideoobjectdetection_amd import backward as B
