@@ -64,7 +64,7 @@ extern "C" {
 #define LLV_E_WORKSPACE (-4)
 #define LLV_E_EXTENT (-5) /* the launch would touch memory outside a declared buffer extent (llv_extents) */
 
-#define LLV_ABI_VERSION 2
+#define LLV_ABI_VERSION 3
 
 #define LLV_MAX_SEG 5 /* pyramid levels batched into one conv launch */
 #define LLV_MAX_SRC 3 /* input tensors concatenated along C by one conv launch */
@@ -98,6 +98,10 @@ typedef struct llv_extents {
 #define LLV_CONV_PS_EMAJOR 256 /* with PIXSHUF: the conv's output channels (weight rows, bias) are packed sub-pixel-major, channel = (2*dy+dx)*(Cout/4) + cc, instead of torch's 4*cc + 2*dy + dx; 3x3/s1 launches on the tap kernel only */
 #define LLV_CONV_ACT_FIRST 128 /* with RES_ADD: y = act(conv + bias) + res (Darknet ResBlock, darknet.py:47-53) instead of act(conv + bias + res) */
 #define LLV_CONV_LEAKY 64      /* y = y > 0 ? y : act_slope*y last (FlowNetSimple LeakyReLU(0.1), flownet_simple.py:66-68) */
+#define LLV_CONV_MASK_POS 1024 /* last: y = mask > 0 ? y : 0, `mask` an fp16 tensor laid out like y (mask_ld channels per pixel). The data
+                                * gradient of a convolution whose INPUT is a ReLU output: dX takes that ReLU's mask from the activation
+                                * itself in the launch that computes it (llv_conv2d_nhwc_dgrad with the flag in the forward descriptor);
+                                * not with PIXSHUF / OUT_F32 / planar groups */
 #define LLV_CONV_CLSMAX 512    /* the class convolution of a dense head (retina_head.py:93-114 `retina_cls`) with the first step of
                                 * get_bboxes (anchor_head.py:636-711: sigmoid, per-anchor class maximum) in its epilogue: with OUT_F32 on the
                                 * 3x3/s1/p1 tap kernel (128-channel tile), channels a*cls_c + c. The launch atomically maximises
@@ -180,6 +184,9 @@ typedef struct llv_conv_desc {
     uint8_t* seg_written;    /* [rows of y][ceil(cout / 128)]: one bit per 16-channel block; every entry of a computed pixel is written */
     int32_t cls_c;           /* classes per anchor */
     float store_thr;         /* a segment is stored when one of its logits is > store_thr: pass logit(score_thr) minus a margin */
+    /* LLV_CONV_MASK_POS: */
+    const void* mask;
+    int32_t mask_ld;
 } llv_conv_desc;
 
 #define LLV_TILE_AUTO 0

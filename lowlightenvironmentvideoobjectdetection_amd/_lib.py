@@ -24,6 +24,7 @@ CONV_LEAKY = 64
 CONV_ACT_FIRST = 128
 CONV_PS_EMAJOR = 256
 CONV_CLSMAX = 512
+CONV_MASK_POS = 1024
 
 TILE_AUTO, TILE_128x128, TILE_64x256, TILE_32x256, TILE_16x256, TILE_64x64 = 0, 1, 2, 3, 4, 5
 TILE_128x128_REGSTAGE = 6
@@ -132,6 +133,7 @@ class ConvDesc(C.Structure):
         ('extents', C.POINTER(Extents)),
         ('offset_dev', C.c_void_p), ('offset_x', C.c_int32), ('offset_res', C.c_int32), ('offset_max', C.c_int64),
         ('clsmax', C.c_void_p), ('seg_written', C.c_void_p), ('cls_c', C.c_int32), ('store_thr', C.c_float),
+        ('mask', C.c_void_p), ('mask_ld', C.c_int32),
     ]
 
 
@@ -285,7 +287,7 @@ def lib():
             fn = getattr(handle, name)  # AttributeError if the ABI lost a symbol
             fn.restype = res
             fn.argtypes = args
-        if handle.llv_abi_version() != 2:
+        if handle.llv_abi_version() != 3:
             raise LlvError('libllv.so ABI version mismatch')
         _lib = handle
     return _lib

@@ -16,7 +16,7 @@ from typing import Optional, Tuple
 import torch
 
 from . import ops
-from ._lib import lib, check, ConvDesc, CONV_PIXSHUF, CONV_RES_ADD
+from ._lib import lib, check, ConvDesc, CONV_MASK_POS, CONV_PIXSHUF, CONV_RES_ADD
 
 
 def _stream():
@@ -210,12 +210,15 @@ def sgd_momentum(w: torch.Tensor, g: torch.Tensor, mom: torch.Tensor, lr: float,
 
 
 def conv_dgrad(dy: torch.Tensor, pcd: ops.PackedConv, dx: torch.Tensor, batch: int, segs, dy_ld: int, dx_ld: int,
-               flags: int, accumulate: bool, in_hw=None, fwd_stride: int = None, fwd_cin: int = None):
+               flags: int, accumulate: bool, in_hw=None, fwd_stride: int = None, fwd_cin: int = None, mask: Optional[torch.Tensor] = None):
     """dX (+)= data gradient through llv_conv2d_nhwc_dgrad. segs: the FORWARD launch's segments (h, w, ho, wo, x_off, y_off);
     pcd: the filter packed for the gradient (dgrad_weight / llv_pack_conv_weights modes 1, 2). flags: CONV_PIXSHUF for a
-    stride-2 forward conv."""
+    stride-2 forward conv. mask: the forward conv's INPUT activation when that is a ReLU output (laid out like dx): dX also takes that
+    ReLU's mask, so the launch it is the output gradient of needs no llv_relu_bwd pass (stride-1 convs only)."""
     s2 = bool(flags & CONV_PIXSHUF)
     f = ConvDesc()
+    if mask is not None:
+        f.x[0], f.x_ld, f.flags = mask.data_ptr(), dx_ld, CONV_MASK_POS
     f.n_src, f.n_seg = 1, len(segs)
     f.stride = 2 if s2 else 1
     f.cin = pcd.cout // 4 if s2 else pcd.cout

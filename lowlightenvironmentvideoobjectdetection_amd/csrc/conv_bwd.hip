@@ -1205,6 +1205,12 @@ extern "C" int llv_conv2d_nhwc_dgrad(const llv_conv_desc* fwd, const void* w_dgr
         d.seg_xoff[s] = fwd->seg_yoff[s]; d.seg_yoff[s] = fwd->seg_xoff[s];
     }
     d.flags = (s2 ? LLV_CONV_PIXSHUF : 0) | (accumulate ? LLV_CONV_RES_ADD : 0);
+    if (fwd->flags & LLV_CONV_MASK_POS) {
+        // dX also takes the ReLU mask of the forward INPUT (x[0], x_ld: the activation dX is the gradient of), so that the launch
+        // that consumes it needs no mask pass of its own; mask((sum of contributions)) = sum of masked contributions
+        if (s2 || !fwd->x[0] || fwd->x_ld != dx_ld) return LLV_E_BADARG;
+        d.mask = fwd->x[0]; d.mask_ld = fwd->x_ld; d.flags |= LLV_CONV_MASK_POS;
+    }
     if (s2) { d.ps_out_h = fwd->seg_h[0]; d.ps_out_w = fwd->seg_w[0]; }
     d.workspace = workspace; d.workspace_bytes = workspace_bytes;
     return llv_conv2d_nhwc_fwd(&d, stream);

@@ -32,6 +32,8 @@ struct ConvKArgs {
     const _Float16* w;
     const float* bias;
     const _Float16* res;
+    const _Float16* mask;      // LLV_CONV_MASK_POS
+    int mask_ld;
     void* y;
     int n_src, src_cvec;
     int x_ld, y_ld, res_ld;
@@ -150,6 +152,11 @@ __device__ __forceinline__ void epi_compute_b(const ConvKArgs& a, const EpiCtx& 
     if (flags & (LLV_CONV_RELU | LLV_CONV_LEAKY)) {
 #pragma unroll
         for (int e = 0; e < 4; ++e) v[e] = act_fn(a, v[e]);
+    }
+    if (flags & LLV_CONV_MASK_POS) {          // a data gradient takes the ReLU mask of the activation it is the gradient of
+        const f16x4 m4 = *reinterpret_cast<const f16x4*>(a.mask + c.opix * a.mask_ld + gco);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) v[e] = (float)m4[e] > 0.f ? v[e] : 0.f;
     }
 }
 
@@ -587,6 +594,21 @@ __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned char* l
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
 
+// LDS reads the compiler must not guard with vmcnt waits (see the implicit-GEMM main loop): the read is inline assembly, the wave's
+// LDS counter is waited for by hand (lds_wait_all_but<N>: at most the N youngest reads still outstanding) and lds_use ties a register
+// to a point after that wait, so its first use cannot be scheduled in front of it.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(unsigned long)((__attribute__((address_space(3))) const unsigned char*)p);
+}
+__device__ __forceinline__ f16x8 lds_read128(unsigned addr) {
+    f16x8 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_all_but() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
+__device__ __forceinline__ void lds_use(f16x8& v) { asm volatile("" : "+v"(v)); }
+
 #ifndef GLDS_STAGES
 #define GLDS_STAGES 2
 #endif
@@ -617,7 +639,8 @@ __global__ __launch_bounds__(256, (BK == 64 ? 2 : (BN * BM >= 128 * 128 ? 3 : 4)
     constexpr int STAGE = (BN + BM) * RB;
     constexpr int TS = BN + 8;
     constexpr int EPI = BM * TS * 2;
-    constexpr int NST = GLDS_STAGES;                         // LDS ring depth: NST-1 k-steps of loads in flight
+    constexpr bool ASM_READS = BN == 64 && BM == 64;         // the small-map tile
+    constexpr int NST = ASM_READS ? 4 : GLDS_STAGES;         // LDS ring depth: NST-1 k-steps of loads in flight
     constexpr int SMEM = NST * STAGE > EPI ? NST * STAGE : EPI;
     constexpr int NWI = BN / RPP, NPI = BM / RPP;            // pieces per k-step: weights, pixels
     constexpr int WPW = (NWI + 3) / 4, PPW = (NPI + 3) / 4;  // per wave (wave w takes pieces w, w+4, ...)
@@ -821,6 +844,14 @@ __global__ __launch_bounds__(256, (BK == 64 ? 2 : (BN * BM >= 128 * 128 ? 3 : 4)
     for (int s = 0; s < NST - 1; ++s)
         if (s < nk) { issue(ks_begin + s, nxt); nxt = nxt + 1 == NST ? 0 : nxt + 1; }
     const int frow = lane & 15, fch = lane >> 4;
+    int foff_w[BK / 32][TN], foff_x[BK / 32][TM];             // byte offsets of this lane's fragment rows inside a stage (ASM_READS)
+#pragma unroll
+    for (int kk = 0; kk < BK / 32; ++kk) {
+#pragma unroll
+        for (int i = 0; i < TN; ++i) foff_w[kk][i] = glds_off<BK>(wn * WN + i * 16 + frow, kk * 4 + fch);
+#pragma unroll
+        for (int j = 0; j < TM; ++j) foff_x[kk][j] = glds_off<BK>(wm * WM + j * 16 + frow, kk * 4 + fch);
+    }
     for (int ks = 0; ks < nk; ++ks) {
         // stages ks .. min(ks+NST-2, nk-1) are outstanding; wait until only those after ks remain
         const int ahead = nk - 1 - ks < NST - 2 ? nk - 1 - ks : NST - 2;
@@ -833,8 +864,43 @@ __global__ __launch_bounds__(256, (BK == 64 ? 2 : (BN * BM >= 128 * 128 ? 3 : 4)
             if (short_wave) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * (PIECES_FULL - 1)) : "memory");
             else asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES_FULL) : "memory");
         }
-        __syncthreads();                                     // stage ks visible to all; everyone is done reading stage ks-1
+        // stage ks visible to all; everyone is done reading stage ks-1 (__syncthreads() would drain the deeper pipeline: vmcnt(0))
+        if constexpr (ASM_READS) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        else __syncthreads();
         if (ks + NST - 1 < nk) { issue(ks_begin + ks + NST - 1, nxt); nxt = nxt + 1 == NST ? 0 : nxt + 1; }
+        if constexpr (ASM_READS) {
+            // Small tiles (single-image maps: one workgroup per CU or fewer, nothing else to hide a load behind) keep three k-steps
+            // of DMA loads in flight. That needs operand reads the compiler does not guard: through plain LDS loads it cannot tell
+            // the reads from the LDS destination of the DMA loads just issued and puts `s_waitcnt vmcnt(0)` in front of the first
+            // fragment read, so every prefetch was waited for before the k-step it was issued under was computed (round 4, found in
+            // the ISA). Inline-assembly reads, the LDS counter waited for by hand, lds_use ties the registers behind the wait.
+            const unsigned sW = lds_addr(smem) + cur * STAGE;
+            const unsigned sX = sW + BN * RB;
+            cur = cur + 1 == NST ? 0 : cur + 1;
+            constexpr int KK = BK / 32;
+            f16x8 af[KK][TN], bf[KK][TM];
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+#pragma unroll
+                for (int i = 0; i < TN; ++i) af[kk][i] = lds_read128(sW + foff_w[kk][i]);
+#pragma unroll
+                for (int j = 0; j < TM; ++j) bf[kk][j] = lds_read128(sX + foff_x[kk][j]);
+            }
+#pragma unroll
+            for (int kk = 0; kk < KK; ++kk) {
+                if (kk + 1 < KK) lds_wait_all_but<(KK - 1) * (TN + TM)>(); else lds_wait_all_but<0>();
+#pragma unroll
+                for (int i = 0; i < TN; ++i) lds_use(af[kk][i]);
+#pragma unroll
+                for (int j = 0; j < TM; ++j) lds_use(bf[kk][j]);
+#pragma unroll
+                for (int i = 0; i < TN; ++i)
+#pragma unroll
+                    for (int j = 0; j < TM; ++j)
+                        acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_f16(af[kk][i], bf[kk][j], acc[i][j], 0, 0, 0);
+            }
+            continue;
+        }
         const unsigned char* sW = smem + cur * STAGE;
         const unsigned char* sX = sW + BN * RB;
         cur = cur + 1 == NST ? 0 : cur + 1;
@@ -2620,6 +2686,12 @@ static int conv_prepare(const llv_conv_desc* d, ConvPrepared& P) {
     k.w = (const _Float16*)d->w;
     k.bias = d->bias;
     k.res = (const _Float16*)d->res;
+    k.mask = (const _Float16*)d->mask; k.mask_ld = d->mask_ld;
+    if (f & LLV_CONV_MASK_POS) {
+        if (!d->mask || (d->mask_ld & 3) || d->mask_ld < d->groups * d->cout || ((uintptr_t)d->mask & 7) || d->y_group_stride ||
+            (f & (LLV_CONV_PIXSHUF | LLV_CONV_OUT_F32 | LLV_CONV_CLSMAX)))
+            return LLV_E_BADARG;
+    }
     k.y = d->y;
     k.n_src = d->n_src; k.src_cvec = d->n_src > 1 ? d->src_cvec : (d->cin >> 3);
     k.x_ld = d->x_ld; k.y_ld = d->y_ld; k.res_ld = d->res_ld;
@@ -2815,7 +2887,7 @@ static int convpair_prepare(const llv_inputcv_desc* p, bool output_block, PairPr
     k.x0 = (const _Float16*)d->x[0];
     k.x1 = (const _Float16*)(output_block ? d->x[0] : d->x[1]);
     k.x2 = (const _Float16*)(output_block ? d->x[0] : d->x[2]);
-    k.bias = d->bias; k.y = d->y; k.res = (const _Float16*)d->res;
+    k.bias = d->bias; k.y = d->y; k.res = (const _Float16*)d->res; k.mask = nullptr; k.mask_ld = 0;
     k.n_src = d->n_src; k.src_cvec = 1; k.x_ld = d->x_ld; k.y_ld = d->y_ld; k.res_ld = d->res_ld;
     k.cin = d->cin; k.cout = d->cout; k.kh = 3; k.kw = 3; k.stride = 1; k.pad = 1; k.dil = 1; k.n_seg = 1;
     for (int s = 0; s < LLV_MAX_SEG; ++s) {

@@ -140,7 +140,38 @@ class TrainGraph:
                                            w_rows=w_rows, k_pad=k_pad, kh=KH, kw=KW, stride=1, pad=pd, groups=pc.groups,
                                            true_macs_per_pixel=0, dilation=dil)
                 op['dflags'] = CONV_PIXSHUF if pc.stride == 2 else 0
+        self._plan_mask_fusion()
         self.trainable = self._trainable_keys()
+
+    # A plain conv + ReLU whose output feeds stride-1 convolutions only: its output gradient is written by those launches' data
+    # gradients, which take the ReLU mask in their epilogue (LLV_CONV_MASK_POS) -- no llv_relu_bwd pass over it (30 of the 43 mask
+    # launches of a RetinaNet R-50 step). LLV_FUSE_RELU_MASK=0: every mask its own launch.
+    fuse_masks = os.environ.get('LLV_FUSE_RELU_MASK', '1') != '0'
+
+    def _plan_mask_fusion(self):
+        def same_view(a, b):
+            return _sptr(a) == _sptr(b) and a.storage_offset() == b.storage_offset() and a.shape == b.shape and a.stride() == b.stride()
+        users: Dict[int, list] = {}
+        for op in self.tape:
+            for x in list(op['xs']) + ([op['res']] if not op.get('custom') and op.get('res') is not None else []):
+                users.setdefault(_sptr(x), []).append(op)
+        # activations whose gradient is also written from outside the tape (the feature map a RoI head hangs off): never fused
+        fed = {_sptr(t) for t in (getattr(self, 'f', None), getattr(self, 'x_out', None)) if torch.is_tensor(t)}
+        for a in self.tape:
+            if not self.fuse_masks or a.get('custom') or _sptr(a['y']) not in self.req or a['y'].dtype != torch.float16 or _sptr(a['y']) in fed:
+                continue
+            fl = a['flags']
+            if not (fl & CONV_RELU) or (fl & (CONV_LEAKY | CONV_RES_ADD | CONV_ACT_FIRST | CONV_PIXSHUF)):
+                continue
+            cons = users.get(_sptr(a['y']), [])
+            ok = bool(cons)
+            for b in cons:
+                ok = ok and not b.get('custom') and len(b['xs']) == 1 and same_view(b['xs'][0], a['y']) and b.get('need_dx', False) \
+                    and b.get('dflags', 0) == 0 and (b.get('res') is None or _sptr(b['res']) != _sptr(a['y'])) and b['pc'].stride == 1
+            if ok:
+                a['mask_fused'] = True
+                for b in cons:
+                    b['mask_dx'] = True
 
     # ---- helpers -------------------------------------------------------------------------------
     def _dy_ld(self, op):
@@ -287,6 +318,8 @@ class TrainGraph:
                         and op['y'].is_contiguous() and gy.numel() == gres.numel() == op['y'].numel():
                     B.relu_res_bwd(gy, op['y'], gres)            # mask + the identity's gradient in one pass (a Bottleneck's output)
                     fused_res = True
+                elif op.get('mask_fused'):
+                    pass                                         # the consumers' data gradients wrote dY masked (_plan_mask_fusion)
                 else:
                     # rows this launch wrote, neighbouring levels of a pyramid buffer as one range (the head towers: 1 launch, not 5)
                     spans = []
@@ -326,7 +359,8 @@ class TrainGraph:
                     for seg in op['segs']:
                         B.conv_dgrad(gy, op['pcd'], gx, op['batch'], [seg], dy_ld, op['x_ld'], op['dflags'], accumulate=True)
                 else:
-                    B.conv_dgrad(gy, op['pcd'], gx, op['batch'], op['segs'], dy_ld, op['x_ld'], 0, accumulate=True)
+                    B.conv_dgrad(gy, op['pcd'], gx, op['batch'], op['segs'], dy_ld, op['x_ld'], 0, accumulate=True,
+                                 mask=op['xs'][0] if op.get('mask_dx') else None)
             if on_op_done is not None and not op['frozen']:
                 on_op_done(op)
 

@@ -25,7 +25,7 @@ def test_header_symbols_are_exported_and_bound():
         assert hasattr(h, n), f'{n} declared in include/llv.h but not exported by libllv.so'
         assert n in _lib.SIGNATURES, f'{n} has no ctypes signature in _lib.py'
     assert sorted(_lib.SIGNATURES) == names
-    assert _lib.lib().llv_abi_version() == 2
+    assert _lib.lib().llv_abi_version() == 3
     assert _lib.lib().llv_strerror(-1) == b'bad argument'
 
 
@@ -41,7 +41,7 @@ def test_clean_build(tmp_path):
     for n in _declared():
         assert hasattr(h, n), n
     h.llv_abi_version.restype = ctypes.c_int
-    assert h.llv_abi_version() == 2
+    assert h.llv_abi_version() == 3
 
 
 def test_no_kernel_needs_scratch_memory_or_spills():

@@ -87,6 +87,27 @@ def test_wgrad_over_pyramid_levels_in_one_call(dev, k):
     assert _rel(db.cpu(), bias.grad) < 2e-3
 
 
+def test_dgrad_takes_the_relu_mask_of_the_activation(dev):
+    """LLV_CONV_MASK_POS: the data gradient of a conv whose input is a ReLU output, masked by that activation in the launch's epilogue
+    (accumulating into a buffer that already holds another consumer's contribution) == autograd through relu -> conv."""
+    from lowlightenvironmentvideoobjectdetection_amd import backward as B, ops
+    g = torch.Generator().manual_seed(9)
+    n, cin, cout, h, w = 2, 64, 96, 14, 19
+    pre = torch.randn(n, cin, h, w, generator=g).half().float().requires_grad_()
+    x = F.relu(pre)
+    wt = (torch.randn(cout, cin, 3, 3, generator=g) / 24).half().float()
+    y = F.conv2d(x, wt, None, 1, 1)
+    dy = torch.randn(y.shape, generator=g).half().float()
+    y.backward(dy)
+    wd, KH, KW, pd, fl = B.dgrad_weight(wt, 1, 1, cin)
+    pcd = ops.pack_conv(wd, None, 1, pd, cout_store=wd.shape[0]).to(dev)
+    other = torch.randn(n, h, w, cin, generator=g).half()          # what another consumer has already accumulated
+    dx = other.clone().to(dev)
+    B.conv_dgrad(_nhwc(dy).half().to(dev), pcd, dx, n, [(h, w, h, w, 0, 0)], cout, cin, 0, accumulate=True, mask=_nhwc(x.detach()).half().to(dev))
+    want = other.float() * (_nhwc(x.detach()) > 0) + _nhwc(pre.grad)
+    assert _rel(dx.float().cpu(), want) < 4e-3
+
+
 def test_wgrad_grouped_towers(dev):
     """groups=2 over a 2x64-channel tensor (the RetinaHead twin-tower layout)."""
     from lowlightenvironmentvideoobjectdetection_amd import backward as B
