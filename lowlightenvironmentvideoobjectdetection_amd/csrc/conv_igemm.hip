@@ -971,7 +971,8 @@ __global__ __launch_bounds__(256, (BK == 64 ? 2 : (BN * BM >= 128 * 128 ? 3 : 4)
             }
             return;
         }
-        if ((a.flags & ~LLV_CONV_RELU) == LLV_CONV_RES_ADD && a.y_gstride == 0 && a.n_seg == 1 && (a.cout & 7) == 0) {
+        if ((a.flags & ~(LLV_CONV_RELU | LLV_CONV_MASK_POS)) == LLV_CONV_RES_ADD && a.y_gstride == 0 && a.n_seg == 1 && (a.cout & 7) == 0 &&
+            (!(a.flags & LLV_CONV_MASK_POS) || (a.mask_ld & 7) == 0)) {
             // residual add (+ ReLU), one segment (Bottleneck conv3 + identity, resnet.py:285-296; in-place gradient
             // accumulation): the residual tile comes in as 16 bytes per lane, whole cache lines per wave, is parked
             // in the staging tile, and each lane then adds its own 4 channels in fp32. Gathering it 8 bytes per lane
@@ -1011,6 +1012,17 @@ __global__ __launch_bounds__(256, (BK == 64 ? 2 : (BN * BM >= 128 * 128 ? 3 : 4)
             __syncthreads();
             if (cok) {
                 _Float16* yb = reinterpret_cast<_Float16*>(a.y) + ((long)a.seg_yoff[0] + (long)tile_m * BM) * a.y_ld + (long)g * a.cout + co8;
+                if (a.flags & LLV_CONV_MASK_POS) {       // (accumulating data gradient) the ReLU mask of the activation, 16 bytes per lane
+                    const _Float16* mb = a.mask + ((long)a.seg_yoff[0] + (long)tile_m * BM) * a.mask_ld + (long)g * a.cout + co8;
+#pragma unroll 4
+                    for (int prow = tid / CPR; prow < rows; prow += 256 / CPR) {
+                        f16x8 v8 = *reinterpret_cast<const f16x8*>(tile + prow * TS + cc * 8);
+                        const f16x8 m8 = *reinterpret_cast<const f16x8*>(mb + (long)prow * a.mask_ld);
+#pragma unroll
+                        for (int t = 0; t < 8; ++t) v8[t] = m8[t] > (_Float16)0.f ? v8[t] : (_Float16)0.f;
+                        *reinterpret_cast<f16x8*>(yb + (long)prow * a.y_ld) = v8;
+                    }
+                } else
 #pragma unroll 4
                 for (int prow = tid / CPR; prow < rows; prow += 256 / CPR)
                     *reinterpret_cast<uint4*>(yb + (long)prow * a.y_ld) = *reinterpret_cast<const uint4*>(tile + prow * TS + cc * 8);
