@@ -729,6 +729,10 @@ int llv_unpack_wgrad_batched(const llv_unpack_job* jobs, int n_jobs, int blocks_
  * segments are). w_dgrad: filter packed by llv_pack_conv_weights mode 1 (stride 1) or 2 (stride 2) with wd_rows x wd_k_pad,
  * window kh x kw and padding `pad` (backward.dgrad_geometry); zero_bias: fp32 zeros, one per output row; dy / dx fp16 NHWC with
  * row strides dy_ld / dx_ld; accumulate != 0 adds to dx in place. Stride 1 and 2, one source; stride 2 one segment per call.
+ * Two optional epilogue inputs ride in `fwd` (stride 1 only): flags & LLV_CONV_MASK_POS -- dx also takes the ReLU mask of the forward
+ * INPUT fwd->x[0] (x_ld == dx_ld), so that the launch whose output gradient dx is needs no llv_relu_bwd pass; fwd->res != NULL
+ * (accumulate must be 0) -- dx = gradient + res instead of an accumulation: a residual block's first conv, res = the gradient of the
+ * block output, whose identity path ends at the same tensor.
  * Workspace as for llv_conv2d_nhwc_fwd (NULL: the launch must not need split-K). */
 int llv_conv2d_nhwc_dgrad(const llv_conv_desc* fwd, const void* w_dgrad, const float* zero_bias, int wd_rows, int wd_k_pad,
                           int kh, int kw, int pad, const void* dy, int dy_ld, void* dx, int dx_ld, int accumulate,

@@ -210,15 +210,20 @@ def sgd_momentum(w: torch.Tensor, g: torch.Tensor, mom: torch.Tensor, lr: float,
 
 
 def conv_dgrad(dy: torch.Tensor, pcd: ops.PackedConv, dx: torch.Tensor, batch: int, segs, dy_ld: int, dx_ld: int,
-               flags: int, accumulate: bool, in_hw=None, fwd_stride: int = None, fwd_cin: int = None, mask: Optional[torch.Tensor] = None):
+               flags: int, accumulate: bool, in_hw=None, fwd_stride: int = None, fwd_cin: int = None, mask: Optional[torch.Tensor] = None,
+               res: Optional[torch.Tensor] = None):
     """dX (+)= data gradient through llv_conv2d_nhwc_dgrad. segs: the FORWARD launch's segments (h, w, ho, wo, x_off, y_off);
     pcd: the filter packed for the gradient (dgrad_weight / llv_pack_conv_weights modes 1, 2). flags: CONV_PIXSHUF for a
     stride-2 forward conv. mask: the forward conv's INPUT activation when that is a ReLU output (laid out like dx): dX also takes that
-    ReLU's mask, so the launch it is the output gradient of needs no llv_relu_bwd pass (stride-1 convs only)."""
+    ReLU's mask, so the launch it is the output gradient of needs no llv_relu_bwd pass (stride-1 convs only). res (laid out like dx,
+    accumulate False): dX = gradient + res, e.g. the gradient of a residual block's output joining at its first conv."""
     s2 = bool(flags & CONV_PIXSHUF)
     f = ConvDesc()
     if mask is not None:
         f.x[0], f.x_ld, f.flags = mask.data_ptr(), dx_ld, CONV_MASK_POS
+    if res is not None:
+        assert not accumulate and not s2
+        f.res, f.res_ld = res.data_ptr(), dx_ld
     f.n_src, f.n_seg = 1, len(segs)
     f.stride = 2 if s2 else 1
     f.cin = pcd.cout // 4 if s2 else pcd.cout
@@ -229,8 +234,8 @@ def conv_dgrad(dy: torch.Tensor, pcd: ops.PackedConv, dx: torch.Tensor, batch: i
     # split-K workspace of the underlying forward launch, if the planner wants one
     probe = ops.make_conv_desc(pcd, [dy], dx, batch,
                                [((ho, wo, (h + 1) // 2, (w + 1) // 2, yo, xo) if s2 else (ho, wo, h, w, yo, xo)) for (h, w, ho, wo, xo, yo) in segs],
-                               dy_ld, dx_ld, dx if accumulate else None, dx_ld if accumulate else 0,
-                               flags | (CONV_RES_ADD if accumulate else 0), ps_out=(segs[0][0], segs[0][1]) if s2 else (0, 0))
+                               dy_ld, dx_ld, dx if (accumulate or res is not None) else None, dx_ld if (accumulate or res is not None) else 0,
+                               flags | (CONV_RES_ADD if (accumulate or res is not None) else 0), ps_out=(segs[0][0], segs[0][1]) if s2 else (0, 0))
     wsb = ops.conv_workspace_bytes(probe)
     ws = torch.empty((wsb,), device=dy.device, dtype=torch.uint8) if wsb else None
     check(lib().llv_conv2d_nhwc_dgrad(C.byref(f), pcd.w.data_ptr(), pcd.bias.data_ptr(), pcd.w_rows, pcd.k_pad, pcd.kh, pcd.kw, pcd.pad,

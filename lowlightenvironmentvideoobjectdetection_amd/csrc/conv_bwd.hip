@@ -1191,8 +1191,12 @@ extern "C" int llv_conv2d_nhwc_dgrad(const llv_conv_desc* fwd, const void* w_dgr
     llv_conv_desc d = {};
     d.dilation = fwd->dilation > 1 ? fwd->dilation : 0;          // the flipped filter keeps the forward conv's dilation
     d.x[0] = dy; d.w = w_dgrad; d.bias = zero_bias; d.y = dx;
-    d.res = accumulate ? dx : nullptr;
-    d.n_src = 1; d.x_ld = dy_ld; d.y_ld = dx_ld; d.res_ld = accumulate ? dx_ld : 0;
+    // fwd->res (fp16, laid out like dX, res_ld channels per pixel): dX = gradient + res, written over dX instead of accumulated into it
+    // (a residual block's first conv: res = the gradient of the block output, whose identity path ends at the same tensor)
+    const bool plus = fwd->res != nullptr;
+    if (plus && (accumulate || (fwd->res_ld & 3) || fwd->stride != 1)) return LLV_E_BADARG;
+    d.res = plus ? fwd->res : (accumulate ? dx : nullptr);
+    d.n_src = 1; d.x_ld = dy_ld; d.y_ld = dx_ld; d.res_ld = plus ? fwd->res_ld : (accumulate ? dx_ld : 0);
     d.cin = dy_ld / fwd->groups;                     // channel pitch of one group inside dY
     d.cout = s2 ? 4 * fwd->cin : fwd->cin;
     d.w_rows = wd_rows; d.k_pad = wd_k_pad;
@@ -1204,7 +1208,7 @@ extern "C" int llv_conv2d_nhwc_dgrad(const llv_conv_desc* fwd, const void* w_dgr
         d.seg_wo[s] = s2 ? (fwd->seg_w[s] + 1) / 2 : fwd->seg_w[s];
         d.seg_xoff[s] = fwd->seg_yoff[s]; d.seg_yoff[s] = fwd->seg_xoff[s];
     }
-    d.flags = (s2 ? LLV_CONV_PIXSHUF : 0) | (accumulate ? LLV_CONV_RES_ADD : 0);
+    d.flags = (s2 ? LLV_CONV_PIXSHUF : 0) | ((accumulate || plus) ? LLV_CONV_RES_ADD : 0);
     if (fwd->flags & LLV_CONV_MASK_POS) {
         // dX also takes the ReLU mask of the forward INPUT (x[0], x_ld: the activation dX is the gradient of), so that the launch
         // that consumes it needs no mask pass of its own; mask((sum of contributions)) = sum of masked contributions

@@ -172,6 +172,37 @@ class TrainGraph:
                 a['mask_fused'] = True
                 for b in cons:
                     b['mask_dx'] = True
+        # Identity blocks: out = relu(conv3(..) + x) with x = the previous block's output, itself relu(conv3 + ..), read by this block's
+        # first conv and by nothing else. g(x) = mask(x) * (dgrad_conv1 + g(out)) then comes out of ONE launch: conv1's data gradient takes
+        # g(out) as its residual and x's mask in the epilogue, written over g(x); neither block needs its mask + identity-add pass
+        # (`relu_res_bwd`) for that edge. Stage boundaries (downsample / lateral consumers) keep theirs.
+        prod = {}
+        for op in self.tape:
+            if not op.get('custom'):
+                prod.setdefault(_sptr(op['y']), []).append(op)
+        plain = lambda fl: (fl & CONV_RELU) and (fl & CONV_RES_ADD) and not (fl & (CONV_LEAKY | CONV_RES_UPS | CONV_ACT_FIRST | CONV_PIXSHUF))
+        for c3 in self.tape:
+            if not self.fuse_masks or c3.get('custom') or not plain(c3['flags']) or c3.get('res') is None or _sptr(c3['y']) not in self.req:
+                continue
+            x = c3['res']
+            px = _sptr(x)
+            if px not in self.req or px in fed or x.dtype != torch.float16 or len(c3['segs']) != 1 or len(prod.get(px, [])) != 1:
+                continue
+            p3 = prod[px][0]
+            if not plain(p3['flags']) or not same_view(p3['y'], x) or len(p3['segs']) != 1 or x.shape != c3['y'].shape \
+                    or not x.is_contiguous() or not c3['y'].is_contiguous():
+                continue
+            us = users.get(px, [])
+            firsts = [b for b in us if not b.get('custom') and len(b['xs']) == 1 and same_view(b['xs'][0], x)]
+            if len(us) != 2 or len(firsts) != 1 or c3 not in us or firsts[0] is c3:
+                continue
+            c1 = firsts[0]
+            if not c1.get('need_dx', False) or c1.get('dflags', 0) != 0 or c1['pc'].stride != 1 or c1.get('res') is not None and _sptr(c1['res']) == px:
+                continue
+            c3['id_via_conv1'] = True             # the identity gradient of this block joins in conv1's launch
+            c1['dx_res_of'] = c3['y']             # ... as the residual g(out), with x's mask, written over g(x)
+            c1['mask_dx'] = True
+            p3['grad_final'] = True               # g(x) arrives masked and complete at the block that produced x
 
     # ---- helpers -------------------------------------------------------------------------------
     def _dy_ld(self, op):
@@ -314,7 +345,15 @@ class TrainGraph:
                 gres = None
                 if (flags & CONV_RES_ADD) and not (flags & (CONV_RES_UPS | CONV_LEAKY)) and op['res'] is not None and _sptr(op['res']) in self.req:
                     gres = self.gview(op['res'])
-                if gres is not None and len(op['segs']) == 1 and op['segs'][0][5] == 0 and gy.is_contiguous() and gres.is_contiguous() \
+                if gres is not None and (op.get('grad_final') or op.get('id_via_conv1')):
+                    # identity-block edges planned by _plan_mask_fusion: dY arrives masked (grad_final) and / or the identity gradient
+                    # joins in conv1's data-gradient launch (id_via_conv1); what is left of the pass, if anything, is one of its halves
+                    if not op.get('grad_final'):
+                        B.relu_bwd(gy, op['y'], gy)
+                    if not op.get('id_via_conv1'):
+                        B.relu_bwd(gres, None, gres, dy2=gy)
+                    fused_res = True
+                elif gres is not None and len(op['segs']) == 1 and op['segs'][0][5] == 0 and gy.is_contiguous() and gres.is_contiguous() \
                         and op['y'].is_contiguous() and gy.numel() == gres.numel() == op['y'].numel():
                     B.relu_res_bwd(gy, op['y'], gres)            # mask + the identity's gradient in one pass (a Bottleneck's output)
                     fused_res = True
@@ -359,8 +398,9 @@ class TrainGraph:
                     for seg in op['segs']:
                         B.conv_dgrad(gy, op['pcd'], gx, op['batch'], [seg], dy_ld, op['x_ld'], op['dflags'], accumulate=True)
                 else:
-                    B.conv_dgrad(gy, op['pcd'], gx, op['batch'], op['segs'], dy_ld, op['x_ld'], 0, accumulate=True,
-                                 mask=op['xs'][0] if op.get('mask_dx') else None)
+                    rsrc = op.get('dx_res_of')
+                    B.conv_dgrad(gy, op['pcd'], gx, op['batch'], op['segs'], dy_ld, op['x_ld'], 0, accumulate=rsrc is None,
+                                 mask=op['xs'][0] if op.get('mask_dx') else None, res=self.gview(rsrc) if rsrc is not None else None)
             if on_op_done is not None and not op['frozen']:
                 on_op_done(op)
 
