@@ -197,6 +197,21 @@ __device__ __forceinline__ void epi_store(const ConvKArgs& a, const EpiCtx& c, i
     }
 }
 
+// LDS reads the compiler must not guard with vmcnt waits (see the implicit-GEMM main loop): the read is inline assembly, the wave's
+// LDS counter is waited for by hand (lds_wait_all_but<N>: at most the N youngest reads still outstanding) and lds_use ties a register
+// to a point after that wait, so its first use cannot be scheduled in front of it.
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+    return (unsigned)(unsigned long)((__attribute__((address_space(3))) const unsigned char*)p);
+}
+__device__ __forceinline__ f16x8 lds_read128(unsigned addr) {
+    f16x8 v;
+    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
+    return v;
+}
+template <int N>
+__device__ __forceinline__ void lds_wait_all_but() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
+__device__ __forceinline__ void lds_use(f16x8& v) { asm volatile("" : "+v"(v)); }
+
 // Phase 2 of the LDS-staged epilogue: the [BM pixels][BN couts] fp16 tile (row stride BN+8 halfs) goes to
 // global memory 16 bytes per lane, consecutive lanes = consecutive channels of a pixel. row_to_m maps a tile
 // row to the output row index m (or -1 when the row is outside the image / past the end).
@@ -593,21 +608,6 @@ __device__ __forceinline__ __amdgpu_buffer_rsrc_t make_rsrc(const void* p, unsig
 __device__ __forceinline__ void dma16(__amdgpu_buffer_rsrc_t r, unsigned char* lds, int voff, int soff) {
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (__attribute__((address_space(3))) void*)lds, 16, voff, soff, 0, 0);
 }
-
-// LDS reads the compiler must not guard with vmcnt waits (see the implicit-GEMM main loop): the read is inline assembly, the wave's
-// LDS counter is waited for by hand (lds_wait_all_but<N>: at most the N youngest reads still outstanding) and lds_use ties a register
-// to a point after that wait, so its first use cannot be scheduled in front of it.
-__device__ __forceinline__ unsigned lds_addr(const void* p) {
-    return (unsigned)(unsigned long)((__attribute__((address_space(3))) const unsigned char*)p);
-}
-__device__ __forceinline__ f16x8 lds_read128(unsigned addr) {
-    f16x8 v;
-    asm volatile("ds_read_b128 %0, %1" : "=v"(v) : "v"(addr));
-    return v;
-}
-template <int N>
-__device__ __forceinline__ void lds_wait_all_but() { asm volatile("s_waitcnt lgkmcnt(%0)" ::"n"(N)); }
-__device__ __forceinline__ void lds_use(f16x8& v) { asm volatile("" : "+v"(v)); }
 
 #ifndef GLDS_STAGES
 #define GLDS_STAGES 2
