@@ -1643,7 +1643,15 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
         // inside one anchor. Per anchor touched by this tile (at most three): maximum over the lane's blocks, over the four lanes (two
         // lane swaps), one atomicMax per pixel. The pixel's 128-channel segment is stored only when it has a logit above store_thr.
         const int A = a.cout / a.cls_c;
-        // (the bias is re-read here, as epi_compute does: keeping the pre-loop copy alive across the main loop would cost 32 registers)
+        // (the bias is re-read here, as epi_compute does: keeping the pre-loop copy alive across the main loop would cost 32 registers --
+        // but ONCE for the tile, all TN loads in flight together: inside the row loop every one of the TM x TN loads was waited for by
+        // itself, 64 exposed load latencies per tile; found in the ISA in round 4)
+        float4 b4s[TN];
+#pragma unroll
+        for (int i = 0; i < TN; ++i) {
+            const int co0 = tile_n * BN + i * 16;
+            b4s[i] = co0 < a.cout ? *reinterpret_cast<const float4*>(a.bias + co0 + fch * 4) : make_float4(0.f, 0.f, 0.f, 0.f);
+        }
 #pragma unroll
         for (int j = 0; j < TM; ++j) {
             const int prow = (2 * wave + (j >> 1)) * 32 + (j & 1) * 16 + frow;
@@ -1656,7 +1664,7 @@ __global__ __launch_bounds__(256, 2) void conv3x3_tap_kernel(const ConvKArgs a, 
                 const int co0 = tile_n * BN + i * 16;
                 const bool live = co0 < a.cout;
                 if (live) {
-                    const float4 b4 = *reinterpret_cast<const float4*>(a.bias + co0 + fch * 4);
+                    const float4 b4 = b4s[i];
                     acc[i][j][0] += b4.x; acc[i][j][1] += b4.y; acc[i][j][2] += b4.z; acc[i][j][3] += b4.w;
                     const float m4 = fmaxf(fmaxf(acc[i][j][0], acc[i][j][1]), fmaxf(acc[i][j][2], acc[i][j][3]));
                     run = fmaxf(run, m4);
