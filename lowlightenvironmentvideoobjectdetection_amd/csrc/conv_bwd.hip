@@ -20,6 +20,15 @@
 #include <type_traits>
 #include "llv.h"
 
+// Knock-out experiments of the weight-gradient kernels (LLV_WGRAD_KNOCK: bit 0 plain stores instead of atomics, bit 1 no stores, bit 2 no
+// DMA, bit 3 no MFMA -- wrong results, timing only; tools/wgrad_bench.py) exist only in a build with -DLLV_KNOCKOUTS
+// (`make EXTRA=-DLLV_KNOCKOUTS`): the product library ignores the variable.
+#ifdef LLV_KNOCKOUTS
+#define LLV_KNOCK(a) ((a).knock)
+#else
+#define LLV_KNOCK(a) 0
+#endif
+
 namespace {
 
 typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
@@ -278,8 +287,8 @@ __device__ __forceinline__ void conv_wgrad_body(const WgArgs& a, const int bid) 
             for (int e = 0; e < 4; ++e) {
                 const int co = co0 + wr * (BCO / 2) + i * 16 + 4 * (lane >> 4) + e;
                 if (co < a.cout) {
-                    if (a.knock == 0) atomicAdd(dwg + (long)co * a.k_pad + tap * a.cin + ci, acc[i][j][e]);
-                    else if (a.knock == 1) dwg[(long)co * a.k_pad + tap * a.cin + ci] = acc[i][j][e];
+                    if (LLV_KNOCK(a) == 0) atomicAdd(dwg + (long)co * a.k_pad + tap * a.cin + ci, acc[i][j][e]);
+                    else if (LLV_KNOCK(a) == 1) dwg[(long)co * a.k_pad + tap * a.cin + ci] = acc[i][j][e];
                     else if (acc[i][j][e] == 123.456f) dwg[0] = 1.f;
                 }
             }
@@ -435,7 +444,7 @@ __device__ __forceinline__ void conv_wgrad3x3_body(const Wg3Args& a, const int b
         unsigned char* sY = smem + buf * STAGE;
         unsigned char* sX = sY + 8 * 1024;
         const int y0 = ity * 8, x0 = itx * 8;
-        if (!(a.knock & 4)) {
+        if (!(LLV_KNOCK(a) & 4)) {
             const int pix0 = (in_ * sH + y0) * sW + x0;
             const int by = (syo + pix0) * a.dy_ld * 2, bx = (sxo + pix0) * a.x_ld * 2;
 #pragma unroll
@@ -506,7 +515,7 @@ __device__ __forceinline__ void conv_wgrad3x3_body(const Wg3Args& a, const int b
         asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
         if (ks + 2 < np) issue(cur >= 1 ? cur - 1 : NST - 1);
         const unsigned st = lds_addr(smem) + cur * STAGE;
-        if (a.knock & 8) { cur = cur + 1 == NST ? 0 : cur + 1; continue; }
+        if (LLV_KNOCK(a) & 8) { cur = cur + 1 == NST ? 0 : cur + 1; continue; }
         // the X fragment of tap t + 1 is requested before the MFMAs of tap t are issued: lds_wait<2> = everything but those two reads
         auto bfrag = [&](int t18) __attribute__((always_inline)) {
             const int sub = t18 / 9, t = t18 - sub * 9, r = t / 3, s3 = t - r * 3;
@@ -557,7 +566,7 @@ __device__ __forceinline__ void conv_wgrad3x3_body(const Wg3Args& a, const int b
     // D[m = co][n = ci]: lane holds rows 4 * (lane >> 4) + e, column lane & 15. 576 values per lane: buffer atomics with one lane offset
     // and a scalar offset per value; rows >= cout fall outside the buffer range and are dropped by the hardware (one compare-and-branch
     // plus 64-bit address arithmetic per value made this epilogue 12 us of a 70 us launch)
-    if (a.knock & 3) return;
+    if (LLV_KNOCK(a) & 3) return;
     const __amdgpu_buffer_rsrc_t rW = make_rsrc(a.dw + (long)g * a.w_rows * a.k_pad, a.dwg_bytes);
     const int ci = ci0 + wave * 16 + (lane & 15);
     const int lane_off = ci < a.cin ? ((co0 + 4 * (lane >> 4)) * a.k_pad + ci) * 4 : 0x7ffffff0;

@@ -1,4 +1,4 @@
-"""llv_conv2d_nhwc_wgrad alone on the shapes of the training step (one 736 x 1280 image, RetinaNet R-50 + FPN): microseconds and
+"""llv_conv2d_nhwc_wgrad alone on the shapes of the training step (knock-outs: LLV_WGRAD_KNOCK with a library built by `make EXTRA=-DLLV_KNOCKOUTS`) (one 736 x 1280 image, RetinaNet R-50 + FPN): microseconds and
 TFLOP/s per launch, nothing else on the device.  python tools/wgrad_bench.py [name-filter]"""
 import os, sys
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
