@@ -398,6 +398,98 @@ def selsa_bench(args, world, rank, dev):
         dist.destroy_process_group()
 
 
+def vid2s_bench(args, world, rank, dev, kind):
+    """The reference's OWN video configs at test time: `configs/vid/dff/dff_faster_rcnn_r50_dc5_1x_imagenetvid.py` (kind 'dff2s': key frame
+    every 10 frames, the others warp the key features with FlowNetSimple) and `configs/vid/fgfa/fgfa_faster_rcnn_r50_dc5_1x_imagenetvid.py`
+    (kind 'fgfa2s': 30 reference frames around every frame, test sampler `test_with_fix_stride`, stride 1, EmbedAggregator over 512 channels)
+    around `_base_/models/faster_rcnn_r50_dc5.py` (ResNet-50 DC5, ChannelMapper 2048 -> 512, RPNHead with 12 anchors and 300 proposals,
+    StandardRoIHead + Shared2FCBBoxHead, 30 classes), 1280x720 frames, one frame per step, fed as the reference's test dataset feeds them
+    (apis.ClipTestFeed). Module-level calls (no launch plan over the whole step yet): a first number for the two-stage branch."""
+    import torch.distributed as dist
+    import lowlightenvironmentvideoobjectdetection_amd.models as M
+    from lowlightenvironmentvideoobjectdetection_amd import apis, data
+    from lowlightenvironmentvideoobjectdetection_amd.synthetic import seeded_weights
+    NC = 30
+    det = dict(
+        type='FasterRCNN', pretrained=None,
+        backbone=dict(type='ResNet', depth=50, num_stages=4, out_indices=(3,), strides=(1, 2, 2, 1), dilations=(1, 1, 1, 2), frozen_stages=-1,
+                      norm_cfg=dict(type='BN', requires_grad=True), norm_eval=True, style='pytorch'),
+        neck=dict(type='ChannelMapper', in_channels=[2048], out_channels=512, kernel_size=3),
+        rpn_head=dict(type='RPNHead', in_channels=512, feat_channels=512,
+                      anchor_generator=dict(type='AnchorGenerator', scales=[4, 8, 16, 32], ratios=[0.5, 1.0, 2.0], strides=[16]),
+                      bbox_coder=dict(type='DeltaXYWHBBoxCoder', target_means=[.0, .0, .0, .0], target_stds=[1.0, 1.0, 1.0, 1.0])),
+        roi_head=dict(type='StandardRoIHead',
+                      bbox_roi_extractor=dict(type='SingleRoIExtractor', roi_layer=dict(type='RoIAlign', output_size=7, sampling_ratio=2),
+                                              out_channels=512, featmap_strides=[16]),
+                      bbox_head=dict(type='Shared2FCBBoxHead', in_channels=512, fc_out_channels=1024, roi_feat_size=7, num_classes=NC,
+                                     bbox_coder=dict(type='DeltaXYWHBBoxCoder', target_means=[0., 0., 0., 0.], target_stds=[0.2, 0.2, 0.2, 0.2]),
+                                     reg_class_agnostic=False)),
+        test_cfg=dict(rpn=dict(nms_across_levels=False, nms_pre=6000, nms_post=300, max_num=300, nms_thr=0.7, min_bbox_size=0),
+                      rcnn=dict(score_thr=0.0001, nms=dict(type='nms', iou_threshold=0.5), max_per_img=100)))
+    flow = dict(type='FlowNetSimple', img_scale_factor=0.5)
+    if kind == 'dff2s':
+        cfg = dict(type='DFF', detector=det, motion=flow, test_cfg=dict(key_frame_interval=10))
+        sampler = None
+    else:
+        cfg = dict(type='FGFA', detector=det, motion=flow, aggregator=dict(type='EmbedAggregator', num_convs=1, channels=512, kernel_size=3))
+        sampler = dict(num_ref_imgs=30, frame_range=[-15, 15], stride=1, method='test_with_fix_stride')
+    model = M.build_model(cfg)
+    seeded_weights(model, seed=0)
+    g = torch.Generator().manual_seed(3)
+    with torch.no_grad():
+        model.detector.rpn_head.rpn_cls.bias.add_(-2.0)
+        model.detector.rpn_head.rpn_reg.weight.mul_(0.3)
+        for p in model.detector.roi_head.parameters():
+            p.copy_(torch.randn(p.shape, generator=g) * ((1.0 / p.shape[1]) ** 0.5 if p.dim() == 2 else 0.05))
+    model = model.to(dev).eval()
+    assert model.two_stage
+    warm = max(args.warmup, 10)                       # a whole key-frame period of DFF; FGFA's frame 0 builds the 31-frame window
+    steps = (args.steps + 9) // 10 * 10
+    T = warm + steps
+    clean = data.synth_clean_clip(min(T + 16, 48), args.height, args.width, seed=100 + rank)
+    clip, img_shape, pad_shape = data.preprocess_clip(data.darken_and_add_noise(clean, seed=200 + rank), dev, size_divisor=128)
+    base = clip[:, :, :, :3].permute(0, 3, 1, 2).float().contiguous()
+    frames = base[torch.arange(T + 16) % base.shape[0]]
+    meta = dict(img_shape=img_shape, pad_shape=pad_shape, ori_shape=img_shape, scale_factor=[1.0, 1.0, 1.0, 1.0], flip=False,
+                img_norm_cfg=dict(mean=[123.675, 116.28, 103.53], std=[58.395, 57.12, 57.375], to_rgb=True))
+    feed = list(apis.make_feed(model, frames, meta, sampler, 0, T))
+    apis.prepare_segment(model, apis.make_feed(model, frames, meta, sampler, 0, T))
+
+    def step(i):
+        with torch.no_grad():
+            return model(return_loss=False, rescale=True, **feed[i][1])
+
+    for i in range(warm):
+        out = step(i)
+    if world > 1:
+        dist.barrier()
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for i in range(warm, T):
+        out = step(i)
+    torch.cuda.synchronize()
+    if world > 1:
+        dist.barrier()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        tt = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tt, op=dist.ReduceOp.MAX)
+        dt = float(tt.item())
+    if rank == 0:
+        what = ('DFF: key frame every 10 frames, FlowNetSimple + feature warp on the others' if kind == 'dff2s' else
+                'FGFA: 30 reference frames per frame (fixed stride 1), flow + warp + EmbedAggregator over 512 channels')
+        print(json.dumps({
+            'metric': f'frames/sec ({what}; Faster R-CNN R-50 DC5 + StandardRoIHead) on 1280x720 video',
+            'value': round(steps * world / dt, 3), 'unit': 'frames/s', 'n_gpus': world, 'steps': steps, 'warmup': warm,
+            'ms_per_step': round(dt / steps * 1e3, 4), 'higher_is_better': True, 'scaling': 'weak', 'vs_baseline': None,
+            'dtype': 'f16', 'data': 'synthetic',
+            'config': {'workload': f"the reference's configs/vid/{'dff' if kind == 'dff2s' else 'fgfa'}/*_faster_rcnn_r50_dc5_1x_imagenetvid.py at "
+                                   f'test time, 1 frame/step, frames padded to {pad_shape[1]}x{pad_shape[0]}, module-level eager launches',
+                       'detections_last_step': int(sum(len(a) for a in out['bbox_results']))}}), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def fgfa_bench(args, world, rank, dev):
     """Config #4 of BASELINE.json: flow-guided feature aggregation over a 10-reference window (mmtracking FGFA with
     EmbedAggregator on the 256-channel FPN levels, RetinaNet R-50+FPN detector, FlowNetSimple), 1280x720 frames, one frame
@@ -513,7 +605,7 @@ def main():
     ap.add_argument('--no-cpu-baseline', action='store_true')
     ap.add_argument('--no-kernel-timing', action='store_true')
     ap.add_argument('--no-latency-mode', action='store_true')
-    ap.add_argument('--mode', choices=['infer', 'train', 'yolo', 'fgfa', 'insert', 'selsa'], default='infer',
+    ap.add_argument('--mode', choices=['infer', 'train', 'yolo', 'fgfa', 'insert', 'selsa', 'dff2s', 'fgfa2s'], default='infer',
                     help="'train' = BASELINE.json config #3: RetinaNet fwd + loss + bwd + gradient all-reduce + SGD, one image per GPU")
     ap.add_argument('--train-batch', type=int, default=1, help='images per GPU per training step')
     ap.add_argument('--shard', choices=['frames', 'clips'], default='frames',
@@ -575,6 +667,8 @@ def main():
         return insert_bench(args, world, rank, dev)
     if args.mode == 'selsa':
         return selsa_bench(args, world, rank, dev)
+    if args.mode in ('dff2s', 'fgfa2s'):
+        return vid2s_bench(args, world, rank, dev, args.mode)
 
     B, T = args.frames_per_step, args.clip_frames
     det, cleaner = build_models(seed=0)
