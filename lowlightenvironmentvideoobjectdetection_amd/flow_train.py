@@ -217,8 +217,8 @@ class FlowNetTrainGraph(train_engine.TrainGraph):
         self.trainable = self.trainable + [d.wkey for d in self.deconvs if self.params[d.wkey].requires_grad]
         self.dfl32 = torch.zeros_like(self.fl32)
 
-    def _repack_each(self):
-        super()._repack_each()
+    def _repack_each(self, ops_list=None):
+        super()._repack_each(ops_list)
         for d in self.deconvs:
             d.repack()
 
