@@ -441,7 +441,12 @@ typedef struct llv_retina_loss_desc {
     float means[4], stds[4];
     float* sums; float* avg_factor; float* losses;
     int* counts;     /* `batch` ints of scratch, ZERO on the first call (every call leaves them and `sums` zero again) */
+    float* partials; /* optional scratch of partials_cap floats, partials_cap >= 2 * n_levels * LLV_RETINA_LOSS_MAX_GROUPS: the workgroups'
+                      * partial sums go to slots of their own and are added in a fixed order (deterministic loss values; with NULL they are
+                      * added to `sums` by fp32 atomics, ~1,800 to the same address for a 736 x 1280 image: 85 us of serialised atomics) */
+    int32_t partials_cap;
 } llv_retina_loss_desc;
+#define LLV_RETINA_LOSS_MAX_GROUPS 2048
 int llv_retina_loss(const llv_retina_loss_desc* desc, void* stream);
 
 /* Modulated deformable convolution, column step (ModulatedDCNPack.forward, denoising_aggregator.py:103-111 ->

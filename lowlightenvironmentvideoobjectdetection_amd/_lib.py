@@ -99,7 +99,8 @@ class RetinaLossDesc(C.Structure):
                 ('gamma', C.c_float), ('alpha', C.c_float), ('cls_weight', C.c_float), ('reg_weight', C.c_float), ('beta', C.c_float),
                 ('pos_weight', C.c_float), ('grad_scale', C.c_float),
                 ('means', C.c_float * 4), ('stds', C.c_float * 4),
-                ('sums', C.c_void_p), ('avg_factor', C.c_void_p), ('losses', C.c_void_p), ('counts', C.c_void_p)]
+                ('sums', C.c_void_p), ('avg_factor', C.c_void_p), ('losses', C.c_void_p), ('counts', C.c_void_p),
+                ('partials', C.c_void_p), ('partials_cap', C.c_int32)]
 
 
 class ConvDesc(C.Structure):

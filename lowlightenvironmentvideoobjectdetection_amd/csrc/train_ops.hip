@@ -239,6 +239,9 @@ __global__ void retina_count_pos_kernel(const int64_t* __restrict__ gt_inds, lon
 // softplus pair shares one exponential (e = exp(-|x|): p = 1/(1+e) or e/(1+e), softplus(-|x|) = log1p(e)). The first version did
 // three 32-bit divisions, a 64-bit gather and three transcendentals per logit: 293 us for the 14.1 M logits of one 736 x 1280 image.
 constexpr int kRlMaxAC = 2048, kRlMaxA = 32, kRlPix = 16;
+// G2: gamma == 2 (every config of the reference): the general powf() path is compiled out of that instance -- inlined twice per logit it
+// tripled the code of the unrolled loop and pushed scalar registers into VGPR lanes
+template <bool G2>
 __global__ __launch_bounds__(256) void retina_loss_kernel(const llv_retina_loss_desc d, const int* __restrict__ counts) {
     const int l = blockIdx.y;
     const int A = d.num_anchors, C = d.num_classes, AC = A * C;
@@ -258,7 +261,7 @@ __global__ __launch_bounds__(256) void retina_loss_kernel(const llv_retina_loss_
     for (int n = 0; n < d.batch; ++n) avg += (float)(counts[n] > 1 ? counts[n] : 1);
     const float inv_avg = 1.f / avg;
     const float gs_cls = d.cls_weight * inv_avg * d.grad_scale, gs_reg = d.reg_weight * inv_avg * d.grad_scale;
-    const bool g2 = d.gamma == 2.f;
+    constexpr bool g2 = G2;
     const float posw = d.pos_weight > 0.f ? d.pos_weight : 1.f;
     _Float16* const dcls = reinterpret_cast<_Float16*>(d.dcls);
     _Float16* const dreg = reinterpret_cast<_Float16*>(d.dreg);
@@ -282,8 +285,9 @@ __global__ __launch_bounds__(256) void retina_loss_kernel(const llv_retina_loss_
         int pp = 0, ch = threadIdx.x;
         while (ch >= AC) { ch -= AC; ++pp; }
         while (pp < np) {
-            // four logits of this thread in flight (one was a chain of exposed load latencies: 45 per thread on the finest level)
-            constexpr int U = 4;
+            // eight logits of this thread in flight (one was a chain of exposed load latencies: 45 per thread on the finest level;
+            // four still left eleven round trips per group: 156 us per image, round 4)
+            constexpr int U = 8;
             int pps[U], chs[U];
             float xs[U];
 #pragma unroll
@@ -302,10 +306,13 @@ __global__ __launch_bounds__(256) void retina_loss_kernel(const llv_retina_loss_
                 const bool pos = s_label[pq * kRlMaxA + a] == (int)s_cls[cq];
                 const float w = s_w[pq * kRlMaxA + a];
                 const float xi = xs[u];
-                const float e = expf(-fabsf(xi));
-                const float r = 1.f / (1.f + e);
+                // hardware exp2 / log2 / rcp (1 ulp each) instead of the library's expf / log1pf / division: with those the kernel was
+                // bound by ~150 ALU instructions per logit (154 us for the 14.1 M logits of an image). log1p(e), e in (0, 1]: the series
+                // below 1/64 (error < e^4/4 = 1.5e-8 relative to e), log(1 + e) above it, where 1 + e is exact to 6e-8 of e / 1.6e-2
+                const float e = __expf(-fabsf(xi));
+                const float r = __builtin_amdgcn_rcpf(1.f + e);
                 const float p = xi >= 0.f ? r : e * r;           // sigmoid(x)
-                const float sp = log1pf(e);
+                const float sp = e < 0.015625f ? e * (1.f - e * (0.5f - e * 0.33333334f)) : __logf(1.f + e);
                 const float log_p = -(fmaxf(-xi, 0.f) + sp), log_1mp = -(fmaxf(xi, 0.f) + sp);
                 float loss, grad;
                 if (pos) {
@@ -362,17 +369,35 @@ __global__ __launch_bounds__(256) void retina_loss_kernel(const llv_retina_loss_
         __syncthreads();
     }
     if (threadIdx.x == 0) {
-        atomicAdd(&d.sums[l], red[0][0]);
-        atomicAdd(&d.sums[d.n_levels + l], red[1][0]);
+        if (d.partials) {
+            // one slot per workgroup and term, summed by retina_loss_finish_kernel in a fixed order. 920 workgroups adding to ONE address
+            // with device-scope fp32 atomics serialised at ~46 ns each: 85 of the kernel's 129 us (round 4: 44.7 us without them)
+            d.partials[(long)l * gridDim.x + blockIdx.x] = red[0][0];
+            d.partials[(long)(d.n_levels + l) * gridDim.x + blockIdx.x] = red[1][0];
+        } else {
+            atomicAdd(&d.sums[l], red[0][0]);
+            atomicAdd(&d.sums[d.n_levels + l], red[1][0]);
+        }
     }
 }
 
 // sums -> losses: [2][n_levels] * loss_weight / avg_factor; leaves sums and counters zero for the next call
 __global__ void retina_loss_finish_kernel(float* __restrict__ sums, int* __restrict__ counts, int batch, float* __restrict__ avg_factor,
-                                          float* __restrict__ out, int n_levels, float cls_weight, float reg_weight) {
+                                          float* __restrict__ out, int n_levels, float cls_weight, float reg_weight,
+                                          const float* __restrict__ partials, int slots) {
     float avg = 0.f;
     for (int n = 0; n < batch; ++n) avg += (float)(counts[n] > 1 ? counts[n] : 1);
     const int i = threadIdx.x;
+    if (partials) {                                   // wave t adds the slots of (term, level) pair t, lane k its slots k, k + 64, ..
+        const int t = i >> 6, lane = i & 63;
+        if (t < 2 * n_levels) {
+            float v = 0.f;
+            for (int k = lane; k < slots; k += 64) v += partials[(long)t * slots + k];
+            for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+            if (lane == 0) sums[t] = v;
+        }
+        __syncthreads();
+    }
     if (i < 2 * n_levels) out[i] = sums[i] * (i < n_levels ? cls_weight : reg_weight) / avg;
     __syncthreads();
     if (i < 2 * n_levels) sums[i] = 0.f;
@@ -498,8 +523,10 @@ extern "C" int llv_retina_loss(const llv_retina_loss_desc* d, void* stream) {
     if (AC > kRlMaxAC || d->num_anchors > kRlMaxA || d->max_gt > (1 << 30)) return LLV_E_UNSUPPORTED;
     long gx = (max_work / AC + kRlPix - 1) / kRlPix;             // pixel groups of the largest level
     gx = gx > 2048 ? 2048 : (gx < 1 ? 1 : gx);
-    hipLaunchKernelGGL(retina_loss_kernel, dim3((int)gx, d->n_levels), dim3(256), 0, st, *d, (const int*)d->counts);
-    hipLaunchKernelGGL(retina_loss_finish_kernel, dim3(1), dim3(64), 0, st, d->sums, d->counts, d->batch, d->avg_factor, d->losses, d->n_levels,
-                       d->cls_weight, d->reg_weight);
+    if (d->partials && d->partials_cap < 2L * d->n_levels * gx) return LLV_E_BADARG;
+    if (d->gamma == 2.f) hipLaunchKernelGGL(retina_loss_kernel<true>, dim3((int)gx, d->n_levels), dim3(256), 0, st, *d, (const int*)d->counts);
+    else hipLaunchKernelGGL(retina_loss_kernel<false>, dim3((int)gx, d->n_levels), dim3(256), 0, st, *d, (const int*)d->counts);
+    hipLaunchKernelGGL(retina_loss_finish_kernel, dim3(1), dim3(d->partials ? 64 * 2 * d->n_levels : 64), 0, st, d->sums, d->counts, d->batch, d->avg_factor, d->losses, d->n_levels,
+                       d->cls_weight, d->reg_weight, (const float*)d->partials, (int)gx);
     return hipGetLastError() == hipSuccess ? LLV_OK : LLV_E_LAUNCH;
 }

@@ -180,6 +180,8 @@ class FusedHeadLoss:
         d.sums, d.avg_factor, d.losses = self.scratch.data_ptr(), self.avg_factor.data_ptr(), self.losses.data_ptr()
         self.counts = torch.zeros(max(n, 1), dtype=torch.int32, device=device)
         d.counts = self.counts.data_ptr()
+        self.partials = torch.zeros(2 * len(hw) * 2048, dtype=torch.float32, device=device)     # a slot per workgroup and term: no atomics
+        d.partials, d.partials_cap = self.partials.data_ptr(), self.partials.numel()
         self.desc = d
         self._set_gt_ptrs()
         self._inside = {}
