@@ -242,15 +242,24 @@ __global__ __launch_bounds__(256) void topk_threshold_kernel(const DecK k) {
     }
 }
 
-// K3: scores above b* go to list A, scores inside b* to list T (unordered appends; the 64-bit keys are distinct)
-__global__ void topk_compact_kernel(const DecK k) {
+// K3: scores above b* go to list A, scores inside b* to list T (unordered appends; the 64-bit keys are distinct).
+// The list counters are per (image, level): one returning global atomic per (wave, level, list) put ~2,000 atomics of an image's finest level
+// on ONE address, and same-address device atomics retire at ~46 ns each (82 us per step for 16 images; the same effect as in the loss
+// kernel of the training step, round 4). A workgroup of 16 waves now counts in LDS first and takes ONE global atomic per (level, list).
+constexpr int kCompactSlots = 4;              // levels a 1024-anchor block can touch (the coarse levels hold 2160 and 540 anchors)
+__global__ __launch_bounds__(1024) void topk_compact_kernel(const DecK k) {
+    __shared__ int s_cnt[2][kCompactSlots], s_base[2][kCompactSlots];
     const int total = k.a0[k.n_levels];
     const int stride = gridDim.x * blockDim.x;
     const int lane = threadIdx.x & 63;
     IMG_SETUP(k)
     for (int g0 = blockIdx.x * blockDim.x; g0 < total; g0 += stride) {
+        const int l0 = level_of_anchor(k, g0);                  // uniform: the level of the block's first anchor
+        __syncthreads();                                        // the previous round's bases are no longer read
+        if (threadIdx.x < 2 * kCompactSlots) s_cnt[threadIdx.x / kCompactSlots][threadIdx.x % kCompactSlots] = 0;
+        __syncthreads();
         const int g = g0 + threadIdx.x;
-        int l = 0, which = 0;   // 1 = A, 2 = T
+        int l = l0, which = 0;   // 1 = A, 2 = T
         uint64_t key = 0;
         if (g < total) {
             l = level_of_anchor(k, g);
@@ -262,7 +271,8 @@ __global__ void topk_compact_kernel(const DecK k) {
                 key = llv::make_key(m, (unsigned)(g - k.a0[l]));
             }
         }
-        // one atomic per (wave, level, list)
+        const int slot = l - l0;                                // < kCompactSlots by the level sizes; checked below
+        int mypos = -1;                                         // position inside the workgroup's run of its (list, level)
         for (int w = 1; w <= 2; ++w) {
             unsigned long long active = __ballot(which == w);
             while (active) {
@@ -270,17 +280,27 @@ __global__ void topk_compact_kernel(const DecK k) {
                 const int ll = __shfl(l, leader);
                 const unsigned long long same = __ballot(which == w && l == ll);
                 int base = 0;
-                if (lane == leader) base = atomicAdd(&meta_i[ll * 4 + 1 + w], (int)__popcll(same));
+                if (lane == leader && ll - l0 < kCompactSlots) base = atomicAdd(&s_cnt[w - 1][ll - l0], (int)__popcll(same));
                 base = __shfl(base, leader);
-                if (which == w && l == ll) {
-                    const int pos = base + __popcll(same & ((1ull << lane) - 1ull));
-                    const int cap = w == 1 ? k.capA : k.a0[ll + 1] - k.a0[ll];     // list A holds < nms_pre keys, list T at most the level
-                    if ((unsigned)pos >= (unsigned)cap) LLV_GUARD_TRIP();
-                    else if (w == 1) listA_i[(long)ll * k.capA + pos] = key;
-                    else listT_i[k.a0[ll] + pos] = key;
-                }
+                if (which == w && l == ll) mypos = base + __popcll(same & ((1ull << lane) - 1ull));
                 active &= ~same;
             }
+        }
+        __syncthreads();
+        if (threadIdx.x < 2 * kCompactSlots) {
+            const int w = threadIdx.x / kCompactSlots, sl = threadIdx.x % kCompactSlots;
+            const int c = s_cnt[w][sl];
+            s_base[w][sl] = (c > 0 && l0 + sl < k.n_levels) ? atomicAdd(&meta_i[(l0 + sl) * 4 + 2 + w], c) : 0;
+        }
+        __syncthreads();
+        if (which && slot >= kCompactSlots) {
+            LLV_GUARD_TRIP();
+        } else if (which) {
+            const int pos = s_base[which - 1][slot] + mypos;
+            const int cap = which == 1 ? k.capA : k.a0[l + 1] - k.a0[l];     // list A holds < nms_pre keys, list T at most the level
+            if ((unsigned)pos >= (unsigned)cap) LLV_GUARD_TRIP();
+            else if (which == 1) listA_i[(long)l * k.capA + pos] = key;
+            else listT_i[k.a0[l] + pos] = key;
         }
     }
 }
@@ -513,7 +533,7 @@ extern "C" int llv_retina_decode_topk(const llv_decode_desc* d, void* stream) {
         }
     }
     hipLaunchKernelGGL(topk_threshold_kernel, dim3(d->n_levels, batch), dim3(256), 0, st, k);
-    hipLaunchKernelGGL(topk_compact_kernel, dim3(grid, batch), dim3(256), 0, st, k);
+    hipLaunchKernelGGL(topk_compact_kernel, dim3((total + 1023) / 1024 > 2048 ? 2048 : (total + 1023) / 1024, batch), dim3(1024), 0, st, k);
     int np2 = 1;
     while (np2 < (d->nms_pre > 0 ? d->nms_pre : 1)) np2 <<= 1;
     hipLaunchKernelGGL(topk_final_kernel, dim3(d->n_levels, batch), dim3(1024), (size_t)(np2 + kSortCap) * 8, st, k);
