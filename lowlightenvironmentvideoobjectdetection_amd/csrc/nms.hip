@@ -659,8 +659,8 @@ extern "C" int llv_multiclass_nms_batched_ex(const float* boxes, const float* sc
     int* cls_cnt = (int*)(ws + o_cnt);
     uint64_t* cls_keys = (uint64_t*)(ws + o_keys);
     uint64_t* cand = (uint64_t*)(ws + o_cand);
-    for (int b = 0; b < batch; ++b)   // counters of every image (small, contiguous per image): zeroed by kernels, not memset nodes
-        llv::zero_words(ws + (size_t)b * stride, o_keys, st);
+    // counters of every image (small, contiguous per image): zeroed by ONE kernel, not memset nodes (and not one launch per image)
+    llv::zero_words_strided(ws, o_keys, (size_t)stride, batch, st);
     if (n > 0) {
         long g = ((long)n * num_classes + 255) / 256;
         g = g > 256 ? 256 : g;

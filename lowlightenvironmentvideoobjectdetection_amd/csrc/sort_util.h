@@ -253,4 +253,19 @@ static inline int zero_words(void* p, size_t bytes, hipStream_t st) {
     return 0;
 }
 
+// the same for `count` regions of `bytes` bytes, `stride` bytes apart: one launch (blockIdx.y = region) instead of one per image
+static __global__ void zero_words_strided_kernel(unsigned char* p, size_t n, size_t stride) {
+    unsigned* q = reinterpret_cast<unsigned*>(p + (size_t)blockIdx.y * stride);
+    for (size_t i = blockIdx.x * (size_t)blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x) q[i] = 0u;
+}
+static inline int zero_words_strided(void* p, size_t bytes, size_t stride, int count, hipStream_t st) {
+    const size_t n = bytes / 4;
+    if (n == 0 || count < 1) return 0;
+    if (count == 1) return zero_words(p, bytes, st);
+    size_t g = (n + 255) / 256;
+    g = g > 64 ? 64 : g;
+    hipLaunchKernelGGL(zero_words_strided_kernel, dim3((unsigned)g, (unsigned)count), dim3(256), 0, st, (unsigned char*)p, n, stride);
+    return 0;
+}
+
 }  // namespace llv
