@@ -692,22 +692,34 @@ class FGFA(TwoStageVideoMixin, BaseVideoDetector):
                     raise LlvError('frame 0 of a video needs ref_img (fgfa.py:224-230,234-246)')
                 self.memo = dict(img=ref_img.float(), feats=[t.clone() for t in ext(ref_img)])
             x = ext(img)
-        else:                                                           # fixed stride
+        else:
+            # Fixed stride: the window (fgfa.py:243-257 `torch.cat((memo, new), dim=0)[k:]`) is a RING here. Window position u (in units of
+            # the stride; the key frame of step j = frame_id // stride is u = j, the window u = j - num_left .. j + right) lives in slot
+            # u % N: a slide overwrites the slot of the position that leaves instead of copying the N - 1 that stay (31 x 512 x 48 x 80
+            # fp32 features + 31 frames: 0.6 GB per frame for the reference's 30-reference test sampler). Flow, warp and the softmax over
+            # the references see the same N frames in slot order; a clip segment that starts mid-video fills the slots the one-rank run
+            # has at that frame, so both take every sum in the same order.
+            j = frame_id // frame_stride
             if frame_id == 0 or self.memo is None:
                 if ref_img is None:
                     raise LlvError('frame 0 of a video needs ref_img (fgfa.py:224-230,234-246)')
-                self.memo = dict(img=ref_img.float(), feats=[t.clone() for t in ext(ref_img)])
-                x = [f[[num_left]] for f in self.memo['feats']]
+                n = ref_img.shape[0]
+                slots = torch.tensor([(j - num_left + i) % n for i in range(n)], device=ref_img.device)
+                ring = lambda t: torch.empty_like(t).index_copy_(0, slots, t)
+                self.memo = dict(img=ring(ref_img.float()), feats=[ring(t) for t in ext(ref_img)])
             elif frame_id % frame_stride == 0:
                 assert ref_img is not None
                 ref_x = ext(ref_img)
-                k = ref_img.shape[0]
-                self.memo['feats'] = [torch.cat((m, r), dim=0)[k:] for m, r in zip(self.memo['feats'], ref_x)]
-                x = [f[[num_left]] for f in self.memo['feats']]
-                self.memo['img'] = torch.cat((self.memo['img'], ref_img.float()), dim=0)[k:]
+                n, k = self.memo['img'].shape[0], ref_img.shape[0]
+                right = n - 1 - num_left
+                slots = torch.tensor([(j + right - k + 1 + m) % n for m in range(k)], device=ref_img.device)
+                self.memo['img'].index_copy_(0, slots, ref_img.float())
+                for m_, r_ in zip(self.memo['feats'], ref_x):
+                    m_.index_copy_(0, slots, r_)
             else:
                 assert ref_img is None
-                x = ext(img)
+            key_slot = j % self.memo['img'].shape[0]
+            x = ext(img) if (frame_id % frame_stride and frame_id != 0) else [f[[key_slot]] for f in self.memo['feats']]
         nr = self.memo['img'].shape[0]
         flows = self.motion(torch.cat((img.float().repeat(nr, 1, 1, 1), self.memo['img']), dim=1), img_metas)
         agg_x = []
@@ -716,7 +728,7 @@ class FGFA(TwoStageVideoMixin, BaseVideoDetector):
             if frame_stride < 1:
                 stack = torch.cat((x[i], stack), dim=0)
             else:
-                stack[num_left] = x[i][0]
+                stack[key_slot] = x[i][0]
             agg_x.append(self.aggregator(x[i], stack.contiguous()))
         return tuple(agg_x)
 
