@@ -2613,6 +2613,14 @@ static int plan_launch(const llv_conv_desc* d, LaunchPlan& lp) {
         const long blocks128 = ((d->cout + 127) / 128) * ((m + 127) / 128) * d->groups;
         if (blocks128 >= 64) lp.tile = LLV_TILE_128x128;
     }
+    // a long reduction on a map that fills the chip (layer4's conv1, K = 2048, and layer4.0's strided conv2, K = 4608, at 16 frames:
+    // 14,720 pixels): 64-wide k-steps, half as many barriers and waits per MFMA -- 75 -> 59 us and 131 -> 110 us (tools/sweep_1x1_tiles.py,
+    // tools/sweep_stride2.py); shorter reductions lose with it (K = 256 / 512: 1.2-1.3x slower). LLV_K64_AUTO=0 turns it off.
+    static const int k64_auto = getenv("LLV_K64_AUTO") ? atoi(getenv("LLV_K64_AUTO")) : 1;
+    if (k64_auto && !d->tile && lp.tile == LLV_TILE_128x128 && d->k_pad >= 2048 && !(d->k_pad & 63) && d->k_splits <= 0) {
+        const long blocks128 = ((d->cout + 127) / 128) * ((m + 127) / 128) * d->groups;
+        if (blocks128 >= 256) lp.tile = LLV_TILE_128x128_K64;
+    }
     const int bk = tile_bk(lp.tile);
     const int nk = (d->k_pad + bk - 1) / bk;
     lp.splits = d->k_splits > 0 ? d->k_splits : pick_splits(lp.tile, d->cout, m, d->groups, nk, d->flags);
