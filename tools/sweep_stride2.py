@@ -12,7 +12,7 @@ from lowlightenvironmentvideoobjectdetection_amd._lib import CONV_RELU
 dev = torch.device('cuda:0')
 TILES = {0: 'auto', 1: '128x128', 2: '64x256', 3: '32x256', 5: '64x64', 7: '128x128K64', 8: '64x256K64'}
 shapes = [(18, 736, 1280, 32, 64, 'temp1.down0.0'), (18, 368, 640, 64, 128, 'temp1.down1.0'), (16, 184, 320, 128, 128, 'layer2.0.conv2'),
-          (16, 92, 160, 256, 256, 'layer3.0.conv2'), (16, 46, 80, 512, 512, 'layer4.0.conv2')]
+          (16, 92, 160, 256, 256, 'layer3.0.conv2'), (16, 46, 80, 512, 512, 'layer4.0.conv2'), (16, 23, 40, 2048, 256, 'neck.fpn3 (P6)')]
 flush = torch.empty(512 << 20, dtype=torch.uint8, device=dev)
 for nb, hh, ww, k, n, name in shapes:
     g = torch.Generator().manual_seed(1)
