@@ -2611,7 +2611,7 @@ static int plan_launch(const llv_conv_desc* d, LaunchPlan& lp) {
     // split K instead of four times as many 64x64 tiles that each stream all of K (45 us against 65 us)
     if (!d->tile && lp.tile == LLV_TILE_64x64 && d->cout >= 128 && d->k_pad >= 2048) {
         const long blocks128 = ((d->cout + 127) / 128) * ((m + 127) / 128) * d->groups;
-        if (blocks128 >= 48) lp.tile = LLV_TILE_128x128;   // (48: the FPN's P6 conv, 2048 -> 256 on 16 x 12 x 20 pixels, 60 blocks: 118 -> 95 us)
+        if (blocks128 >= 64) lp.tile = LLV_TILE_128x128;   // (not lower: single-image layer3 conv2, 58 blocks, is 26.6 us on 64x64 tiles, 31.3 on these)
     }
     // a long reduction on a map that fills the chip (layer4's conv1, K = 2048, and layer4.0's strided conv2, K = 4608, at 16 frames:
     // 14,720 pixels): 64-wide k-steps, half as many barriers and waits per MFMA -- 75 -> 59 us and 131 -> 110 us (tools/sweep_1x1_tiles.py,
