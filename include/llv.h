@@ -197,6 +197,7 @@ typedef struct llv_conv_desc {
 #define LLV_TILE_64x64 5
 #define LLV_TILE_128x128_K64 7 /* 128x128 tile, 64-wide k-steps (128-byte rows = full L2 lines per request) */
 #define LLV_TILE_64x256_K64 8
+#define LLV_TILE_64x64_K64 14 /* 64x64 tile, 64-wide k-steps, four-stage ring (single-image maps: half the barriers per MFMA) */
 #define LLV_TILE_TAP128 9 /* 3x3/s1/p1 tap-streamed kernel: 8x32-pixel tile x 128 channels, halo resident in LDS */
 #define LLV_TILE_TAP64_R4 11 /* tap kernel, 64 channels, weight ring of 4 (slices requested 3 steps ahead; 2 workgroups per CU) */
 #define LLV_TILE_TAP64 10  /* same, 64 output channels per workgroup */

@@ -29,6 +29,7 @@ CONV_MASK_POS = 1024
 TILE_AUTO, TILE_128x128, TILE_64x256, TILE_32x256, TILE_16x256, TILE_64x64 = 0, 1, 2, 3, 4, 5
 TILE_128x128_REGSTAGE = 6
 TILE_128x128_K64, TILE_64x256_K64 = 7, 8
+TILE_64x64_K64 = 14
 TILE_TAP128, TILE_TAP64 = 9, 10
 TILE_TAP64_R4 = 11
 TILE_TAP64_G3 = 12

@@ -2563,7 +2563,7 @@ unsigned int* llv_conv_guard_addr_() {
 
 struct LaunchPlan { int tile, splits, nk_per; long m; };
 
-static int tile_bk(int tile) { return (tile == LLV_TILE_128x128_K64 || tile == LLV_TILE_64x256_K64) ? 64 : 32; }
+static int tile_bk(int tile) { return (tile == LLV_TILE_128x128_K64 || tile == LLV_TILE_64x256_K64 || tile == LLV_TILE_64x64_K64) ? 64 : 32; }
 
 static int plan_launch(const llv_conv_desc* d, LaunchPlan& lp) {
     long m = 0;
@@ -2621,6 +2621,13 @@ static int plan_launch(const llv_conv_desc* d, LaunchPlan& lp) {
         const long blocks128 = ((d->cout + 127) / 128) * ((m + 127) / 128) * d->groups;
         if (blocks128 >= 256) lp.tile = LLV_TILE_128x128_K64;
     }
+    // the small-map tile with 64-wide k-steps for reductions of 1024 .. 2304 (single-image layer3 / layer4 conv1, their 3x3s, the data
+    // gradients of the conv3s): 5-16 % per launch alone on the device (tools/sweep_single_image.py), +0.3-0.7 % on the per-frame modes --
+    // but its 64 KB of LDS cost the training step 1.2 % (235.8 against 238.7 images/s, same box: those launches run beside the weight
+    // gradients there). Off unless LLV_K64_SMALL=1; LLV_TILE_64x64_K64 can be forced per launch.
+    static const int k64_small = getenv("LLV_K64_SMALL") ? atoi(getenv("LLV_K64_SMALL")) : 0;
+    if (k64_small && !d->tile && lp.tile == LLV_TILE_64x64 && d->k_pad >= 1024 && d->k_pad <= 2304 && !(d->k_pad & 63) && d->k_splits <= 0)
+        lp.tile = LLV_TILE_64x64_K64;
     const int bk = tile_bk(lp.tile);
     const int nk = (d->k_pad + bk - 1) / bk;
     lp.splits = d->k_splits > 0 ? d->k_splits : pick_splits(lp.tile, d->cout, m, d->groups, nk, d->flags);
@@ -2829,7 +2836,7 @@ static int conv_prepare(const llv_conv_desc* d, ConvPrepared& P) {
     if ((f & LLV_CONV_PIXSHUF) && tile == LLV_TILE_16x256) k.stage_out = 0;
     if ((tile == LLV_TILE_TAP128 || tile == LLV_TILE_TAP64 || tile == LLV_TILE_TAP64_R4 || tile == LLV_TILE_TAP64_G3) && !tap_eligible(d)) return LLV_E_BADARG;
     if (tile == LLV_TILE_TAP512 && !tap512_supported(d)) return LLV_E_UNSUPPORTED;
-    if (tile < LLV_TILE_128x128 || tile > LLV_TILE_TAP512) return LLV_E_UNSUPPORTED;
+    if (tile < LLV_TILE_128x128 || tile > LLV_TILE_64x64_K64) return LLV_E_UNSUPPORTED;
     return LLV_OK;
 }
 
@@ -2868,6 +2875,7 @@ extern "C" int llv_conv2d_nhwc_fwd(const llv_conv_desc* d, void* stream) {
         case LLV_TILE_32x256:  return launch_glds<32, 256, 32, 64>(k, d->groups, st);
         case LLV_TILE_16x256:  return launch_glds<16, 256, 16, 64>(k, d->groups, st);
         case LLV_TILE_64x64:   return launch_glds<64, 64, 32, 32>(k, d->groups, st);
+        case LLV_TILE_64x64_K64: return launch_glds<64, 64, 32, 32, 64>(k, d->groups, st);
         case LLV_TILE_128x128_REGSTAGE: return launch<128, 128, 64, 64>(k, d->groups, st);   // register-staged loop, kept for A/B
         case LLV_TILE_128x128_K64: return launch_glds<128, 128, 64, 64, 64>(k, d->groups, st);
         case LLV_TILE_TAP128: return tap_eligible(d) ? launch_tap<128>(k, d, st) : LLV_E_BADARG;

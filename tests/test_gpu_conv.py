@@ -37,7 +37,7 @@ def _check(y, ref, cout, tol=2e-3):
         assert y.float().cpu()[..., cout:].abs().max().item() == 0.0
 
 
-@pytest.mark.parametrize('tile', [1, 2, 3, 4, 5, 6, 7, 8])
+@pytest.mark.parametrize('tile', [1, 2, 3, 4, 5, 6, 7, 8, 14])
 @pytest.mark.parametrize('cfg', [
     # n, cin, cout, h, w, k, stride, pad
     (1, 64, 64, 20, 33, 3, 1, 1),

@@ -10,7 +10,7 @@ from lowlightenvironmentvideoobjectdetection_amd import ops
 from lowlightenvironmentvideoobjectdetection_amd._lib import CONV_RELU, CONV_RES_ADD
 
 dev = torch.device('cuda:0')
-TILES = {0: 'auto', 1: '128x128', 2: '64x256', 3: '32x256', 4: '16x256', 5: '64x64', 7: '128x128K64', 8: '64x256K64'}
+TILES = {0: 'auto', 1: '128x128', 5: '64x64', 14: '64x64K64', 7: '128x128K64'}
 shapes = [(92, 160, 512, 128, 1, False, 'layer2 conv1'), (92, 160, 128, 512, 1, True, 'layer2 conv3'), (92, 160, 128, 128, 3, False, 'layer2 conv2'),
           (46, 80, 1024, 256, 1, False, 'layer3 conv1'), (46, 80, 256, 1024, 1, True, 'layer3 conv3'), (46, 80, 256, 256, 3, False, 'layer3 conv2'),
           (23, 40, 2048, 512, 1, False, 'layer4 conv1'), (23, 40, 512, 2048, 1, True, 'layer4 conv3'), (23, 40, 512, 512, 3, False, 'layer4 conv2'),
